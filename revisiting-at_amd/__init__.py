@@ -1,0 +1,14 @@
+"""revisiting-at_amd — MI355X-native APGD adversarial-training inner loop.
+
+Drop-in for the ``adv.attack=apgd`` path of nmndeep/revisiting-at
+(``main.py:260-301, 831-844`` + ``autopgd_train_clean.py``).  Import as
+``revisiting_at_amd`` (see the shim ``revisiting_at_amd.py`` at the repo root).
+"""
+from . import _lib
+from .apgd import apgd_train, checkpoint_schedule, criterion_names
+from .wrapped_model import WrappedModel
+from .config import AdvConfig, build_perturb, wrap_model_for_at
+
+__version__ = "0.1.0"
+__all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "WrappedModel", "AdvConfig",
+           "build_perturb", "wrap_model_for_at", "_lib"]

@@ -1,0 +1,94 @@
+"""ctypes binding of libapgd_hip.so (C ABI declared in include/apgd_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, the product path
+raises.  (The CPU restatement in ``oracle/`` is test infrastructure and is never imported
+from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libapgd_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+F32, BF16, F16 = 0, 1, 2
+FLAG_NEW_BEST, FLAG_MISCLS, FLAG_HALVE = 1, 2, 4
+
+_p, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+
+# name -> (restype, argtypes); must match include/apgd_hip.h (tests/test_capi_symbols.py checks it)
+PROTOTYPES = {
+    "apgd_hip_version": (C.c_int, []),
+    "apgd_hip_strerror": (C.c_char_p, [C.c_int]),
+    "apgd_init_f32": (C.c_int, [_p, _p, _p, _p, _i64, _p]),
+    "apgd_linf_step_f32": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _f, _f, _p]),
+    "apgd_linf_step_f32_ex": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _f, _f,
+                                        _i32, _i32, _i32, _p]),
+    "apgd_l2_parts": (C.c_int, []),
+    "apgd_l2_step_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _p]),
+    "apgd_loss_pred": (C.c_int, [_p, C.c_int, _i64, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _p]),
+    "apgd_state_update": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p]),
+    "apgd_track_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _p]),
+    "apgd_check_imgs_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p]),
+}
+
+
+class ApgdHipError(RuntimeError):
+    pass
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load(path: str | None = None):
+    """Load (once) and return the ctypes handle; raises ApgdHipError if it cannot."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or os.environ.get("APGD_HIP_LIB", LIB_PATH)
+        if not os.path.exists(p):
+            raise ApgdHipError(
+                f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C revisiting-at_amd/csrc`. There is no CPU fallback for the APGD path.")
+        try:
+            lib = C.CDLL(p)
+        except OSError as e:  # pragma: no cover
+            raise ApgdHipError(f"cannot load {p}: {e}") from e
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise ApgdHipError(f"{p} does not export {name}") from e
+            fn.restype, fn.argtypes = res, args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().apgd_hip_strerror(code)
+        raise ApgdHipError(f"{what} failed: {code} ({msg.decode() if msg else '?'})")
+
+
+def dtype_code(t) -> int:
+    import torch
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    if t == torch.float16:
+        return F16
+    raise ApgdHipError(f"unsupported dtype {t}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

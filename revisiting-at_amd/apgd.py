@@ -1,0 +1,236 @@
+"""MI355X-native APGD inner loop behind the reference's ``apgd_train`` boundary.
+
+Host mirror of ``/root/reference/autopgd_train_clean.py:123-371``: same name, same
+arguments, same return tuple, same error behaviour — but the per-iteration element-wise
+update, the per-sample loss / prediction, the best-point tracking and the step-size state
+machine run as hand-written HIP kernels (``csrc/apgd_kernels.hip`` through the C ABI of
+``include/apgd_hip.h``) and the loop performs **no host synchronisation**: the check-point
+schedule depends only on ``n_iter`` and is computed on the host, every data-dependent
+decision stays on the device as a per-sample flag byte.
+
+What the model sees is unchanged: ``n_iter + 1`` eval-mode forwards and ``n_iter``
+input-gradient backwards, issued from Python on the current torch stream.  The gradient
+of ``sum_b CE_b`` w.r.t. the logits is produced by the loss kernel and fed to
+``torch.autograd.grad(logits, x_adv, grad_outputs=dlogits)``, so no parameter gradient is
+touched (``autopgd_train_clean.py:182-185``).
+
+There is no CPU fallback: CPU tensors or a missing ``libapgd_hip.so`` raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+__all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "ApgdWorkspace"]
+
+# losses the reference's criterion_dict names (autopgd_train_clean.py:113-114)
+criterion_names = ("ce", "softloss", "dlr", "dlr-targeted")
+
+
+def checkpoint_schedule(n_iter: int) -> List[Tuple[int, int]]:
+    """``[(i, k)]``: iterations at which ``counter3 == k`` fires and the window ``k`` used.
+
+    ``autopgd_train_clean.py:154-157`` (n_iter_2 / n_iter_min / size_decr) and ``:327-329,
+    348-349``.  Depends on ``n_iter`` only, which is what lets the loop run without reading
+    anything back from the device.
+    """
+    k = max(int(0.22 * n_iter), 1)
+    k_min = max(int(0.06 * n_iter), 1)
+    size_decr = max(int(0.03 * n_iter), 1)
+    out, counter = [], 0
+    for i in range(n_iter):
+        counter += 1
+        if counter == k:
+            out.append((i, k))
+            counter = 0
+            k = max(k - size_decr, k_min)
+    return out
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dense_rows(x: torch.Tensor) -> bool:
+    """True if ``x`` is [B, ...] with each sample one contiguous run of E elements."""
+    if x.dim() < 2:
+        return False
+    if x.is_contiguous():
+        return True
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        return True
+    if x.dim() == 5 and x.is_contiguous(memory_format=torch.channels_last_3d):
+        return True
+    return False
+
+
+def _loss_pred(logits: torch.Tensor, y_hard, y_soft, loss_out, pred_out, want_dlogits: bool):
+    """K2: per-sample CE, prediction and d(sum CE)/dlogits (``:113, 181-185, 194-197``).
+
+    Kept as a module-level function so tests can substitute recorded losses.
+    """
+    lib = _lib.load()
+    if logits.dim() != 2:
+        raise _lib.ApgdHipError(f"model output must be [B, n_cls], got {tuple(logits.shape)}")
+    lg = logits.detach()
+    if lg.stride(1) != 1:
+        lg = lg.contiguous()
+    dl = torch.empty_like(lg) if want_dlogits else None
+    if dl is not None and dl.stride() != lg.stride():
+        dl = torch.empty_strided(lg.shape, lg.stride(), dtype=lg.dtype, device=lg.device)
+    _lib.check(lib.apgd_loss_pred(lg.data_ptr(), _lib.dtype_code(lg.dtype), lg.stride(0) if lg.shape[0] > 1 else lg.shape[1],
+                                  _lib.ptr(y_hard), _lib.ptr(y_soft), 0,
+                                  loss_out.data_ptr(), pred_out.data_ptr(), _lib.ptr(dl),
+                                  lg.shape[0], lg.shape[1], _stream_ptr()), "apgd_loss_pred")
+    return dl
+
+
+class ApgdWorkspace:
+    """Per-call device state of the attack: three rotating iterates,
+    best points, per-sample scalars.  All buffers share ``x``'s memory format."""
+
+    def __init__(self, x: torch.Tensor, n_iter: int, n_rot: int):
+        B = x.shape[0]
+        dev = x.device
+        self.rot = [torch.empty_like(x) for _ in range(n_rot)]
+        self.x_best = torch.empty_like(x)
+        self.x_best_adv = torch.empty_like(x)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.loss = torch.empty(B, **f32)
+        self.loss_best = torch.empty(B, **f32)
+        self.loss_best_last = torch.empty(B, **f32)
+        self.reduced_last = torch.ones(B, **f32)                    # :201
+        self.loss_steps = torch.zeros(n_iter, B, **f32)             # :144
+        self.pred = torch.empty(B, device=dev, dtype=torch.uint8)
+        self.acc = torch.empty(B, device=dev, dtype=torch.uint8)
+        self.flags = torch.empty(B, device=dev, dtype=torch.uint8)
+
+
+def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace, loss_out, pred_out,
+                   need_grad: bool):
+    """One model call of the attack: forward, K2, and (optionally) the input gradient.
+
+    ``autopgd_train_clean.py:174-192`` (first call) and ``:266-287`` (in-loop calls; the last
+    one skips the backward, ``:281-283``).
+    """
+    if need_grad:
+        x_in.requires_grad_(True)
+        with torch.enable_grad():
+            logits = model(x_in)
+        dl = _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, True)
+        if dl.shape != logits.shape or dl.dtype != logits.dtype:
+            raise _lib.ApgdHipError("dlogits/logits mismatch")
+        grad = torch.autograd.grad([logits], [x_in], grad_outputs=[dl.view_as(logits)])[0].detach()
+        x_in.requires_grad_(False)
+        if grad.stride() != x_in.stride():
+            g2 = torch.empty_like(x_in, dtype=grad.dtype)
+            g2.copy_(grad)
+            grad = g2
+        return grad
+    with torch.no_grad():
+        logits = model(x_in)
+    _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, False)
+    return None
+
+
+def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
+               verbose=False, mixup=None, is_train=True):
+    """Drop-in for the reference's ``apgd_train`` (``autopgd_train_clean.py:123-124``).
+
+    Returns ``(x_best, acc, loss_best, x_best_adv)`` (``:371``): fresh, detached tensors with
+    ``x``'s shape and memory format; ``acc`` is bool ``[B]``, ``loss_best`` fp32 ``[B]``.
+    ``y`` is int64 ``[B]``, or fp32 ``[B, n_cls]`` probabilities iff ``mixup is not None``
+    (``:194-197``).  Supported: ``norm in {'Linf', 'L2'}``, ``loss == 'ce'``.
+    """
+    assert not model.training                                           # :125
+    if use_rs:
+        # the reference executes `raise NotImplemented` here (:137); any exception type would do
+        raise NotImplementedError("use_rs=True is not supported (autopgd_train_clean.py:137)")
+    if loss not in criterion_names:
+        raise KeyError(loss)                                            # criterion_dict[loss] (:149)
+    if loss != 'ce':
+        raise NotImplementedError(f"loss={loss!r}: only 'ce' is implemented in the HIP path")
+    if norm not in ('Linf', 'L2'):
+        raise NotImplementedError(f"norm={norm!r}: the HIP path covers Linf and L2 (SURVEY.md §8 a2, a8)")
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise _lib.ApgdHipError("apgd_train needs a device (MI355X) tensor; there is no CPU fallback")
+    if x.dtype != torch.float32:
+        raise _lib.ApgdHipError(f"attack state is fp32 (got {x.dtype})")
+    lib = _lib.load()
+    n_iter = int(n_iter)
+    if n_iter < 1:
+        # range(0) in the reference: returns the clamped clean point after one forward; keep it simple
+        raise ValueError("n_iter must be >= 1")
+
+    x = x.detach()
+    if not _dense_rows(x):
+        x = x.contiguous()
+    B = x.shape[0]
+    E = x[0].numel() if B > 0 else 0
+    stream = _stream_ptr()
+    soft = mixup is not None
+    if soft:
+        y_soft, y_hard = y.detach().to(torch.float32).contiguous(), None
+    else:
+        y_hard, y_soft = y.detach().to(torch.int64).contiguous(), None
+
+    ws = ApgdWorkspace(x, n_iter, n_rot=3 if n_iter > 1 else 2)
+    cur = ws.rot[0]
+    _lib.check(lib.apgd_init_f32(x.data_ptr(), cur.data_ptr(), ws.x_best.data_ptr(), ws.x_best_adv.data_ptr(),
+                                 x.numel(), stream), "apgd_init_f32")       # :135, 141-143
+    alpha = 2.0                                                              # :159
+    step_size = torch.full((B,), alpha * eps, device=x.device, dtype=torch.float32)   # :169-170
+    sched = dict(checkpoint_schedule(n_iter))
+    l2_ws = None
+    if norm == 'L2':
+        l2_ws = torch.empty(3 * B * lib.apgd_l2_parts(), device=x.device, dtype=torch.float32)
+
+    # first forward/backward: acc, loss_best are written directly by the loss kernel (:194-200)
+    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True)
+    grad_best = torch.empty_like(grad)                                       # :189
+    grad_best.copy_(grad)
+    ws.loss_best_last.copy_(ws.loss_best)                                    # :200
+    old = cur                                                                # :205 (x_adv_old == x_adv)
+    free = [ws.rot[1]] + ([ws.rot[2]] if n_iter > 1 else [])
+
+    for i in range(n_iter):                                                  # :209
+        a = 0.75 if i > 0 else 1.0                                           # :218
+        out = free.pop()
+        if norm == 'Linf':
+            g_code = _lib.dtype_code(grad.dtype)
+            _lib.check(lib.apgd_linf_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
+                                              step_size.data_ptr(), out.data_ptr(), None, B, E, eps, a, stream),
+                       "apgd_linf_step_f32")                                 # :214-226
+        else:
+            _lib.check(lib.apgd_l2_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(),
+                                            step_size.data_ptr(), out.data_ptr(), l2_ws.data_ptr(), B, E, eps, a,
+                                            stream), "apgd_l2_step_f32")     # :229-237
+        if old is not cur:
+            free.append(old)
+        old, cur = cur, out                                                  # :215, 260 (buffer rotation)
+
+        last = i == n_iter - 1
+        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last)   # :266-287
+        if g_new is not None:
+            grad = g_new
+
+        do_check = i in sched                                                # :329
+        k = sched.get(i, 1)
+        _lib.check(lib.apgd_state_update(ws.loss.data_ptr(), ws.pred.data_ptr(), ws.acc.data_ptr(),
+                                         ws.loss_best.data_ptr(), ws.loss_best_last.data_ptr(),
+                                         ws.reduced_last.data_ptr(), step_size.data_ptr(), ws.loss_steps.data_ptr(),
+                                         ws.flags.data_ptr(), B, n_iter, i, int(do_check), k, float(k * 0.75), stream),
+                   "apgd_state_update")                                      # :296, 319-343
+        _lib.check(lib.apgd_track_rows(ws.flags.data_ptr(), cur.data_ptr(), grad.data_ptr(), ws.x_best.data_ptr(),
+                                       grad_best.data_ptr(), ws.x_best_adv.data_ptr(), grad.element_size(), B, E,
+                                       int(last), stream), "apgd_track_rows")  # :304, 322-323, 345-346
+        if verbose:                                                          # :306-311 (host sync, debug only)
+            print('iteration: {} - best loss: {:.6f} curr loss {:.6f} - robust accuracy: {:.2%} - step size: {:.5f}'.format(
+                i, ws.loss_best.sum().item(), ws.loss.mean().item(), ws.acc.float().mean().item(),
+                step_size.mean().item()))
+
+    return ws.x_best, ws.acc.view(torch.bool), ws.loss_best, ws.x_best_adv   # :371

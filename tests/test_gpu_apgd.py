@@ -1,0 +1,464 @@
+"""GPU parity tests (run with ``-m gpu`` on the MI355X box): HIP kernels called through the
+C ABI (include/apgd_hip.h) versus the pinned CPU oracle (oracle/apgd_oracle.py) and the
+golden trajectories recorded from the reference (tests/golden/apgd_*.npz).
+
+Bar: bit-exact for the fp32 attack state, class indices and flags; 1e-5 relative / 3e-7
+absolute for the per-sample loss (torch's own fp32 log-softmax carries that error); 1e-5 for
+the L2 path (reduction order)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal, golden_cases, load_golden
+from oracle import apgd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LINF = [c for c in golden_cases() if c.startswith("linf")]
+L2 = [c for c in golden_cases() if c.startswith("l2")]
+TIE_FREE = ["linf_k1", "linf_k2", "linf_k3", "linf_cl_k3", "linf_flat_k5", "linf_scripted_k4", "linf_soft_k2"]
+
+
+@pytest.fixture(scope="module")
+def R():
+    import revisiting_at_amd as R
+    assert torch.cuda.is_available()
+    R._lib.load()          # fails loudly if the HIP extension is missing
+    return R
+
+
+@pytest.fixture(scope="module")
+def lib(R):
+    return R._lib.load()
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().float().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+# --------------------------------------------------------------------------- K0 prologue
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 1023, 4096 + 5, 6 * 3 * 224 * 224])
+def test_init_clamp_and_copies(lib, n):
+    rng = np.random.default_rng(n)
+    x = (rng.random(n, dtype=np.float32) * 1.4 - 0.2).astype(np.float32)
+    xd = dev(x) if n else torch.empty(0, device="cuda")
+    a, b, c = (torch.full_like(xd, 7.0) for _ in range(3))
+    assert lib.apgd_init_f32(xd.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), n, S()) == 0
+    want = np.clip(x, 0, 1)
+    for t in (a, b, c):
+        assert bits_equal(t.cpu().numpy(), want)
+
+
+def test_init_unaligned_and_null(lib):
+    x = torch.rand(1001, device="cuda") * 2 - 0.5
+    a = torch.zeros(1001, device="cuda")
+    assert lib.apgd_init_f32(x[1:].data_ptr(), a[1:].data_ptr(), None, None, 1000, S()) == 0
+    assert torch.equal(a[1:], x[1:].clamp(0, 1)) and a[0] == 0
+    assert lib.apgd_init_f32(None, a.data_ptr(), None, None, 10, S()) == -1
+    assert lib.apgd_init_f32(x.data_ptr(), a.data_ptr(), None, None, -1, S()) == -2
+
+
+# --------------------------------------------------------------------------- K1 Linf step
+def _step_inputs(B, E, seed, eps):
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, E), dtype=np.float32)
+    x[:, : min(E, 7)] = np.array([0, 1, eps, 1 - eps, 0.5, 2 * eps, 1e-8], np.float32)[: min(E, 7)]
+    xa = np.clip(x + rng.uniform(-eps, eps, (B, E)).astype(np.float32), 0, 1).astype(np.float32)
+    xo = np.clip(x + rng.uniform(-eps, eps, (B, E)).astype(np.float32), 0, 1).astype(np.float32)
+    g = (rng.standard_normal((B, E)) * 1e-3).astype(np.float32)
+    g[rng.random((B, E)) < 0.02] = 0.0
+    g[rng.random((B, E)) < 0.01] = -0.0
+    g[rng.random((B, E)) < 0.005] = np.nan
+    g[rng.random((B, E)) < 0.005] = 1e-42
+    step = (np.float32(2 * eps) / np.float32(2.0) ** rng.integers(0, 4, B)).astype(np.float32)
+    return x, xa, xo, g, step
+
+
+@pytest.mark.parametrize("B,E", [(1, 4), (3, 50), (5, 3 * 12 * 12), (2, 3 * 64 * 64), (7, 1021), (4, 3 * 224 * 224)])
+@pytest.mark.parametrize("a", [1.0, 0.75])
+def test_linf_step_bit_exact(lib, B, E, a):
+    eps = 4 / 255
+    x, xa, xo, g, step = _step_inputs(B, E, B * 1000 + E, eps)
+    if a == 1.0:
+        xo = xa.copy()
+    want = O.linf_step(x, xa, xo, g, step, eps, a)
+    xd, xad, xod, gd, sd = map(dev, (x, xa, xo, g, step))
+    out = torch.empty_like(xd)
+    assert lib.apgd_linf_step_f32(xd.data_ptr(), xad.data_ptr(), xod.data_ptr(), gd.data_ptr(), 0, sd.data_ptr(),
+                                  out.data_ptr(), None, B, E, eps, a, S()) == 0
+    assert bits_equal(out.cpu().numpy(), want)
+    # launch-shape variants give the same bits
+    for bps, un, nt in [(1, 1, 0), (3, 2, 1), (8, 4, 0), (2, 4, 1)]:
+        o2 = torch.zeros_like(xd)
+        assert lib.apgd_linf_step_f32_ex(xd.data_ptr(), xad.data_ptr(), xod.data_ptr(), gd.data_ptr(), 0,
+                                         sd.data_ptr(), o2.data_ptr(), None, B, E, eps, a, bps, un, nt, S()) == 0
+        assert bits_equal(o2.cpu().numpy(), want), (bps, un, nt)
+    # bf16 gradient (only the sign is used) and bf16 copy of the output
+    gb = gd.to(torch.bfloat16)
+    want_b = O.linf_step(x, xa, xo, gb.float().cpu().numpy(), step, eps, a)
+    o3 = torch.zeros_like(xd)
+    ob = torch.zeros(B, E, device="cuda", dtype=torch.bfloat16)
+    assert lib.apgd_linf_step_f32(xd.data_ptr(), xad.data_ptr(), xod.data_ptr(), gb.data_ptr(), 1, sd.data_ptr(),
+                                  o3.data_ptr(), ob.data_ptr(), B, E, eps, a, S()) == 0
+    assert bits_equal(o3.cpu().numpy(), want_b)
+    assert torch.equal(ob, o3.to(torch.bfloat16))
+
+
+def test_linf_step_unaligned_rows(lib):
+    eps, B, E = 8 / 255, 3, 64
+    x, xa, xo, g, step = _step_inputs(B, E + 1, 5, eps)
+    want = O.linf_step(x[:, 1:], xa[:, 1:], xo[:, 1:], g[:, 1:], step, eps, 0.75)
+    flat = [dev(np.ascontiguousarray(t[:, 1:]).reshape(-1)) for t in (x, xa, xo, g)]
+    pad = [torch.cat([torch.zeros(1, device="cuda"), t]) for t in flat]       # data starts 4 bytes off alignment
+    out = torch.zeros(B * E + 1, device="cuda")
+    sd = dev(step)
+    assert lib.apgd_linf_step_f32(pad[0][1:].data_ptr(), pad[1][1:].data_ptr(), pad[2][1:].data_ptr(),
+                                  pad[3][1:].data_ptr(), 0, sd.data_ptr(), out[1:].data_ptr(), None, B, E, eps, 0.75,
+                                  S()) == 0
+    assert bits_equal(out[1:].cpu().numpy().reshape(B, E), want)
+
+
+def test_linf_step_argument_errors(lib):
+    t = torch.zeros(16, device="cuda")
+    p = t.data_ptr()
+    assert lib.apgd_linf_step_f32(p, p, p, p, 0, p, None, None, 1, 16, 0.1, 1.0, S()) == -1
+    assert lib.apgd_linf_step_f32(p, p, p, p, 0, p, p, None, 1, 16, 0.1, 1.0, S()) == -4      # out aliases an input
+    o = torch.zeros(16, device="cuda")
+    assert lib.apgd_linf_step_f32(p, p, p, p, 7, p, o.data_ptr(), None, 1, 16, 0.1, 1.0, S()) == -3
+    assert lib.apgd_linf_step_f32(p, p, p, p, 0, p, o.data_ptr(), None, -1, 16, 0.1, 1.0, S()) == -2
+    assert lib.apgd_linf_step_f32(p, p, p, p, 0, p, o.data_ptr(), None, 0, 16, 0.1, 1.0, S()) == 0   # empty batch
+
+
+def test_linf_step_full_size_properties(lib):
+    """BASELINE config #2 size (B=256, 3x224x224): bit-exact vs the oracle on a slice, and the
+    eps-ball / box invariants (utils_eval.py:67-81) on everything via the device checker."""
+    eps, B, E = 4 / 255, 256, 3 * 224 * 224
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(B, E, device="cuda", generator=gen)
+    xa = (x + (torch.rand(B, E, device="cuda", generator=gen) * 2 - 1) * eps).clamp(0, 1)
+    xo = (x + (torch.rand(B, E, device="cuda", generator=gen) * 2 - 1) * eps).clamp(0, 1)
+    g = torch.randn(B, E, device="cuda", generator=gen) * 1e-3
+    step = torch.full((B,), 2 * eps, device="cuda")
+    step[::3] /= 2
+    step[::5] /= 4
+    out = torch.empty_like(x)
+    assert lib.apgd_linf_step_f32(x.data_ptr(), xa.data_ptr(), xo.data_ptr(), g.data_ptr(), 0, step.data_ptr(),
+                                  out.data_ptr(), None, B, E, eps, 0.75, S()) == 0
+    sl = slice(0, 256, 37)
+    want = O.linf_step(*(t[sl].cpu().numpy() for t in (x, xa, xo, g, step)), eps, 0.75)
+    assert bits_equal(out[sl].cpu().numpy(), want)
+    chk = torch.empty(B, 3, device="cuda")
+    assert lib.apgd_check_imgs_f32(out.data_ptr(), x.data_ptr(), chk.data_ptr(), B, E, S()) == 0
+    chk = chk.cpu().numpy()
+    assert chk[:, 0].max() <= np.float32(eps) * (1 + 2e-7) + 6e-8 and chk[:, 1].min() >= 0 and chk[:, 2].max() <= 1
+    # idempotence of the projection: stepping with a zero gradient from a point already inside
+    # the ball with x_adv_old == x_adv leaves it unchanged
+    z = torch.zeros_like(g)
+    o2 = torch.empty_like(x)
+    assert lib.apgd_linf_step_f32(x.data_ptr(), out.data_ptr(), out.data_ptr(), z.data_ptr(), 0, step.data_ptr(),
+                                  o2.data_ptr(), None, B, E, eps, 0.75, S()) == 0
+    assert torch.equal(o2, out)
+
+
+# --------------------------------------------------------------------------- K2 loss / pred / dlogits
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C", [(1, 2), (5, 10), (33, 1000), (256, 1000), (3, 63), (4, 65)])
+@pytest.mark.parametrize("soft", [False, True])
+def test_loss_pred_vs_oracle(R, lib, dtype, B, C, soft):
+    rng = np.random.default_rng(B * 7 + C)
+    z = (rng.standard_normal((B, C)) * 3).astype(np.float32)
+    z[0, :] = 0.5                                   # all-equal row: argmax must be index 0
+    if B > 2:
+        z[2, C // 2] = z[2].max() + 1
+        z[2, C - 1] = z[2, C // 2]                  # tie between two maxima: first index wins
+    zt = dev(z).to(dtype)
+    zf = zt.float().cpu().numpy()
+    if soft:
+        y = np.exp(rng.standard_normal((B, C))).astype(np.float32)
+        y /= y.sum(1, keepdims=True)
+        yd, yh, ys = dev(y), None, dev(y)
+    else:
+        y = rng.integers(0, C, B)
+        y[0] = 0
+        if B > 2:
+            y[2] = C // 2
+        yd, yh, ys = dev(y), dev(y), None
+    loss = torch.empty(B, device="cuda")
+    pred = torch.empty(B, device="cuda", dtype=torch.uint8)
+    dl = torch.empty_like(zt)
+    assert lib.apgd_loss_pred(zt.data_ptr(), R._lib.dtype_code(dtype), C, None if yh is None else yh.data_ptr(),
+                              None if ys is None else ys.data_ptr(), 0, loss.data_ptr(), pred.data_ptr(),
+                              dl.data_ptr(), B, C, S()) == 0
+    np.testing.assert_allclose(loss.cpu().numpy(), O.ce_loss(zf, y), rtol=1e-5, atol=3e-7)
+    assert np.array_equal(pred.cpu().numpy().astype(bool), O.predict(zf, y))
+    tol = {torch.float32: 2e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+    np.testing.assert_allclose(dl.float().cpu().numpy(), O.ce_dlogits(zf, y), atol=tol, rtol=tol)
+    # against torch's own GPU cross-entropy + autograd (what the reference would run here)
+    zt2 = zt.clone().requires_grad_()
+    li = torch.nn.functional.cross_entropy(zt2.float(), yd, reduction="none")
+    (gt,) = torch.autograd.grad(li.sum(), zt2)
+    np.testing.assert_allclose(loss.cpu().numpy(), li.detach().cpu().numpy(), rtol=1e-5, atol=3e-7)
+    np.testing.assert_allclose(dl.float().cpu().numpy(), gt.float().cpu().numpy(), atol=tol, rtol=tol)
+
+
+def test_loss_pred_strided_rows_and_errors(R, lib):
+    B, C, ld = 6, 10, 16
+    buf = torch.randn(B, ld, device="cuda")
+    y = torch.randint(0, C, (B,), device="cuda")
+    loss = torch.empty(B, device="cuda")
+    pred = torch.empty(B, device="cuda", dtype=torch.uint8)
+    assert lib.apgd_loss_pred(buf.data_ptr(), 0, ld, y.data_ptr(), None, 0, loss.data_ptr(), pred.data_ptr(), None, B,
+                              C, S()) == 0
+    want = torch.nn.functional.cross_entropy(buf[:, :C], y, reduction="none")
+    np.testing.assert_allclose(loss.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=3e-7)
+    assert torch.equal(pred.bool(), buf[:, :C].argmax(1) == y)
+    assert lib.apgd_loss_pred(buf.data_ptr(), 0, ld, None, None, 0, loss.data_ptr(), pred.data_ptr(), None, B, C, S()) == -4
+    assert lib.apgd_loss_pred(buf.data_ptr(), 9, ld, y.data_ptr(), None, 0, loss.data_ptr(), pred.data_ptr(), None, B, C, S()) == -3
+    assert lib.apgd_loss_pred(buf.data_ptr(), 0, 4, y.data_ptr(), None, 0, loss.data_ptr(), pred.data_ptr(), None, B, C, S()) == -2
+
+
+# --------------------------------------------------------------------------- K3 rows
+@pytest.mark.parametrize("E,gelt", [(48, 4), (3 * 32 * 32, 4), (50, 4), (3 * 32 * 32, 2), (6, 2)])
+@pytest.mark.parametrize("final", [0, 1])
+def test_track_rows_semantics(lib, E, gelt, final):
+    B = 16
+    rng = np.random.default_rng(E + final)
+    flags = (np.arange(B) % 8).astype(np.uint8)
+    rng.shuffle(flags)
+    gdt = torch.float32 if gelt == 4 else torch.bfloat16
+    xa, xb, xba = (torch.rand(B, E, device="cuda") for _ in range(3))
+    g, gb = (torch.randn(B, E, device="cuda").to(gdt) for _ in range(2))
+    w = [t.clone() for t in (xa, g, xb, gb, xba)]
+    for b in range(B):                                   # reference order: :304, :322-323, :345-346
+        f = int(flags[b])
+        if f & 2:
+            w[4][b] = w[0][b]
+        if f & 1:
+            w[2][b] = w[0][b]
+            if not final:
+                w[3][b] = w[1][b]
+        if f & 4 and not final:
+            w[0][b] = w[2][b]
+            w[1][b] = w[3][b]
+    fd = dev(flags)
+    assert lib.apgd_track_rows(fd.data_ptr(), xa.data_ptr(), g.data_ptr(), xb.data_ptr(), gb.data_ptr(),
+                               xba.data_ptr(), gelt, B, E, final, S()) == 0
+    for got, want in zip((xa, g, xb, gb, xba), w):
+        assert torch.equal(got, want)
+
+
+# --------------------------------------------------------------------------- end to end: replayed trajectories
+class _ScriptedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, logits, grad):
+        ctx.g = grad
+        return logits.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ctx.g.clone(), None, None
+
+
+class ReplayModule(torch.nn.Module):
+    """Device twin of oracle.ReplayModel: returns the recorded logits / input gradients and
+    remembers the sha256 of every iterate it is handed."""
+
+    def __init__(self, g, channels_last=False):
+        super().__init__()
+        self.logits = [dev(l) for l in g["logits"]]
+        self.grads = [dev(t) for t in g["grads"]]
+        if channels_last:
+            self.grads = [t.contiguous(memory_format=torch.channels_last) for t in self.grads]
+        self.n, self.seen = 0, []
+
+    def forward(self, x):
+        n = self.n
+        self.n += 1
+        self.seen.append(sha(x))
+        if x.requires_grad:
+            return _ScriptedFn.apply(x, self.logits[n], self.grads[n])
+        return self.logits[n].clone()
+
+
+def _inject_losses(monkeypatch, R, losses):
+    """Replace the loss the K2 kernel wrote by the reference's own fp32 value (keeps pred/dlogits):
+    isolates K1/K3/state machine/host loop so EVERY golden case must be bit-exact."""
+    real = R.apgd._loss_pred
+    calls = {"n": 0}
+
+    def patched(logits, y_hard, y_soft, loss_out, pred_out, want):
+        dl = real(logits, y_hard, y_soft, loss_out, pred_out, want)
+        loss_out.copy_(dev(losses[calls["n"]]))
+        calls["n"] += 1
+        return dl
+    monkeypatch.setattr(R.apgd, "_loss_pred", patched)
+
+
+def _run_replay(R, g, norm):
+    x = dev(g["x"])
+    if g["channels_last"]:
+        x = x.contiguous(memory_format=torch.channels_last)
+    y = dev(g["y"])
+    m = ReplayModule(g, g["channels_last"]).eval()
+    out = R.apgd_train(m, x, y, norm=norm, eps=g["eps"], n_iter=g["n_iter"], mixup=object() if g["soft"] else None)
+    torch.cuda.synchronize()
+    return x, m, out
+
+
+@pytest.mark.parametrize("case", LINF)
+def test_apgd_linf_golden_bit_exact_with_reference_losses(R, monkeypatch, case):
+    g = load_golden(case)
+    _inject_losses(monkeypatch, R, g["losses"])
+    x, m, (xb, acc, lb, xba) = _run_replay(R, g, "Linf")
+    assert m.seen == list(g["x_adv_sha"])                 # every iterate fed to the model, bit for bit
+    assert bits_equal(xb.cpu().numpy(), g["x_best"])
+    assert bits_equal(xba.cpu().numpy(), g["x_best_adv"])
+    assert np.array_equal(acc.cpu().numpy(), g["acc"]) and acc.dtype == torch.bool
+    assert bits_equal(lb.cpu().numpy(), g["loss_best"])
+    assert xb.stride() == x.stride() and not xb.requires_grad    # memory format preserved
+
+
+@pytest.mark.parametrize("case", TIE_FREE)
+def test_apgd_linf_golden_full_hip_path(R, case):
+    """No injection: the loss comes from the HIP kernel (tie-free cases, see test_oracle_golden.py)."""
+    g = load_golden(case)
+    x, m, (xb, acc, lb, xba) = _run_replay(R, g, "Linf")
+    assert m.seen == list(g["x_adv_sha"])
+    assert bits_equal(xb.cpu().numpy(), g["x_best"]) and bits_equal(xba.cpu().numpy(), g["x_best_adv"])
+    assert np.array_equal(acc.cpu().numpy(), g["acc"])
+    np.testing.assert_allclose(lb.cpu().numpy(), g["loss_best"], rtol=1e-5, atol=3e-7)
+
+
+@pytest.mark.parametrize("case", L2)
+def test_apgd_l2_golden(R, monkeypatch, case):
+    g = load_golden(case)
+    _inject_losses(monkeypatch, R, g["losses"])
+    x, m, (xb, acc, lb, xba) = _run_replay(R, g, "L2")
+    np.testing.assert_allclose(xb.cpu().numpy(), g["x_best"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xba.cpu().numpy(), g["x_best_adv"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(acc.cpu().numpy(), g["acc"])
+    assert bits_equal(lb.cpu().numpy(), g["loss_best"])
+    assert O.check_imgs(xb.cpu().numpy(), g["x"], "L2", g["eps"])[0] <= g["eps"] * (1 + 1e-5)
+
+
+@pytest.mark.parametrize("B,E", [(3, 50), (4, 3 * 8 * 8), (2, 1021)])
+def test_l2_step_vs_oracle(lib, B, E):
+    eps = 0.5
+    x, xa, xo, g, step = _step_inputs(B, E, 11, 0.05)
+    g = np.nan_to_num(g)
+    step = np.full(B, 1.0, np.float32)
+    want = O.l2_step(x, xa, xo, g, step, eps, 0.75)
+    xd, xad, xod, gd, sd = map(dev, (x, xa, xo, g, step))
+    out = torch.empty_like(xd)
+    ws = torch.empty(3 * B * lib.apgd_l2_parts(), device="cuda")
+    assert lib.apgd_l2_step_f32(xd.data_ptr(), xad.data_ptr(), xod.data_ptr(), gd.data_ptr(), sd.data_ptr(),
+                                out.data_ptr(), ws.data_ptr(), B, E, eps, 0.75, S()) == 0
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("K", [2, 7, 40])
+def test_apgd_fuzz_against_oracle(R, monkeypatch, K):
+    """Random scripted trajectories (many ties, halvings, mis-classifications): the oracle is the
+    yardstick, driven by the same logits/grads/losses."""
+    rng = np.random.default_rng(K)
+    B, C, shape = 9, 6, (3, 5, 5)
+    x = rng.random((B,) + shape, dtype=np.float32)
+    y = rng.integers(0, C, B)
+    logits = (rng.standard_normal((K + 1, B, C)) * 2).astype(np.float32)
+    for n in range(2, K + 1, 3):
+        logits[n, ::2] = logits[n - 1, ::2]                     # exact loss ties
+    grads = rng.standard_normal((K,) + x.shape).astype(np.float32)
+    grads[rng.random(grads.shape) < 0.05] = 0
+    losses = np.stack([O.ce_loss(l, y) for l in logits])
+    g = dict(x=x, y=y, logits=logits, grads=grads, losses=losses, eps=8 / 255, n_iter=K, soft=False,
+             channels_last=False)
+    rep = O.ReplayModel(logits, grads, losses)
+    oxb, oacc, olb, oxba, tr = O.apgd_train_oracle(rep, x, y, "Linf", g["eps"], K, use_model_loss=True)
+    _inject_losses(monkeypatch, R, losses)
+    _, m, (xb, acc, lb, xba) = _run_replay(R, g, "Linf")
+    assert m.seen == rep.seen_sha
+    assert bits_equal(xb.cpu().numpy(), oxb) and bits_equal(xba.cpu().numpy(), oxba)
+    assert np.array_equal(acc.cpu().numpy(), oacc) and bits_equal(lb.cpu().numpy(), olb)
+    if K >= 7:
+        assert tr.n_halvings > 0
+
+
+# --------------------------------------------------------------------------- live model, boundary, errors
+class _Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1 = torch.nn.Conv2d(3, 8, 3, padding=1)
+        self.fc = torch.nn.Linear(8, 10)
+
+    def forward(self, x):
+        return self.fc(torch.nn.functional.gelu(self.c1(x)).mean((-2, -1))) * 4
+
+
+def test_apgd_live_model_matches_oracle_statistically(R):
+    """Same weights on the device (HIP attack) and on the CPU (oracle attack + torch CPU model).
+    GPU/CPU convolutions round differently, so a few gradient signs may flip: require the
+    invariants exactly and agreement of the perturbation on >= 99 % of the pixels."""
+    torch.manual_seed(0)
+    m = _Tiny().eval()
+    x = torch.rand(16, 3, 16, 16)
+    y = torch.randint(0, 10, (16,))
+    eps, K = 4 / 255, 3
+    oxb, oacc, olb, oxba, _ = O.apgd_train_oracle(O.TorchModelAdapter(m, y.numpy()), x.numpy(), y.numpy(), "Linf", eps, K)
+    xb, acc, lb, xba = R.apgd_train(m.cuda(), x.cuda(), y.cuda(), norm="Linf", eps=eps, n_iter=K)
+    mx, n_nan, lo, hi = O.check_imgs(xb.cpu().numpy(), x.numpy(), "Linf", eps)
+    assert n_nan == 0 and lo >= 0 and hi <= 1 and mx <= eps * (1 + 1e-6) + 1e-7
+    assert (xb.cpu().numpy() == oxb).mean() >= 0.99
+    assert np.array_equal(acc.cpu().numpy(), oacc)
+    np.testing.assert_allclose(lb.cpu().numpy(), olb, rtol=2e-3, atol=1e-4)
+
+
+def test_wrapped_model_boundary_and_autocast(R):
+    torch.manual_seed(1)
+    base = _Tiny().cuda()
+    wm = R.wrap_model_for_at(base, R.AdvConfig.from_argv("--adv.attack apgd --adv.n_iter 2 --adv.eps 4/255".split()))
+    assert isinstance(wm, R.WrappedModel) and all(k.startswith("base_model.") for k in wm.state_dict())
+    x = torch.rand(8, 3, 16, 16, device="cuda")
+    y = torch.randint(0, 10, (8,), device="cuda")
+    wm.train()
+    clean = wm(x)                                   # perturb off -> clean forward (main.py:295-298)
+    assert torch.equal(clean, base(x))
+    wm.set_perturb(True)
+    with pytest.raises(AssertionError):
+        wm(x)                                       # y is required (main.py:276)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = wm(x, y)
+    assert out.dtype == torch.bfloat16 and base.training          # train mode restored (main.py:289)
+    out.float().sum().backward()
+    assert all(p.grad is not None for p in base.parameters())
+    # mixup-style soft labels through the same boundary
+    ys = torch.softmax(torch.randn(8, 10, device="cuda"), 1)
+    xb, acc, lb, xba = R.apgd_train(base.eval(), x, ys, norm="Linf", eps=4 / 255, n_iter=2, mixup=object())
+    assert acc.dtype == torch.bool and xb.shape == x.shape and float((xb - x).abs().max()) <= 4 / 255 + 1e-7
+
+
+def test_error_behaviour(R):
+    m = _Tiny().cuda()
+    x = torch.rand(2, 3, 8, 8, device="cuda")
+    y = torch.zeros(2, dtype=torch.long, device="cuda")
+    with pytest.raises(AssertionError):
+        R.apgd_train(m.train(), x, y, norm="Linf", eps=0.1, n_iter=1)        # autopgd_train_clean.py:125
+    m.eval()
+    with pytest.raises(KeyError):
+        R.apgd_train(m, x, y, norm="Linf", eps=0.1, n_iter=1, loss="nope")   # :149
+    with pytest.raises(Exception):
+        R.apgd_train(m, x, y, norm="Linf", eps=0.1, n_iter=1, use_rs=True)   # :137
+    with pytest.raises(R._lib.ApgdHipError):
+        R.apgd_train(m, x.cpu(), y.cpu(), norm="Linf", eps=0.1, n_iter=1)    # no CPU fallback
+    with pytest.raises(NotImplementedError):
+        R.apgd_train(m, x, y, norm="L1", eps=0.1, n_iter=1)                  # L1/L0 are outside the HIP path

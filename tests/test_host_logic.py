@@ -1,0 +1,101 @@
+"""Host-side logic of the product package that needs no GPU: schedule, flag parsing, the
+WrappedModel boundary (main.py:260-301) and the no-CPU-fallback rule."""
+import functools
+
+import pytest
+import torch
+import torch.nn as nn
+
+import revisiting_at_amd as R
+from oracle import apgd_oracle as O
+
+
+@pytest.mark.parametrize("n_iter", list(range(1, 60)) + [100, 250, 1000])
+def test_schedule_matches_oracle(n_iter):
+    assert R.checkpoint_schedule(n_iter) == O.checkpoint_schedule(n_iter)
+
+
+def test_schedule_k_never_exceeds_history():
+    # the device state machine reads loss_steps[i-k+1 .. i]; the C ABI rejects k > i+1
+    for n in range(1, 300):
+        for i, k in R.checkpoint_schedule(n):
+            assert 1 <= k <= i + 1 < n + 1
+
+
+def test_adv_flags_defaults_and_parsing():
+    c = R.AdvConfig()
+    assert (c.attack, c.norm, c.n_iter) == ("none", "Linf", 2) and abs(c.eps - 4 / 255) < 1e-12   # main.py:175-184
+    c = R.AdvConfig.from_argv("--data.num_workers 4 --adv.attack apgd --adv.n_iter=3 --adv.norm L2 --adv.eps 0.5 "
+                              "--adv.verbose 1 --lr.lr 1e-3".split())
+    assert (c.attack, c.n_iter, c.norm, c.eps, c.verbose) == ("apgd", 3, "L2", 0.5, 1)
+    assert abs(R.AdvConfig.from_argv(["--adv.eps", "8/255"]).eps - 8 / 255) < 1e-12
+    with pytest.raises(ValueError):
+        R.AdvConfig.from_argv(["--adv.bogus", "1"])
+
+
+def test_build_perturb_wiring():
+    assert R.build_perturb(R.AdvConfig()) is None                       # attack 'none': model is not wrapped
+    mix = object()
+    p = R.build_perturb(R.AdvConfig(attack="apgd", n_iter=5, eps=0.1, norm="L2", verbose=1), mixup=mix)
+    assert isinstance(p, functools.partial) and p.func is R.apgd_train  # main.py:834-835
+    assert p.keywords == dict(norm="L2", eps=0.1, n_iter=5, verbose=True, mixup=mix)
+    with pytest.raises(NotImplementedError):
+        R.build_perturb(R.AdvConfig(attack="fgsm"))
+    with pytest.raises(ValueError):
+        R.build_perturb(R.AdvConfig(attack="pgd"))
+    m = nn.Linear(3, 2)
+    assert R.wrap_model_for_at(m, R.AdvConfig()) is m
+
+
+def test_wrapped_model_protocol_on_cpu():
+    calls = []
+
+    class Base(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l = nn.Linear(4, 3)
+
+        def forward(self, x):
+            calls.append(("fwd", self.training))
+            return self.l(x)
+
+    def perturb(model, x, y):
+        calls.append(("perturb", model.training))
+        return (x + 1.0, "acc", "loss", "x_best_adv")
+
+    wm = R.WrappedModel(Base(), perturb)
+    assert list(wm.state_dict()) == ["base_model.l.weight", "base_model.l.bias"]
+    x = torch.zeros(2, 4)
+    wm.train()
+    assert torch.equal(wm(x), wm.base_model.l(x)) and calls == [("fwd", True)]
+    wm.set_perturb(True)
+    with pytest.raises(AssertionError):
+        wm(x)
+    calls.clear()
+    out = wm(x, torch.zeros(2, dtype=torch.long))
+    assert calls == [("perturb", False), ("fwd", True)]                 # eval during the attack, train after
+    assert torch.equal(out, wm.base_model.l(x + 1.0))                   # z[0] is what gets trained on
+    wm.perturb = lambda m, a, b: a + 2.0                                # a bare tensor is accepted too (main.py:291)
+    assert torch.equal(wm(x, 0), wm.base_model.l(x + 2.0))
+
+
+def test_apgd_train_has_no_cpu_fallback():
+    m = nn.Linear(4, 3).eval()
+    x, y = torch.rand(2, 4), torch.zeros(2, dtype=torch.long)
+    with pytest.raises(R._lib.ApgdHipError, match="no CPU fallback"):
+        R.apgd_train(m, x, y, norm="Linf", eps=0.1, n_iter=2)
+    with pytest.raises(AssertionError):
+        R.apgd_train(m.train(), x, y, norm="Linf", eps=0.1)
+    with pytest.raises(KeyError):
+        R.apgd_train(m.eval(), x, y, norm="Linf", eps=0.1, loss="hinge")
+
+
+def test_product_package_never_imports_the_oracle():
+    import os
+    import re
+    pkg = os.path.dirname(R.__file__)
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
