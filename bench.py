@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: adversarial images/sec of the APGD-2 adversarial-training step,
+ConvNeXt-T-CvSt @224, bf16, per-GPU batch 256, synthetic data (BASELINE.json configs[1]).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one synthetic batch per GPU: APGD attack
+(K+1 eval forwards, K input-gradient backwards, fused HIP update/track kernels) + train-mode
+forward on x_best + backward (DDP/RCCL gradient all-reduce when N > 1) + AdamW + EMA.
+Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).
+
+`roofline` is for the hand-written APGD Linf update kernel (HBM-bound, 20 algorithmic bytes
+per element per launch): its launches inside the timed region are bracketed with
+HIP events on the stream they run on.  `cpu_baseline` times the CPU oracle (numpy attack +
+plain-torch model) on a bounded sample of the same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+K1_BYTES_PER_ELEM = 20.0       # read x, x_adv, x_adv_old, grad (16 B) + write x_adv (4 B)
+K1_BYTES_PER_ELEM_IT0 = 16.0   # at i=0 x_adv_old aliases x_adv: one tensor fewer comes from HBM
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--arch", default="convnext_tiny")
+    p.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    p.add_argument("--res", type=int, default=224)
+    p.add_argument("--n-iter", type=int, default=2)
+    p.add_argument("--eps", type=float, default=4 / 255)
+    p.add_argument("--soft-labels", action="store_true", help="mixup-style [B,1000] targets")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-batch", type=int, default=8)
+    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--attack-only", action="store_true", help="time only apgd_train (extra info line on stderr)")
+    return p.parse_args()
+
+
+def cpu_baseline(args):
+    """CPU oracle (numpy APGD restatement + plain-torch ConvNeXt-T-CvSt), full AT step, fp32."""
+    import numpy as np
+    from oracle import apgd_oracle as O
+    from oracle import models_ref as M
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = M.build(args.arch, not_original=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    B = args.cpu_batch
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, 3, args.res, args.res, generator=g)
+    y = torch.randint(0, 1000, (B,), generator=g)
+
+    def one_step():
+        model.eval()
+        xb, _, _, _, _ = O.apgd_train_oracle(O.TorchModelAdapter(model, y.numpy()), x.numpy(), y.numpy(), "Linf",
+                                             args.eps, args.n_iter)
+        model.train()
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(torch.from_numpy(xb)), y)
+        loss.backward()
+        opt.step()
+
+    one_step()                                   # warm-up (allocator, oneDNN primitive cache)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        one_step()
+    dt = time.perf_counter() - t0
+    return {"value": round(B * args.cpu_steps / dt, 3), "unit": "img/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{args.cpu_steps} full AT steps (APGD-{args.n_iter} + train fwd/bwd + AdamW), batch {B}, "
+                      f"{args.res}x{args.res}, fp32, oracle/apgd_oracle.py + oracle/models_ref.py, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import revisiting_at_amd as R
+    from revisiting_at_amd import apgd as apgd_mod
+    import torch.distributed as dist
+
+    rank, local, world = R.setup_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback for the product path"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    R._lib.load()
+    torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = True                      # main.py:25
+
+    model = R.get_new_model(args.arch, pretrained=False, not_original=True)
+    adv = R.AdvConfig(attack="apgd", norm="Linf", eps=args.eps, n_iter=args.n_iter)
+    trainer = R.ATTrainStep(model, args.arch, adv, dev, lr=1e-3, distributed=world > 1, channels_last=True,
+                            amp_dtype=torch.bfloat16, ema=True, mixup=object() if args.soft_labels else None,
+                            soft_targets=args.soft_labels)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    B = args.batch
+    x = torch.rand(B, 3, args.res, args.res, device=dev, generator=g)        # synthetic 224x224x3 batch in [0,1)
+    if args.soft_labels:
+        y = torch.softmax(torch.randn(B, 1000, device=dev, generator=g), dim=1)
+    else:
+        y = torch.randint(0, 1000, (B,), device=dev, generator=g)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(x, y)
+    sync()
+    apgd_mod.PROFILE_EVENTS = []                                # K1 launches get bracketed by HIP events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(x, y)
+    sync()
+    dt = time.perf_counter() - t0
+    events = apgd_mod.PROFILE_EVENTS
+    apgd_mod.PROFILE_EVENTS = None
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # roofline of the dominant hand-written kernel (APGD Linf update)
+    k1 = [(i, a.elapsed_time(b)) for (name, i, a, b) in events if name == "apgd_linf_step_f32"]
+    k1_ms = [t for _, t in k1]
+    n_elem = B * 3 * args.res * args.res
+    roof = None
+    if k1_ms:
+        avg_ms = sum(k1_ms) / len(k1_ms)
+        alg_bytes = sum((K1_BYTES_PER_ELEM_IT0 if i == 0 else K1_BYTES_PER_ELEM) * n_elem for i, _ in k1)
+        ach = alg_bytes / (sum(k1_ms) * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "linf_step_vec4_kernel (apgd_linf_step_f32)", "launches": len(k1_ms),
+                "avg_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bytes / len(k1_ms)}
+
+    extra = {}
+    if args.attack_only or True:
+        # attack-only throughput (same tensors, eval mode), a few repetitions
+        base = trainer.inner.base_model
+        base.eval()
+        reps = max(2, min(args.steps, 5))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            R.apgd_train(base, x, y, norm="Linf", eps=args.eps, n_iter=args.n_iter,
+                         mixup=object() if args.soft_labels else None)
+            sync()
+            ta = time.perf_counter()
+            for _ in range(reps):
+                R.apgd_train(base, x, y, norm="Linf", eps=args.eps, n_iter=args.n_iter,
+                             mixup=object() if args.soft_labels else None)
+            sync()
+            extra["attack_only_img_s"] = round(world * B * reps / (time.perf_counter() - ta), 1)
+        base.train()
+        extra["ops_mode"] = R.ops.MODE
+        extra["device"] = torch.cuda.get_device_name(dev)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        line = {
+            "metric": "adversarial images/sec, ConvNeXt-T-CvSt APGD-2 AT @224" if args.arch == "convnext_tiny"
+                      and args.n_iter == 2 and args.res == 224 else
+                      f"adversarial images/sec, {args.arch}-CvSt APGD-{args.n_iter} AT @{args.res}",
+            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.arch}-CvSt APGD-{args.n_iter} adversarial-training step, eps={args.eps:.6f} Linf, "
+                                   f"{args.res}x{args.res}x3 fp32 inputs, bf16 autocast, per-GPU batch {B}, "
+                                   f"{'soft (mixup-style)' if args.soft_labels else 'hard'} labels, AdamW + EMA, "
+                                   f"{'DDP over RCCL' if world > 1 else 'single GPU'}",
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

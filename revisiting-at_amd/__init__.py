@@ -8,7 +8,10 @@ from . import _lib
 from .apgd import apgd_train, checkpoint_schedule, criterion_names
 from .wrapped_model import WrappedModel
 from .config import AdvConfig, build_perturb, wrap_model_for_at
+from .architecture import get_new_model, normalize_model
+from .train_step import ATTrainStep, create_optimizer, setup_distributed
 
 __version__ = "0.1.0"
 __all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "WrappedModel", "AdvConfig",
-           "build_perturb", "wrap_model_for_at", "_lib"]
+           "build_perturb", "wrap_model_for_at", "get_new_model", "normalize_model", "ATTrainStep", "create_optimizer",
+           "setup_distributed", "_lib"]

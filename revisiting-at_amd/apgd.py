@@ -27,6 +27,10 @@ from . import _lib
 
 __all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "ApgdWorkspace"]
 
+# bench.py sets this to a list to have every Linf-update launch bracketed by HIP events recorded on
+# the stream the kernel runs on: entries are (name, iteration, start_event, end_event).
+PROFILE_EVENTS = None
+
 # losses the reference's criterion_dict names (autopgd_train_clean.py:113-114)
 criterion_names = ("ce", "softloss", "dlr", "dlr-targeted")
 
@@ -202,9 +206,16 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
         out = free.pop()
         if norm == 'Linf':
             g_code = _lib.dtype_code(grad.dtype)
+            if PROFILE_EVENTS is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
             _lib.check(lib.apgd_linf_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
                                               step_size.data_ptr(), out.data_ptr(), None, B, E, eps, a, stream),
                        "apgd_linf_step_f32")                                 # :214-226
+            if PROFILE_EVENTS is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                PROFILE_EVENTS.append(("apgd_linf_step_f32", i, ev0, ev1))
         else:
             _lib.check(lib.apgd_l2_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(),
                                             step_size.data_ptr(), out.data_ptr(), l2_ws.data_ptr(), B, E, eps, a,

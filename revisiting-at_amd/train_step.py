@@ -1,0 +1,119 @@
+"""Outer adversarial-training step (``/root/reference/main.py:961-997``) and its DDP wiring
+(``main.py:351-359, 889-890``): per-iteration LR, ``zero_grad(set_to_none)``, autocast forward
+through ``WrappedModel`` (attack inside), loss, backward (RCCL gradient all-reduce fired by DDP's
+hooks — the only collective of the path), AdamW step, EMA update.
+
+Differences from the reference, all MI355X-motivated (SURVEY.md §7 "hard parts"):
+  * bf16 autocast, no GradScaler (the reference uses fp16 + GradScaler, ``main.py:797, 992-994``);
+  * the EMA copy lives on the device and is updated with one multi-tensor lerp instead of a
+    per-step device->host copy of every parameter (``main.py:885, 996-997``).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .config import AdvConfig, wrap_model_for_at
+
+
+def get_cosine_lr(epoch, lr, epochs, lr_peak_epoch):
+    """Linear warm-up to ``lr`` then cosine to 5e-6 (``main.py:227-243``)."""
+    if epoch <= lr_peak_epoch:
+        return float(np.interp([epoch], [0, lr_peak_epoch], [1e-4 * lr, lr])[0])
+    lr_min = 5e-6
+    return lr_min + .5 * (lr - lr_min) * (1 + math.cos(math.pi * (epoch - lr_peak_epoch) / (epochs - lr_peak_epoch)))
+
+
+def iteration_lrs(epoch, iters, **kw):
+    """Per-iteration LR table of one epoch (``main.py:956-958``)."""
+    return np.interp(np.arange(iters), [0, iters], [get_cosine_lr(epoch, **kw), get_cosine_lr(epoch + 1, **kw)])
+
+
+def create_optimizer(model: nn.Module, arch: str, weight_decay: float = 0.05):
+    """AdamW(betas=(0.9, 0.95)) with the reference's two parameter groups (``main.py:395-459``):
+    for convnext/resnet archs the names containing ``bn`` or ``.bias`` are not decayed (LayerNorm
+    weights and gammas ARE); otherwise 1-D parameters and biases are not decayed."""
+    named = [(k, v) for k, v in model.named_parameters() if v.requires_grad]
+    if 'convnext' in arch or 'resnet' in arch:
+        excluded = ['bn', '.bias']
+        no_decay = [v for k, v in named if any(c in k for c in excluded)]
+        decay = [v for k, v in named if not any(c in k for c in excluded)]
+    else:
+        no_decay = [v for k, v in named if v.ndim <= 1 or k.endswith('.bias')]
+        decay = [v for k, v in named if not (v.ndim <= 1 or k.endswith('.bias'))]
+    groups = [{'params': no_decay, 'weight_decay': 0.}, {'params': decay, 'weight_decay': weight_decay}]
+    return torch.optim.AdamW(groups, betas=(0.9, 0.95), fused=decay[0].is_cuda)
+
+
+class DeviceEma:
+    """``ModelEmaV2(decay)`` semantics (``ema = decay*ema + (1-decay)*model`` over the whole
+    state dict) kept on the device and updated by one ``_foreach_lerp_``."""
+
+    def __init__(self, model: nn.Module, decay: float = 0.9999):
+        self.decay = decay
+        self.src = [t for t in model.state_dict().values() if t.is_floating_point()]
+        self.ema = [t.detach().clone() for t in self.src]
+
+    @torch.no_grad()
+    def update(self):
+        torch._foreach_lerp_(self.ema, [s.detach() for s in self.src], 1.0 - self.decay)
+
+
+def setup_distributed():
+    """One process per GPU, RCCL via the "nccl" backend (``main.py:351-356``); reads the torchrun env."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class ATTrainStep:
+    """Builds ``DDP(WrappedModel(model, apgd))`` + optimizer (+EMA) and runs single steps."""
+
+    def __init__(self, model: nn.Module, arch: str, adv: AdvConfig, device, lr: float = 1e-3,
+                 weight_decay: float = 0.05, distributed: bool = False, channels_last: bool = True,
+                 amp_dtype: Optional[torch.dtype] = torch.bfloat16, ema: bool = True, mixup=None,
+                 soft_targets: bool = False):
+        self.device = torch.device(device)
+        if channels_last:
+            model = model.to(memory_format=torch.channels_last)            # main.py:815-817
+        wrapped = wrap_model_for_at(model, adv, mixup=mixup).to(self.device)  # main.py:831-844, 881
+        self.ema = DeviceEma(wrapped) if ema else None                     # before DDP (main.py:882-887)
+        self.perturb = adv.attack != 'none'
+        self.inner = wrapped
+        if distributed:
+            ids = [self.device.index] if self.device.type == 'cuda' else None
+            wrapped = nn.parallel.DistributedDataParallel(wrapped, device_ids=ids)   # main.py:889-890
+        self.model = wrapped
+        self.optimizer = create_optimizer(self.inner, arch, weight_decay)
+        self.loss = (lambda o, t: torch.sum(-t * torch.log_softmax(o.float(), dim=-1), dim=-1).mean()) \
+            if soft_targets else nn.CrossEntropyLoss()                     # SoftTargetCrossEntropy / CE (main.py:461-466)
+        self.amp_dtype = amp_dtype
+        self.lr = lr
+        if self.perturb:
+            self.inner.set_perturb(True)                                   # main.py:950-954
+        self.model.train()
+
+    def step(self, images, target, lr: Optional[float] = None):
+        for g in self.optimizer.param_groups:                              # main.py:973-974
+            g['lr'] = self.lr if lr is None else lr
+        self.optimizer.zero_grad(set_to_none=True)                         # main.py:984
+        with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            output = self.model(images, target) if self.perturb else self.model(images)   # main.py:985-989
+            loss = self.loss(output, target)                               # main.py:990
+        loss.backward()                                                    # main.py:992 (DDP all-reduce inside)
+        self.optimizer.step()                                              # main.py:993
+        if self.ema is not None:
+            self.ema.update()                                              # main.py:996-997
+        return loss.detach()
