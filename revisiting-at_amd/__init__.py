@@ -5,6 +5,7 @@ Drop-in for the ``adv.attack=apgd`` path of nmndeep/revisiting-at
 ``revisiting_at_amd`` (see the shim ``revisiting_at_amd.py`` at the repo root).
 """
 from . import _lib
+from . import ops, architecture
 from .apgd import apgd_train, checkpoint_schedule, criterion_names
 from .wrapped_model import WrappedModel
 from .config import AdvConfig, build_perturb, wrap_model_for_at

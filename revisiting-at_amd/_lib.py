@@ -33,6 +33,14 @@ PROTOTYPES = {
     "apgd_state_update": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p]),
     "apgd_track_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _p]),
     "apgd_check_imgs_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p]),
+    # include/convnext_hip.h
+    "cnx_dwconv7x7_nhwc": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, C.c_int, _i64, _i32, _i32, _i32, _i32, _p]),
+    "cnx_dwconv7x7_wgrad_ws_floats": (C.c_int64, [_i32]),
+    "cnx_dwconv7x7_wgrad_nhwc": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_layernorm_fwd": (C.c_int, [_p, C.c_int, _p, _p, _f, _p, C.c_int, _p, _p, _i64, _i32, _i32, _p]),
+    "cnx_layernorm_bwd_ws_floats": (C.c_int64, [_i32]),
+    "cnx_layernorm_bwd": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32,
+                                    _i32, _p]),
 }
 
 

@@ -522,13 +522,13 @@ int apgd_linf_step_f32_ex(const float* x, const float* x_adv, const float* x_adv
                          static_cast<const float*>(grad), step_size, out, out_bf16, E, eps, a, oma);
     return launch_status();
   }
-  const int U = unroll > 0 ? unroll : 2;
+  const int U = unroll > 0 ? unroll : 1;
   const int64_t E4 = E / 4;
   int bps = blocks_per_sample;
   if (bps <= 0) {
-    // enough blocks to cover 256 CUs x 8 resident blocks, but never more than one pass needs
-    const int64_t want = (256 * 8 * 2 + B - 1) / B;
-    bps = blocks_for(E4, static_cast<int64_t>(kBlock) * U, want < 1 ? 1 : want);
+    // measured on MI355X (tools/k1_sweep.py, B=256 x 3x224x224): one float4 per stream per thread and
+    // as many workgroups as that takes (147 x 256 = 37632 here) beats block-stride loops by ~8 %
+    bps = blocks_for(E4, static_cast<int64_t>(kBlock) * U, 65535);
   }
   const float* gf = static_cast<const float*>(grad);
   const uint16_t* gh = static_cast<const uint16_t*>(grad);

@@ -8,13 +8,14 @@ import pytest
 from conftest import ROOT
 
 HEADER = os.path.join(ROOT, "include", "apgd_hip.h")
+HEADERS = [HEADER, os.path.join(ROOT, "include", "convnext_hip.h")]
 
 
 def declared_functions():
-    src = open(HEADER).read()
+    src = "\n".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(apgd_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+((?:apgd|cnx)_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         out[m.group(1)] = n
@@ -32,7 +33,8 @@ def R():
 def test_header_declares_the_expected_entry_points():
     d = declared_functions()
     for name in ("apgd_hip_version", "apgd_init_f32", "apgd_linf_step_f32", "apgd_l2_step_f32", "apgd_loss_pred",
-                 "apgd_state_update", "apgd_track_rows", "apgd_check_imgs_f32"):
+                 "apgd_state_update", "apgd_track_rows", "apgd_check_imgs_f32", "cnx_dwconv7x7_nhwc",
+                 "cnx_dwconv7x7_wgrad_nhwc", "cnx_layernorm_fwd", "cnx_layernorm_bwd"):
         assert name in d
 
 
@@ -53,7 +55,7 @@ def test_python_prototypes_match_header(R):
 
 
 def test_no_torch_or_cxx_types_in_the_abi():
-    src = open(HEADER).read()
+    src = "\n".join(open(h).read() for h in HEADERS)
     assert 'extern "C"' in src and "at::" not in src and "torch" not in src.lower().replace("pytorch", "")
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "revisiting-at_amd", "libapgd_hip.so")],
                          capture_output=True, text=True, check=True).stdout

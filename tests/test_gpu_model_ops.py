@@ -1,0 +1,208 @@
+"""GPU tests of the model-side HIP kernels (include/convnext_hip.h) against plain fp32 torch on the
+CPU (oracle/models_ref.py restates the reference's modules; F.conv2d / F.layer_norm are the
+fp32 reference of each floating-point kernel).  Tolerances are written next to each check."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import models_ref as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    import revisiting_at_amd as R
+    assert torch.cuda.is_available()
+    R._lib.load()
+    return R
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 96, 14, 14), (1, 192, 7, 7), (2, 384, 9, 11), (3, 8, 5, 20), (1, 768, 7, 7),
+                                     (2, 200, 6, 8), (1, 96, 56, 56)])
+@pytest.mark.parametrize("xdt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+def test_dwconv7x7_fwd_bwd_data_wgrad(R, N, C, H, W, xdt, odt):
+    lib = R._lib.load()
+    g = torch.Generator().manual_seed(N * 1000 + C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, 7, 7, generator=g) * 0.2
+    b = torch.randn(C, generator=g)
+    add = torch.randn(N, H, W, C, generator=g)
+    xq = x.to(xdt).float()                                   # the kernel sees the quantised input
+    xr = xq.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    br = b.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, br, padding=3, groups=C)          # fp32 CPU reference
+    x_rows = xq.permute(0, 2, 3, 1).contiguous().to(xdt).cuda()
+    w49c = w.reshape(C, 49).t().contiguous().cuda()
+    out = torch.empty(N, H, W, C, device="cuda", dtype=odt)
+    code = R._lib.dtype_code
+    assert lib.cnx_dwconv7x7_nhwc(x_rows.data_ptr(), code(xdt), w49c.data_ptr(), b.cuda().data_ptr(), None,
+                                  out.data_ptr(), code(odt), N, H, W, C, 0, S()) == 0
+    tol = 1e-4 if odt == torch.float32 else 2e-2              # bf16 output: 2^-8 relative
+    close(out.permute(0, 3, 1, 2), ref, tol, tol)
+    # fused "+ add"
+    addc = add.cuda()
+    out2 = torch.empty(N, H, W, C, device="cuda", dtype=torch.float32)
+    assert lib.cnx_dwconv7x7_nhwc(x_rows.data_ptr(), code(xdt), w49c.data_ptr(), None, addc.data_ptr(), out2.data_ptr(),
+                                  0, N, H, W, C, 0, S()) == 0
+    close(out2.permute(0, 3, 1, 2), ref - b.view(1, C, 1, 1) + add.permute(0, 3, 1, 2), 1e-4, 1e-4)
+    # input gradient = same kernel with the rotated filter; filter/bias gradient kernel
+    dy = torch.randn(N, C, H, W, generator=g)
+    dyq = dy.to(odt).float()
+    gx, gw, gb = torch.autograd.grad(ref, (xr, wr, br), dyq)
+    dy_rows = dyq.permute(0, 2, 3, 1).contiguous().to(odt).cuda()
+    dx = torch.empty(N, H, W, C, device="cuda", dtype=torch.float32)
+    assert lib.cnx_dwconv7x7_nhwc(dy_rows.data_ptr(), code(odt), w49c.data_ptr(), None, None, dx.data_ptr(), 0, N, H, W,
+                                  C, 1, S()) == 0
+    close(dx.permute(0, 3, 1, 2), gx, 1e-4, 1e-4)
+    dw = torch.empty(49, C, device="cuda")
+    db = torch.empty(C, device="cuda")
+    ws = torch.empty(lib.cnx_dwconv7x7_wgrad_ws_floats(C), device="cuda")
+    assert lib.cnx_dwconv7x7_wgrad_nhwc(x_rows.data_ptr(), code(xdt), dy_rows.data_ptr(), code(odt), dw.data_ptr(),
+                                        db.data_ptr(), ws.data_ptr(), N, H, W, C, S()) == 0
+    scale = float(gw.abs().max()) + 1e-6
+    close(dw.t().reshape(C, 1, 7, 7), gw, 1e-4, 2e-5 * scale + 1e-5)       # fp32 accumulation, different order
+    close(db, gb, 1e-4, 1e-4 * float(gb.abs().max()) + 1e-5)
+
+
+@pytest.mark.parametrize("M_,C", [(5, 48), (37, 96), (64, 64), (10, 144), (33, 192), (21, 384), (9, 768), (4, 1536), (3, 8)])
+@pytest.mark.parametrize("gelu", [0, 1])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_layernorm_rows_fwd_bwd(R, M_, C, gelu, dt):
+    lib = R._lib.load()
+    code = R._lib.dtype_code
+    g = torch.Generator().manual_seed(M_ * 31 + C)
+    x = (torch.randn(M_, C, generator=g) * 2 + 0.3).to(dt).float()
+    w = torch.randn(C, generator=g) * 0.5 + 1
+    b = torch.randn(C, generator=g) * 0.5
+    dy = torch.randn(M_, C, generator=g).to(dt).float()
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    ref = F.layer_norm(xr, (C,), wr, br, 1e-6)
+    if gelu:
+        ref = F.gelu(ref)
+    gx, gw, gb = torch.autograd.grad(ref, (xr, wr, br), dy)
+    xd, wd, bd, dyd = x.to(dt).cuda(), w.cuda(), b.cuda(), dy.to(dt).cuda()
+    y = torch.empty(M_, C, device="cuda", dtype=dt)
+    mean, rstd = torch.empty(M_, device="cuda"), torch.empty(M_, device="cuda")
+    assert lib.cnx_layernorm_fwd(xd.data_ptr(), code(dt), wd.data_ptr(), bd.data_ptr(), 1e-6, y.data_ptr(), code(dt),
+                                 mean.data_ptr(), rstd.data_ptr(), M_, C, gelu, S()) == 0
+    tol = 2e-5 if dt == torch.float32 else 1.6e-2
+    close(y, ref, tol, tol)
+    close(mean, x.mean(1), 1e-5, 1e-5)
+    close(rstd, 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-6), 1e-4, 1e-5)
+    dx = torch.empty(M_, C, device="cuda", dtype=dt)
+    dw, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device="cuda")
+    assert lib.cnx_layernorm_bwd(dyd.data_ptr(), code(dt), xd.data_ptr(), code(dt), wd.data_ptr(), bd.data_ptr(),
+                                 mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), code(dt), dw.data_ptr(), db.data_ptr(),
+                                 ws.data_ptr(), M_, C, gelu, S()) == 0
+    close(dx, gx, 5 * tol, 5 * tol)
+    close(dw, gw, 1e-4, 1e-4 * float(gw.abs().max()) + 1e-5)
+    close(db, gb, 1e-4, 1e-4 * float(gb.abs().max()) + 1e-5)
+    # input-gradient only (the attack's backward): parameter outputs may be NULL
+    dx2 = torch.empty_like(dx)
+    assert lib.cnx_layernorm_bwd(dyd.data_ptr(), code(dt), xd.data_ptr(), code(dt), wd.data_ptr(), bd.data_ptr(),
+                                 mean.data_ptr(), rstd.data_ptr(), dx2.data_ptr(), code(dt), None, None, None, M_, C, gelu,
+                                 S()) == 0
+    assert torch.equal(dx, dx2)
+
+
+def _grads(out, inputs, cot):
+    return torch.autograd.grad(out, inputs, cot, allow_unused=True)
+
+
+@pytest.mark.parametrize("C,H", [(96, 14), (192, 7), (384, 6)])
+@pytest.mark.parametrize("gamma", [True, False])
+def test_convnext_block_matches_reference_block(R, C, H, gamma):
+    torch.manual_seed(C + H)
+    ref = M.CNBlock(C, ls_init=0.5 if gamma else 0).eval()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.2)
+    x = torch.randn(2, C, H, H)
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    cot = torch.randn_like(yr)
+    params = list(ref.parameters())
+    gref = _grads(yr, [xr] + params, cot)
+    # product block, fp32 (no autocast)
+    blk = R.architecture.ConvNeXtBlock(C, ls_init_value=0.5 if gamma else 0).cuda().eval()
+    blk.load_state_dict(ref.state_dict())
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    yd = blk(xd)
+    gd = _grads(yd, [xd] + list(blk.parameters()), cot.cuda())
+    close(yd, yr, 2e-4, 2e-4)
+    for a, b, (n, _) in zip(gd, gref, [("x", None)] + list(ref.named_parameters())):
+        close(a, b, 2e-3, 2e-4 * float(b.abs().max()) + 1e-5)
+    # bf16 autocast: activations bf16 / fp32 accumulation; bar = bf16 <= 1e-2 relative (north_star)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        xd2 = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        yb = blk(xd2)
+    assert yb.dtype == torch.float32 if gamma else True
+    gb = _grads(yb, [xd2], cot.cuda())[0]
+    res_ref = (yr - x).detach()
+    res_dev = (yb.float().cpu() - x).detach()
+    assert float((res_dev - res_ref).norm() / res_ref.norm()) < 1e-2
+    assert float((gb.float().cpu() - gref[0]).norm() / gref[0].norm()) < 1.5e-2
+
+
+def test_full_model_matches_reference_model_fp32(R):
+    torch.manual_seed(0)
+    ref = M.ConvNeXtTimm(depths=(1, 1, 2, 1), dims=(32, 64, 96, 128), num_classes=10)
+    ref.stem = M.ConvStem('block1', 16)
+    ref.eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(4.0) if p.ndim > 1 else p.add_(torch.randn_like(p) * 0.1)
+    A = R.architecture
+    dev = A.ConvNeXt(depths=(1, 1, 2, 1), dims=(32, 64, 96, 128), num_classes=10)
+    dev.stem = A.ConvBlock1(16)
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.cuda().to(memory_format=torch.channels_last).eval()
+    x = torch.rand(3, 3, 64, 64)
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    (gr,) = torch.autograd.grad(yr.sum(), xr)
+    xd = x.cuda().requires_grad_()
+    yd = dev(xd)
+    (gd,) = torch.autograd.grad(yd.sum(), xd)
+    close(yd, yr, 1e-3, 1e-3)
+    assert float((gd.cpu() - gr).norm() / gr.norm()) < 2e-3
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yb = dev(x.cuda())
+    assert float((yb.float().cpu() - yr).norm() / yr.norm()) < 2e-2
+
+
+def test_fused_ops_refuse_cpu_tensors(R):
+    blk = R.architecture.ConvNeXtBlock(8)
+    with pytest.raises(R._lib.ApgdHipError):
+        blk(torch.randn(1, 8, 7, 7))
+
+
+def test_apgd_train_on_product_model_under_autocast(R):
+    torch.manual_seed(0)
+    A = R.architecture
+    m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(32, 64, 96, 128), num_classes=10)
+    m.stem = A.ConvBlock1(16)
+    m = m.cuda().to(memory_format=torch.channels_last).eval()
+    x = torch.rand(8, 3, 64, 64, device="cuda")
+    y = torch.randint(0, 10, (8,), device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        xb, acc, lb, xba = R.apgd_train(m, x, y, norm="Linf", eps=4 / 255, n_iter=3)
+    assert xb.dtype == torch.float32 and float((xb - x).abs().max()) <= 4 / 255 + 1e-7
+    assert float(xb.min()) >= 0 and float(xb.max()) <= 1 and torch.isfinite(lb).all()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        clean = F.cross_entropy(m(x).float(), y, reduction="none")
+    assert (lb >= clean - 1e-2).all()        # loss_best never falls below the clean loss (up to bf16 noise)
