@@ -44,8 +44,8 @@ def parse():
     p.add_argument("--eps", type=float, default=4 / 255)
     p.add_argument("--soft-labels", action="store_true", help="mixup-style [B,1000] targets")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-batch", type=int, default=8)
-    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--cpu-batch", type=int, default=16)
+    p.add_argument("--cpu-steps", type=int, default=6)
     p.add_argument("--cpu-threads", type=int, default=32)
     p.add_argument("--attack-only", action="store_true", help="time only apgd_train (extra info line on stderr)")
     return p.parse_args()
@@ -82,7 +82,7 @@ def cpu_baseline(args):
 
     times = []
     t_all = time.perf_counter()
-    while len(times) < args.cpu_steps + 1 and (time.perf_counter() - t_all) < 30.0:
+    while len(times) < args.cpu_steps + 1 and (time.perf_counter() - t_all) < 40.0:
         t0 = time.perf_counter()
         one_step()
         times.append(time.perf_counter() - t0)

@@ -23,7 +23,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 __all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "ApgdWorkspace"]
 
@@ -128,7 +128,8 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
         dl = _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, True)
         if dl.shape != logits.shape or dl.dtype != logits.dtype:
             raise _lib.ApgdHipError("dlogits/logits mismatch")
-        grad = torch.autograd.grad([logits], [x_in], grad_outputs=[dl.view_as(logits)])[0].detach()
+        with ops.input_grad_only():
+            grad = torch.autograd.grad([logits], [x_in], grad_outputs=[dl.view_as(logits)])[0].detach()
         x_in.requires_grad_(False)
         if grad.stride() != x_in.stride():
             g2 = torch.empty_like(x_in, dtype=grad.dtype)

@@ -179,21 +179,28 @@ __global__ __launch_bounds__(7 * 48) void dwconv7x7_wgrad_kernel(const TX* __res
   if (kh == 0) store4(p + 49 * C + c0, accb);
 }
 
-// out[j] = sum_p ws[p*len + j] in fixed order p = 0..nparts-1
+// out[j] = sum_p ws[p*len + j]: 64 outputs per block, the parts split over 4 thread groups whose
+// partial sums are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ ws, float* __restrict__ out0,
                                                            float* __restrict__ out1, int split, int len, int nparts) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= len) return;
+  __shared__ float part[4][64];
+  const int jl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += ws[static_cast<long>(p) * len + j];
-  if (j < split) out0[j] = s; else if (out1) out1[j - split] = s;
+  if (j < len)
+    for (int p = pg; p < nparts; p += 4) s += ws[static_cast<long>(p) * len + j];
+  part[pg][jl] = s;
+  __syncthreads();
+  if (pg == 0 && j < len) {
+    s = (part[0][jl] + part[1][jl]) + (part[2][jl] + part[3][jl]);
+    if (j < split) out0[j] = s; else if (out1) out1[j - split] = s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over C of [M, C] rows (+ optional exact GELU).  GROUP lanes cooperate on one row,
 // 64/GROUP rows per wavefront, 4 channels per lane-chunk, up to NV chunks per lane in registers.
 // ------------------------------------------------------------------------------------------------
-constexpr int kNV = 8;
 __device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float z) {
   const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
@@ -432,7 +439,7 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
   else WG_LAUNCH(uint16_t, uint16_t);
 #undef WG_LAUNCH
   const int len = 50 * C;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 255) / 256), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, nb);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 63) / 64), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, nb);
   return launch_status();
 }
 
@@ -489,7 +496,7 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
   if (rc != APGD_OK) return rc;
   if (dweight) {
     const int len = 2 * C;
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 255) / 256), dim3(256), 0, s, ws, dweight, dbias, C, len, nb);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 63) / 64), dim3(256), 0, s, ws, dweight, dbias, C, len, nb);
     return launch_status();
   }
   return APGD_OK;

@@ -23,6 +23,27 @@ from . import _lib
 
 MODE = os.environ.get("APGD_OPS", "hip")
 
+# Set (process-wide, read at backward time from the autograd engine's thread) while the attack asks
+# for the input gradient only (autopgd_train_clean.py:185, 283: autograd.grad(loss, [x_adv])).
+# torch's own ops get this from the engine's per-call output mask; Python Functions only see the
+# static ctx.needs_input_grad, so the fused operators consult this flag to skip parameter gradients.
+_INPUT_GRAD_ONLY = False
+
+
+class input_grad_only:
+    """Context manager used by apgd_train around its ``torch.autograd.grad`` call."""
+
+    def __enter__(self):
+        global _INPUT_GRAD_ONLY
+        self._prev = _INPUT_GRAD_ONLY
+        _INPUT_GRAD_ONLY = True
+        return self
+
+    def __exit__(self, *exc):
+        global _INPUT_GRAD_ONLY
+        _INPUT_GRAD_ONLY = self._prev
+        return False
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -30,7 +51,7 @@ def _stream():
 
 def _act_dtype(x):
     if torch.is_autocast_enabled():
-        return torch.get_autocast_gpu_dtype()
+        return torch.get_autocast_dtype('cuda')
     return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
 
@@ -75,7 +96,7 @@ class _LayerNormRows(torch.autograd.Function):
         dy = dy.contiguous()
         C, M = ctx.C, ctx.M
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
-        want_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        want_p = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY
         dw = db = ws = None
         if want_p:
             dw = torch.empty(C, device=x.device, dtype=torch.float32)
@@ -142,8 +163,8 @@ class _DwConvLN(torch.autograd.Function):
         N, H, W, C = x.shape
         M = N * H * W
         dy = dy.contiguous()
-        need_ln_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        need_dw_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        need_ln_p = (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) and not _INPUT_GRAD_ONLY
+        need_dw_p = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY
         d_dwo = torch.empty_like(dwo)
         dlw = dlb = ws = None
         if need_ln_p:

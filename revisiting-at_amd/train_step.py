@@ -84,13 +84,17 @@ class ATTrainStep:
     def __init__(self, model: nn.Module, arch: str, adv: AdvConfig, device, lr: float = 1e-3,
                  weight_decay: float = 0.05, distributed: bool = False, channels_last: bool = True,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ema: bool = True, mixup=None,
-                 soft_targets: bool = False):
+                 soft_targets: bool = False, perturb=None):
         self.device = torch.device(device)
         if channels_last:
             model = model.to(memory_format=torch.channels_last)            # main.py:815-817
-        wrapped = wrap_model_for_at(model, adv, mixup=mixup).to(self.device)  # main.py:831-844, 881
+        if perturb is not None:                                            # any callable(model, x, y), as main.py:844
+            from .wrapped_model import WrappedModel
+            wrapped = WrappedModel(model, perturb).to(self.device)
+        else:
+            wrapped = wrap_model_for_at(model, adv, mixup=mixup).to(self.device)  # main.py:831-844, 881
         self.ema = DeviceEma(wrapped) if ema else None                     # before DDP (main.py:882-887)
-        self.perturb = adv.attack != 'none'
+        self.perturb = adv.attack != 'none' or perturb is not None
         self.inner = wrapped
         if distributed:
             ids = [self.device.index] if self.device.type == 'cuda' else None
