@@ -52,6 +52,20 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
                       void* dx, int dx_dtype, float* dweight, float* dbias, float* ws,
                       int64_t M, int32_t C, int32_t gelu, void* stream);
 
+/* Fused ConvNeXt MLP (models/convnext.py:42-49), two chained bf16 MFMA GEMMs with the 4C-wide hidden
+ * activation kept in registers:
+ *     out[m, :] = resid[m, :] + gamma * (GELU(A[m, :] W1^T + b1) W2^T + b2)
+ * A [M, C] bf16; W1 [4C, C] bf16 (nn.Linear layout); W2p [C, 4C] bf16 = W2 with its hidden index
+ * permuted inside every group of 32: position t*16 + half*8 + e holds h = (e&3) + 8*(2t + (e>>2)) + 4*half
+ * (the order the MFMA accumulators enumerate it); b1 [4C], b2 [C], gamma [C] fp32 (gamma, resid may be
+ * NULL); resid / out [M, C] fp32 or bf16; y2_out (nullable) receives the pre-gamma fc2 output in bf16
+ * (needed for d(gamma) in the training backward).  Exact-erf GELU (|err| <= 1.5e-7), fp32 accumulate.
+ * cnx_mlp_fwd_supported(C) tells which widths have a kernel (96, 192, 384). */
+int cnx_mlp_fwd_supported(int32_t C);
+int cnx_mlp_fwd(const void* A, const void* W1, const float* b1, const void* W2p, const float* b2,
+                const float* gamma, const void* resid, int resid_dtype, void* out, int out_dtype,
+                void* y2_out, int64_t M, int32_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

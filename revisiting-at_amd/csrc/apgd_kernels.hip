@@ -153,6 +153,47 @@ __device__ __forceinline__ G4 ldg4(const uint16_t* p, int64_t v, bool nt) {
 
 // grid = (blocks_per_sample, B).  Each block walks its sample's float4 range with a
 // block-stride loop, U independent float4 per stream in flight per thread.
+// iteration 0 (autopgd_train_clean.py:205, 218): x_adv_old == x_adv and a == 1, so grad2 == +0 and
+// grad2*(1-a) == +0; u = (x_adv + (x1 - x_adv)*1) + 0 is evaluated without fetching x_adv_old.
+// Bit-identical to the general form ((t - xa)*1.0f and "+ 0.0f" are exact for the finite, non-negative
+// operands of this path) and one stream lighter: 16 B/element.
+__device__ __forceinline__ float linf_elem_first(float x, float xa, float g, float st, float eps) {
+  const float lo = x - eps;
+  const float hi = x + eps;
+  const float sg = (g > 0.0f) ? st : ((g < 0.0f) ? -st : 0.0f);
+  float t = xa + sg;
+  t = clamp01(fminf(fmaxf(t, lo), hi));
+  const float u = xa + (t - xa);
+  return clamp01(fminf(fmaxf(u, lo), hi));
+}
+
+template <typename GT, bool BF16_OUT>
+__global__ __launch_bounds__(kBlock) void linf_step_first_vec4_kernel(
+    const float* __restrict__ x, const float* __restrict__ xa, const GT* __restrict__ g,
+    const float* __restrict__ step, float* __restrict__ out, uint16_t* __restrict__ out_bf16, int64_t E, float eps) {
+  const int64_t b = blockIdx.y;
+  const float st = step[b];
+  const int64_t row = b * E;
+  const int64_t E4 = E >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t v = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; v < E4; v += stride) {
+    const float4 X = ld4(x + row, v, false), A = ld4(xa + row, v, false);
+    const G4 Gd = ldg4(g + row, v, false);
+    float4 r;
+    r.x = linf_elem_first(X.x, A.x, Gd.x, st, eps);
+    r.y = linf_elem_first(X.y, A.y, Gd.y, st, eps);
+    r.z = linf_elem_first(X.z, A.z, Gd.z, st, eps);
+    r.w = linf_elem_first(X.w, A.w, Gd.w, st, eps);
+    st4(out + row, v, r, false);
+    if (BF16_OUT) {
+      uint2 pk;
+      pk.x = static_cast<uint32_t>(f32_to_bf16_rne(r.x)) | (static_cast<uint32_t>(f32_to_bf16_rne(r.y)) << 16);
+      pk.y = static_cast<uint32_t>(f32_to_bf16_rne(r.z)) | (static_cast<uint32_t>(f32_to_bf16_rne(r.w)) << 16);
+      reinterpret_cast<uint2*>(out_bf16 + row)[v] = pk;
+    }
+  }
+}
+
 template <typename GT, int U, bool BF16_OUT, bool NT>
 __global__ __launch_bounds__(kBlock) void linf_step_vec4_kernel(
     const float* __restrict__ x, const float* __restrict__ xa, const float* __restrict__ xo,
@@ -532,6 +573,16 @@ int apgd_linf_step_f32_ex(const float* x, const float* x_adv, const float* x_adv
   }
   const float* gf = static_cast<const float*>(grad);
   const uint16_t* gh = static_cast<const uint16_t*>(grad);
+  if (x_adv_old == x_adv && a == 1.0f && blocks_per_sample <= 0 && unroll <= 0 && !nontemporal) {
+    const dim3 grid(bps, static_cast<unsigned>(B));
+#define APGD_FIRST(GT, GP, BO)                                                                                   \
+  hipLaunchKernelGGL((linf_step_first_vec4_kernel<GT, BO>), grid, dim3(kBlock), 0, s, x, x_adv, GP, step_size, out, \
+                     out_bf16, E, eps)
+    if (g16) { if (out_bf16) APGD_FIRST(uint16_t, gh, true); else APGD_FIRST(uint16_t, gh, false); }
+    else { if (out_bf16) APGD_FIRST(float, gf, true); else APGD_FIRST(float, gf, false); }
+#undef APGD_FIRST
+    return launch_status();
+  }
 #define APGD_DISPATCH_U(UU)                                                                                          \
   if (U == UU) {                                                                                                     \
     if (nontemporal)                                                                                                 \

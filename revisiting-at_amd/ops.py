@@ -203,13 +203,110 @@ def dwconv_ln(x_rows, dw_w, dw_b, ln_w, ln_b, eps):
     return _DwConvLN.apply(x_rows, dw_w, dw_b, ln_w, ln_b, float(eps), _act_dtype(x_rows))
 
 
+# ------------------------------------------------------------------------------ fused MLP (MFMA)
+def _w2_perm(n_hidden, device):
+    """Hidden-index order the MFMA accumulators enumerate (see csrc/mlp_kernels.hip / convnext_hip.h)."""
+    p = torch.arange(32)
+    t, half, e = p // 16, (p // 8) % 2, p % 8
+    src = (e & 3) + 8 * (2 * t + (e >> 2)) + 4 * half
+    return (torch.arange(0, n_hidden, 32).view(-1, 1) + src.view(1, -1)).reshape(-1).to(device)
+
+
+_wcache = {}
+
+
+def _cached(param, tag, fn):
+    """bf16 / permuted copies of a parameter, rebuilt only when the parameter changes
+    (optimizer steps bump ``_version``); the attack's 3 forwards and the train forward share them."""
+    key = (id(param), tag)
+    ver = (param._version, param.data_ptr())
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        val = fn(param.detach())
+    _wcache[key] = (ver, val)
+    return val
+
+
+class _MlpFused(torch.autograd.Function):
+    """rows a [.., C] (bf16) , residual x [.., C] -> x + gamma * fc2(GELU(fc1(a)))  (``models/convnext.py:42-49``).
+
+    Forward: one MFMA kernel (``cnx_mlp_fwd``), hidden activation stays on-chip.  Backward recomputes the
+    hidden pre-activation instead of storing it (M x 4C bf16 per block is the largest tensor of the model)."""
+
+    @staticmethod
+    def forward(ctx, a, x, w1, b1, w2, b2, gamma):
+        lib = _lib.load()
+        C = a.shape[-1]
+        M = a.numel() // C
+        w1b = _cached(w1, "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+        w2b = _cached(w2, "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+        w2p = _cached(w2, "perm", lambda w: w.to(torch.bfloat16)[:, _w2_perm(w.shape[1], w.device)].contiguous())
+        b1f, b2f = _f32(b1), _f32(b2)
+        gf = _f32(gamma) if gamma is not None else None
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32 if (gamma is not None or x.dtype == torch.float32)
+                          else x.dtype)
+        need_p = any(ctx.needs_input_grad[2:])
+        y2 = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16) if (need_p and gamma is not None
+                                                                              and torch.is_grad_enabled()) else None
+        _lib.check(lib.cnx_mlp_fwd(a.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2p.data_ptr(), b2f.data_ptr(),
+                                   _lib.ptr(gf), x.data_ptr(), _code(x), out.data_ptr(), _code(out), _lib.ptr(y2), M, C,
+                                   _stream()), "cnx_mlp_fwd")
+        ctx.save_for_backward(a, w1b, w2b, b1f, b2f, gf, y2)
+        ctx.x_dtype = x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w1b, w2b, b1f, b2f, gf, y2 = ctx.saved_tensors
+        C = a.shape[-1]
+        g2 = g.reshape(-1, C)
+        a2 = a.reshape(-1, C)
+        dos = (g2 * gf if gf is not None else g2).to(torch.bfloat16)            # d(fc2 out)
+        hpre = torch.addmm(b1f.to(torch.bfloat16), a2, w1b.t())                  # recomputed, [M, 4C]
+        dh = dos @ w2b                                                           # [M, 4C]
+        dhpre = torch.ops.aten.gelu_backward(dh, hpre)
+        da = (dhpre @ w1b).view_as(a) if ctx.needs_input_grad[0] else None
+        dx = g.to(ctx.x_dtype) if ctx.needs_input_grad[1] else None
+        dw1 = db1 = dw2 = db2 = dgamma = None
+        if any(ctx.needs_input_grad[2:]) and not _INPUT_GRAD_ONLY:
+            h = F.gelu(hpre)
+            dw2 = (dos.t() @ h).float()
+            db2 = dos.float().sum(0)
+            dw1 = (dhpre.t() @ a2).float()
+            db1 = dhpre.float().sum(0)
+            if gf is not None:
+                y2v = y2.reshape(-1, C) if y2 is not None else torch.addmm(b2f.to(torch.bfloat16), h, w2b.t())
+                dgamma = (g2.float() * y2v.float()).sum(0)
+        return da, dx, dw1, db1, dw2, db2, dgamma
+
+
+def mlp_fused_supported(C):
+    return bool(_lib.load().cnx_mlp_fwd_supported(C))
+
+
+# Widths for which the fused MFMA MLP forward is switched on.  Measured on MI355X (tools/mlp_bench.py,
+# B=256): it beats the hipBLASLt + aten composition only where the block is HBM-bound (C=96); at
+# C>=192 the in-register GELU makes it VALU-bound and the library GEMMs win, so those stay on
+# hipBLASLt until the kernel is tuned.  APGD_MLP_FUSED="96,192,384" / "" overrides.
+_FUSED_MLP_WIDTHS = {int(v) for v in os.environ.get("APGD_MLP_FUSED", "").split(",") if v.strip()}
+
+
+def _use_fused_mlp(C):
+    return MODE != "eager" and C in _FUSED_MLP_WIDTHS and mlp_fused_supported(C)
+
+
 def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
     """``x + gamma * fc2(GELU(fc1(LN(dw7x7(x)))))`` on ``[N,C,H,W]`` (``models/convnext.py:37-50``)."""
     if MODE == "eager":
         y = F.conv2d(x, dw_w, dw_b, padding=3, groups=x.shape[1]).permute(0, 2, 3, 1)
         y = F.layer_norm(y, ln_w.shape, ln_w, ln_b, eps)
     else:
-        y = dwconv_ln(_rows(x), dw_w, dw_b, ln_w, ln_b, eps)
+        xr = _rows(x)
+        y = dwconv_ln(xr, dw_w, dw_b, ln_w, ln_b, eps)
+        if _use_fused_mlp(x.shape[1]) and y.dtype == torch.bfloat16:
+            return _MlpFused.apply(y, xr, w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
     y = F.linear(F.gelu(F.linear(y, w1, b1)), w2, b2)
     if gamma is not None:
         y = y * gamma

@@ -98,6 +98,11 @@ def test_linf_step_bit_exact(lib, B, E, a):
     assert lib.apgd_linf_step_f32(xd.data_ptr(), xad.data_ptr(), xod.data_ptr(), gd.data_ptr(), 0, sd.data_ptr(),
                                   out.data_ptr(), None, B, E, eps, a, S()) == 0
     assert bits_equal(out.cpu().numpy(), want)
+    if a == 1.0:    # iteration-0 form: x_adv_old IS x_adv (same pointer) -> the 3-stream kernel, same bits
+        o0 = torch.zeros_like(xd)
+        assert lib.apgd_linf_step_f32(xd.data_ptr(), xad.data_ptr(), xad.data_ptr(), gd.data_ptr(), 0, sd.data_ptr(),
+                                      o0.data_ptr(), None, B, E, eps, a, S()) == 0
+        assert bits_equal(o0.cpu().numpy(), want)
     # launch-shape variants give the same bits
     for bps, un, nt in [(1, 1, 0), (3, 2, 1), (8, 4, 0), (2, 4, 1)]:
         o2 = torch.zeros_like(xd)

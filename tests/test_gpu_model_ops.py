@@ -206,3 +206,49 @@ def test_apgd_train_on_product_model_under_autocast(R):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         clean = F.cross_entropy(m(x).float(), y, reduction="none")
     assert (lb >= clean - 1e-2).all()        # loss_best never falls below the clean loss (up to bf16 noise)
+
+
+@pytest.mark.parametrize("C", [96, 192, 384])
+@pytest.mark.parametrize("M_", [1, 31, 128, 300, 1000])
+@pytest.mark.parametrize("gamma", [True, False])
+def test_fused_mlp_forward_vs_fp32_reference(R, C, M_, gamma):
+    """cnx_mlp_fwd (two chained MFMA GEMMs, GELU in registers) vs an fp32 torch evaluation on the same
+    bf16-quantised operands.  Bar: the product's bf16 <= 1e-2 relative tolerance (north_star)."""
+    lib = R._lib.load()
+    g = torch.Generator().manual_seed(C + M_)
+    a = (torch.randn(M_, C, generator=g)).to(torch.bfloat16)
+    w1 = (torch.randn(4 * C, C, generator=g) * C ** -0.5).to(torch.bfloat16)
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).to(torch.bfloat16)
+    b1, b2 = torch.randn(4 * C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    gm = torch.randn(C, generator=g) if gamma else None
+    x = torch.randn(M_, C, generator=g)
+    h = F.gelu(a.float() @ w1.float().t() + b1)
+    y2 = h @ w2.float().t() + b2
+    ref = x + (y2 * gm if gamma else y2)
+    perm = R.ops._w2_perm(4 * C, "cpu")
+    ad, w1d, w2p = a.cuda(), w1.cuda(), w2[:, perm].contiguous().cuda()
+    out = torch.empty(M_, C, device="cuda")
+    y2d = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+    xd = x.cuda()
+    assert lib.cnx_mlp_fwd(ad.data_ptr(), w1d.data_ptr(), b1.cuda().data_ptr(), w2p.data_ptr(), b2.cuda().data_ptr(),
+                           gm.cuda().data_ptr() if gamma else None, xd.data_ptr(), 0, out.data_ptr(), 0, y2d.data_ptr(),
+                           M_, C, S()) == 0
+    err = float((out.cpu() - ref).norm() / (ref - x).norm())
+    assert err < 6e-3, err                       # the only rounding besides fp32 accumulation: h -> bf16 (2^-9)
+    assert float((y2d.float().cpu() - y2).norm() / y2.norm()) < 8e-3
+    # bf16 residual / bf16 output variant
+    outb = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+    xb = x.to(torch.bfloat16).cuda()
+    assert lib.cnx_mlp_fwd(ad.data_ptr(), w1d.data_ptr(), b1.cuda().data_ptr(), w2p.data_ptr(), b2.cuda().data_ptr(),
+                           gm.cuda().data_ptr() if gamma else None, xb.data_ptr(), 1, outb.data_ptr(), 1, None, M_, C,
+                           S()) == 0
+    refb = xb.float().cpu() + (y2 * gm if gamma else y2)
+    assert float((outb.float().cpu() - refb).norm() / refb.norm()) < 1e-2
+
+
+def test_fused_mlp_unsupported_width_is_reported(R):
+    lib = R._lib.load()
+    assert lib.cnx_mlp_fwd_supported(96) == 1 and lib.cnx_mlp_fwd_supported(100) == 0
+    t = torch.zeros(64, device="cuda")
+    assert lib.cnx_mlp_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, None, 0,
+                           t.data_ptr(), 0, None, 1, 100, S()) == -4
