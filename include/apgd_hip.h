@@ -90,7 +90,7 @@ int apgd_l2_step_f32(const float* x, const float* x_adv, const float* x_adv_old,
 
 /* a3/a4 per-sample loss, prediction and d(sum loss)/d logits —
  * criterion_dict['ce'] (autopgd_train_clean.py:113, 181, 275), acc/pred (:194-197, 291-294),
- * dlr_loss (:99-104, loss_kind 1; hard labels only, no dlogits).
+ * dlr_loss (:99-104) with loss_kind 1 (hard labels, n_cls >= 3; dlogits = its exact gradient).
  * logits: [B, n_cls] with row stride `ld` elements, dtype APGD_F32/BF16/F16.
  * Exactly one of y_hard (int64 [B]) / y_soft (fp32 [B, n_cls], mixup) is non-NULL.
  * loss[B] fp32;  pred[B] = (argmax(logits) == y) or (== argmax(y_soft)), first maximal index.

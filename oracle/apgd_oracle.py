@@ -168,7 +168,7 @@ def dlr_loss(logits: np.ndarray, y: np.ndarray) -> np.ndarray:
     """``dlr_loss`` — ``autopgd_train_clean.py:99-104`` (fp32, op by op)."""
     z = logits.astype(F32)
     zs = np.sort(z, axis=1)
-    top = np.argmax(z, axis=1)  # ind_sorted[:, -1]; ties: see tests (distinct logits)
+    top = z.shape[1] - 1 - np.argmax(z[:, ::-1], axis=1)  # ind_sorted[:, -1]: torch.sort is stable -> highest index among ties
     ind = (top == y).astype(F32)
     u = np.arange(z.shape[0])
     num = z[u, y] - zs[:, -2] * ind - zs[:, -1] * (F32(1.0) - ind)

@@ -72,7 +72,10 @@ def _dense_rows(x: torch.Tensor) -> bool:
     return False
 
 
-def _loss_pred(logits: torch.Tensor, y_hard, y_soft, loss_out, pred_out, want_dlogits: bool):
+LOSS_KIND = {'ce': 0, 'dlr': 1}
+
+
+def _loss_pred(logits: torch.Tensor, y_hard, y_soft, loss_out, pred_out, want_dlogits: bool, kind: int = 0):
     """K2: per-sample CE, prediction and d(sum CE)/dlogits (``:113, 181-185, 194-197``).
 
     Kept as a module-level function so tests can substitute recorded losses.
@@ -87,7 +90,7 @@ def _loss_pred(logits: torch.Tensor, y_hard, y_soft, loss_out, pred_out, want_dl
     if dl is not None and dl.stride() != lg.stride():
         dl = torch.empty_strided(lg.shape, lg.stride(), dtype=lg.dtype, device=lg.device)
     _lib.check(lib.apgd_loss_pred(lg.data_ptr(), _lib.dtype_code(lg.dtype), lg.stride(0) if lg.shape[0] > 1 else lg.shape[1],
-                                  _lib.ptr(y_hard), _lib.ptr(y_soft), 0,
+                                  _lib.ptr(y_hard), _lib.ptr(y_soft), kind,
                                   loss_out.data_ptr(), pred_out.data_ptr(), _lib.ptr(dl),
                                   lg.shape[0], lg.shape[1], _stream_ptr()), "apgd_loss_pred")
     return dl
@@ -115,7 +118,7 @@ class ApgdWorkspace:
 
 
 def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace, loss_out, pred_out,
-                   need_grad: bool):
+                   need_grad: bool, kind: int = 0):
     """One model call of the attack: forward, K2, and (optionally) the input gradient.
 
     ``autopgd_train_clean.py:174-192`` (first call) and ``:266-287`` (in-loop calls; the last
@@ -125,7 +128,7 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
         x_in.requires_grad_(True)
         with torch.enable_grad():
             logits = model(x_in)
-        dl = _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, True)
+        dl = _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, True, kind)
         if dl.shape != logits.shape or dl.dtype != logits.dtype:
             raise _lib.ApgdHipError("dlogits/logits mismatch")
         with ops.input_grad_only():
@@ -138,7 +141,7 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
         return grad
     with torch.no_grad():
         logits = model(x_in)
-    _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, False)
+    _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, False, kind)
     return None
 
 
@@ -149,7 +152,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
     Returns ``(x_best, acc, loss_best, x_best_adv)`` (``:371``): fresh, detached tensors with
     ``x``'s shape and memory format; ``acc`` is bool ``[B]``, ``loss_best`` fp32 ``[B]``.
     ``y`` is int64 ``[B]``, or fp32 ``[B, n_cls]`` probabilities iff ``mixup is not None``
-    (``:194-197``).  Supported: ``norm in {'Linf', 'L2'}``, ``loss == 'ce'``.
+    (``:194-197``).  Supported: ``norm in {'Linf', 'L2'}``, ``loss in {'ce', 'dlr'}``.
     """
     assert not model.training                                           # :125
     if use_rs:
@@ -157,8 +160,13 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
         raise NotImplementedError("use_rs=True is not supported (autopgd_train_clean.py:137)")
     if loss not in criterion_names:
         raise KeyError(loss)                                            # criterion_dict[loss] (:149)
-    if loss != 'ce':
-        raise NotImplementedError(f"loss={loss!r}: only 'ce' is implemented in the HIP path")
+    if loss not in LOSS_KIND:
+        # 'softloss' returns a scalar and 'dlr-targeted' takes 3 arguments: neither can be driven by the
+        # reference's own loop (criterion_indiv(logits, y) then .sum(), :181-182) either
+        raise NotImplementedError(f"loss={loss!r}: the HIP path implements 'ce' and 'dlr'")
+    kind = LOSS_KIND[loss]
+    if kind == 1 and mixup is not None:
+        raise NotImplementedError("loss='dlr' needs hard labels (dlr_loss indexes x[arange, y], :103)")
     if norm not in ('Linf', 'L2'):
         raise NotImplementedError(f"norm={norm!r}: the HIP path covers Linf and L2 (SURVEY.md §8 a2, a8)")
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
@@ -195,7 +203,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
         l2_ws = torch.empty(3 * B * lib.apgd_l2_parts(), device=x.device, dtype=torch.float32)
 
     # first forward/backward: acc, loss_best are written directly by the loss kernel (:194-200)
-    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True)
+    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind)
     grad_best = torch.empty_like(grad)                                       # :189
     grad_best.copy_(grad)
     ws.loss_best_last.copy_(ws.loss_best)                                    # :200
@@ -226,7 +234,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
         old, cur = cur, out                                                  # :215, 260 (buffer rotation)
 
         last = i == n_iter - 1
-        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last)   # :266-287
+        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind)   # :266-287
         if g_new is not None:
             grad = g_new
 

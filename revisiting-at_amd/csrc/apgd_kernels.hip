@@ -381,6 +381,66 @@ __global__ __launch_bounds__(kBlock) void ce_pred_kernel(
   }
 }
 
+// ---------------------------------------------------------------- a18: DLR loss (dlr_loss, :99-104)
+// Sorted-order semantics of torch.sort (stable, ascending): among equal values the HIGHER index sorts
+// later, so "descending" order here is (value desc, index desc).
+struct Top3 { float v[3]; int i[3]; };
+__device__ __forceinline__ bool dlr_before(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia > ib); }
+__device__ __forceinline__ void top3_insert(Top3& t, float v, int i) {
+  if (dlr_before(v, i, t.v[0], t.i[0])) { t.v[2] = t.v[1]; t.i[2] = t.i[1]; t.v[1] = t.v[0]; t.i[1] = t.i[0]; t.v[0] = v; t.i[0] = i; }
+  else if (dlr_before(v, i, t.v[1], t.i[1])) { t.v[2] = t.v[1]; t.i[2] = t.i[1]; t.v[1] = v; t.i[1] = i; }
+  else if (dlr_before(v, i, t.v[2], t.i[2])) { t.v[2] = v; t.i[2] = i; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dlr_pred_kernel(const T* __restrict__ logits, int64_t ld,
+                                                          const int64_t* __restrict__ y_hard, float* __restrict__ loss,
+                                                          uint8_t* __restrict__ pred, T* __restrict__ dlogits, int64_t B,
+                                                          int64_t C) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;
+  if (b >= B) return;
+  const T* z = logits + b * ld;
+  Top3 t; float m = -INFINITY; int am = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { t.v[k] = -INFINITY; t.i[k] = -1 - k; }
+  for (int64_t c = lane; c < C; c += kWave) {
+    const float v = Elt<T>::load(z, c);
+    top3_insert(t, v, static_cast<int>(c));
+    if (v > m) { m = v; am = static_cast<int>(c); }
+  }
+#pragma unroll
+  for (int mk = kWave / 2; mk > 0; mk >>= 1) {
+    float ov[3]; int oi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ov[k] = __shfl_xor(t.v[k], mk, kWave); oi[k] = __shfl_xor(t.i[k], mk, kWave); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) top3_insert(t, ov[k], oi[k]);
+  }
+  wave_argmax(m, am);                                          // first maximal index: logits.max(1)[1] (:197, 294)
+  const int64_t yh = y_hard[b];
+  const bool ok = yh >= 0 && yh < C;
+  const float zy = ok ? Elt<T>::load(z, yh) : NAN;
+  const float ind = (static_cast<int64_t>(t.i[0]) == yh) ? 1.0f : 0.0f;      // ind_sorted[:, -1] == y  (:101)
+  const float num = (zy - t.v[1] * ind) - t.v[0] * (1.0f - ind);            // :103
+  const float den = (t.v[0] - t.v[2]) + 1e-12f;                              // :104
+  if (lane == 0) { loss[b] = -num / den; pred[b] = static_cast<int64_t>(am) == yh; }
+  if (dlogits) {
+    // loss = -N/D: dN = +1 at y, -1 at (ind ? i2 : i1); dD = +1 at i1, -1 at i3
+    T* dz = dlogits + b * ld;
+    const float inv = 1.0f / den, nd2 = num * inv * inv;
+    const int isub = ind != 0.0f ? t.i[1] : t.i[0];
+    for (int64_t c = lane; c < C; c += kWave) {
+      float gsum = 0.0f;
+      if (c == yh) gsum -= inv;
+      if (c == isub) gsum += inv;
+      if (c == t.i[0]) gsum += nd2;
+      if (c == t.i[2]) gsum -= nd2;
+      Elt<T>::store(dz, c, gsum);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- a4-a6: per-sample state machine
 __global__ __launch_bounds__(kBlock) void state_update_kernel(
     const float* __restrict__ loss, const uint8_t* __restrict__ pred, uint8_t* __restrict__ acc,
@@ -633,10 +693,29 @@ int apgd_loss_pred(const void* logits, int dtype, int64_t ld, const int64_t* y_h
   if (B == 0) return APGD_OK;
   if (!logits || !loss || !pred) return APGD_ERR_NULL;
   if ((y_hard == nullptr) == (y_soft == nullptr)) return APGD_ERR_ARG;
-  if (loss_kind != 0) return APGD_ERR_ARG;
+  if (loss_kind != 0 && loss_kind != 1) return APGD_ERR_ARG;
+  if (loss_kind == 1 && (!y_hard || n_cls < 3)) return APGD_ERR_ARG;     // dlr: hard labels, >= 3 classes (:99-104)
   if (n_cls > 0x7ffffffe) return APGD_ERR_SIZE;
   hipStream_t s = as_stream(stream);
   const dim3 grid(static_cast<unsigned>((B + kBlock / kWave - 1) / (kBlock / kWave)));
+  if (loss_kind == 1) {
+    switch (dtype) {
+      case APGD_F32:
+        hipLaunchKernelGGL(dlr_pred_kernel<float>, grid, dim3(kBlock), 0, s, static_cast<const float*>(logits), ld, y_hard,
+                           loss, pred, static_cast<float*>(dlogits), B, n_cls);
+        break;
+      case APGD_BF16:
+        hipLaunchKernelGGL(dlr_pred_kernel<uint16_t>, grid, dim3(kBlock), 0, s, static_cast<const uint16_t*>(logits), ld,
+                           y_hard, loss, pred, static_cast<uint16_t*>(dlogits), B, n_cls);
+        break;
+      case APGD_F16:
+        hipLaunchKernelGGL(dlr_pred_kernel<_Float16>, grid, dim3(kBlock), 0, s, static_cast<const _Float16*>(logits), ld,
+                           y_hard, loss, pred, static_cast<_Float16*>(dlogits), B, n_cls);
+        break;
+      default: return APGD_ERR_DTYPE;
+    }
+    return launch_status();
+  }
   switch (dtype) {
     case APGD_F32:
       hipLaunchKernelGGL(ce_pred_kernel<float>, grid, dim3(kBlock), 0, s, static_cast<const float*>(logits), ld, y_hard,

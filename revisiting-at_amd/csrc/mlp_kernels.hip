@@ -50,8 +50,7 @@ __device__ __forceinline__ float gelu_fast(float z) { return 0.5f * z * (1.0f + 
 
 template <int C>
 struct Cfg {
-  static constexpr int MB = 1;                           // 32-row blocks of M per wavefront (1: small register
-                                                         // footprint -> 2-3 workgroups per CU overlap MFMA / GELU / staging)
+  static constexpr int MB = (C <= 192) ? 2 : 1;          // 32-row blocks of M per wavefront (measured: 2 beats 1 at C=96/192)
   static constexpr int BM = 4 * 32 * MB;                 // rows of M per workgroup
   static constexpr int ROW1 = C * 2 + 16;                // bytes per padded row of the [32][C] W1 slice
   static constexpr int ROW2 = 64 + 16;                   // bytes per padded row of the [C][32] W2p slice

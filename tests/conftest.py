@@ -27,6 +27,7 @@ def load_golden(name):
     out["norm"] = str(out["norm"])
     out["soft"] = bool(out["soft"])
     out["channels_last"] = bool(out["channels_last"])
+    out["loss"] = str(out["loss"]) if "loss" in out else "ce"
     return out
 
 

@@ -115,17 +115,19 @@ class ScriptedModel(nn.Module):
         return self.logits_seq[n].clone()
 
 
-def run_case(name, model, x, y, norm, eps, n_iter, soft=False, keep_fed=False):
+def run_case(name, model, x, y, norm, eps, n_iter, soft=False, keep_fed=False, loss='ce'):
+    if ONLY and name not in ONLY:
+        return
     model.eval()
     rec = Recorder(model).eval()
     mixup = object() if soft else None
-    xb, acc, lb, xba = ref.apgd_train(rec, x, y, norm=norm, eps=eps, n_iter=n_iter, mixup=mixup)
+    xb, acc, lb, xba = ref.apgd_train(rec, x, y, norm=norm, eps=eps, n_iter=n_iter, mixup=mixup, loss=loss)
     assert len(rec.logits) == n_iter + 1 and len(rec.grads) == n_iter, (len(rec.logits), len(rec.grads))
     logits = torch.stack(rec.logits)
-    losses = torch.stack([F.cross_entropy(l, y, reduction="none") for l in rec.logits])
+    losses = torch.stack([ref.criterion_dict[loss](l, y) for l in rec.logits])   # the reference's own criterion
     out = dict(
         x=x.numpy(), y=y.numpy(), eps=np.float64(eps), n_iter=np.int64(n_iter), norm=np.array(norm),
-        soft=np.bool_(soft), channels_last=np.bool_(x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+        soft=np.bool_(soft), loss=np.array(loss), channels_last=np.bool_(x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
                                                     and not x.is_contiguous()),
         logits=logits.numpy(), grads=torch.stack(rec.grads).numpy(), losses=losses.numpy(),
         x_adv_sha=np.array([sha(t) for t in rec.xs]),
@@ -147,6 +149,9 @@ def labels_for(model, x, n_cls, g):
     y = clean.clone()
     y[1::2] = rnd[1::2]  # even samples start correctly classified, odd ones get a random label
     return y
+
+
+ONLY = set(sys.argv[1:])      # optional: regenerate only the named cases
 
 
 def main():
@@ -214,6 +219,14 @@ def main():
     logits[2] = logits[1]                 # equal losses: strict '>' must not fire (:321)
     y = torch.randint(0, C, (B,), generator=g)
     run_case("linf_scripted_k4", ScriptedModel(list(logits), list(grads)), x, y, "Linf", 4 / 255, K, keep_fed=True)
+
+    # --- Linf with the DLR loss (criterion_dict['dlr'], :99-104) -------------------------------------
+    g = torch.Generator().manual_seed(800)
+    torch.manual_seed(95)
+    m = ToyConv()
+    x = torch.rand(6, 3, 12, 12, generator=g)
+    y = labels_for(m, x, 10, g)
+    run_case("linf_dlr_k5", m, x, y, "Linf", 8 / 255, 5, keep_fed=True, loss='dlr')
 
     # --- L2 ---------------------------------------------------------------------------------
     for k in (2, 10):

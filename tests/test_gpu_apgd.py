@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 LINF = [c for c in golden_cases() if c.startswith("linf")]
 L2 = [c for c in golden_cases() if c.startswith("l2")]
-TIE_FREE = ["linf_k1", "linf_k2", "linf_k3", "linf_cl_k3", "linf_flat_k5", "linf_scripted_k4", "linf_soft_k2"]
+TIE_FREE = ["linf_k1", "linf_k2", "linf_k3", "linf_cl_k3", "linf_flat_k5", "linf_scripted_k4", "linf_soft_k2",
+            "linf_dlr_k5"]
 
 
 @pytest.fixture(scope="module")
@@ -217,6 +218,40 @@ def test_loss_pred_vs_oracle(R, lib, dtype, B, C, soft):
     np.testing.assert_allclose(dl.float().cpu().numpy(), gt.float().cpu().numpy(), atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C", [(1, 3), (7, 10), (64, 1000), (5, 65)])
+def test_dlr_loss_pred_and_gradient(R, lib, dtype, B, C):
+    """loss_kind 1 = dlr_loss (autopgd_train_clean.py:99-104): loss bit-exact vs the oracle (it is +,-,*,/ only),
+    gradient vs torch autograd of the same formula on the CPU."""
+    rng = np.random.default_rng(B + C)
+    z = (rng.standard_normal((B, C)) * 3).astype(np.float32)
+    y = rng.integers(0, C, B)
+    y[0] = int(np.argmax(z[0]))                     # one correctly classified sample (ind = 1 branch)
+    if B > 4:
+        z[4, 1] = z[4, 2] = z[4].max() + 1          # tied maxima: stable-sort order decides `ind`
+        y[4] = 2
+    zt = dev(z).to(dtype)
+    zf = zt.float().cpu()
+    loss = torch.empty(B, device="cuda")
+    pred = torch.empty(B, device="cuda", dtype=torch.uint8)
+    dl = torch.empty_like(zt)
+    yd = dev(y)
+    assert lib.apgd_loss_pred(zt.data_ptr(), R._lib.dtype_code(dtype), C, yd.data_ptr(), None, 1, loss.data_ptr(),
+                              pred.data_ptr(), dl.data_ptr(), B, C, S()) == 0
+    assert bits_equal(loss.cpu().numpy(), O.dlr_loss(zf.numpy(), y))
+    assert np.array_equal(pred.cpu().numpy().astype(bool), O.predict(zf.numpy(), y))
+    zr = zf.clone().requires_grad_()
+    zs, idx = zr.sort(dim=1)
+    ind = (idx[:, -1] == torch.as_tensor(y)).float()
+    u = torch.arange(B)
+    ref = -(zr[u, torch.as_tensor(y)] - zs[:, -2] * ind - zs[:, -1] * (1. - ind)) / (zs[:, -1] - zs[:, -3] + 1e-12)
+    (gr,) = torch.autograd.grad(ref.sum(), zr)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    np.testing.assert_allclose(dl.float().cpu().numpy(), gr.numpy(), rtol=tol, atol=tol * float(gr.abs().max()))
+    assert lib.apgd_loss_pred(zt.data_ptr(), R._lib.dtype_code(dtype), C, None, dl.data_ptr(), 1, loss.data_ptr(),
+                              pred.data_ptr(), None, B, C, S()) == -4          # dlr needs hard labels
+
+
 def test_loss_pred_strided_rows_and_errors(R, lib):
     B, C, ld = 6, 10, 16
     buf = torch.randn(B, ld, device="cuda")
@@ -302,8 +337,8 @@ def _inject_losses(monkeypatch, R, losses):
     real = R.apgd._loss_pred
     calls = {"n": 0}
 
-    def patched(logits, y_hard, y_soft, loss_out, pred_out, want):
-        dl = real(logits, y_hard, y_soft, loss_out, pred_out, want)
+    def patched(logits, y_hard, y_soft, loss_out, pred_out, want, kind=0):
+        dl = real(logits, y_hard, y_soft, loss_out, pred_out, want, kind)
         loss_out.copy_(dev(losses[calls["n"]]))
         calls["n"] += 1
         return dl
@@ -316,7 +351,8 @@ def _run_replay(R, g, norm):
         x = x.contiguous(memory_format=torch.channels_last)
     y = dev(g["y"])
     m = ReplayModule(g, g["channels_last"]).eval()
-    out = R.apgd_train(m, x, y, norm=norm, eps=g["eps"], n_iter=g["n_iter"], mixup=object() if g["soft"] else None)
+    out = R.apgd_train(m, x, y, norm=norm, eps=g["eps"], n_iter=g["n_iter"], mixup=object() if g["soft"] else None,
+                       loss=g.get("loss", "ce"))
     torch.cuda.synchronize()
     return x, m, out
 

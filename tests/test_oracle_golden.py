@@ -31,7 +31,8 @@ def test_checkpoint_schedule(n_iter, expected):
 # implementation (this oracle's fp64->fp32 one, or torch's own GPU kernel) can flip those
 # comparisons when two iterates' losses agree to the last bits.  With the reference's own
 # losses injected (use_model_loss=True) every case is bit-exact.
-TIE_FREE = ["linf_k1", "linf_k2", "linf_k3", "linf_cl_k3", "linf_flat_k5", "linf_scripted_k4", "linf_soft_k2"]
+TIE_FREE = ["linf_k1", "linf_k2", "linf_k3", "linf_cl_k3", "linf_flat_k5", "linf_scripted_k4", "linf_soft_k2",
+            "linf_dlr_k5"]
 
 
 @pytest.mark.parametrize("case,use_model_loss",
@@ -39,7 +40,7 @@ TIE_FREE = ["linf_k1", "linf_k2", "linf_k3", "linf_cl_k3", "linf_flat_k5", "linf
 def test_linf_bit_exact(case, use_model_loss):
     g = load_golden(case)
     rep = O.ReplayModel(g["logits"], g["grads"], g["losses"])
-    xb, acc, lb, xba, tr = O.apgd_train_oracle(rep, g["x"], g["y"], "Linf", g["eps"], g["n_iter"],
+    xb, acc, lb, xba, tr = O.apgd_train_oracle(rep, g["x"], g["y"], "Linf", g["eps"], g["n_iter"], loss=g["loss"],
                                                soft_labels=g["soft"], keep_trace=True,
                                                use_model_loss=use_model_loss)
     # every iterate handed to the model is bit-identical to the reference's
@@ -54,6 +55,8 @@ def test_linf_bit_exact(case, use_model_loss):
         assert bits_equal(lb, g["loss_best"])
     else:
         np.testing.assert_allclose(lb, g["loss_best"], rtol=1e-6, atol=1e-7)
+        if g["loss"] == "dlr":                       # dlr is +,-,*,/ only: the fp32 restatement is bit-exact
+            assert bits_equal(lb, g["loss_best"])
     mx, n_nan, lo, hi = O.check_imgs(xb, g["x"], "Linf", g["eps"])
     assert n_nan == 0 and lo >= 0.0 and hi <= 1.0
     assert mx <= g["eps"] * (1 + 1e-6) + 1e-7 or case == "linf_scripted_k4"  # scripted x leaves [0,1]
@@ -92,3 +95,13 @@ def test_ce_loss_and_pred_match_reference(case):
     for n in range(g["logits"].shape[0]):
         # torch's fp32 log-softmax has ~1e-7 ABSOLUTE error (cancellation when the true class dominates)
         np.testing.assert_allclose(O.ce_loss(g["logits"][n], g["y"]), g["losses"][n], rtol=1e-5, atol=3e-7)
+
+
+def test_dlr_loss_bit_exact_and_tie_order():
+    g = load_golden("linf_dlr_k5")
+    for n in range(g["logits"].shape[0]):
+        assert bits_equal(O.dlr_loss(g["logits"][n], g["y"]), g["losses"][n])
+    # torch.sort is stable: among equal maxima the highest index is "the" top entry (autopgd_train_clean.py:100-101)
+    z = np.array([[1.0, 3.0, 3.0, 0.0]], np.float32)
+    assert O.dlr_loss(z, np.array([2]))[0] == np.float32(-(3.0 - 3.0) / (3.0 - 1.0 + 1e-12))
+    assert O.dlr_loss(z, np.array([1]))[0] == np.float32(-(3.0 - 3.0) / (3.0 - 1.0 + 1e-12))
