@@ -52,19 +52,37 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
                       void* dx, int dx_dtype, float* dweight, float* dbias, float* ws,
                       int64_t M, int32_t C, int32_t gelu, void* stream);
 
-/* Fused ConvNeXt MLP (models/convnext.py:42-49), two chained bf16 MFMA GEMMs with the 4C-wide hidden
- * activation kept in registers:
- *     out[m, :] = resid[m, :] + gamma * (GELU(A[m, :] W1^T + b1) W2^T + b2)
- * A [M, C] bf16; W1 [4C, C] bf16 (nn.Linear layout); W2p [C, 4C] bf16 = W2 with its hidden index
- * permuted inside every group of 32: position t*16 + half*8 + e holds h = (e&3) + 8*(2t + (e>>2)) + 4*half
- * (the order the MFMA accumulators enumerate it); b1 [4C], b2 [C], gamma [C] fp32 (gamma, resid may be
- * NULL); resid / out [M, C] fp32 or bf16; y2_out (nullable) receives the pre-gamma fc2 output in bf16
- * (needed for d(gamma) in the training backward).  Exact-erf GELU (|err| <= 1.5e-7), fp32 accumulate.
- * cnx_mlp_fwd_supported(C) tells which widths have a kernel (96, 192, 384). */
-int cnx_mlp_fwd_supported(int32_t C);
-int cnx_mlp_fwd(const void* A, const void* W1, const float* b1, const void* W2p, const float* b2,
-                const float* gamma, const void* resid, int resid_dtype, void* out, int out_dtype,
-                void* y2_out, int64_t M, int32_t C, void* stream);
+/* Fused block tail (models/convnext.py:40-49): LayerNorm -> fc1 -> GELU -> fc2 -> gamma -> +residual, ONE kernel:
+ *     out[m, :] = resid[m, :] + gamma * (GELU(LN(u[m, :]) W1^T + b1) W2^T + b2)
+ * u [M, C] bf16 = depthwise-conv output; LN (eps inside the sqrt, fp32 statistics, two-pass) is applied when
+ * ln_w != NULL (mean / rstd [M] fp32 are then written if non-NULL), otherwise u is taken as already normalised.
+ * Wf = cnx_mlp_pack_weights(W1 [4C, C], W2 [C, 4C]) : bf16 weights in MFMA-fragment order, cnx_mlp_packed_elems(C)
+ * elements (re-pack after every optimizer step).  b1 [4C], b2 [C], gamma [C] fp32 (gamma, resid may be NULL);
+ * resid / out fp32 or bf16; y2_out (nullable) = pre-gamma fc2 output in bf16 (for d(gamma)).
+ * GELU is the exact-erf form evaluated with |error| <= 1.2e-6; bf16 MFMA, fp32 accumulate. */
+int cnx_block_mlp_supported(int32_t C);
+int64_t cnx_mlp_packed_elems(int32_t C);
+int cnx_mlp_pack_weights(const void* W1, const void* W2, int w_dtype, void* Wf, int32_t C, void* stream);
+int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
+                      const void* Wf, const float* b1, const float* b2, const float* gamma,
+                      const void* resid, int resid_dtype, void* out, int out_dtype, void* y2_out,
+                      int64_t M, int32_t C, void* stream);
+
+/* Backward of the block tail w.r.t. a = LN(u) (the input-gradient chain of models/convnext.py:41-49), ONE kernel:
+ *     dO = g * gamma;  dH = dO W2;  Hpre = a W1^T + b1 (recomputed);  dHpre = dH * GELU'(Hpre);  da = dHpre W1
+ * u, ln_w, ln_b, mean, rstd as in / from the forward; g [M, C] fp32 or bf16 = gradient w.r.t. the block output;
+ * Wb = cnx_mlp_pack_weights_bwd(W1, W2), cnx_mlp_packed_bwd_elems(C) bf16 elements; da [M, C] bf16 (feed it to
+ * cnx_layernorm_bwd).  Training backward: pass all four emit pointers to also get the operands of the weight
+ * gradients: a_out, do_out [M, C] bf16 and ht_out = GELU(Hpre)^T, dhpt_out = dHpre^T as [4C, M] bf16
+ *     dW1 = dHpre^T a,  db1 = rowsum(dHpre^T),  dW2 = (H^T dO)^T,  db2 = colsum(dO).
+ * cnx_block_mlp_bwd_supported(C): widths with a kernel (96, 192). */
+int cnx_block_mlp_bwd_supported(int32_t C);
+int64_t cnx_mlp_packed_bwd_elems(int32_t C);
+int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* Wb, int32_t C, void* stream);
+int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                      const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
+                      void* a_out, void* do_out, void* ht_out, void* dhpt_out,
+                      int64_t M, int32_t C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -39,8 +39,10 @@ PROTOTYPES = {
     "cnx_dwconv7x7_wgrad_nhwc": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_layernorm_fwd": (C.c_int, [_p, C.c_int, _p, _p, _f, _p, C.c_int, _p, _p, _i64, _i32, _i32, _p]),
     "cnx_layernorm_bwd_ws_floats": (C.c_int64, [_i32]),
-    "cnx_mlp_fwd_supported": (C.c_int, [_i32]),
-    "cnx_mlp_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _i64, _i32, _p]),
+    "cnx_block_mlp_supported": (C.c_int, [_i32]),
+    "cnx_mlp_packed_elems": (C.c_int64, [_i32]),
+    "cnx_mlp_pack_weights": (C.c_int, [_p, _p, C.c_int, _p, _i32, _p]),
+    "cnx_block_mlp_fwd": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _i64, _i32, _p]),
     "cnx_layernorm_bwd": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32,
                                     _i32, _p]),
 }

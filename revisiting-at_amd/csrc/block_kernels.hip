@@ -1,0 +1,670 @@
+// block_kernels.hip — fused ConvNeXt block tail for gfx950 (MI355X):
+//     out = x + gamma * ( GELU( LN(u) W1^T + b1 ) W2^T + b2 )          u = depthwise-7x7 output
+// (/root/reference/models/convnext.py:40-49: norm -> pwconv1 -> GELU -> pwconv2 -> gamma -> residual).
+//
+// One kernel per direction; LayerNorm is the prologue, the 4C-wide hidden activation never leaves the CU.
+//
+// Work decomposition.  A workgroup is 4 wavefronts; each wavefront owns 32 rows of M for the whole kernel
+// (its LN'd rows live in registers as MFMA operands, its 32 x C fp32 output tile lives in accumulators).
+// The hidden dimension is walked in slices of 32:
+//     GEMM1  Ht[32 h][32 m]  = W1[slice] (A operand, from LDS) x LN(u)^T (B operand, registers)   mfma 32x32x16 bf16
+//     GELU   on the 16 accumulator registers per lane (bias pre-loaded into the accumulator), packed to bf16 —
+//            the accumulator layout of Ht IS an A-operand layout of H with the k index permuted inside the slice
+//     GEMM2  O[32 m][32 c]  += H (A operand, registers) x W2[slice]^T (B operand, from LDS)
+// so nothing but weights goes through LDS.  Weights are pre-arranged (cnx_mlp_pack_weights) in the exact
+// order the lanes read them ("fragment order": 1 KiB per MFMA operand, lane l at byte 16*l), which makes
+// every ds_read_b128 linear and conflict-free without padding and lets the slices stream HBM/L2 -> LDS with
+// global_load_lds (async DMA, no VGPR staging) through a 3-deep ring: one s_barrier per slice, DMA two
+// slices ahead, counted vmcnt.  GEMM2 produces O (not O^T): for a fixed accumulator register the 32 lanes of
+// a half-wave hold 32 consecutive channels of one row, so the epilogue (b2, gamma, residual, store) is
+// coalesced without an LDS transpose.
+//
+// K-index conventions (any permutation of a contraction index is legal as long as both operands agree):
+//   GEMM1 k = channel:  lane (row = l&31, half = l>>5) holds channels  half*C/2 + ks*8 + e  (e = 0..7) in
+//                       k-step ks  -> every lane loads one contiguous half row of u (C bytes).
+//   GEMM2 k = hidden:   register t*8+e of lane-half `half` is hidden unit (e&3) + 8*(2t + (e>>2)) + 4*half
+//                       of the slice (the 32x32 accumulator row map).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "apgd_hip.h"
+#include "convnext_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+
+// fp32 pair -> packed bf16 pair, round to nearest even (one v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// GELU(z) = z * Phi(z) with erfc(|z|/sqrt 2) = 2^Q(|z|), Q a degree-5 polynomial (max |error| of the
+// resulting GELU 1.2e-6 over all z, fitted against scipy's erfc; tools/fit_gelu.py):
+//   GELU(z) = max(z, 0) - 0.5 |z| 2^Q(|z|)             (one v_exp_f32, no division, no branch)
+__device__ __forceinline__ float erfc_q(float az) {
+  float q = fmaf(-0.00041175442346105595f, az, 0.006678475199902348f);
+  q = fmaf(q, az, -0.050879760394516485f);
+  q = fmaf(q, az, -0.46094072908550926f);
+  q = fmaf(q, az, -1.150400682855232f);
+  q = fmaf(q, az, -8.454223479528131e-05f);
+  return __builtin_amdgcn_exp2f(q);
+}
+__device__ __forceinline__ float gelu_f(float z) {
+  const float az = fabsf(z);
+  return fmaf(az * erfc_q(az), -0.5f, fmaxf(z, 0.0f));
+}
+// GELU'(z) = Phi(z) + z phi(z),  Phi(z) = z > 0 ? 1 - e/2 : e/2,  phi(z) = exp(-z^2/2)/sqrt(2 pi)
+__device__ __forceinline__ float gelu_grad_f(float z) {
+  const float az = fabsf(z);
+  const float he = 0.5f * erfc_q(az);
+  const float Phi = z > 0.0f ? 1.0f - he : he;
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.7213475204444817f * z * z);
+  return fmaf(z, pdf, Phi);
+}
+
+template <int C>
+struct Geo {
+  static constexpr int KS = C / 16;                 // k-steps of a GEMM whose contraction runs over channels
+  static constexpr int CB = C / 32;                 // 32-wide blocks of channels
+  static constexpr int NHB = C / 8;                 // 32-wide slices of the hidden dimension (4C / 32)
+  static constexpr int FWD_PIECES = KS + 2 * CB;    // 1 KiB operand fragments per slice: W1 (KS) + W2 (2 CB)
+  static constexpr int FWD_SLICE = FWD_PIECES * 1024;
+  static constexpr int FWD_ROUNDS = FWD_PIECES / 4; // DMA instructions per wavefront per slice (4 wavefronts)
+  static constexpr int DEPTH = 3;                   // ring slots
+  static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 16 * C;   // + b1 (4C fp32)
+  static constexpr int BM = 128;                    // rows per workgroup
+  static_assert(FWD_PIECES % 4 == 0, "pieces must divide over 4 wavefronts");
+};
+
+// ------------------------------------------------------------------ weight pre-arrangement
+// Wf: [NHB][FWD_PIECES][64 lanes][8] bf16.  piece p < KS: W1 operand of k-step p; else W2 operand (cb, t).
+template <typename TW>
+__global__ __launch_bounds__(256) void pack_fwd_kernel(const TW* __restrict__ W1, const TW* __restrict__ W2,
+                                                       uint16_t* __restrict__ Wf, int C) {
+  const int KS = C / 16, PIECES = KS + 2 * (C / 32);
+  const long total = static_cast<long>(C / 8) * PIECES * 64;
+  const long q = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (q >= total) return;
+  const int lane = static_cast<int>(q & 63), l32 = lane & 31, half = lane >> 5;
+  const int p = static_cast<int>((q >> 6) % PIECES);
+  const int hb = static_cast<int>((q >> 6) / PIECES);
+  float v[8];
+  if (p < KS) {
+    const TW* src = W1 + static_cast<long>(hb * 32 + l32) * C + half * (C / 2) + p * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = static_cast<float>(src[e]);
+  } else {
+    const int cb = (p - KS) >> 1, t = (p - KS) & 1;
+    const TW* src = W2 + static_cast<long>(cb * 32 + l32) * (4 * C) + hb * 32;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = static_cast<float>(src[(e & 3) + 8 * (2 * t + (e >> 2)) + 4 * half]);
+  }
+  uint4 o;
+  o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
+  reinterpret_cast<uint4*>(Wf)[q] = o;
+}
+
+struct BlkFwdArgs {
+  const uint16_t* u;       // [M, C] bf16: depthwise-conv output (ln_w != NULL) or already-normalised rows
+  const float* ln_w;       // [C] or NULL
+  const float* ln_b;       // [C]
+  float eps;
+  float* mean;             // [M] or NULL (written when LN is applied)
+  float* rstd;             // [M] or NULL
+  const uint16_t* Wf;      // packed weights
+  const float* b1;         // [4C]
+  const float* b2;         // [C]
+  const float* gamma;      // [C] or NULL
+  const void* resid;       // [M, C] TX or NULL
+  void* out;               // [M, C] TO
+  uint16_t* y2;            // [M, C] bf16 pre-gamma fc2 output, or NULL
+  long M;
+};
+
+template <int C, typename TX, typename TO>
+__global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(const BlkFwdArgs p) {
+  using G = Geo<C>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* ring = lds;
+  float* b1s = reinterpret_cast<float*>(lds + G::DEPTH * G::FWD_SLICE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+  const long m0 = static_cast<long>(blockIdx.x) * G::BM + wave * 32;
+
+  // ---- weight stream: slice s -> ring slot s % DEPTH, 1 KiB pieces, piece = round*4 + wave
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf) + lane * 16;
+#define DMA_SLICE(S)                                                                                       \
+  {                                                                                                        \
+    const unsigned char* gs = wsrc + static_cast<long>(S) * G::FWD_SLICE;                                  \
+    unsigned char* ls = ring + ((S) % G::DEPTH) * G::FWD_SLICE;                                            \
+    _Pragma("unroll") for (int i = 0; i < G::FWD_ROUNDS; ++i) {                                            \
+      const int piece = i * 4 + wave;                                                                      \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
+    }                                                                                                      \
+  }
+  DMA_SLICE(0)
+  DMA_SLICE(1)
+
+  for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+
+  // ---- this lane's half row of u  ->  (LayerNorm)  ->  GEMM1 B-operand fragments
+  long row = m0 + l32;
+  const bool row_ok = row < p.M;
+  if (!row_ok) row = p.M - 1;
+  bf16x8 af[G::KS];
+  {
+    uint4 raw[G::KS];
+    const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) raw[ks] = up[ks];
+    if (p.ln_w) {
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += bf16_lo(w[j]) + bf16_hi(w[j]);
+      }
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s * (1.0f / C);
+      float ss = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf16_lo(w[j]) - mean, b = bf16_hi(w[j]) - mean;
+          ss = fmaf(a, a, ss);
+          ss = fmaf(b, b, ss);
+        }
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      const float rstd = rsqrtf(ss * (1.0f / C) + p.eps);
+      if (p.mean && half == 0 && row_ok) { p.mean[row] = mean; p.rstd[row] = rstd; }
+      const float4* lw = reinterpret_cast<const float4*>(p.ln_w + half * (C / 2));
+      const float4* lb = reinterpret_cast<const float4*>(p.ln_b + half * (C / 2));
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+        const float4 w0 = lw[2 * ks], w1 = lw[2 * ks + 1], c0 = lb[2 * ks], c1 = lb[2 * ks + 1];
+        const float g[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const float o[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        uint32_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = fmaf((bf16_lo(w[j]) - mean) * rstd, g[2 * j], o[2 * j]);
+          const float b = fmaf((bf16_hi(w[j]) - mean) * rstd, g[2 * j + 1], o[2 * j + 1]);
+          pk[j] = pack_bf16(a, b);
+        }
+        af[ks] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));   // opaque: never re-loaded in the loop
+        af[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
+      }
+    }
+  }
+
+  f32x16 acc2[G::CB];
+#pragma unroll
+  for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[cb][r] = 0.f;
+
+  // ---- hidden-slice loop
+  for (int s = 0; s < G::NHB; ++s) {
+    // slice s has landed once this wavefront's own pieces are in (counted wait: slice s+1 may stay in flight) and
+    // every wavefront has passed the barrier; the slot of slice s+2 held slice s-1, which nobody reads any more
+    if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < G::NHB) DMA_SLICE(s + 2)
+    const unsigned char* sl = ring + (s % G::DEPTH) * G::FWD_SLICE + lane * 16;
+
+    // GEMM1, accumulator pre-loaded with b1 (register r <-> hidden (r&3) + 8*(r>>2) + 4*half)
+    f32x16 acc1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *reinterpret_cast<const float4*>(b1s + s * 32 + 8 * g + 4 * half);
+      acc1[4 * g + 0] = b4.x; acc1[4 * g + 1] = b4.y; acc1[4 * g + 2] = b4.z; acc1[4 * g + 3] = b4.w;
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const bf16x8 wa = *reinterpret_cast<const bf16x8*>(sl + ks * 1024);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, af[ks], acc1, 0, 0, 0);
+    }
+    // GELU -> bf16 A-operand fragments of GEMM2
+    bf16x8 hf[2];
+    {
+      uint32_t pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(gelu_f(acc1[r]), gelu_f(acc1[r + 1]));
+      hf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+      hf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
+    }
+    // GEMM2
+#pragma unroll
+    for (int cb = 0; cb < G::CB; ++cb) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sl + (G::KS + cb * 2 + t) * 1024);
+        acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[t], wb, acc2[cb], 0, 0, 0);
+      }
+    }
+  }
+#undef DMA_SLICE
+
+  // ---- epilogue: acc2[cb][r] = O[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]
+  const TX* resid = static_cast<const TX*>(p.resid);
+  TO* out = static_cast<TO*>(p.out);
+#pragma unroll
+  for (int cb = 0; cb < G::CB; ++cb) {
+    const int c = cb * 32 + l32;
+    const float bb = p.b2[c];
+    const float gg = p.gamma ? p.gamma[c] : 1.0f;
+    float xv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= p.M) m = p.M - 1;
+      xv[r] = 0.f;
+      if (resid) {
+        if constexpr (sizeof(TX) == 4) xv[r] = reinterpret_cast<const float*>(resid)[m * C + c];
+        else xv[r] = __uint_as_float(static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(resid)[m * C + c]) << 16);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < p.M) {
+        const float y = acc2[cb][r] + bb;
+        if (p.y2) p.y2[m * C + c] = static_cast<uint16_t>(pack_bf16(y, 0.f));
+        const float o = fmaf(y, gg, xv[r]);
+        if constexpr (sizeof(TO) == 4) reinterpret_cast<float*>(out)[m * C + c] = o;
+        else reinterpret_cast<uint16_t*>(out)[m * C + c] = static_cast<uint16_t>(pack_bf16(o, 0.f));
+      }
+    }
+  }
+}
+
+template <int C>
+int launch_blk_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
+  using G = Geo<C>;
+  const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(256);
+#define BLK_LAUNCH(TX, TO)                                                                                       \
+  {                                                                                                              \
+    auto kfn = blk_mlp_fwd_kernel<C, TX, TO>;                                                                    \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                G::FWD_LDS);                                                                     \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, G::FWD_LDS, s, a);                                                      \
+  }
+  if (resid_dtype == APGD_F32 && out_dtype == APGD_F32) BLK_LAUNCH(float, float)
+  else if (resid_dtype == APGD_F32) BLK_LAUNCH(float, uint16_t)
+  else if (out_dtype == APGD_F32) BLK_LAUNCH(uint16_t, float)
+  else BLK_LAUNCH(uint16_t, uint16_t)
+#undef BLK_LAUNCH
+  return launch_status();
+}
+
+
+// =====================================================================================================================
+// Backward of the block tail w.r.t. the LayerNorm output a = LN(u)  (input gradient of models/convnext.py:41-49):
+//     dO = g * gamma                       (g = d loss / d block output)
+//     dH = dO W2            Hpre = a W1^T + b1 (recomputed)          dHpre = dH * GELU'(Hpre)
+//     da = dHpre W1
+// Same decomposition as the forward: a wavefront owns 32 rows; a and dO live in registers as B-operand fragments,
+// the 32 x C fp32 da tile in accumulators; per 32-wide hidden slice three MFMA GEMMs
+//     GEMM1  Hpre^T[h][m] = W1[slice]    (A, LDS) x a^T  (B, regs)          k = channel
+//     GEMM2  dH^T  [h][m] = W2[:,slice]^T (A, LDS) x dO^T (B, regs)          k = channel
+//     GEMM3  da[m][c]    += dHpre (A, regs: the accumulator layout again) x W1[slice] (B, LDS)   k = hidden
+// When `emit` outputs are given (training backward) the kernel also writes what the weight gradients need:
+// a and dO as [M, C] bf16 and H^T = GELU(Hpre)^T, dHpre^T as [4C, M] bf16 (K-contiguous operands for
+//     dW1 = dHpre^T a,   dW2^T = H^T dO ).
+// Wb: [NHB][3C/16 pieces][64 lanes][8] bf16: pieces [0,KS) = W1 A-fragments (as in the forward pack),
+// [KS, 2KS) = W2^T A-fragments, [2KS, 2KS + 2CB) = W1 B-fragments (cb, t).
+template <typename TW>
+__global__ __launch_bounds__(256) void pack_bwd_kernel(const TW* __restrict__ W1, const TW* __restrict__ W2,
+                                                       uint16_t* __restrict__ Wb, int C) {
+  const int KS = C / 16, PIECES = 2 * KS + 2 * (C / 32);
+  const long total = static_cast<long>(C / 8) * PIECES * 64;
+  const long q = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (q >= total) return;
+  const int lane = static_cast<int>(q & 63), l32 = lane & 31, half = lane >> 5;
+  const int p = static_cast<int>((q >> 6) % PIECES);
+  const int hb = static_cast<int>((q >> 6) / PIECES);
+  float v[8];
+  if (p < KS) {                                   // W1[h][c], lane = h, k = channel
+    const TW* src = W1 + static_cast<long>(hb * 32 + l32) * C + half * (C / 2) + p * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = static_cast<float>(src[e]);
+  } else if (p < 2 * KS) {                        // W2[c][h], lane = h, k = channel
+    const int ks = p - KS;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      v[e] = static_cast<float>(W2[static_cast<long>(half * (C / 2) + ks * 8 + e) * (4 * C) + hb * 32 + l32]);
+  } else {                                        // W1[h][c], lane = c, k = hidden (accumulator order)
+    const int cb = (p - 2 * KS) >> 1, t = (p - 2 * KS) & 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      v[e] = static_cast<float>(W1[static_cast<long>(hb * 32 + (e & 3) + 8 * (2 * t + (e >> 2)) + 4 * half) * C + cb * 32 + l32]);
+  }
+  uint4 o;
+  o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
+  reinterpret_cast<uint4*>(Wb)[q] = o;
+}
+
+struct BlkBwdArgs {
+  const uint16_t* u;       // [M, C] bf16 depthwise-conv output
+  const float* ln_w;       // [C]
+  const float* ln_b;       // [C]
+  const float* mean;       // [M]  (saved by the forward)
+  const float* rstd;       // [M]
+  const void* g;           // [M, C] TG: gradient w.r.t. the block output
+  const float* gamma;      // [C] or NULL
+  const uint16_t* Wb;      // packed backward weights
+  const float* b1;         // [4C]
+  uint16_t* da;            // [M, C] bf16: gradient w.r.t. LN(u)
+  uint16_t* a_out;         // emit: [M, C] bf16 LN(u)           (all four NULL or all four set)
+  uint16_t* do_out;        // emit: [M, C] bf16 g * gamma
+  uint16_t* ht_out;        // emit: [4C, M] bf16 GELU(Hpre)^T
+  uint16_t* dhpt_out;      // emit: [4C, M] bf16 dHpre^T
+  long M;
+};
+
+template <int C>
+struct GeoB {
+  static constexpr int KS = C / 16, CB = C / 32, NHB = C / 8;
+  static constexpr int WAVES = (C <= 96) ? 8 : 4;
+  static constexpr int PIECES = 2 * KS + 2 * CB;
+  static constexpr int SLICE = PIECES * 1024;
+  static constexpr int ROUNDS = (PIECES + WAVES - 1) / WAVES;      // DMA instructions per wavefront per slice (upper bound)
+  static constexpr int MIN_ROUNDS = PIECES / WAVES;                // ... lower bound (the counted wait must use this one)
+  static constexpr int DEPTH = 3;
+  static constexpr int LDS = DEPTH * SLICE + 16 * C;
+  static constexpr int BM = WAVES * 32;
+};
+
+template <int C, typename TG, bool EMIT>
+__global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_mlp_bwd_kernel(const BlkBwdArgs p) {
+  using G = GeoB<C>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* ring = lds;
+  float* b1s = reinterpret_cast<float*>(lds + G::DEPTH * G::SLICE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+  const long m0 = static_cast<long>(blockIdx.x) * G::BM + wave * 32;
+
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wb) + lane * 16;
+#define DMA_SLICE(S)                                                                                       \
+  {                                                                                                        \
+    const unsigned char* gs = wsrc + static_cast<long>(S) * G::SLICE;                                      \
+    unsigned char* ls = ring + ((S) % G::DEPTH) * G::SLICE;                                                \
+    _Pragma("unroll") for (int i = 0; i < G::ROUNDS; ++i) {                                                \
+      const int piece = i * G::WAVES + wave;                                                               \
+      if (piece < G::PIECES)                                                                               \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
+    }                                                                                                      \
+  }
+  DMA_SLICE(0)
+  DMA_SLICE(1)
+  for (int i = tid; i < C; i += G::WAVES * 64) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+
+  long row = m0 + l32;
+  const bool row_ok = row < p.M;
+  if (!row_ok) row = p.M - 1;
+  // ---- a = LN(u) with the saved statistics, and dO = g * gamma: B-operand fragments (lane = row, k = channel)
+  bf16x8 af[G::KS], gf[G::KS];
+  {
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
+    const float4* lw = reinterpret_cast<const float4*>(p.ln_w + half * (C / 2));
+    const float4* lb = reinterpret_cast<const float4*>(p.ln_b + half * (C / 2));
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const uint4 raw = up[ks];
+      const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+      const float4 w0 = lw[2 * ks], w1 = lw[2 * ks + 1], c0 = lb[2 * ks], c1 = lb[2 * ks + 1];
+      const float gw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      const float o[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      uint32_t pk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = fmaf((bf16_lo(w[j]) - mean) * rstd, gw[2 * j], o[2 * j]);
+        const float b = fmaf((bf16_hi(w[j]) - mean) * rstd, gw[2 * j + 1], o[2 * j + 1]);
+        pk[j] = pack_bf16(a, b);
+      }
+      const uint4 packed = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      af[ks] = __builtin_bit_cast(bf16x8, packed);
+      if (EMIT && row_ok) reinterpret_cast<uint4*>(p.a_out + row * C + half * (C / 2))[ks] = packed;
+    }
+    const float4* gmp = p.gamma ? reinterpret_cast<const float4*>(p.gamma + half * (C / 2)) : nullptr;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      float v[8];
+      if constexpr (sizeof(TG) == 4) {
+        const float4* gp = reinterpret_cast<const float4*>(static_cast<const float*>(p.g) + row * C + half * (C / 2));
+        const float4 g0 = gp[2 * ks], g1 = gp[2 * ks + 1];
+        v[0] = g0.x; v[1] = g0.y; v[2] = g0.z; v[3] = g0.w; v[4] = g1.x; v[5] = g1.y; v[6] = g1.z; v[7] = g1.w;
+      } else {
+        const uint4 raw = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.g) + row * C + half * (C / 2))[ks];
+        v[0] = bf16_lo(raw.x); v[1] = bf16_hi(raw.x); v[2] = bf16_lo(raw.y); v[3] = bf16_hi(raw.y);
+        v[4] = bf16_lo(raw.z); v[5] = bf16_hi(raw.z); v[6] = bf16_lo(raw.w); v[7] = bf16_hi(raw.w);
+      }
+      if (gmp) {
+        const float4 m0v = gmp[2 * ks], m1v = gmp[2 * ks + 1];
+        v[0] *= m0v.x; v[1] *= m0v.y; v[2] *= m0v.z; v[3] *= m0v.w; v[4] *= m1v.x; v[5] *= m1v.y; v[6] *= m1v.z; v[7] *= m1v.w;
+      }
+      const uint4 packed = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+      gf[ks] = __builtin_bit_cast(bf16x8, packed);
+      if (EMIT && row_ok) reinterpret_cast<uint4*>(p.do_out + row * C + half * (C / 2))[ks] = packed;
+    }
+  }
+
+  f32x16 acc3[G::CB];
+#pragma unroll
+  for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc3[cb][r] = 0.f;
+
+  for (int s = 0; s < G::NHB; ++s) {
+    if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::MIN_ROUNDS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < G::NHB) DMA_SLICE(s + 2)
+    const unsigned char* sl = ring + (s % G::DEPTH) * G::SLICE + lane * 16;
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 b4 = *reinterpret_cast<const float4*>(b1s + s * 32 + 8 * g4 + 4 * half);
+      acc1[4 * g4 + 0] = b4.x; acc1[4 * g4 + 1] = b4.y; acc1[4 * g4 + 2] = b4.z; acc1[4 * g4 + 3] = b4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const bf16x8 w1a = *reinterpret_cast<const bf16x8*>(sl + ks * 1024);
+      const bf16x8 w2a = *reinterpret_cast<const bf16x8*>(sl + (G::KS + ks) * 1024);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1a, af[ks], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2a, gf[ks], acc2, 0, 0, 0);
+    }
+    bf16x8 dhf[2];
+    {
+      uint32_t pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float d0 = acc2[r] * gelu_grad_f(acc1[r]), d1 = acc2[r + 1] * gelu_grad_f(acc1[r + 1]);
+        pk[r >> 1] = pack_bf16(d0, d1);
+      }
+      dhf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+      dhf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
+      if constexpr (EMIT) {
+        if (row_ok) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long h = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const uint32_t d = pk[r >> 1];
+            p.dhpt_out[h * p.M + row] = static_cast<uint16_t>((r & 1) ? (d >> 16) : (d & 0xffffu));
+            p.ht_out[h * p.M + row] = static_cast<uint16_t>(pack_bf16(gelu_f(acc1[r]), 0.f));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < G::CB; ++cb) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sl + (2 * G::KS + cb * 2 + t) * 1024);
+        acc3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf[t], wb, acc3[cb], 0, 0, 0);
+      }
+    }
+  }
+#undef DMA_SLICE
+
+  // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]
+#pragma unroll
+  for (int cb = 0; cb < G::CB; ++cb) {
+    const int c = cb * 32 + l32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < p.M) p.da[m * C + c] = static_cast<uint16_t>(pack_bf16(acc3[cb][r], 0.f));
+    }
+  }
+}
+
+template <int C>
+int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
+  using G = GeoB<C>;
+  const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(G::WAVES * 64);
+  const bool emit = a.a_out != nullptr;
+#define BLK_LAUNCH(TG, EM)                                                                                       \
+  {                                                                                                              \
+    auto kfn = blk_mlp_bwd_kernel<C, TG, EM>;                                                                    \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                G::LDS);                                                                         \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, G::LDS, s, a);                                                          \
+  }
+  if (g_dtype == APGD_F32) { if (emit) BLK_LAUNCH(float, true) else BLK_LAUNCH(float, false) }
+  else { if (emit) BLK_LAUNCH(uint16_t, true) else BLK_LAUNCH(uint16_t, false) }
+#undef BLK_LAUNCH
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cnx_block_mlp_supported(int32_t C) { return (C == 96 || C == 192 || C == 384) ? 1 : 0; }
+
+int64_t cnx_mlp_packed_elems(int32_t C) { return static_cast<int64_t>(8) * C * C; }
+
+int cnx_mlp_pack_weights(const void* W1, const void* W2, int w_dtype, void* Wf, int32_t C, void* stream) {
+  if (C <= 0 || C % 32 != 0) return APGD_ERR_SIZE;
+  if (!W1 || !W2 || !Wf) return APGD_ERR_NULL;
+  const long total = static_cast<long>(C / 8) * (C / 16 + 2 * (C / 32)) * 64;
+  const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
+  hipStream_t s = as_stream(stream);
+  if (w_dtype == APGD_F32)
+    hipLaunchKernelGGL(pack_fwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(W1), static_cast<const float*>(W2),
+                       static_cast<uint16_t*>(Wf), C);
+  else if (w_dtype == APGD_BF16)
+    hipLaunchKernelGGL(pack_fwd_kernel<__bf16>, grid, block, 0, s, static_cast<const __bf16*>(W1),
+                       static_cast<const __bf16*>(W2), static_cast<uint16_t*>(Wf), C);
+  else return APGD_ERR_DTYPE;
+  return launch_status();
+}
+
+int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
+                      const void* Wf, const float* b1, const float* b2, const float* gamma, const void* resid,
+                      int resid_dtype, void* out, int out_dtype, void* y2_out, int64_t M, int32_t C, void* stream) {
+  if (M < 0 || C <= 0) return APGD_ERR_SIZE;
+  if (M == 0) return APGD_OK;
+  if (!u || !Wf || !b1 || !b2 || !out) return APGD_ERR_NULL;
+  if (ln_w && !ln_b) return APGD_ERR_NULL;
+  if ((mean == nullptr) != (rstd == nullptr)) return APGD_ERR_NULL;
+  if ((resid_dtype != APGD_F32 && resid_dtype != APGD_BF16) || (out_dtype != APGD_F32 && out_dtype != APGD_BF16))
+    return APGD_ERR_DTYPE;
+  BlkFwdArgs a;
+  a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.mean = mean; a.rstd = rstd;
+  a.Wf = static_cast<const uint16_t*>(Wf); a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.resid = resid; a.out = out;
+  a.y2 = static_cast<uint16_t*>(y2_out); a.M = M;
+  hipStream_t s = as_stream(stream);
+  switch (C) {
+    case 96: return launch_blk_fwd<96>(a, resid_dtype, out_dtype, s);
+    case 192: return launch_blk_fwd<192>(a, resid_dtype, out_dtype, s);
+    case 384: return launch_blk_fwd<384>(a, resid_dtype, out_dtype, s);
+    default: return APGD_ERR_ARG;
+  }
+}
+
+int64_t cnx_mlp_packed_bwd_elems(int32_t C) { return static_cast<int64_t>(12) * C * C; }
+
+int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* Wb, int32_t C, void* stream) {
+  if (C <= 0 || C % 32 != 0) return APGD_ERR_SIZE;
+  if (!W1 || !W2 || !Wb) return APGD_ERR_NULL;
+  const long total = static_cast<long>(C / 8) * (2 * (C / 16) + 2 * (C / 32)) * 64;
+  const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
+  hipStream_t s = as_stream(stream);
+  if (w_dtype == APGD_F32)
+    hipLaunchKernelGGL(pack_bwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(W1), static_cast<const float*>(W2),
+                       static_cast<uint16_t*>(Wb), C);
+  else if (w_dtype == APGD_BF16)
+    hipLaunchKernelGGL(pack_bwd_kernel<__bf16>, grid, block, 0, s, static_cast<const __bf16*>(W1),
+                       static_cast<const __bf16*>(W2), static_cast<uint16_t*>(Wb), C);
+  else return APGD_ERR_DTYPE;
+  return launch_status();
+}
+
+int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                      const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
+                      void* a_out, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C, void* stream) {
+  if (M < 0 || C <= 0) return APGD_ERR_SIZE;
+  if (M == 0) return APGD_OK;
+  if (!u || !ln_w || !ln_b || !mean || !rstd || !g || !Wb || !b1 || !da) return APGD_ERR_NULL;
+  const int n_emit = (a_out != nullptr) + (do_out != nullptr) + (ht_out != nullptr) + (dhpt_out != nullptr);
+  if (n_emit != 0 && n_emit != 4) return APGD_ERR_NULL;
+  if (g_dtype != APGD_F32 && g_dtype != APGD_BF16) return APGD_ERR_DTYPE;
+  BlkBwdArgs a;
+  a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = ln_b; a.mean = mean; a.rstd = rstd; a.g = g; a.gamma = gamma;
+  a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = b1; a.da = static_cast<uint16_t*>(da);
+  a.a_out = static_cast<uint16_t*>(a_out); a.do_out = static_cast<uint16_t*>(do_out);
+  a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.M = M;
+  hipStream_t s = as_stream(stream);
+  switch (C) {
+    case 96: return launch_blk_bwd<96>(a, g_dtype, s);
+    case 192: return launch_blk_bwd<192>(a, g_dtype, s);
+    default: return APGD_ERR_ARG;
+  }
+}
+
+int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 192) ? 1 : 0; }
+
+}  // extern "C"

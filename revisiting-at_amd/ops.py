@@ -203,98 +203,176 @@ def dwconv_ln(x_rows, dw_w, dw_b, ln_w, ln_b, eps):
     return _DwConvLN.apply(x_rows, dw_w, dw_b, ln_w, ln_b, float(eps), _act_dtype(x_rows))
 
 
-# ------------------------------------------------------------------------------ fused MLP (MFMA)
-def _w2_perm(n_hidden, device):
-    """Hidden-index order the MFMA accumulators enumerate (see csrc/mlp_kernels.hip / convnext_hip.h)."""
-    p = torch.arange(32)
-    t, half, e = p // 16, (p // 8) % 2, p % 8
-    src = (e & 3) + 8 * (2 * t + (e >> 2)) + 4 * half
-    return (torch.arange(0, n_hidden, 32).view(-1, 1) + src.view(1, -1)).reshape(-1).to(device)
-
-
+# ------------------------------------------------------------------------------ fused block tail (MFMA)
 _wcache = {}
 
 
-def _cached(param, tag, fn):
-    """bf16 / permuted copies of a parameter, rebuilt only when the parameter changes
-    (optimizer steps bump ``_version``); the attack's 3 forwards and the train forward share them."""
-    key = (id(param), tag)
-    ver = (param._version, param.data_ptr())
+def _cached(params, tag, fn):
+    """Derived copies of parameters (bf16 casts, MFMA-fragment packing), rebuilt only when a parameter changes
+    (optimizer steps bump ``_version``); the attack's forwards and the train forward share them."""
+    key = tuple(id(q) for q in params) + (tag,)
+    ver = tuple((q._version, q.data_ptr()) for q in params)
     hit = _wcache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     with torch.no_grad():
-        val = fn(param.detach())
+        val = fn(*[q.detach() for q in params])
     _wcache[key] = (ver, val)
     return val
 
 
-class _MlpFused(torch.autograd.Function):
-    """rows a [.., C] (bf16) , residual x [.., C] -> x + gamma * fc2(GELU(fc1(a)))  (``models/convnext.py:42-49``).
+def _pack_mlp(w1, w2):
+    """fc1 / fc2 weights -> bf16 in the order the fused kernel's MFMA lanes read them (``cnx_mlp_pack_weights``)."""
+    lib = _lib.load()
+    C = w1.shape[1]
+    w1, w2 = w1.contiguous(), w2.contiguous()
+    if w1.dtype != w2.dtype or w1.dtype not in (torch.float32, torch.bfloat16):
+        w1, w2 = w1.float(), w2.float()
+    wf = torch.empty(lib.cnx_mlp_packed_elems(C), device=w1.device, dtype=torch.bfloat16)
+    _lib.check(lib.cnx_mlp_pack_weights(w1.data_ptr(), w2.data_ptr(), _code(w1), wf.data_ptr(), C, _stream()),
+               "cnx_mlp_pack_weights")
+    return wf
 
-    Forward: one MFMA kernel (``cnx_mlp_fwd``), hidden activation stays on-chip.  Backward recomputes the
-    hidden pre-activation instead of storing it (M x 4C bf16 per block is the largest tensor of the model)."""
+
+def _wgrad(x, y):
+    """``x^T y`` for tall operands (``x`` [M, N1], ``y`` [M, N2], M >> N) -> fp32 [N1, N2].
+
+    The weight gradients of the early stages contract over M = N*H*W (802 816 rows at 56x56, batch 256) into a
+    384x96 result: as one GEMM that is a handful of output tiles with an enormous K and runs at ~45 TFLOP/s in
+    hipBLASLt.  Split K into S batches of a batched GEMM (every batch fills its own output tiles, S of them fill
+    the chip) and sum the S partial products in fp32."""
+    M = x.shape[0]
+    S = 1
+    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 2048:
+        S *= 2
+    if S == 1:
+        return (x.t() @ y).float()
+    part = torch.bmm(x.view(S, M // S, x.shape[1]).transpose(1, 2), y.view(S, M // S, y.shape[1]))
+    return part.float().sum(0)
+
+
+class _BlockFused(torch.autograd.Function):
+    """One ConvNeXt block on channels-last rows (``models/convnext.py:37-50``):
+
+        x [N,H,W,C] -> u = dw7x7(x) (bf16)  ->  x + gamma * fc2(GELU(fc1(LN(u))))
+
+    Forward = two kernels: the depthwise stencil and ``cnx_block_mlp_fwd`` (LN prologue, two chained MFMA GEMMs with
+    the 4C-wide hidden activation kept on-chip, bias / layer-scale / residual epilogue).  Saved for backward: x, u and
+    the LN statistics only; the hidden activation is recomputed (M x 4C bf16 per block is the largest tensor of the
+    model and is never materialised in the forward)."""
 
     @staticmethod
-    def forward(ctx, a, x, w1, b1, w2, b2, gamma):
+    def forward(ctx, x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
         lib = _lib.load()
-        C = a.shape[-1]
-        M = a.numel() // C
-        w1b = _cached(w1, "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-        w2b = _cached(w2, "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-        w2p = _cached(w2, "perm", lambda w: w.to(torch.bfloat16)[:, _w2_perm(w.shape[1], w.device)].contiguous())
-        b1f, b2f = _f32(b1), _f32(b2)
+        N, H, W, C = x.shape
+        M = N * H * W
+        w49c = _cached((dw_w,), "w49c", lambda w: w.float().reshape(C, 49).t().contiguous())
+        dwb = _f32(dw_b) if dw_b is not None else None
+        lw, lb, b1f, b2f = _f32(ln_w), _f32(ln_b), _f32(b1), _f32(b2)
         gf = _f32(gamma) if gamma is not None else None
-        out = torch.empty(x.shape, device=x.device, dtype=torch.float32 if (gamma is not None or x.dtype == torch.float32)
-                          else x.dtype)
-        need_p = any(ctx.needs_input_grad[2:])
-        y2 = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16) if (need_p and gamma is not None
-                                                                              and torch.is_grad_enabled()) else None
-        _lib.check(lib.cnx_mlp_fwd(a.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2p.data_ptr(), b2f.data_ptr(),
-                                   _lib.ptr(gf), x.data_ptr(), _code(x), out.data_ptr(), _code(out), _lib.ptr(y2), M, C,
-                                   _stream()), "cnx_mlp_fwd")
-        ctx.save_for_backward(a, w1b, w2b, b1f, b2f, gf, y2)
-        ctx.x_dtype = x.dtype
+        wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
+        u = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+        _lib.check(lib.cnx_dwconv7x7_nhwc(x.data_ptr(), _code(x), w49c.data_ptr(), _lib.ptr(dwb), None, u.data_ptr(),
+                                          _code(u), N, H, W, C, 0, _stream()), "cnx_dwconv7x7_nhwc")
+        out = torch.empty(x.shape, device=x.device,
+                          dtype=torch.float32 if (gamma is not None or x.dtype == torch.float32) else x.dtype)
+        need_grad = any(ctx.needs_input_grad)        # all False when the caller runs under no_grad
+        need_p = need_grad and any(ctx.needs_input_grad[1:])
+        mean = rstd = y2 = None
+        if need_grad:
+            mean = torch.empty(M, device=x.device, dtype=torch.float32)
+            rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        if need_p and gamma is not None:
+            y2 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+        _lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, _lib.ptr(mean), _lib.ptr(rstd),
+                                         wf.data_ptr(), b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), _code(x),
+                                         out.data_ptr(), _code(out), _lib.ptr(y2), M, C, _stream()), "cnx_block_mlp_fwd")
+        if need_grad:
+            w1b = _cached((w1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+            w2b = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+            ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, w1b, w2b, b1f, b2f, gf, y2)
+            ctx.has_dw_bias, ctx.eps = dw_b is not None, eps
         return out
 
     @staticmethod
     def backward(ctx, g):
-        a, w1b, w2b, b1f, b2f, gf, y2 = ctx.saved_tensors
-        C = a.shape[-1]
-        g2 = g.reshape(-1, C)
-        a2 = a.reshape(-1, C)
-        dos = (g2 * gf if gf is not None else g2).to(torch.bfloat16)            # d(fc2 out)
-        hpre = torch.addmm(b1f.to(torch.bfloat16), a2, w1b.t())                  # recomputed, [M, 4C]
-        dh = dos @ w2b                                                           # [M, 4C]
+        lib = _lib.load()
+        x, w49c, u, mean, rstd, lw, lb, w1b, w2b, b1f, b2f, gf, y2 = ctx.saved_tensors
+        N, H, W, C = x.shape
+        M = N * H * W
+        nig = ctx.needs_input_grad
+        want_p = any(nig[1:]) and not _INPUT_GRAD_ONLY
+        g = g.contiguous()
+        g2 = g.reshape(M, C)
+        # ---- MLP backward on the recomputed activations
+        a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)             # LN(u), recomputed
+        _lib.check(lib.cnx_layernorm_fwd(u.data_ptr(), _code(u), lw.data_ptr(), lb.data_ptr(), ctx.eps, a.data_ptr(),
+                                         _code(a), None, None, M, C, 0, _stream()), "cnx_layernorm_fwd")
+        dos = (g2 * gf if gf is not None else g2).to(torch.bfloat16)             # d(fc2 out)
+        hpre = torch.addmm(b1f.to(torch.bfloat16), a, w1b.t())                   # [M, 4C]
+        dh = dos @ w2b
         dhpre = torch.ops.aten.gelu_backward(dh, hpre)
-        da = (dhpre @ w1b).view_as(a) if ctx.needs_input_grad[0] else None
-        dx = g.to(ctx.x_dtype) if ctx.needs_input_grad[1] else None
+        del dh
+        da = dhpre @ w1b                                                         # [M, C] bf16
         dw1 = db1 = dw2 = db2 = dgamma = None
-        if any(ctx.needs_input_grad[2:]) and not _INPUT_GRAD_ONLY:
+        if want_p:
             h = F.gelu(hpre)
-            dw2 = (dos.t() @ h).float()
+            dw2 = _wgrad(dos, h)
             db2 = dos.float().sum(0)
-            dw1 = (dhpre.t() @ a2).float()
+            dw1 = _wgrad(dhpre, a)
             db1 = dhpre.float().sum(0)
             if gf is not None:
-                y2v = y2.reshape(-1, C) if y2 is not None else torch.addmm(b2f.to(torch.bfloat16), h, w2b.t())
-                dgamma = (g2.float() * y2v.float()).sum(0)
-        return da, dx, dw1, db1, dw2, db2, dgamma
+                dgamma = (g2.float() * y2.reshape(M, C).float()).sum(0)
+            del h
+        del hpre, dhpre
+        # ---- LayerNorm backward
+        d_u = torch.empty_like(u)
+        dlw = dlb = ws = None
+        if want_p:
+            dlw = torch.empty(C, device=x.device, dtype=torch.float32)
+            dlb = torch.empty(C, device=x.device, dtype=torch.float32)
+            ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device=x.device, dtype=torch.float32)
+        _lib.check(lib.cnx_layernorm_bwd(da.data_ptr(), _code(da), u.data_ptr(), _code(u), lw.data_ptr(), None,
+                                         mean.data_ptr(), rstd.data_ptr(), d_u.data_ptr(), _code(d_u),
+                                         _lib.ptr(dlw), _lib.ptr(dlb), _lib.ptr(ws), M, C, 0, _stream()),
+                   "cnx_layernorm_bwd")
+        # ---- depthwise conv backward; the residual branch's gradient rides along as the stencil's `add` input
+        dx = None
+        if nig[0]:
+            dx = torch.empty_like(x)
+            gadd = g if g.dtype == torch.float32 else g.float()
+            _lib.check(lib.cnx_dwconv7x7_nhwc(d_u.data_ptr(), _code(d_u), w49c.data_ptr(), None, gadd.data_ptr(),
+                                              dx.data_ptr(), _code(dx), N, H, W, C, 1, _stream()),
+                       "cnx_dwconv7x7_nhwc(flip)")
+        dww = dwb = None
+        if want_p:
+            g49 = torch.empty(49, C, device=x.device, dtype=torch.float32)
+            dwb = torch.empty(C, device=x.device, dtype=torch.float32)
+            ws2 = torch.empty(lib.cnx_dwconv7x7_wgrad_ws_floats(C), device=x.device, dtype=torch.float32)
+            _lib.check(lib.cnx_dwconv7x7_wgrad_nhwc(x.data_ptr(), _code(x), d_u.data_ptr(), _code(d_u), g49.data_ptr(),
+                                                    dwb.data_ptr(), ws2.data_ptr(), N, H, W, C, _stream()),
+                       "cnx_dwconv7x7_wgrad_nhwc")
+            dww = g49.t().reshape(C, 1, 7, 7)
+            if not ctx.has_dw_bias:
+                dwb = None
+        return dx, dww, dwb, dlw, dlb, None, dw1, db1, dw2, db2, dgamma
 
 
-def mlp_fused_supported(C):
-    return bool(_lib.load().cnx_mlp_fwd_supported(C))
+def block_fused_supported(C):
+    return bool(_lib.load().cnx_block_mlp_supported(C))
 
 
-# Widths for which the fused MFMA MLP forward is switched on.  Measured on MI355X (tools/mlp_bench.py,
-# B=256): it beats the hipBLASLt + aten composition only where the block is HBM-bound (C=96); at
-# C>=192 the in-register GELU makes it VALU-bound and the library GEMMs win, so those stay on
-# hipBLASLt until the kernel is tuned.  APGD_MLP_FUSED="96,192,384" / "" overrides.
-_FUSED_MLP_WIDTHS = {int(v) for v in os.environ.get("APGD_MLP_FUSED", "").split(",") if v.strip()}
+# Widths routed through the fused LN+MLP kernel.  Measured on MI355X (tools/block_bench.py, batch 256): a clear win
+# where the unfused block is HBM-bound (C = 96, 192); at C = 384 the weight stream (128 rows per workgroup) caps it
+# below the hipBLASLt composition, so that width stays on the library path for now.  APGD_BLOCK_FUSED overrides.
+_FUSED_WIDTHS = os.environ.get("APGD_BLOCK_FUSED", "96,192")
+_FUSED_WIDTHS = {int(v) for v in _FUSED_WIDTHS.split(",") if v.strip()}
 
 
-def _use_fused_mlp(C):
-    return MODE != "eager" and C in _FUSED_MLP_WIDTHS and mlp_fused_supported(C)
+def _use_fused_block(C):
+    if MODE == "eager" or C not in _FUSED_WIDTHS:
+        return False
+    return block_fused_supported(C)
 
 
 def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
@@ -303,10 +381,14 @@ def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
         y = F.conv2d(x, dw_w, dw_b, padding=3, groups=x.shape[1]).permute(0, 2, 3, 1)
         y = F.layer_norm(y, ln_w.shape, ln_w, ln_b, eps)
     else:
+        if not x.is_cuda:
+            raise _lib.ApgdHipError("the fused ConvNeXt block needs a device tensor (no CPU path in the product)")
         xr = _rows(x)
+        if xr.dtype not in (torch.float32, torch.bfloat16):
+            xr = xr.float()
+        if _act_dtype(xr) == torch.bfloat16 and _use_fused_block(x.shape[1]):
+            return _BlockFused.apply(xr, dw_w, dw_b, ln_w, ln_b, float(eps), w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
         y = dwconv_ln(xr, dw_w, dw_b, ln_w, ln_b, eps)
-        if _use_fused_mlp(x.shape[1]) and y.dtype == torch.bfloat16:
-            return _MlpFused.apply(y, xr, w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
     y = F.linear(F.gelu(F.linear(y, w1, b1)), w2, b2)
     if gamma is not None:
         y = y * gamma

@@ -247,7 +247,17 @@ def test_dlr_loss_pred_and_gradient(R, lib, dtype, B, C):
     ref = -(zr[u, torch.as_tensor(y)] - zs[:, -2] * ind - zs[:, -1] * (1. - ind)) / (zs[:, -1] - zs[:, -3] + 1e-12)
     (gr,) = torch.autograd.grad(ref.sum(), zr)
     tol = 1e-5 if dtype == torch.float32 else 1e-2
-    np.testing.assert_allclose(dl.float().cpu().numpy(), gr.numpy(), rtol=tol, atol=tol * float(gr.abs().max()))
+    # bf16 rounding creates accidental ties among the 4 largest logits; which of two equal entries receives the
+    # gradient is then the sort's tie order (undefined for the reference's device sort) — compare the other rows,
+    # plus row 4 whose tie is constructed and follows the stable order documented in the kernel
+    top4 = zs.detach()[:, -4:] if C >= 4 else zs.detach()
+    clean = ((top4[:, 1:] - top4[:, :-1]) != 0).all(dim=1).numpy()
+    if B > 4:
+        clean[4] = bool((top4[4, 1:-1] - top4[4, :-2] != 0).all())
+    assert clean.sum() >= B // 2
+    got = dl.float().cpu().numpy()
+    gmax = float(gr[torch.as_tensor(clean)].abs().max())
+    np.testing.assert_allclose(got[clean], gr.numpy()[clean], rtol=tol, atol=tol * gmax)
     assert lib.apgd_loss_pred(zt.data_ptr(), R._lib.dtype_code(dtype), C, None, dl.data_ptr(), 1, loss.data_ptr(),
                               pred.data_ptr(), None, B, C, S()) == -4          # dlr needs hard labels
 
