@@ -251,6 +251,31 @@ def _wgrad(x, y):
     return part.float().sum(0)
 
 
+def _wgrad_t(xt, y):
+    """Same contraction with the left operand already transposed: ``xt`` [N1, M] (K-contiguous), ``y`` [M, N2]."""
+    N1, M = xt.shape
+    S = 1
+    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 2048:
+        S *= 2
+    if S == 1:
+        return (xt @ y).float()
+    part = torch.bmm(xt.view(N1, S, M // S).transpose(0, 1), y.view(S, M // S, y.shape[1]))
+    return part.float().sum(0)
+
+
+def _pack_mlp_bwd(w1, w2):
+    """fc1 / fc2 weights -> the three operand-fragment sets of the fused backward (``cnx_mlp_pack_weights_bwd``)."""
+    lib = _lib.load()
+    C = w1.shape[1]
+    w1, w2 = w1.contiguous(), w2.contiguous()
+    if w1.dtype != w2.dtype or w1.dtype not in (torch.float32, torch.bfloat16):
+        w1, w2 = w1.float(), w2.float()
+    wb = torch.empty(lib.cnx_mlp_packed_bwd_elems(C), device=w1.device, dtype=torch.bfloat16)
+    _lib.check(lib.cnx_mlp_pack_weights_bwd(w1.data_ptr(), w2.data_ptr(), _code(w1), wb.data_ptr(), C, _stream()),
+               "cnx_mlp_pack_weights_bwd")
+    return wb
+
+
 class _BlockFused(torch.autograd.Function):
     """One ConvNeXt block on channels-last rows (``models/convnext.py:37-50``):
 
@@ -288,8 +313,13 @@ class _BlockFused(torch.autograd.Function):
                                          wf.data_ptr(), b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), _code(x),
                                          out.data_ptr(), _code(out), _lib.ptr(y2), M, C, _stream()), "cnx_block_mlp_fwd")
         if need_grad:
-            w1b = _cached((w1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-            w2b = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+            ctx.fused_bwd = bool(lib.cnx_block_mlp_bwd_supported(C))
+            if ctx.fused_bwd:
+                w1b = _cached((w1, w2), "mlp_packed_bwd", _pack_mlp_bwd)
+                w2b = None
+            else:
+                w1b = _cached((w1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+                w2b = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
             ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, w1b, w2b, b1f, b2f, gf, y2)
             ctx.has_dw_bias, ctx.eps = dw_b is not None, eps
         return out
@@ -304,27 +334,51 @@ class _BlockFused(torch.autograd.Function):
         want_p = any(nig[1:]) and not _INPUT_GRAD_ONLY
         g = g.contiguous()
         g2 = g.reshape(M, C)
-        # ---- MLP backward on the recomputed activations
-        a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)             # LN(u), recomputed
-        _lib.check(lib.cnx_layernorm_fwd(u.data_ptr(), _code(u), lw.data_ptr(), lb.data_ptr(), ctx.eps, a.data_ptr(),
-                                         _code(a), None, None, M, C, 0, _stream()), "cnx_layernorm_fwd")
-        dos = (g2 * gf if gf is not None else g2).to(torch.bfloat16)             # d(fc2 out)
-        hpre = torch.addmm(b1f.to(torch.bfloat16), a, w1b.t())                   # [M, 4C]
-        dh = dos @ w2b
-        dhpre = torch.ops.aten.gelu_backward(dh, hpre)
-        del dh
-        da = dhpre @ w1b                                                         # [M, C] bf16
         dw1 = db1 = dw2 = db2 = dgamma = None
-        if want_p:
-            h = F.gelu(hpre)
-            dw2 = _wgrad(dos, h)
-            db2 = dos.float().sum(0)
-            dw1 = _wgrad(dhpre, a)
-            db1 = dhpre.float().sum(0)
-            if gf is not None:
-                dgamma = (g2.float() * y2.reshape(M, C).float()).sum(0)
-            del h
-        del hpre, dhpre
+        da = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)            # gradient w.r.t. LN(u)
+        if ctx.fused_bwd:
+            # ---- one kernel: LN recompute, dO = g*gamma, Hpre / dH / dHpre per hidden slice on-chip, da
+            a = dos = ht = dhpt = None
+            if want_p:
+                a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+                dos = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+                ht = torch.empty(4 * C, M, device=x.device, dtype=torch.bfloat16)
+                dhpt = torch.empty(4 * C, M, device=x.device, dtype=torch.bfloat16)
+            if g2.dtype not in (torch.float32, torch.bfloat16):
+                g2 = g2.float()
+            _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
+                                             da.data_ptr(), _lib.ptr(a), _lib.ptr(dos), _lib.ptr(ht), _lib.ptr(dhpt), M, C,
+                                             _stream()), "cnx_block_mlp_bwd")
+            if want_p:
+                dw1 = _wgrad_t(dhpt, a)                                          # [4C, C]
+                db1 = dhpt.sum(1, dtype=torch.float32)
+                dw2 = _wgrad_t(ht, dos).t()                                      # [C, 4C]
+                db2 = dos.sum(0, dtype=torch.float32)
+                if gf is not None:
+                    dgamma = (g2.float() * y2.reshape(M, C).float()).sum(0)
+                del a, dos, ht, dhpt
+        else:
+            # ---- library composition on the recomputed activations
+            a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)         # LN(u), recomputed
+            _lib.check(lib.cnx_layernorm_fwd(u.data_ptr(), _code(u), lw.data_ptr(), lb.data_ptr(), ctx.eps, a.data_ptr(),
+                                             _code(a), None, None, M, C, 0, _stream()), "cnx_layernorm_fwd")
+            dos = (g2 * gf if gf is not None else g2).to(torch.bfloat16)         # d(fc2 out)
+            hpre = torch.addmm(b1f.to(torch.bfloat16), a, w1b.t())               # [M, 4C]
+            dh = dos @ w2b
+            dhpre = torch.ops.aten.gelu_backward(dh, hpre)
+            del dh
+            da = dhpre @ w1b                                                     # [M, C] bf16
+            if want_p:
+                h = F.gelu(hpre)
+                dw2 = _wgrad(dos, h)
+                db2 = dos.float().sum(0)
+                dw1 = _wgrad(dhpre, a)
+                db1 = dhpre.float().sum(0)
+                if gf is not None:
+                    dgamma = (g2.float() * y2.reshape(M, C).float()).sum(0)
+                del h
+            del hpre, dhpre
         # ---- LayerNorm backward
         d_u = torch.empty_like(u)
         dlw = dlb = ws = None

@@ -151,7 +151,11 @@ def test_convnext_block_matches_reference_block(R, C, H, gamma):
         xd2 = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
         yb = blk(xd2)
     assert yb.dtype == torch.float32 if gamma else True
-    gb = _grads(yb, [xd2], cot.cuda())[0]
+    gall = _grads(yb, [xd2] + list(blk.parameters()), cot.cuda())
+    gb = gall[0]
+    for a, b, (n, _) in zip(gall[1:], gref[1:], ref.named_parameters()):        # parameter gradients (training backward)
+        rel = float((a.float().cpu() - b).norm() / b.norm())
+        assert rel < 2e-2, (n, rel)
     res_ref = (yr - x).detach()
     res_dev = (yb.float().cpu() - x).detach()
     assert float((res_dev - res_ref).norm() / res_ref.norm()) < 1e-2
@@ -271,3 +275,59 @@ def test_fused_block_tail_argument_errors(R):
     assert lib.cnx_block_mlp_fwd(*args(96, -1)) != 0
     assert lib.cnx_mlp_pack_weights(None, t.data_ptr(), 0, t.data_ptr(), 96, S()) == -1
     assert lib.cnx_mlp_pack_weights(t.data_ptr(), t.data_ptr(), 2, t.data_ptr(), 96, S()) != 0   # fp16 masters: unsupported
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("M_", [1, 33, 256, 700])
+@pytest.mark.parametrize("gamma,emit,gdt", [(True, True, torch.float32), (False, False, torch.float32),
+                                            (True, False, torch.bfloat16)])
+def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt):
+    """cnx_block_mlp_bwd (LN recompute + three chained MFMA GEMMs, GELU' in registers) vs fp32 autograd of the same
+    chain on the same bf16-quantised operands; emitted weight-gradient operands vs their definitions."""
+    lib = R._lib.load()
+    gen = torch.Generator().manual_seed(C * 7 + M_)
+    u = (torch.randn(M_, C, generator=gen) * 1.5 + 0.3).to(torch.bfloat16)
+    w1 = (torch.randn(4 * C, C, generator=gen) * C ** -0.5).to(torch.bfloat16).float()
+    w2 = (torch.randn(C, 4 * C, generator=gen) * (4 * C) ** -0.5).to(torch.bfloat16).float()
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen)
+    b1 = torch.randn(4 * C, generator=gen) * 0.3
+    gm = torch.randn(C, generator=gen) if gamma else None
+    g = torch.randn(M_, C, generator=gen).to(gdt)
+    mu = u.float().mean(1)
+    rstd = (u.float().var(1, unbiased=False) + 1e-6).rsqrt()
+    a = (((u.float() - mu[:, None]) * rstd[:, None]) * lw + lb).to(torch.bfloat16).float().requires_grad_()
+    dO = (g.float() * gm if gamma else g.float()).to(torch.bfloat16).float()
+    hpre = a @ w1.t() + b1
+    h = F.gelu(hpre)
+    (da_ref,) = torch.autograd.grad(h @ w2.t(), a, dO)
+    dh = dO @ w2
+    wb = R.ops._pack_mlp_bwd(w1.cuda(), w2.cuda())
+    assert wb.numel() == lib.cnx_mlp_packed_bwd_elems(C) == 12 * C * C
+    dev_ = lambda t: t.detach().cuda().contiguous()
+    ud, gd, lwd, lbd, b1d, mud, rsd = dev_(u), dev_(g), dev_(lw), dev_(lb), dev_(b1), dev_(mu), dev_(rstd)
+    gmd = dev_(gm) if gamma else None
+    da = torch.full((M_, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ao = dob = ht = dhpt = None
+    if emit:
+        ao = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+        dob = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+        ht = torch.empty(4 * C, M_, device="cuda", dtype=torch.bfloat16)
+        dhpt = torch.empty(4 * C, M_, device="cuda", dtype=torch.bfloat16)
+    P = R._lib.ptr
+    assert lib.cnx_block_mlp_bwd(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), gd.data_ptr(),
+                                 R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), P(ao), P(dob),
+                                 P(ht), P(dhpt), M_, C, S()) == 0
+    err = float((da.float().cpu() - da_ref).norm() / da_ref.norm())
+    assert err < 8e-3, err                     # bf16 roundings of dHpre and of the stored result
+    if emit:
+        close(ao, a.detach(), 8e-3, 1e-3)           # one bf16 ulp: fma vs separate mul/add before the rounding
+        close(dob, dO, 8e-3, 1e-3)
+        close(ht.float().t(), h.detach(), 1e-2, 1e-3)
+        hp2 = hpre.detach().clone().requires_grad_()
+        (dhpre,) = torch.autograd.grad(F.gelu(hp2), hp2, dh)
+        assert float((dhpt.float().t().cpu() - dhpre).norm() / dhpre.norm()) < 6e-3
+    # argument errors
+    assert lib.cnx_block_mlp_bwd(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), gd.data_ptr(),
+                                 R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), da.data_ptr(),
+                                 None, None, None, M_, C, S()) == -1          # emit pointers: all four or none
+    assert lib.cnx_block_mlp_bwd_supported(384) == 0

@@ -3,6 +3,7 @@
 //   ./blk_probe [iters]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -142,6 +143,83 @@ int main(int argc, char** argv) {
     const double med = ts[ts.size() / 2], flops = 16.0 * M * C * C, bytes = static_cast<double>(M) * C * (2 + 4 + 4);
     printf("      fwd median %.1f us (min %.1f)   %.0f TFLOP/s   %.0f GB/s algorithmic\n", med * 1e3, ts[0] * 1e3, flops / med / 1e9,
            bytes / med / 1e6);
+    // ================= backward (input gradient) =================
+    if (cnx_block_mlp_bwd_supported(C)) {
+      std::vector<float> g(M * C);
+      for (auto& v : g) v = nd(rng);
+      float* dg = dev(g);
+      uint16_t *dWb, *dda, *da_o, *ddo_o, *dht, *ddhpt;
+      CK(hipMalloc(&dWb, cnx_mlp_packed_bwd_elems(C) * 2));
+      CK(hipMalloc(&dda, M * C * 2));
+      CK(hipMalloc(&da_o, M * C * 2));
+      CK(hipMalloc(&ddo_o, M * C * 2));
+      CK(hipMalloc(&dht, M * 4 * C * 2));
+      CK(hipMalloc(&ddhpt, M * 4 * C * 2));
+      rc = cnx_mlp_pack_weights_bwd(dW1, dW2, APGD_F32, dWb, C, nullptr);
+      if (rc) { printf("pack bwd rc=%d\n", rc); return 2; }
+      rc = cnx_block_mlp_bwd(du, dlnw, dlnb, dmean, drstd, dg, APGD_F32, dgm, dWb, db1, dda, da_o, ddo_o, dht, ddhpt, M, C, nullptr);
+      if (rc) { printf("bwd rc=%d\n", rc); return 2; }
+      CK(hipDeviceSynchronize());
+      std::vector<uint16_t> da(M * C), ht(M * 4 * C), dhpt(M * 4 * C), ao(M * C), doo(M * C);
+      CK(hipMemcpy(da.data(), dda, M * C * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(ao.data(), da_o, M * C * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(doo.data(), ddo_o, M * C * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(ht.data(), dht, M * 4 * C * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(dhpt.data(), ddhpt, M * 4 * C * 2, hipMemcpyDeviceToHost));
+      double e_da = 0, r_da = 0, e_h = 0, r_h = 0, e_dh = 0, r_dh = 0, e_a = 0, e_do = 0;
+      std::vector<float> dO(C), dhp(4 * C);
+      for (long m : rows) {
+        const double mu = mean[m], rs = rstd[m];
+        for (int c = 0; c < C; ++c) {
+          a[c] = rbf(static_cast<float>((bf2f(u[m * C + c]) - mu) * rs * lnw[c] + lnb[c]));
+          dO[c] = rbf(g[m * C + c] * gm[c]);
+          e_a = std::fmax(e_a, std::fabs(a[c] - bf2f(ao[m * C + c])));
+          e_do = std::fmax(e_do, std::fabs(dO[c] - bf2f(doo[m * C + c])));
+        }
+        for (int j = 0; j < 4 * C; ++j) {
+          double hp = b1[j], dh = 0;
+          for (int c = 0; c < C; ++c) {
+            hp += static_cast<double>(rbf(W1[static_cast<long>(j) * C + c])) * a[c];
+            dh += static_cast<double>(rbf(W2[static_cast<long>(c) * 4 * C + j])) * dO[c];
+          }
+          const double Phi = 0.5 * (1.0 + std::erf(hp * 0.7071067811865476));
+          const double gp = Phi + hp * std::exp(-0.5 * hp * hp) * 0.3989422804014327;
+          dhp[j] = rbf(static_cast<float>(dh * gp));
+          const double hh = hp * Phi;
+          e_h = std::fmax(e_h, std::fabs(hh - bf2f(ht[static_cast<long>(j) * M + m])));
+          r_h = std::fmax(r_h, std::fabs(hh));
+          e_dh = std::fmax(e_dh, std::fabs(dh * gp - bf2f(dhpt[static_cast<long>(j) * M + m])));
+          r_dh = std::fmax(r_dh, std::fabs(dh * gp));
+        }
+        for (int c = 0; c < C; ++c) {
+          double acc = 0;
+          for (int j = 0; j < 4 * C; ++j) acc += static_cast<double>(rbf(W1[static_cast<long>(j) * C + c])) * dhp[j];
+          e_da = std::fmax(e_da, std::fabs(acc - bf2f(da[m * C + c])));
+          r_da = std::fmax(r_da, std::fabs(acc));
+        }
+      }
+      const bool okb = e_da < 1.5e-2 * r_da && e_h < 1e-2 * r_h && e_dh < 1e-2 * r_dh && e_a < 1e-6 && e_do < 1e-6;
+      printf("      bwd: da err %.3e (max %.2f)  H^T err %.3e (max %.2f)  dHpre^T err %.3e (max %.2f)  a/dO err %.1e/%.1e  %s\n",
+             e_da, r_da, e_h, r_h, e_dh, r_dh, e_a, e_do, okb ? "OK" : "MISMATCH");
+      bad_total += !okb;
+      for (int em = 0; em < 2; ++em) {
+        std::vector<float> tb;
+        for (int it = 0; it < iters + 3; ++it) {
+          CK(hipEventRecord(e0));
+          cnx_block_mlp_bwd(du, dlnw, dlnb, dmean, drstd, dg, APGD_F32, dgm, dWb, db1, dda, em ? da_o : nullptr, em ? ddo_o : nullptr,
+                            em ? dht : nullptr, em ? ddhpt : nullptr, M, C, nullptr);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (it >= 3) tb.push_back(ms);
+        }
+        std::sort(tb.begin(), tb.end());
+        const double mb = tb[tb.size() / 2];
+        printf("      bwd%s median %.1f us (min %.1f)   %.0f TFLOP/s\n", em ? " +emit" : "      ", mb * 1e3, tb[0] * 1e3, 1.5 * flops / mb / 1e9);
+      }
+      hipFree(dg); hipFree(dWb); hipFree(dda); hipFree(da_o); hipFree(ddo_o); hipFree(dht); hipFree(ddhpt);
+    }
     hipFree(du); hipFree(dx); hipFree(dout); hipFree(dmean); hipFree(drstd); hipFree(dy2); hipFree(dWf); hipFree(dW1); hipFree(dW2);
   }
   return bad_total ? 1 : 0;
