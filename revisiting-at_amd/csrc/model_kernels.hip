@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256) void dwconv7x7_kernel(const TI* __restrict__ x
                                                         const float* __restrict__ bias, const float* __restrict__ add,
                                                         TO* __restrict__ out, int H, int W, int C, int flip,
                                                         int tiles_h, int tiles_w, long n_strips) {
+  // a call with any bf16 operand is the autocast convolution: input and filter rounded to bf16, fp32 accumulation
+  // (same numerics as the packed-dot kernel the ConvNeXt shapes take)
+  constexpr bool kMixed = sizeof(TI) == 2 || sizeof(TO) == 2;
   extern __shared__ float wl[];                       // [49][cc]
   const int cbase = blockIdx.y * kCC;
   const int cc = min(kCC, C - cbase);
@@ -65,7 +68,9 @@ __global__ __launch_bounds__(256) void dwconv7x7_kernel(const TI* __restrict__ x
   const int nthr = blockDim.x * blockDim.y, tid = py * blockDim.x + lc;
   for (int i = tid; i < 49 * cc; i += nthr) {
     const int tap = i / cc, c = i - tap * cc;
-    wl[(flip ? 48 - tap : tap) * cc + c] = w49c[tap * C + cbase + c];
+    float wv = w49c[tap * C + cbase + c];
+    if constexpr (kMixed) wv = __uint_as_float(static_cast<uint32_t>(f2bf(wv)) << 16);
+    wl[(flip ? 48 - tap : tap) * cc + c] = wv;
   }
   __syncthreads();
   const long s = static_cast<long>(blockIdx.x) * blockDim.y + py;
@@ -96,6 +101,10 @@ __global__ __launch_bounds__(256) void dwconv7x7_kernel(const TI* __restrict__ x
     for (int j = 0; j < kTW + 6; ++j) {
       const int col = w0 - 3 + j;
       in[j] = (col >= 0 && col < W) ? load4(xr + static_cast<long>(col) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (kMixed && sizeof(TI) == 4) {
+        in[j].x = __uint_as_float(static_cast<uint32_t>(f2bf(in[j].x)) << 16); in[j].y = __uint_as_float(static_cast<uint32_t>(f2bf(in[j].y)) << 16);
+        in[j].z = __uint_as_float(static_cast<uint32_t>(f2bf(in[j].z)) << 16); in[j].w = __uint_as_float(static_cast<uint32_t>(f2bf(in[j].w)) << 16);
+      }
     }
 #pragma unroll
     for (int oh = 0; oh < kRH; ++oh) {
@@ -123,6 +132,291 @@ __global__ __launch_bounds__(256) void dwconv7x7_kernel(const TI* __restrict__ x
       store4(out + off, v);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise 7x7, LDS-tiled variant (the one the ConvNeXt shapes take).
+//   The strip kernel above reads every input element ~7x through the vector L1 (13 x 8 loads per 14 outputs): it is
+//   bound by load-instruction issue, not by HBM.  Here a workgroup stages a zero-padded (TH+6) x (W+6) x CC input
+//   tile in LDS once (each global element is read once per workgroup, 16 bytes per lane, coalesced along C), then
+//   every thread computes a 2 x 7 output strip for 4 channels out of LDS with the same sliding register window.
+//   Staging type TS: bf16 when the input or the output is bf16 (autocast rounds the convolution's input to bf16
+//   anyway), fp32 for the all-fp32 instantiation.  Lane order: channel group fastest, then strips along W, so the
+//   4 (or 2) strips of a 32-lane group hit distinct LDS bank quarters (7 positions x CC x 2 B = 192 mod 256).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_put4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void lds_put4(uint16_t* p, float4 v) { store4(p, v); }
+
+template <typename TI, typename TO, typename TS, int CC>
+__global__ __launch_bounds__(512) void dwconv7x7_tile_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
+                                                              const float* __restrict__ bias, const float* __restrict__ add,
+                                                              TO* __restrict__ out, int H, int W, int C, int flip, int TH,
+                                                              int tiles_h) {
+  constexpr int LC = CC / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);                              // [49][CC]
+  TS* tile = reinterpret_cast<TS*>(smem + 49 * CC * sizeof(float));        // [TH+6][W+6][CC]
+  const int Wp = W + 6;
+  const long n = blockIdx.x / tiles_h;
+  const int h0 = static_cast<int>(blockIdx.x % tiles_h) * TH;
+  const int cbase = blockIdx.y * CC;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+
+  for (int i = tid; i < 49 * LC; i += nthr) {
+    const int tap = i / LC, l = i - tap * LC;
+    *reinterpret_cast<float4*>(&wl[(flip ? 48 - tap : tap) * CC + l * 4]) =
+        *reinterpret_cast<const float4*>(&w49c[tap * C + cbase + l * 4]);
+  }
+  // staging, batched: kSR rows x 2 units per thread are loaded before anything is stored, so 8 global loads are in
+  // flight per thread (a one-load-per-iteration loop exposes the full memory latency 27x per workgroup)
+  constexpr int kSR = 4;
+  const int row_units = Wp * LC;
+  for (int tr0 = 0; tr0 < TH + 6; tr0 += kSR) {
+    for (int i0 = tid; i0 < row_units; i0 += 2 * nthr) {
+      float4 v[kSR][2];
+#pragma unroll
+      for (int rr = 0; rr < kSR; ++rr) {
+        const int hh = h0 - 3 + tr0 + rr;
+        const bool row_in = hh >= 0 && hh < H && tr0 + rr < TH + 6;
+        const TI* xr = x + ((n * H + (row_in ? hh : 0)) * static_cast<long>(W)) * C + cbase;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = i0 + k * nthr;
+          const int col = i / LC, l = i - col * LC;
+          const int ww = col - 3;
+          v[rr][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row_in && i < row_units && ww >= 0 && ww < W) v[rr][k] = load4(xr + static_cast<long>(ww) * C + l * 4);
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < kSR; ++rr) {
+        if (tr0 + rr >= TH + 6) continue;
+        TS* trow = tile + static_cast<long>(tr0 + rr) * Wp * CC;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = i0 + k * nthr;
+          if (i < row_units) lds_put4(trow + i * 4, v[rr][k]);          // unit i of a row = (col, l) at col*CC + l*4 = 4*i
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int n_sc = (W + kTW - 1) / kTW, n_sr = (TH + kRH - 1) / kRH;
+  const int lc = tid % LC, sidx = tid / LC;
+  if (sidx >= n_sr * n_sc) return;
+  const int sc = sidx % n_sc, sr = sidx / n_sc;
+  const int cl = lc * 4, c0 = cbase + cl;
+
+  float4 acc[kRH][kTW];
+  const float4 b4 = bias ? load4(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int oh = 0; oh < kRH; ++oh)
+#pragma unroll
+    for (int t = 0; t < kTW; ++t) acc[oh][t] = b4;
+
+#pragma unroll
+  for (int r = 0; r < kRH + 6; ++r) {
+    const int tr = sr * kRH + r;
+    if (tr >= TH + 6) continue;
+    const TS* trow = tile + (static_cast<long>(tr) * Wp + sc * kTW) * CC + cl;
+    float4 in[kTW + 6];
+#pragma unroll
+    for (int j = 0; j < kTW + 6; ++j)
+      in[j] = (sc * kTW + j < Wp) ? load4(trow + j * CC) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int oh = 0; oh < kRH; ++oh) {
+      const int kh = r - oh;
+      if (kh < 0 || kh > 6) continue;
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const float4 wv = *reinterpret_cast<const float4*>(&wl[(kh * 7 + kw) * CC + cl]);
+#pragma unroll
+        for (int t = 0; t < kTW; ++t) fma4(acc[oh][t], wv, in[t + kw]);
+      }
+    }
+  }
+  const int h_end = min(H, h0 + TH);
+#pragma unroll
+  for (int oh = 0; oh < kRH; ++oh) {
+    const int h = h0 + sr * kRH + oh;
+    if (h >= h_end) continue;
+#pragma unroll
+    for (int t = 0; t < kTW; ++t) {
+      const int w = sc * kTW + t;
+      if (w >= W) continue;
+      const long off = ((n * H + h) * static_cast<long>(W) + w) * C + c0;
+      float4 v = acc[oh][t];
+      if (add) { const float4 a = load4(add + off); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+      store4(out + off, v);
+    }
+  }
+}
+
+// geometry of the tiled kernel for (H, W, C); returns false when the shape does not fit (caller uses the strip kernel)
+struct DwTile { int cc, th, threads; size_t lds; };
+inline bool dw_tile_plan(int H, int W, int C, size_t stage_elt, DwTile* t) {
+  int cc = 0;
+  if (C % 32 != 0) return false;
+  if (C % 128 == 0 && W <= 8) cc = 128;
+  else if (C % 64 == 0 && W <= 16) cc = 64;
+  else cc = 32;
+  const int n_sc = (W + kTW - 1) / kTW;
+  int th = H;
+  // rows per tile: as many as keep threads <= 256..512 and the tile under ~64 KiB (two workgroups per CU)
+  auto lds_of = [&](int rows) { return static_cast<size_t>(49) * cc * 4 + static_cast<size_t>(rows + 6) * (W + 6) * cc * stage_elt; };
+  auto thr_of = [&](int rows) { return (cc / 4) * ((rows + kRH - 1) / kRH) * n_sc; };
+  while (th > 2 && (thr_of(th) > 512 || lds_of(th) > 72 * 1024)) th = (th + 1) / 2;
+  th = (th + 1) & ~1;                                   // even number of rows (pairs of output rows per thread)
+  if (th > H) th = H;
+  if (thr_of(th) > 512 || lds_of(th) > 150 * 1024) return false;
+  t->cc = cc; t->th = th; t->threads = ((thr_of(th) + 63) / 64) * 64; t->lds = lds_of(th);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise 7x7 on bf16 operands with packed dot products (the autocast path: all ConvNeXt-T calls of the AT step).
+//   49 fp32 FMAs per output make the stencil VALU-bound long before HBM (3.8 G FMA per call at 56x56x96, batch 256).
+//   v_dot2c_f32_bf16 (acc += a.lo*b.lo + a.hi*b.hi, fp32 accumulate) halves that IF two W-adjacent inputs of ONE channel
+//   share a dword — which NHWC memory does not give.  So the staging pass transposes pairs: the workgroup's zero-padded
+//   tile is stored in LDS as  tile[row][pair m][channel] = (x[2m] | x[2m+1] << 16)  in padded column coordinates
+//   (p = w + 3), one dword per channel.  A thread owns ONE channel (lane = channel: LDS reads are 32 consecutive dwords,
+//   conflict-free) and a 4 x 8 output strip; per input row it reads 7 pair-dwords and issues 4 dot2 per output and
+//   filter row:   even w = 2q  : pairs q..q+3 . {(f0,f1),(f2,f3),(f4,f5),(f6,0)}
+//                 odd  w = 2q+1: pairs q..q+3 . {(0,f0),(f1,f2),(f3,f4),(f5,f6)}      (no realignment needed)
+//   = 28 VALU per output instead of 49 + unpacking.  The 56 packed filter dwords of the lane's channel stay in registers.
+//   Numerics = the reference's autocast convolution: bf16 inputs and weights, fp32 accumulation.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+constexpr int kDT = 8, kDR = 4, kDC = 32;
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(uint16_t* p, float v) { *p = static_cast<uint16_t>(pack2_bf16(v, 0.f)); }
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
+                                                             const float* __restrict__ bias, const float* __restrict__ add,
+                                                             TO* __restrict__ out, int H, int W, int C, int flip, int TH,
+                                                             int tiles_h) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile2[];       // [TH+6][P2][32]
+  const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
+  const long n = blockIdx.x / tiles_h;
+  const int h0 = static_cast<int>(blockIdx.x % tiles_h) * TH;
+  const int cbase = blockIdx.y * kDC;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+
+  // ---- staging: unit = (row, pair m, 4-channel group): two 4-channel loads (padded cols 2m, 2m+1) -> 4 packed dwords
+  constexpr int kSR = 4;
+  const int row_units = P2 * (kDC / 4);
+  for (int tr0 = 0; tr0 < TH + 6; tr0 += kSR) {
+    for (int i = tid; i < row_units; i += nthr) {
+      const int m = i / (kDC / 4), l4 = i - m * (kDC / 4);
+      const int w0 = 2 * m - 3, w1 = w0 + 1;
+      float4 v0[kSR], v1[kSR];
+#pragma unroll
+      for (int rr = 0; rr < kSR; ++rr) {
+        const int hh = h0 - 3 + tr0 + rr;
+        const bool row_in = hh >= 0 && hh < H && tr0 + rr < TH + 6;
+        const TI* xr = x + ((n * H + (row_in ? hh : 0)) * static_cast<long>(W)) * C + cbase + l4 * 4;
+        v0[rr] = (row_in && w0 >= 0 && w0 < W) ? load4(xr + static_cast<long>(w0) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v1[rr] = (row_in && w1 >= 0 && w1 < W) ? load4(xr + static_cast<long>(w1) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int rr = 0; rr < kSR; ++rr) {
+        if (tr0 + rr >= TH + 6) continue;
+        uint4 d;
+        d.x = pack2_bf16(v0[rr].x, v1[rr].x); d.y = pack2_bf16(v0[rr].y, v1[rr].y);
+        d.z = pack2_bf16(v0[rr].z, v1[rr].z); d.w = pack2_bf16(v0[rr].w, v1[rr].w);
+        *reinterpret_cast<uint4*>(&tile2[(static_cast<long>(tr0 + rr) * P2 + m) * kDC + l4 * 4]) = d;
+      }
+    }
+  }
+
+  // ---- this lane's channel: packed filter rows (rotated by 180 degrees when flip)
+  const int lc = tid & (kDC - 1), sidx = tid / kDC;
+  const int c = cbase + lc;
+  uint32_t we[7][4], wo[7][4];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+    float f[7];
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int tap = kh * 7 + kw;
+      f[kw] = w49c[(flip ? 48 - tap : tap) * C + c];
+    }
+    we[kh][0] = pack2_bf16(f[0], f[1]); we[kh][1] = pack2_bf16(f[2], f[3]); we[kh][2] = pack2_bf16(f[4], f[5]); we[kh][3] = pack2_bf16(f[6], 0.f);
+    wo[kh][0] = pack2_bf16(0.f, f[0]); wo[kh][1] = pack2_bf16(f[1], f[2]); wo[kh][2] = pack2_bf16(f[3], f[4]); wo[kh][3] = pack2_bf16(f[5], f[6]);
+  }
+  __syncthreads();
+
+  const int n_sr = (TH + kDR - 1) / kDR;
+  if (sidx >= n_sr * n_sc) return;
+  const int sc = sidx % n_sc, sr = sidx / n_sc;
+  float acc[kDR][kDT];
+  const float b0 = bias ? bias[c] : 0.f;
+#pragma unroll
+  for (int oh = 0; oh < kDR; ++oh)
+#pragma unroll
+    for (int t = 0; t < kDT; ++t) acc[oh][t] = b0;
+
+#pragma unroll
+  for (int r = 0; r < kDR + 6; ++r) {
+    const int tr = sr * kDR + r;
+    if (tr >= TH + 6) continue;
+    const uint32_t* trow = tile2 + (static_cast<long>(tr) * P2 + sc * (kDT / 2)) * kDC + lc;
+    uint32_t d[kDT / 2 + 3];
+#pragma unroll
+    for (int i = 0; i < kDT / 2 + 3; ++i) d[i] = trow[i * kDC];
+#pragma unroll
+    for (int oh = 0; oh < kDR; ++oh) {
+      const int kh = r - oh;
+      if (kh < 0 || kh > 6) continue;
+#pragma unroll
+      for (int q = 0; q < kDT / 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[oh][2 * q] = dot2(d[q + i], we[kh][i], acc[oh][2 * q]);
+          acc[oh][2 * q + 1] = dot2(d[q + i], wo[kh][i], acc[oh][2 * q + 1]);
+        }
+      }
+    }
+  }
+  const int h_end = min(H, h0 + TH);
+#pragma unroll
+  for (int oh = 0; oh < kDR; ++oh) {
+    const int h = h0 + sr * kDR + oh;
+    if (h >= h_end) continue;
+#pragma unroll
+    for (int t = 0; t < kDT; ++t) {
+      const int w = sc * kDT + t;
+      if (w >= W) continue;
+      const long off = ((n * H + h) * static_cast<long>(W) + w) * C + c;
+      float v = acc[oh][t];
+      if (add) v += add[off];
+      store1(out + off, v);
+    }
+  }
+}
+
+struct DwDot { int th, threads; size_t lds; };
+inline bool dw_dot2_plan(int H, int W, int C, DwDot* t) {
+  if (C % kDC != 0) return false;
+  const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
+  if (n_sc > 16) return false;
+  int max_sr = 16 / n_sc;                                  // <= 512 threads
+  int th = H < kDR * max_sr ? H : kDR * max_sr;
+  while (th > kDR && static_cast<size_t>(th + 6) * P2 * kDC * 4 > 64 * 1024) th -= kDR;
+  const int n_sr = (th + kDR - 1) / kDR;
+  t->th = th; t->threads = ((n_sr * n_sc * kDC + 63) / 64) * 64; t->lds = static_cast<size_t>(th + 6) * P2 * kDC * 4;
+  return t->lds <= 150 * 1024;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,6 +689,54 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
   if (C % 4 != 0) return APGD_ERR_ARG;
   if ((x_dtype != APGD_F32 && x_dtype != APGD_BF16) || (out_dtype != APGD_F32 && out_dtype != APGD_BF16))
     return APGD_ERR_DTYPE;
+  hipStream_t s = as_stream(stream);
+  const bool all_f32 = x_dtype == APGD_F32 && out_dtype == APGD_F32;
+  if (!all_f32) {
+    DwDot dp;
+    if (dw_dot2_plan(H, W, C, &dp)) {
+      const int tiles_h = (H + dp.th - 1) / dp.th;
+      const dim3 grid(static_cast<unsigned>(N * tiles_h), C / kDC), block(dp.threads);
+#define DWD_LAUNCH(TI, TO)                                                                                            \
+  {                                                                                                                   \
+    auto kfn = dwconv7x7_dot2_kernel<TI, TO>;                                                                         \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, grid, block, dp.lds, s, static_cast<const TI*>(x), w49c, bias, add, static_cast<TO*>(out), H, W, \
+                       C, flip, dp.th, tiles_h);                                                                       \
+  }
+      if (x_dtype == APGD_F32) DWD_LAUNCH(float, uint16_t)
+      else if (out_dtype == APGD_F32) DWD_LAUNCH(uint16_t, float)
+      else DWD_LAUNCH(uint16_t, uint16_t)
+#undef DWD_LAUNCH
+      return launch_status();
+    }
+  }
+  {
+    DwTile tp;
+    if (all_f32 && dw_tile_plan(H, W, C, 4, &tp)) {
+      const int tiles_h = (H + tp.th - 1) / tp.th;
+      const dim3 grid(static_cast<unsigned>(N * tiles_h), C / tp.cc), block(tp.threads);
+#define DWT_LAUNCH(TI, TO, TS, CCV)                                                                                   \
+  {                                                                                                                   \
+    auto kfn = dwconv7x7_tile_kernel<TI, TO, TS, CCV>;                                                                \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, grid, block, tp.lds, s, static_cast<const TI*>(x), w49c, bias, add, static_cast<TO*>(out), H, W, \
+                       C, flip, tp.th, tiles_h);                                                                       \
+  }
+#define DWT_TYPES(CCV) DWT_LAUNCH(float, float, float, CCV)
+      if (tp.cc == 32) { DWT_TYPES(32) } else if (tp.cc == 64) { DWT_TYPES(64) } else { DWT_TYPES(128) }
+#undef DWT_TYPES
+#undef DWT_LAUNCH
+      return launch_status();
+    }
+  }
   const int cc = C < kCC ? C : kCC;
   const int lc = cc / 4;
   const int py = 240 / lc > 0 ? 240 / lc : 1;
@@ -402,7 +744,6 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
   const long n_strips = static_cast<long>(N) * tiles_h * tiles_w;
   const dim3 block(lc, py), grid(static_cast<unsigned>((n_strips + py - 1) / py), (C + kCC - 1) / kCC);
   const size_t lds = static_cast<size_t>(49) * cc * sizeof(float);
-  hipStream_t s = as_stream(stream);
 #define DW_LAUNCH(TI, TO)                                                                                       \
   hipLaunchKernelGGL((dwconv7x7_kernel<TI, TO>), grid, block, lds, s, static_cast<const TI*>(x), w49c, bias, add, \
                      static_cast<TO*>(out), H, W, C, flip, tiles_h, tiles_w, n_strips)

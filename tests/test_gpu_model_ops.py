@@ -32,40 +32,53 @@ def close(a, b, rtol, atol):
 @pytest.mark.parametrize("xdt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
 def test_dwconv7x7_fwd_bwd_data_wgrad(R, N, C, H, W, xdt, odt):
+    """All-fp32 calls are exact fp32 stencils.  Any call with a bf16 operand is the autocast convolution: input AND
+    filter rounded to bf16, fp32 accumulation (packed bf16 dot products) - the references below round the same way."""
     lib = R._lib.load()
     g = torch.Generator().manual_seed(N * 1000 + C + H)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(C, 1, 7, 7, generator=g) * 0.2
     b = torch.randn(C, generator=g)
     add = torch.randn(N, H, W, C, generator=g)
-    xq = x.to(xdt).float()                                   # the kernel sees the quantised input
-    xr = xq.clone().requires_grad_()
-    wr = w.clone().requires_grad_()
-    br = b.clone().requires_grad_()
-    ref = F.conv2d(xr, wr, br, padding=3, groups=C)          # fp32 CPU reference
+    bf = lambda t: t.to(torch.bfloat16).float()
+
+    def operands(in_dt, out_dt, t):                          # what the kernel multiplies for this dtype pair
+        mixed = in_dt != torch.float32 or out_dt != torch.float32
+        return (bf(t) if mixed else t.to(in_dt).float()), (bf(w) if mixed else w)
+
+    xq = x.to(xdt).float()                                   # the stored input
     x_rows = xq.permute(0, 2, 3, 1).contiguous().to(xdt).cuda()
     w49c = w.reshape(C, 49).t().contiguous().cuda()
     out = torch.empty(N, H, W, C, device="cuda", dtype=odt)
     code = R._lib.dtype_code
     assert lib.cnx_dwconv7x7_nhwc(x_rows.data_ptr(), code(xdt), w49c.data_ptr(), b.cuda().data_ptr(), None,
                                   out.data_ptr(), code(odt), N, H, W, C, 0, S()) == 0
+    xm, wm = operands(xdt, odt, xq)
+    ref = F.conv2d(xm, wm, b, padding=3, groups=C)
     tol = 1e-4 if odt == torch.float32 else 2e-2              # bf16 output: 2^-8 relative
     close(out.permute(0, 3, 1, 2), ref, tol, tol)
-    # fused "+ add"
+    # fused "+ add", fp32 output
     addc = add.cuda()
     out2 = torch.empty(N, H, W, C, device="cuda", dtype=torch.float32)
     assert lib.cnx_dwconv7x7_nhwc(x_rows.data_ptr(), code(xdt), w49c.data_ptr(), None, addc.data_ptr(), out2.data_ptr(),
                                   0, N, H, W, C, 0, S()) == 0
-    close(out2.permute(0, 3, 1, 2), ref - b.view(1, C, 1, 1) + add.permute(0, 3, 1, 2), 1e-4, 1e-4)
-    # input gradient = same kernel with the rotated filter; filter/bias gradient kernel
+    xm, wm = operands(xdt, torch.float32, xq)
+    close(out2.permute(0, 3, 1, 2), F.conv2d(xm, wm, None, padding=3, groups=C) + add.permute(0, 3, 1, 2), 1e-4, 1e-4)
+    # input gradient = same kernel with the rotated filter
     dy = torch.randn(N, C, H, W, generator=g)
     dyq = dy.to(odt).float()
-    gx, gw, gb = torch.autograd.grad(ref, (xr, wr, br), dyq)
     dy_rows = dyq.permute(0, 2, 3, 1).contiguous().to(odt).cuda()
     dx = torch.empty(N, H, W, C, device="cuda", dtype=torch.float32)
     assert lib.cnx_dwconv7x7_nhwc(dy_rows.data_ptr(), code(odt), w49c.data_ptr(), None, None, dx.data_ptr(), 0, N, H, W,
                                   C, 1, S()) == 0
+    dym, wm = operands(odt, torch.float32, dyq)
+    xr = xq.clone().requires_grad_()
+    (gx,) = torch.autograd.grad(F.conv2d(xr, wm, None, padding=3, groups=C), xr, dym)
     close(dx.permute(0, 3, 1, 2), gx, 1e-4, 1e-4)
+    # filter / bias gradient kernel (fp32 arithmetic on the stored operands)
+    wr = w.clone().requires_grad_()
+    br = b.clone().requires_grad_()
+    gw, gb = torch.autograd.grad(F.conv2d(xq, wr, br, padding=3, groups=C), (wr, br), dyq)
     dw = torch.empty(49, C, device="cuda")
     db = torch.empty(C, device="cuda")
     ws = torch.empty(lib.cnx_dwconv7x7_wgrad_ws_floats(C), device="cuda")
