@@ -33,7 +33,9 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
 
 /* Filter / bias gradient of the same convolution:
  *   dw49c[(kh*7+kw)*C + c] = sum_{n,h,w} dy[n,h,w,c] * x[n,h+kh-3,w+kw-3,c];  dbias[c] = sum dy.
- * Deterministic two-stage reduction; ws is scratch of cnx_dwconv7x7_wgrad_ws_floats(C) floats. */
+ * Deterministic two-stage reduction; ws is scratch of cnx_dwconv7x7_wgrad_ws_floats(C) floats.  With a bf16 dy (the
+ * autocast backward) x is taken in bf16 as well (an fp32 x is rounded, as the forward convolution did) and the sums run
+ * on packed bf16 dot products with fp32 accumulation; other dtype pairs use fp32 FMAs on the stored operands. */
 int64_t cnx_dwconv7x7_wgrad_ws_floats(int32_t C);
 int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_dtype,
                              float* dw49c, float* dbias, float* ws,

@@ -26,6 +26,7 @@
 //                       of the slice (the 32x32 accumulator row map).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "apgd_hip.h"
 #include "convnext_hip.h"
@@ -75,6 +76,18 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
   return fmaf(z, pdf, Phi);
 }
 
+// MFMA with the accumulator pinned in the AGPR half of the register file.  At C = 384 a wavefront's state (96 operand
+// registers + 192 accumulator registers) exceeds the 256 architectural VGPRs; left to itself the register allocator
+// parks OPERANDS in AGPRs and copies them back before every MFMA (273 v_accvgpr_read per slice measured).  Pinning the
+// big accumulator tile - which only MFMAs touch inside the loop - in AGPRs leaves everything else in VGPRs.
+// (hipcc pads nothing inside asm: `s_nop 1` covers a VALU-written operand; the accumulators are read back only after
+// MFMA_DRAIN.)
+#define MFMA_AGPR(ACC, A, B) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+#define MFMA_VGPR(ACC, A, B) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+
 template <int C>
 struct Geo {
   static constexpr int KS = C / 16;                 // k-steps of a GEMM whose contraction runs over channels
@@ -86,11 +99,12 @@ struct Geo {
   static constexpr int DEPTH = 3;                   // ring slots
   static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 16 * C;   // + b1 (4C fp32)
   static constexpr int BM = 128;                    // rows per workgroup
+  static constexpr bool AGPR_ACC = C >= 384;        // output accumulators pinned in AGPRs (inline-asm MFMA)
   static_assert(FWD_PIECES % 4 == 0, "pieces must divide over 4 wavefronts");
 };
 
 // ------------------------------------------------------------------ weight pre-arrangement
-// Wf: [NHB][FWD_PIECES][64 lanes][8] bf16.  piece p < KS: W1 operand of k-step p; else W2 operand (cb, t).
+// Wf: [NHB][FWD_PIECES][64 lanes][8] bf16.  piece p < KS: W1 operand of k-step p; then the W2 operands, (t, cb) order.
 template <typename TW>
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const TW* __restrict__ W1, const TW* __restrict__ W2,
                                                        uint16_t* __restrict__ Wf, int C) {
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const TW* __restrict__ W1
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = static_cast<float>(src[e]);
   } else {
-    const int cb = (p - KS) >> 1, t = (p - KS) & 1;
+    const int t = (p - KS) / (C / 32), cb = (p - KS) % (C / 32);      // t-major: consecutive MFMAs hit different accumulators
     const TW* src = W2 + static_cast<long>(cb * 32 + l32) * (4 * C) + hb * 32;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = static_cast<float>(src[(e & 3) + 8 * (2 * t + (e >> 2)) + 4 * half]);
@@ -132,6 +146,7 @@ struct BlkFwdArgs {
   void* out;               // [M, C] TO
   uint16_t* y2;            // [M, C] bf16 pre-gamma fc2 output, or NULL
   long M;
+  int dbg;                 // timing experiments only (APGD_BLK_DBG): 1 = no weight DMA after the prologue, 2 = no GELU
 };
 
 template <int C, typename TX, typename TO>
@@ -228,16 +243,46 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(co
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[cb][r] = 0.f;
 
+  // ---- pull this wavefront's residual tile (32 rows x C, contiguous) towards the L2 now: one lane per 128-byte line.
+  //      The epilogue's loads then pay an L2 hit instead of an HBM round trip per batch (the epilogue alone measured
+  //      ~2/3 of the kernel at C = 96: latency-bound, ~4 KiB in flight per wavefront).
+  constexpr int kResLines = (32 * C * static_cast<int>(sizeof(TX)) + 127) / 128;
+  constexpr int kResPf = (kResLines + 63) / 64;
+  uint32_t pf[kResPf];
+  if (p.resid) {
+    const unsigned char* rb = static_cast<const unsigned char*>(p.resid) + m0 * C * static_cast<long>(sizeof(TX));
+    const long lim = (p.M - m0) * C * static_cast<long>(sizeof(TX));          // bytes of the tile that exist
+#pragma unroll
+    for (int i = 0; i < kResPf; ++i) {
+      long off = (static_cast<long>(i) * 64 + lane) * 128;
+      if (off >= lim) off = 0;
+      pf[i] = (lim > 0) ? *reinterpret_cast<const uint32_t*>(rb + off) : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kResPf; ++i) pf[i] = 0u;
+  }
+
   // ---- hidden-slice loop
-  for (int s = 0; s < G::NHB; ++s) {
+  const int n_slices = (p.dbg & 8) ? 0 : G::NHB;          // dbg 8: prologue + epilogue only
+  for (int s = 0; s < n_slices; ++s) {
     // slice s has landed once this wavefront's own pieces are in (counted wait: slice s+1 may stay in flight) and
     // every wavefront has passed the barrier; the slot of slice s+2 held slice s-1, which nobody reads any more
-    if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (s + 2 < G::NHB) DMA_SLICE(s + 2)
+    if (!(p.dbg & 4)) {
+      if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (s + 2 < G::NHB && !(p.dbg & 1)) DMA_SLICE(s + 2)
     const unsigned char* sl = ring + (s % G::DEPTH) * G::FWD_SLICE + lane * 16;
 
+    // One stream of NF = KS + 2 CB operand fragments per slice (1 KiB each, fragment i feeds MFMA i).  The reads run
+    // PF fragments ahead of the MFMAs so that the LDS latency (~100+ cycles) hides behind the 32-cycle MFMAs instead of
+    // serialising with them (a compiler-scheduled read-wait-MFMA chain measured ~110 cycles per MFMA).
+    constexpr int NF = G::KS + 2 * G::CB, PF = 4;
+    bf16x8 fr[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);
     // GEMM1, accumulator pre-loaded with b1 (register r <-> hidden (r&3) + 8*(r>>2) + 4*half)
     f32x16 acc1;
 #pragma unroll
@@ -245,33 +290,62 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(co
       const float4 b4 = *reinterpret_cast<const float4*>(b1s + s * 32 + 8 * g + 4 * half);
       acc1[4 * g + 0] = b4.x; acc1[4 * g + 1] = b4.y; acc1[4 * g + 2] = b4.z; acc1[4 * g + 3] = b4.w;
     }
+    // two interleaved accumulation chains: a single chain would issue each MFMA only after the previous one has
+    // written back (dependent-accumulator latency > issue interval)
+    f32x16 acc1b;
 #pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {
-      const bf16x8 wa = *reinterpret_cast<const bf16x8*>(sl + ks * 1024);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, af[ks], acc1, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) acc1b[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < G::KS; ++i) {
+      if constexpr (G::AGPR_ACC) {
+        if (i & 1) { MFMA_VGPR(acc1b, fr[i % PF], af[i]); } else { MFMA_VGPR(acc1, fr[i % PF], af[i]); }
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+      } else {
+        if (i & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], acc1b, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], acc1, 0, 0, 0);
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+      }
     }
+    if constexpr (G::AGPR_ACC) MFMA_DRAIN();                    // asm MFMA results are about to be read by VALU code
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
     // GELU -> bf16 A-operand fragments of GEMM2
     bf16x8 hf[2];
     {
       uint32_t pk[8];
+      if (p.dbg & 2) {
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(gelu_f(acc1[r]), gelu_f(acc1[r + 1]));
+        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(acc1[r], acc1[r + 1]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(gelu_f(acc1[r]), gelu_f(acc1[r + 1]));
+      }
       hf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       hf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
     }
     // GEMM2
 #pragma unroll
-    for (int cb = 0; cb < G::CB; ++cb) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sl + (G::KS + cb * 2 + t) * 1024);
-        acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[t], wb, acc2[cb], 0, 0, 0);
+    for (int j = 0; j < 2 * G::CB; ++j) {                      // fragment order in the slice is (t, cb): j = t*CB + cb
+      const int i = G::KS + j;
+      if constexpr (G::AGPR_ACC) {
+        MFMA_AGPR(acc2[j % G::CB], hf[j / G::CB], fr[i % PF]);
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+      } else {
+        acc2[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[j / G::CB], fr[i % PF], acc2[j % G::CB], 0, 0, 0);
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
     }
   }
+  if constexpr (G::AGPR_ACC) MFMA_DRAIN();
 #undef DMA_SLICE
 
   // ---- epilogue: acc2[cb][r] = O[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]
+#pragma unroll
+  for (int i = 0; i < kResPf; ++i) asm volatile("" ::"v"(pf[i]));       // the prefetch loads are complete (and were not dropped)
   const TX* resid = static_cast<const TX*>(p.resid);
   TO* out = static_cast<TO*>(p.out);
 #pragma unroll
@@ -616,6 +690,8 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
   a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.mean = mean; a.rstd = rstd;
   a.Wf = static_cast<const uint16_t*>(Wf); a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.resid = resid; a.out = out;
   a.y2 = static_cast<uint16_t*>(y2_out); a.M = M;
+  static const int dbg = getenv("APGD_BLK_DBG") ? atoi(getenv("APGD_BLK_DBG")) : 0;
+  a.dbg = dbg;
   hipStream_t s = as_stream(stream);
   switch (C) {
     case 96: return launch_blk_fwd<96>(a, resid_dtype, out_dtype, s);

@@ -473,6 +473,118 @@ __global__ __launch_bounds__(7 * 48) void dwconv7x7_wgrad_kernel(const TX* __res
   if (kh == 0) store4(p + 49 * C + c0, accb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// depthwise 7x7 filter gradient on bf16 operands with packed dot products (autocast path).
+//   dw[c][kh][kw] = sum_{n,h,w} dy[n,h,w,c] * x[n,h+kh-3,w+kw-3,c]          db[c] = sum dy
+//   Same LDS image as the forward (pairs of W-adjacent values of one channel per dword, padded coordinates p = w+3),
+//   plus the dy tile in pair form.  A thread owns (channel = lane, filter row kh) and walks the tile's output rows:
+//   per pair step m it reads one dy pair and one new x pair, rebuilds the three odd-offset pairs with v_alignbit and
+//   issues 7 dot2 (one per kw):   even kw = 2j : pair m+j          odd kw = 2j+1 : (hi(pair m+j), lo(pair m+j+1)).
+//   A workgroup = (image group, 32-channel chunk); it keeps its 49 x 32 partial sums in registers over all of its
+//   tiles and writes them once to ws[part][50][C] (tap 49 = bias gradient); reduce_parts_kernel sums the parts in a
+//   fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+template <typename TX, typename TD>
+__global__ __launch_bounds__(256) void dwconv7x7_wgrad_dot2_kernel(const TX* __restrict__ x, const TD* __restrict__ dy,
+                                                                   float* __restrict__ ws, long N, int H, int W, int C,
+                                                                   int TH, int tiles_h, int imgs) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t wg_lds[];
+  const int D2 = (W + 1) / 2, P2 = D2 + 3;
+  uint32_t* xt = wg_lds;                                         // [TH+6][P2][32]
+  uint32_t* dt = wg_lds + static_cast<long>(TH + 6) * P2 * kDC;  // [TH][D2][32]
+  const int cbase = blockIdx.y * kDC;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lc = tid & (kDC - 1), kh = tid / kDC;                // kh == 7: staging helper only
+
+  float acc[7], accb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc[k] = 0.f;
+  const uint32_t ones = 0x3f803f80u;                             // (1.0bf16, 1.0bf16)
+
+  const long n_begin = static_cast<long>(blockIdx.x) * imgs;
+  const long n_end = n_begin + imgs < N ? n_begin + imgs : N;
+  for (long n = n_begin; n < n_end; ++n) {
+    for (int th = 0; th < tiles_h; ++th) {
+      const int h0 = th * TH;
+      // ---- stage x (zero-padded, pairs) and dy (pairs)
+      const int xu = P2 * (kDC / 4);
+      for (int tr0 = 0; tr0 < TH + 6; tr0 += 4) {
+        for (int i = tid; i < xu; i += nthr) {
+          const int m = i / (kDC / 4), l4 = i - m * (kDC / 4);
+          const int w0 = 2 * m - 3, w1 = w0 + 1;
+          float4 v0[4], v1[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int hh = h0 - 3 + tr0 + rr;
+            const bool row_in = hh >= 0 && hh < H && tr0 + rr < TH + 6;
+            const TX* xr = x + ((n * H + (row_in ? hh : 0)) * static_cast<long>(W)) * C + cbase + l4 * 4;
+            v0[rr] = (row_in && w0 >= 0 && w0 < W) ? load4(xr + static_cast<long>(w0) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v1[rr] = (row_in && w1 >= 0 && w1 < W) ? load4(xr + static_cast<long>(w1) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            if (tr0 + rr >= TH + 6) continue;
+            uint4 d;
+            d.x = pack2_bf16(v0[rr].x, v1[rr].x); d.y = pack2_bf16(v0[rr].y, v1[rr].y);
+            d.z = pack2_bf16(v0[rr].z, v1[rr].z); d.w = pack2_bf16(v0[rr].w, v1[rr].w);
+            *reinterpret_cast<uint4*>(&xt[(static_cast<long>(tr0 + rr) * P2 + m) * kDC + l4 * 4]) = d;
+          }
+        }
+      }
+      const int du = D2 * (kDC / 4);
+      for (int r0 = 0; r0 < TH; r0 += 4) {
+        for (int i = tid; i < du; i += nthr) {
+          const int m = i / (kDC / 4), l4 = i - m * (kDC / 4);
+          const int w0 = 2 * m, w1 = w0 + 1;
+          float4 v0[4], v1[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int hh = h0 + r0 + rr;
+            const bool row_in = hh < H && r0 + rr < TH;
+            const TD* dr = dy + ((n * H + (row_in ? hh : 0)) * static_cast<long>(W)) * C + cbase + l4 * 4;
+            v0[rr] = row_in ? load4(dr + static_cast<long>(w0) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v1[rr] = (row_in && w1 < W) ? load4(dr + static_cast<long>(w1) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            if (r0 + rr >= TH) continue;
+            uint4 d;
+            d.x = pack2_bf16(v0[rr].x, v1[rr].x); d.y = pack2_bf16(v0[rr].y, v1[rr].y);
+            d.z = pack2_bf16(v0[rr].z, v1[rr].z); d.w = pack2_bf16(v0[rr].w, v1[rr].w);
+            *reinterpret_cast<uint4*>(&dt[(static_cast<long>(r0 + rr) * D2 + m) * kDC + l4 * 4]) = d;
+          }
+        }
+      }
+      __syncthreads();
+      if (kh < 7) {
+        for (int r = 0; r < TH; ++r) {
+          const uint32_t* xrow = xt + static_cast<long>(r + kh) * P2 * kDC + lc;
+          const uint32_t* drow = dt + static_cast<long>(r) * D2 * kDC + lc;
+          uint32_t e0 = xrow[0], e1 = xrow[kDC], e2 = xrow[2 * kDC], e3 = xrow[3 * kDC];
+          for (int m = 0; m < D2; ++m) {
+            const uint32_t d = drow[m * kDC];
+            const uint32_t o0 = __builtin_amdgcn_alignbit(e1, e0, 16), o1 = __builtin_amdgcn_alignbit(e2, e1, 16),
+                           o2 = __builtin_amdgcn_alignbit(e3, e2, 16);
+            acc[0] = dot2(d, e0, acc[0]); acc[1] = dot2(d, o0, acc[1]); acc[2] = dot2(d, e1, acc[2]);
+            acc[3] = dot2(d, o1, acc[3]); acc[4] = dot2(d, e2, acc[4]); acc[5] = dot2(d, o2, acc[5]);
+            acc[6] = dot2(d, e3, acc[6]);
+            if (kh == 3) accb = dot2(d, ones, accb);
+            e0 = e1; e1 = e2; e2 = e3;
+            e3 = (m + 4 < P2) ? xrow[(m + 4) * kDC] : 0u;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (kh < 7) {
+    float* pw = ws + static_cast<long>(blockIdx.x) * 50 * C + cbase + lc;
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) pw[(kh * 7 + kw) * C] = acc[kw];
+    if (kh == 3) pw[49 * C] = accb;
+  }
+}
+
 // out[j] = sum_p ws[p*len + j]: 64 outputs per block, the parts split over 4 thread groups whose
 // partial sums are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ ws, float* __restrict__ out0,
@@ -764,13 +876,43 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
   if (C % 4 != 0) return APGD_ERR_ARG;
   if ((x_dtype != APGD_F32 && x_dtype != APGD_BF16) || (dy_dtype != APGD_F32 && dy_dtype != APGD_BF16))
     return APGD_ERR_DTYPE;
+  hipStream_t s = as_stream(stream);
+  if (N == 0) return APGD_OK;
+  if (dy_dtype == APGD_BF16 && C % kDC == 0 && W <= 128) {
+    // autocast path: bf16 output gradient; an fp32 x is rounded to bf16 (as the convolution itself did); packed dot products
+    const int D2 = (W + 1) / 2, P2 = D2 + 3;
+    int th = H < 8 ? H : 8;
+    auto lds_of = [&](int rows) { return (static_cast<size_t>(rows + 6) * P2 + static_cast<size_t>(rows) * D2) * kDC * 4; };
+    while (th > 1 && lds_of(th) > 56 * 1024) --th;
+    const int tiles_h = (H + th - 1) / th;
+    int imgs = H * W >= 784 ? 1 : (H * W >= 196 ? 2 : 4);
+    while ((N + imgs - 1) / imgs > kWgradBlocks) ++imgs;
+    const int nparts = static_cast<int>((N + imgs - 1) / imgs);
+    const dim3 grid(nparts, C / kDC), block(256);
+#define WGD_LAUNCH(TX, TD)                                                                                            \
+  {                                                                                                                   \
+    auto kfn = dwconv7x7_wgrad_dot2_kernel<TX, TD>;                                                                   \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, grid, block, lds_of(th), s, static_cast<const TX*>(x), static_cast<const TD*>(dy), ws,     \
+                       static_cast<long>(N), H, W, C, th, tiles_h, imgs);                                              \
+  }
+    if (x_dtype == APGD_F32) WGD_LAUNCH(float, uint16_t)
+    else WGD_LAUNCH(uint16_t, uint16_t)
+#undef WGD_LAUNCH
+    const int len = 50 * C;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 63) / 64), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, nparts);
+    return launch_status();
+  }
   const int cc = C < kCC ? C : kCC;
   const int tiles_w = (W + kTW - 1) / kTW;
   const long n_strips = static_cast<long>(N) * H * tiles_w;
   int nb = kWgradBlocks;
   if (n_strips < nb) nb = static_cast<int>(n_strips > 0 ? n_strips : 1);
   const dim3 block(cc / 4, 7), grid(nb, (C + kCC - 1) / kCC);
-  hipStream_t s = as_stream(stream);
 #define WG_LAUNCH(TX, TD)                                                                                   \
   hipLaunchKernelGGL((dwconv7x7_wgrad_kernel<TX, TD>), grid, block, 0, s, static_cast<const TX*>(x),          \
                      static_cast<const TD*>(dy), ws, H, W, C, tiles_w, n_strips)

@@ -75,10 +75,12 @@ def test_dwconv7x7_fwd_bwd_data_wgrad(R, N, C, H, W, xdt, odt):
     xr = xq.clone().requires_grad_()
     (gx,) = torch.autograd.grad(F.conv2d(xr, wm, None, padding=3, groups=C), xr, dym)
     close(dx.permute(0, 3, 1, 2), gx, 1e-4, 1e-4)
-    # filter / bias gradient kernel (fp32 arithmetic on the stored operands)
+    # filter / bias gradient kernel: with a bf16 dy (autocast) an fp32 x is rounded to bf16 like the convolution did
+    # (packed-dot kernel, C % 32 == 0); otherwise fp32 arithmetic on the stored operands
     wr = w.clone().requires_grad_()
     br = b.clone().requires_grad_()
-    gw, gb = torch.autograd.grad(F.conv2d(xq, wr, br, padding=3, groups=C), (wr, br), dyq)
+    xw = bf(xq) if (odt == torch.bfloat16 and C % 32 == 0) else xq
+    gw, gb = torch.autograd.grad(F.conv2d(xw, wr, br, padding=3, groups=C), (wr, br), dyq)
     dw = torch.empty(49, C, device="cuda")
     db = torch.empty(C, device="cuda")
     ws = torch.empty(lib.cnx_dwconv7x7_wgrad_ws_floats(C), device="cuda")
