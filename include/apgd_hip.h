@@ -101,6 +101,16 @@ int apgd_loss_pred(const void* logits, int dtype, int64_t ld,
                    float* loss, uint8_t* pred, void* dlogits,
                    int64_t B, int64_t n_cls, void* stream);
 
+/* a18 targeted DLR — dlr_loss_targeted (autopgd_train_clean.py:106-111), the APGD-T criterion of the
+ * AutoAttack evaluation AA_eval.py drives (:226-239):
+ *     loss = -(z[y] - z[y_target]) / (z_(1) - 0.5 (z_(3) + z_(4)) + 1e-12),   z_(k) = k-th largest logit.
+ * Same conventions as apgd_loss_pred (pred = argmax == y; dlogits nullable = exact gradient of sum(loss));
+ * y_hard, y_target int64 [B]; n_cls >= 4. */
+int apgd_loss_pred_targeted(const void* logits, int dtype, int64_t ld,
+                            const int64_t* y_hard, const int64_t* y_target,
+                            float* loss, uint8_t* pred, void* dlogits,
+                            int64_t B, int64_t n_cls, void* stream);
+
 /* a4-a6 per-sample state machine — autopgd_train_clean.py:296, 319-324, 329-343
  * (+ check_oscillation :116-121).  One thread per sample, no host round trip:
  *   acc &= pred; loss_steps[i] = loss; new_best = loss > loss_best; loss_best = max-update;

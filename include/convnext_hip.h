@@ -26,7 +26,7 @@ extern "C" {
  * rotated filter: with x := d(loss)/d(out) this is the gradient w.r.t. the forward input.
  * bias / add (fp32 [C] / fp32 [N,H,W,C]) may be NULL.  fp32 accumulation.  An all-fp32 call is an exact fp32 stencil;
  * a call with a bf16 operand (x or out) is the autocast convolution: x AND the filter are rounded to bf16 first
- * (packed bf16 dot products, v_dot2c_f32_bf16), as torch.autocast does for F.conv2d. */
+ * (packed bf16 dot products, v_dot2c_f32_bf16),, as the reference run under autocast computes its convolutions. */
 int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const float* bias,
                        const float* add, void* out, int out_dtype,
                        int64_t N, int32_t H, int32_t W, int32_t C, int32_t flip, void* stream);

@@ -176,6 +176,16 @@ def dlr_loss(logits: np.ndarray, y: np.ndarray) -> np.ndarray:
     return (-(num) / den).astype(F32)
 
 
+def dlr_loss_targeted(logits: np.ndarray, y: np.ndarray, y_target: np.ndarray) -> np.ndarray:
+    """``dlr_loss_targeted`` — ``autopgd_train_clean.py:106-111`` (fp32, op by op)."""
+    z = logits.astype(F32)
+    zs = np.sort(z, axis=1)
+    u = np.arange(z.shape[0])
+    num = z[u, y] - z[u, y_target]
+    den = (zs[:, -1] - F32(0.5) * (zs[:, -3] + zs[:, -4])) + F32(1e-12)
+    return (-num / den).astype(F32)
+
+
 def predict(logits: np.ndarray, y: np.ndarray) -> np.ndarray:
     """``argmax(logits) == y`` (first maximal index, as torch CPU), or
     ``== argmax(y)`` for soft labels (``:194-197, 291-294``)."""
@@ -281,8 +291,13 @@ class ApgdTrace:
 
 def apgd_train_oracle(fwd_bwd: Callable, x: np.ndarray, y: np.ndarray, norm: str, eps: float,
                       n_iter: int = 10, loss: str = "ce", soft_labels: bool = False,
-                      keep_trace: bool = False, use_model_loss: bool = False):
+                      keep_trace: bool = False, use_model_loss: bool = False,
+                      y_target: Optional[np.ndarray] = None, x_init: Optional[np.ndarray] = None):
     """numpy restatement of ``apgd_train`` for ``norm in {'Linf','L2'}``.
+
+    ``loss='dlr-targeted'`` with ``y_target`` and a start point ``x_init`` other than the clean image are the two
+    things an AutoAttack-style evaluation adds on top of the reference's loop (which cannot drive them itself,
+    ``:137, 181``); the update / tracking / step-size arithmetic is unchanged.
 
     Returns ``(x_best, acc, loss_best, x_best_adv, trace)``; the first four are
     the reference's return tuple (``:371``).  ``soft_labels`` mirrors
@@ -292,8 +307,10 @@ def apgd_train_oracle(fwd_bwd: Callable, x: np.ndarray, y: np.ndarray, norm: str
     """
     if norm not in ("Linf", "L2"):
         raise ValueError("oracle covers Linf and L2 (SURVEY.md §8 a2, a8)")
-    if loss not in ("ce", "dlr"):
+    if loss not in ("ce", "dlr", "dlr-targeted"):
         raise KeyError(loss)
+    if (loss == "dlr-targeted") != (y_target is not None):
+        raise ValueError("y_target goes with loss='dlr-targeted'")
     x = np.asarray(x, dtype=F32)
     B = x.shape[0]
     eps32 = F32(eps)
@@ -302,9 +319,12 @@ def apgd_train_oracle(fwd_bwd: Callable, x: np.ndarray, y: np.ndarray, norm: str
     def loss_of(logits, li_model):
         if use_model_loss and li_model is not None:
             return np.asarray(li_model, dtype=F32)
+        if loss == "dlr-targeted":
+            return dlr_loss_targeted(logits, y, y_target)
         return ce_loss(logits, y) if loss == "ce" else dlr_loss(logits, y)
 
-    x_adv = np.minimum(np.maximum(x.copy(), F32(0.0)), F32(1.0))      # :135, 141
+    start = x if x_init is None else np.asarray(x_init, dtype=F32)
+    x_adv = np.minimum(np.maximum(start.copy(), F32(0.0)), F32(1.0))  # :135, 141
     x_best = x_adv.copy()                                             # :142
     x_best_adv = x_adv.copy()                                         # :143
     loss_steps = np.zeros((n_iter, B), dtype=F32)                     # :144

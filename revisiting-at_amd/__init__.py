@@ -7,6 +7,8 @@ Drop-in for the ``adv.attack=apgd`` path of nmndeep/revisiting-at
 from . import _lib
 from . import ops, architecture
 from .apgd import apgd_train, checkpoint_schedule, criterion_names
+from . import aa_eval
+from .aa_eval import apgd_attack, run_standard_evaluation, robust_accuracy
 from .wrapped_model import WrappedModel
 from .config import AdvConfig, build_perturb, wrap_model_for_at
 from .architecture import get_new_model, normalize_model

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "apgd_l2_parts": (C.c_int, []),
     "apgd_l2_step_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _p]),
     "apgd_loss_pred": (C.c_int, [_p, C.c_int, _i64, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _p]),
+    "apgd_loss_pred_targeted": (C.c_int, [_p, C.c_int, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "apgd_state_update": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p]),
     "apgd_track_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _p]),
     "apgd_check_imgs_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p]),

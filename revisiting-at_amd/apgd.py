@@ -75,7 +75,8 @@ def _dense_rows(x: torch.Tensor) -> bool:
 LOSS_KIND = {'ce': 0, 'dlr': 1}
 
 
-def _loss_pred(logits: torch.Tensor, y_hard, y_soft, loss_out, pred_out, want_dlogits: bool, kind: int = 0):
+def _loss_pred(logits: torch.Tensor, y_hard, y_soft, loss_out, pred_out, want_dlogits: bool, kind: int = 0,
+               y_target=None):
     """K2: per-sample CE, prediction and d(sum CE)/dlogits (``:113, 181-185, 194-197``).
 
     Kept as a module-level function so tests can substitute recorded losses.
@@ -89,6 +90,12 @@ def _loss_pred(logits: torch.Tensor, y_hard, y_soft, loss_out, pred_out, want_dl
     dl = torch.empty_like(lg) if want_dlogits else None
     if dl is not None and dl.stride() != lg.stride():
         dl = torch.empty_strided(lg.shape, lg.stride(), dtype=lg.dtype, device=lg.device)
+    if kind == 2:                                    # dlr_loss_targeted (:106-111)
+        _lib.check(lib.apgd_loss_pred_targeted(lg.data_ptr(), _lib.dtype_code(lg.dtype),
+                                               lg.stride(0) if lg.shape[0] > 1 else lg.shape[1], y_hard.data_ptr(),
+                                               y_target.data_ptr(), loss_out.data_ptr(), pred_out.data_ptr(), _lib.ptr(dl),
+                                               lg.shape[0], lg.shape[1], _stream_ptr()), "apgd_loss_pred_targeted")
+        return dl
     _lib.check(lib.apgd_loss_pred(lg.data_ptr(), _lib.dtype_code(lg.dtype), lg.stride(0) if lg.shape[0] > 1 else lg.shape[1],
                                   _lib.ptr(y_hard), _lib.ptr(y_soft), kind,
                                   loss_out.data_ptr(), pred_out.data_ptr(), _lib.ptr(dl),
@@ -118,7 +125,7 @@ class ApgdWorkspace:
 
 
 def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace, loss_out, pred_out,
-                   need_grad: bool, kind: int = 0):
+                   need_grad: bool, kind: int = 0, y_target=None):
     """One model call of the attack: forward, K2, and (optionally) the input gradient.
 
     ``autopgd_train_clean.py:174-192`` (first call) and ``:266-287`` (in-loop calls; the last
@@ -128,7 +135,7 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
         x_in.requires_grad_(True)
         with torch.enable_grad():
             logits = model(x_in)
-        dl = _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, True, kind)
+        dl = _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, True, kind, *(() if y_target is None else (y_target,)))
         if dl.shape != logits.shape or dl.dtype != logits.dtype:
             raise _lib.ApgdHipError("dlogits/logits mismatch")
         with ops.input_grad_only():
@@ -141,7 +148,7 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
         return grad
     with torch.no_grad():
         logits = model(x_in)
-    _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, False, kind)
+    _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, False, kind, *(() if y_target is None else (y_target,)))
     return None
 
 
@@ -169,6 +176,15 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
         raise NotImplementedError("loss='dlr' needs hard labels (dlr_loss indexes x[arange, y], :103)")
     if norm not in ('Linf', 'L2'):
         raise NotImplementedError(f"norm={norm!r}: the HIP path covers Linf and L2 (SURVEY.md §8 a2, a8)")
+    return _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=mixup is not None, verbose=verbose)
+
+
+def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, y_target=None, x_init=None):
+    """The device loop shared by ``apgd_train`` and the evaluation attacks (``aa_eval.apgd_attack``).
+
+    ``x_init`` (optional) replaces the clean image as the start point (AutoAttack's random start); the ball stays
+    centred on ``x``.  ``kind`` 2 = targeted DLR with ``y_target``.
+    """
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise _lib.ApgdHipError("apgd_train needs a device (MI355X) tensor; there is no CPU fallback")
     if x.dtype != torch.float32:
@@ -185,7 +201,6 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
     B = x.shape[0]
     E = x[0].numel() if B > 0 else 0
     stream = _stream_ptr()
-    soft = mixup is not None
     if soft:
         y_soft, y_hard = y.detach().to(torch.float32).contiguous(), None
     else:
@@ -193,7 +208,14 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
 
     ws = ApgdWorkspace(x, n_iter, n_rot=3 if n_iter > 1 else 2)
     cur = ws.rot[0]
-    _lib.check(lib.apgd_init_f32(x.data_ptr(), cur.data_ptr(), ws.x_best.data_ptr(), ws.x_best_adv.data_ptr(),
+    start = x
+    if x_init is not None:
+        start = x_init.detach().to(torch.float32)
+        if start.shape != x.shape or start.stride() != x.stride():
+            start = torch.empty_like(x).copy_(x_init)
+    if y_target is not None:
+        y_target = y_target.detach().to(torch.int64).contiguous()
+    _lib.check(lib.apgd_init_f32(start.data_ptr(), cur.data_ptr(), ws.x_best.data_ptr(), ws.x_best_adv.data_ptr(),
                                  x.numel(), stream), "apgd_init_f32")       # :135, 141-143
     alpha = 2.0                                                              # :159
     step_size = torch.full((B,), alpha * eps, device=x.device, dtype=torch.float32)   # :169-170
@@ -203,7 +225,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
         l2_ws = torch.empty(3 * B * lib.apgd_l2_parts(), device=x.device, dtype=torch.float32)
 
     # first forward/backward: acc, loss_best are written directly by the loss kernel (:194-200)
-    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind)
+    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target)
     grad_best = torch.empty_like(grad)                                       # :189
     grad_best.copy_(grad)
     ws.loss_best_last.copy_(ws.loss_best)                                    # :200
@@ -234,7 +256,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
         old, cur = cur, out                                                  # :215, 260 (buffer rotation)
 
         last = i == n_iter - 1
-        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind)   # :266-287
+        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind, y_target)   # :266-287
         if g_new is not None:
             grad = g_new
 

@@ -441,6 +441,73 @@ __global__ __launch_bounds__(kBlock) void dlr_pred_kernel(const T* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------- a18: targeted DLR (dlr_loss_targeted, :106-111)
+//   loss = -(z_y - z_t) / (z_(1) - 0.5 (z_(3) + z_(4)) + 1e-12),  z_(k) = k-th largest logit.
+// Top-4 per row with the same (value desc, index desc) order as above; gradient:
+//   d loss = -(e_y - e_t)/D + N/D^2 (e_i1 - 0.5 e_i3 - 0.5 e_i4).
+struct Top4 { float v[4]; int i[4]; };
+__device__ __forceinline__ void top4_insert(Top4& t, float v, int i) {
+  if (dlr_before(v, i, t.v[3], t.i[3])) {
+    t.v[3] = v; t.i[3] = i;
+#pragma unroll
+    for (int k = 3; k > 0; --k) {
+      if (dlr_before(t.v[k], t.i[k], t.v[k - 1], t.i[k - 1])) {
+        const float fv = t.v[k]; t.v[k] = t.v[k - 1]; t.v[k - 1] = fv;
+        const int fi = t.i[k]; t.i[k] = t.i[k - 1]; t.i[k - 1] = fi;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dlr_targeted_pred_kernel(const T* __restrict__ logits, int64_t ld,
+                                                                   const int64_t* __restrict__ y_hard,
+                                                                   const int64_t* __restrict__ y_target,
+                                                                   float* __restrict__ loss, uint8_t* __restrict__ pred,
+                                                                   T* __restrict__ dlogits, int64_t B, int64_t C) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;
+  if (b >= B) return;
+  const T* z = logits + b * ld;
+  Top4 t; float m = -INFINITY; int am = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { t.v[k] = -INFINITY; t.i[k] = -1 - k; }
+  for (int64_t c = lane; c < C; c += kWave) {
+    const float v = Elt<T>::load(z, c);
+    top4_insert(t, v, static_cast<int>(c));
+    if (v > m) { m = v; am = static_cast<int>(c); }
+  }
+#pragma unroll
+  for (int mk = kWave / 2; mk > 0; mk >>= 1) {
+    float ov[4]; int oi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ov[k] = __shfl_xor(t.v[k], mk, kWave); oi[k] = __shfl_xor(t.i[k], mk, kWave); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) top4_insert(t, ov[k], oi[k]);
+  }
+  wave_argmax(m, am);
+  const int64_t yh = y_hard[b], yt = y_target[b];
+  const bool ok = yh >= 0 && yh < C && yt >= 0 && yt < C;
+  const float zy = ok ? Elt<T>::load(z, yh) : NAN;
+  const float zt = ok ? Elt<T>::load(z, yt) : NAN;
+  const float num = zy - zt;                                                 // :110
+  const float den = (t.v[0] - 0.5f * (t.v[2] + t.v[3])) + 1e-12f;            // :110-111
+  if (lane == 0) { loss[b] = -num / den; pred[b] = static_cast<int64_t>(am) == yh; }
+  if (dlogits) {
+    T* dz = dlogits + b * ld;
+    const float inv = 1.0f / den, nd2 = num * inv * inv;
+    for (int64_t c = lane; c < C; c += kWave) {
+      float gsum = 0.0f;
+      if (c == yh) gsum -= inv;
+      if (c == yt) gsum += inv;
+      if (c == t.i[0]) gsum += nd2;
+      if (c == t.i[2]) gsum -= 0.5f * nd2;
+      if (c == t.i[3]) gsum -= 0.5f * nd2;
+      Elt<T>::store(dz, c, gsum);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- a4-a6: per-sample state machine
 __global__ __launch_bounds__(kBlock) void state_update_kernel(
     const float* __restrict__ loss, const uint8_t* __restrict__ pred, uint8_t* __restrict__ acc,
@@ -728,6 +795,33 @@ int apgd_loss_pred(const void* logits, int dtype, int64_t ld, const int64_t* y_h
     case APGD_F16:
       hipLaunchKernelGGL(ce_pred_kernel<_Float16>, grid, dim3(kBlock), 0, s, static_cast<const _Float16*>(logits), ld,
                          y_hard, y_soft, loss, pred, static_cast<_Float16*>(dlogits), B, n_cls);
+      break;
+    default: return APGD_ERR_DTYPE;
+  }
+  return launch_status();
+}
+
+int apgd_loss_pred_targeted(const void* logits, int dtype, int64_t ld, const int64_t* y_hard, const int64_t* y_target,
+                            float* loss, uint8_t* pred, void* dlogits, int64_t B, int64_t n_cls, void* stream) {
+  if (B < 0 || n_cls <= 0 || ld < n_cls) return APGD_ERR_SIZE;
+  if (B == 0) return APGD_OK;
+  if (!logits || !loss || !pred || !y_hard || !y_target) return APGD_ERR_NULL;
+  if (n_cls < 4) return APGD_ERR_ARG;                                     // :110 indexes the 4th largest logit
+  if (n_cls > 0x7ffffffe) return APGD_ERR_SIZE;
+  hipStream_t s = as_stream(stream);
+  const dim3 grid(static_cast<unsigned>((B + kBlock / kWave - 1) / (kBlock / kWave)));
+  switch (dtype) {
+    case APGD_F32:
+      hipLaunchKernelGGL(dlr_targeted_pred_kernel<float>, grid, dim3(kBlock), 0, s, static_cast<const float*>(logits), ld,
+                         y_hard, y_target, loss, pred, static_cast<float*>(dlogits), B, n_cls);
+      break;
+    case APGD_BF16:
+      hipLaunchKernelGGL(dlr_targeted_pred_kernel<uint16_t>, grid, dim3(kBlock), 0, s, static_cast<const uint16_t*>(logits),
+                         ld, y_hard, y_target, loss, pred, static_cast<uint16_t*>(dlogits), B, n_cls);
+      break;
+    case APGD_F16:
+      hipLaunchKernelGGL(dlr_targeted_pred_kernel<_Float16>, grid, dim3(kBlock), 0, s, static_cast<const _Float16*>(logits),
+                         ld, y_hard, y_target, loss, pred, static_cast<_Float16*>(dlogits), B, n_cls);
       break;
     default: return APGD_ERR_DTYPE;
   }

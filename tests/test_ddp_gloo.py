@@ -108,3 +108,32 @@ def test_optimizer_groups_follow_reference_rules():
     names = {id(p): n for n, p in v.named_parameters()}
     assert {'cls_token', 'pos_embed'} <= {names[id(p)] for p in opt.param_groups[1]['params']}   # ndim 3 -> decayed (main.py:440)
     assert 'blocks.0.norm1.weight' in {names[id(p)] for p in opt.param_groups[0]['params']}
+
+
+def _robust_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import revisiting_at_amd as R
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stats = {"n": 10 + rank, "clean_correct": 8 + rank, "robust": 3 + 2 * rank}
+    q.put((rank, R.aa_eval.robust_accuracy(stats)))
+    dist.destroy_process_group()
+
+
+def test_eval_counts_are_summed_over_ranks():
+    """The evaluation's only exchange (aa_eval.robust_accuracy): one sum of three counts, world_size 2 over gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29621
+    ps = [ctx.Process(target=_robust_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(2):
+        ca, ra = res[r]
+        assert abs(ca - 17 / 21) < 1e-12 and abs(ra - 8 / 21) < 1e-12

@@ -513,3 +513,111 @@ def test_error_behaviour(R):
         R.apgd_train(m, x.cpu(), y.cpu(), norm="Linf", eps=0.1, n_iter=1)    # no CPU fallback
     with pytest.raises(NotImplementedError):
         R.apgd_train(m, x, y, norm="L1", eps=0.1, n_iter=1)                  # L1/L0 are outside the HIP path
+
+
+# ------------------------------------------------------------------------------ evaluation attacks (AA_eval.py path)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dlr_targeted_kernel_vs_reference_vectors(R, lib, dtype):
+    """apgd_loss_pred_targeted vs the reference's own dlr_loss_targeted values / autograd gradients
+    (tests/golden/loss_dlr_vectors.npz): fp32 bit-exact loss, gradient to 1e-5; bf16 logits vs the oracle on the
+    rounded logits."""
+    import os
+    from conftest import ROOT
+    v = np.load(os.path.join(ROOT, "tests", "golden", "loss_dlr_vectors.npz"))
+    for tag in "abc":
+        z, y, yt = v[f"{tag}_z"], v[f"{tag}_y"], v[f"{tag}_yt"]
+        B, C = z.shape
+        zt = dev(z).to(dtype)
+        loss = torch.empty(B, device="cuda")
+        pred = torch.empty(B, device="cuda", dtype=torch.uint8)
+        dl = torch.empty_like(zt)
+        assert lib.apgd_loss_pred_targeted(zt.data_ptr(), R._lib.dtype_code(dtype), C, dev(y).data_ptr(), dev(yt).data_ptr(),
+                                           loss.data_ptr(), pred.data_ptr(), dl.data_ptr(), B, C, S()) == 0
+        zf = zt.float().cpu().numpy()
+        assert bits_equal(loss.cpu().numpy(), O.dlr_loss_targeted(zf, y, yt))
+        assert np.array_equal(pred.cpu().numpy().astype(bool), O.predict(zf, y))
+        if dtype == torch.float32:
+            assert bits_equal(loss.cpu().numpy(), v[f"{tag}_dlr_t"])
+            g = v[f"{tag}_dlr_t_grad"]
+            np.testing.assert_allclose(dl.cpu().numpy(), g, rtol=1e-5, atol=1e-5 * float(np.abs(g).max()))
+    assert lib.apgd_loss_pred_targeted(zt.data_ptr(), 0, 3, dev(y).data_ptr(), dev(yt).data_ptr(), loss.data_ptr(),
+                                       pred.data_ptr(), None, 1, 3, S()) == -4            # needs >= 4 classes
+
+
+def test_apgd_attack_targeted_random_start_matches_oracle(R):
+    """aa_eval.apgd_attack (random start, targeted DLR, 12 iterations) vs the numpy oracle fed the SAME start point and
+    the logits / input gradients the device model produced: bit-exact iterates and outputs."""
+    torch.manual_seed(5)
+    m = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 8 * 8, 32), torch.nn.Tanh(), torch.nn.Linear(32, 10)).cuda().eval()
+    B, K, eps = 9, 12, 8 / 255
+    x = torch.rand(B, 3, 8, 8, device="cuda")
+    y = torch.randint(0, 10, (B,), device="cuda")
+    with torch.no_grad():
+        order = m(x).argsort(dim=1, descending=True)
+    yt = torch.where(order[:, 1] == y, order[:, 0], order[:, 1])
+    rec = {"logits": [], "grads": []}
+
+    class Tap(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            rec["grads"].append(g.detach().float().cpu().numpy())
+            return g
+
+    class Rec(torch.nn.Module):
+        def forward(self, t):
+            out = m(Tap.apply(t) if t.requires_grad else t)
+            rec["logits"].append(out.detach().float().cpu().numpy())
+            return out
+
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x0 = R.aa_eval.random_start(x, eps, "Linf", torch.Generator(device="cuda").manual_seed(11))
+    assert float((x0 - x).abs().amax()) <= eps * (1 + 1e-6)
+    assert torch.allclose((x0 - x).reshape(B, -1).abs().amax(1), torch.full((B,), eps, device="cuda"), rtol=1e-5)
+    xba, acc, lb, xb = R.aa_eval.apgd_attack(Rec().eval(), x, y, "Linf", eps, K, "dlr-targeted", yt, True, gen)
+    torch.cuda.synchronize()
+    rep = O.ReplayModel(np.stack(rec["logits"]), np.stack(rec["grads"]))
+    oxb, oacc, olb, oxba, _ = O.apgd_train_oracle(rep, x.cpu().numpy(), y.cpu().numpy(), "Linf", eps, K, loss="dlr-targeted",
+                                                  y_target=yt.cpu().numpy(), x_init=x0.cpu().numpy())
+    assert bits_equal(xb.cpu().numpy(), oxb) and bits_equal(xba.cpu().numpy(), oxba)
+    assert np.array_equal(acc.cpu().numpy(), oacc) and bits_equal(lb.cpu().numpy(), olb)
+    with pytest.raises(ValueError):
+        R.aa_eval.apgd_attack(m, x, y, loss="dlr-targeted")
+    with pytest.raises(KeyError):
+        R.aa_eval.apgd_attack(m, x, y, loss="nope")
+
+
+def test_run_standard_evaluation_invariants_and_sharding(R):
+    """AA_eval.py's caller shape: host tensors in, APGD-CE + APGD-T on still-robust points only, adversarials inside the
+    ball, flags consistent with the model's predictions, shards rank::world cover the set exactly once."""
+    torch.manual_seed(2)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, 2, 1), torch.nn.GELU(), torch.nn.Flatten(),
+                            torch.nn.Linear(8 * 8 * 8, 12)).cuda().eval()
+    n, eps = 26, 8 / 255
+    x = torch.rand(n, 3, 16, 16)
+    with torch.no_grad():
+        y = m(x.cuda()).argmax(1).cpu()
+    y[::5] = (y[::5] + 1) % 12                                    # some clean errors
+    tot = {"n": 0, "clean_correct": 0, "robust": 0}
+    for rank in range(2):
+        x_adv, st = R.aa_eval.run_standard_evaluation(m, x, y, bs=7, eps=eps, n_iter=10, n_target_classes=3, seed=1, rank=rank,
+                                                      world=2, device="cuda")
+        xs, ys = x[rank::2], y[rank::2]
+        assert x_adv.shape == xs.shape and st["n"] == xs.shape[0]
+        assert float((x_adv - xs).abs().max()) <= eps * (1 + 1e-6) + 1e-7 and float(x_adv.min()) >= 0 and float(x_adv.max()) <= 1
+        with torch.no_grad():
+            clean_ok = (m(xs.cuda()).argmax(1).cpu() == ys)
+            adv_ok = (m(x_adv.cuda()).argmax(1).cpu() == ys)
+        assert st["clean_correct"] == int(clean_ok.sum())
+        assert st["robust"] == int((clean_ok & adv_ok).sum())           # broken points carry a misclassified iterate
+        assert torch.equal(x_adv[~clean_ok], xs[~clean_ok])             # never attacked
+        for k in tot:
+            tot[k] += st[k]
+    assert tot["n"] == n and tot["robust"] <= tot["clean_correct"] <= n
+    ca, ra = R.aa_eval.robust_accuracy(tot)
+    assert abs(ca - tot["clean_correct"] / n) < 1e-12 and abs(ra - tot["robust"] / n) < 1e-12
+    with pytest.raises(NotImplementedError):
+        R.aa_eval.run_standard_evaluation(m, x, y, attacks_to_run=("square",), device="cuda")

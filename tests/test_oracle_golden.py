@@ -105,3 +105,52 @@ def test_dlr_loss_bit_exact_and_tie_order():
     z = np.array([[1.0, 3.0, 3.0, 0.0]], np.float32)
     assert O.dlr_loss(z, np.array([2]))[0] == np.float32(-(3.0 - 3.0) / (3.0 - 1.0 + 1e-12))
     assert O.dlr_loss(z, np.array([1]))[0] == np.float32(-(3.0 - 3.0) / (3.0 - 1.0 + 1e-12))
+
+
+def test_dlr_criteria_match_reference_vectors():
+    """oracle.dlr_loss / dlr_loss_targeted vs values the reference's own functions produced
+    (tests/golden/make_loss_golden.py -> loss_dlr_vectors.npz): bit-exact (they are +,-,*,/ on fp32)."""
+    import os
+    from conftest import ROOT
+    v = np.load(os.path.join(ROOT, "tests", "golden", "loss_dlr_vectors.npz"))
+    for tag in "abc":
+        z, y, yt = v[f"{tag}_z"], v[f"{tag}_y"], v[f"{tag}_yt"]
+        assert bits_equal(O.dlr_loss_targeted(z, y, yt), v[f"{tag}_dlr_t"])
+        assert bits_equal(O.dlr_loss(z, y), v[f"{tag}_dlr"])
+
+
+def test_oracle_targeted_attack_with_start_point_keeps_invariants():
+    """The evaluation extras of the oracle (targeted DLR, explicit start point) on a toy linear model: the ball and
+    box invariants hold and the targeted loss of the returned best point is not below the start point's."""
+    rng = np.random.default_rng(3)
+    B, E, C = 6, 48, 10
+    W = rng.standard_normal((E, C)).astype(np.float32)
+    x = rng.random((B, E)).astype(np.float32)
+    y = rng.integers(0, C, B)
+    yt = (y + 1 + rng.integers(0, C - 1, B)) % C
+    eps = 8 / 255
+    x0 = np.clip(x + eps * (2 * rng.random((B, E)).astype(np.float32) - 1), 0, 1).astype(np.float32)
+
+    def fwd_bwd(xa, need_grad):
+        z = xa @ W
+        if not need_grad:
+            return z, None, None
+        zs = np.sort(z, axis=1)
+        den = (zs[:, -1] - 0.5 * (zs[:, -3] + zs[:, -4])) + 1e-12
+        u = np.arange(B)
+        num = z[u, y] - z[u, yt]
+        dz = np.zeros_like(z)
+        dz[u, y] -= 1 / den
+        dz[u, yt] += 1 / den
+        i1, i3, i4 = np.argsort(z, axis=1)[:, -1], np.argsort(z, axis=1)[:, -3], np.argsort(z, axis=1)[:, -4]
+        dz[u, i1] += num / den ** 2
+        dz[u, i3] -= 0.5 * num / den ** 2
+        dz[u, i4] -= 0.5 * num / den ** 2
+        return z, (dz @ W.T).astype(np.float32), None
+
+    xb, acc, lb, xba, _ = O.apgd_train_oracle(fwd_bwd, x, y, "Linf", eps, 20, loss="dlr-targeted", y_target=yt, x_init=x0)
+    mx, n_nan, lo, hi = O.check_imgs(xb, x, "Linf", eps)
+    assert n_nan == 0 and lo >= 0 and hi <= 1 and mx <= eps * (1 + 1e-6) + 1e-7
+    assert (lb >= O.dlr_loss_targeted(x0 @ W, y, yt) - 1e-6).all()
+    with pytest.raises(ValueError):
+        O.apgd_train_oracle(fwd_bwd, x, y, "Linf", eps, 2, loss="dlr-targeted")
