@@ -88,6 +88,17 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       void* a_out, void* do_out, void* ht_out, void* dhpt_out,
                       int64_t M, int32_t C, void* stream);
 
+/* Fused multi-head softmax attention of the ViT family (timm 0.8 `Attention.forward`, reached through the models of
+ * /root/reference/utils_architecture.py:272-301):
+ *     q, k, v = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4);   out = softmax(q k^T * scale) v
+ * qkv [B, N, 3*H*d] bf16 (the packed projection, token-major), out [B, N, H*d] bf16, lse (nullable) [B, H, N] fp32 =
+ * log-sum-exp of the scaled scores per query (saved for the backward).  One workgroup per (batch, head); K and V of
+ * the head stay in LDS, the N x N scores stay in MFMA accumulators (bf16 MFMA, fp32 softmax).
+ * cnx_attention_supported(N, d): d == 64 and N <= 416 (197 tokens @224, 401 @320). */
+int cnx_attention_supported(int32_t N, int32_t head_dim);
+int cnx_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int32_t N, int32_t H, int32_t head_dim,
+                      float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,11 +449,55 @@ def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
     return x + y.permute(0, 3, 1, 2)
 
 
+class _AttentionFused(torch.autograd.Function):
+    """Packed ``[B,N,3C]`` bf16 projection -> ``[B,N,C]`` attention output through ``cnx_attention_fwd`` (one workgroup
+    per (batch, head), K/V in LDS, scores in MFMA accumulators).  Saved for backward: qkv and the per-row log-sum-exp;
+    the backward rebuilds the probabilities from them (library GEMMs for now — the forward is what the 4 no-grad /
+    eval passes of an AT step run)."""
+
+    @staticmethod
+    def forward(ctx, qkv, num_heads, scale):
+        lib = _lib.load()
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        qkv = qkv.contiguous()
+        out = torch.empty(B, N, C, device=qkv.device, dtype=torch.bfloat16)
+        need_grad = ctx.needs_input_grad[0]
+        lse = torch.empty(B, num_heads, N, device=qkv.device, dtype=torch.float32) if need_grad else None
+        _lib.check(lib.cnx_attention_fwd(qkv.data_ptr(), out.data_ptr(), _lib.ptr(lse), B, N, num_heads, C // num_heads,
+                                         float(scale), _stream()), "cnx_attention_fwd")
+        if need_grad:
+            ctx.save_for_backward(qkv, lse)
+            ctx.num_heads, ctx.scale = num_heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, lse = ctx.saved_tensors
+        B, N, C3 = qkv.shape
+        C, h = C3 // 3, ctx.num_heads
+        q, k, v = qkv.reshape(B, N, 3, h, C // h).permute(2, 0, 3, 1, 4).unbind(0)        # [B,h,N,d]
+        do_ = do.reshape(B, N, h, C // h).permute(0, 2, 1, 3).to(torch.bfloat16)
+        # scores in fp32: a bf16 GEMM output would round them (|s| ~ 10) by ~0.05, i.e. 5 % in the probabilities
+        p = torch.exp((q.float() @ k.float().transpose(-2, -1)) * ctx.scale - lse.unsqueeze(-1))   # [B,h,N,N] fp32
+        pb = p.to(torch.bfloat16)
+        dv = pb.transpose(-2, -1) @ do_
+        dp = (do_ @ v.transpose(-2, -1)).float()
+        ds = (p * (dp - (dp * p).sum(-1, keepdim=True)) * ctx.scale).to(torch.bfloat16)
+        dq = ds @ k
+        dk = ds.transpose(-2, -1) @ q
+        dqkv = torch.stack((dq, dk, dv), 0).permute(1, 3, 0, 2, 4).reshape(B, N, C3)
+        return dqkv, None, None
+
+
 def attention(qkv, num_heads, scale):
     """Multi-head softmax attention from a packed ``[B,N,3C]`` projection -> ``[B,N,C]``
     (timm 0.8 ``Attention.forward``)."""
     B, N, C3 = qkv.shape
     C = C3 // 3
+    if (MODE != "eager" and qkv.is_cuda and qkv.dtype == torch.bfloat16
+            and _lib.load().cnx_attention_supported(N, C // num_heads)):
+        return _AttentionFused.apply(qkv, num_heads, float(scale))
     q, k, v = qkv.reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)
     a = ((q @ k.transpose(-2, -1)) * scale).softmax(dim=-1)
     return (a @ v).transpose(1, 2).reshape(B, N, C)

@@ -346,3 +346,35 @@ def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt)
                                  R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), da.data_ptr(),
                                  None, None, None, M_, C, S()) == -1          # emit pointers: all four or none
     assert lib.cnx_block_mlp_bwd_supported(384) == 0
+
+
+@pytest.mark.parametrize("N", [1, 5, 32, 33, 197, 224, 401])
+@pytest.mark.parametrize("B,H", [(2, 3), (1, 12)])
+def test_fused_attention_forward_and_backward_vs_fp32_reference(R, N, B, H):
+    """cnx_attention_fwd (K/V in LDS, scores in MFMA accumulators) vs fp32 torch attention on the same bf16 qkv; the
+    autograd wrapper's backward vs fp32 autograd.  Bar: bf16 <= 1e-2 relative (north_star)."""
+    lib = R._lib.load()
+    d = 64
+    C = H * d
+    g = torch.Generator().manual_seed(N * 31 + H)
+    qkv = (torch.randn(B, N, 3 * C, generator=g) * 1.5).to(torch.bfloat16)
+    scale = d ** -0.5
+    qr = qkv.float().requires_grad_()
+    q, k, v = qr.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).unbind(0)
+    sc = (q @ k.transpose(-2, -1)) * scale
+    ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(B, N, C)
+    assert lib.cnx_attention_supported(N, d) == 1 and lib.cnx_attention_supported(N, 32) == 0
+    qd = qkv.cuda().requires_grad_()
+    out = R.ops.attention(qd, H, scale)
+    assert out.dtype == torch.bfloat16 and out.shape == (B, N, C)
+    err = float((out.float().cpu() - ref).norm() / ref.norm())
+    assert err < 8e-3, err
+    lse = torch.empty(B, H, N, device="cuda")
+    o2 = torch.empty(B, N, C, device="cuda", dtype=torch.bfloat16)
+    assert lib.cnx_attention_fwd(qd.data_ptr(), o2.data_ptr(), lse.data_ptr(), B, N, H, d, scale, S()) == 0
+    close(lse, torch.logsumexp(sc, dim=-1), 2e-3, 2e-3)
+    cot = torch.randn(B, N, C, generator=g)
+    (gr,) = torch.autograd.grad(ref, qr, cot)
+    (gd,) = torch.autograd.grad(out, qd, cot.cuda().to(torch.bfloat16))
+    assert float((gd.float().cpu() - gr).norm() / gr.norm()) < 1.5e-2
+    assert lib.cnx_attention_fwd(qd.data_ptr(), o2.data_ptr(), None, B, 500, H, d, scale, S()) == -4     # N too long
