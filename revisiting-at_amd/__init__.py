@@ -13,6 +13,8 @@ from .wrapped_model import WrappedModel
 from .config import AdvConfig, build_perturb, wrap_model_for_at
 from .architecture import get_new_model, normalize_model
 from .train_step import ATTrainStep, create_optimizer, setup_distributed
+from . import mixup, checkpoint
+from .mixup import Mixup, SoftTargetCrossEntropy
 
 __version__ = "0.1.0"
 __all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "WrappedModel", "AdvConfig",

@@ -105,6 +105,7 @@ class ATTrainStep:
             if soft_targets else nn.CrossEntropyLoss()                     # SoftTargetCrossEntropy / CE (main.py:461-466)
         self.amp_dtype = amp_dtype
         self.lr = lr
+        self.mixup_fn = mixup if callable(mixup) else None                # timm-style Mixup object (main.py:599-607)
         if self.perturb:
             self.inner.set_perturb(True)                                   # main.py:950-954
         self.model.train()
@@ -112,6 +113,8 @@ class ATTrainStep:
     def step(self, images, target, lr: Optional[float] = None):
         for g in self.optimizer.param_groups:                              # main.py:973-974
             g['lr'] = self.lr if lr is None else lr
+        if self.mixup_fn is not None:
+            images, target = self.mixup_fn(images, target)                 # main.py:965-966 (soft labels [B, n_cls])
         self.optimizer.zero_grad(set_to_none=True)                         # main.py:984
         with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             output = self.model(images, target) if self.perturb else self.model(images)   # main.py:985-989
