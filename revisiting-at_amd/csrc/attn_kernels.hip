@@ -159,6 +159,251 @@ __global__ __launch_bounds__(256, (NKB <= 7 ? 2 : 1)) void attn_fwd_kernel(const
   }
 }
 
+// =====================================================================================================================
+// Backward.  With P = exp(S*scale - lse) (lse saved by the forward) no second softmax pass is needed and both kernels
+// stream 32x32 blocks of the score matrix through 32 accumulator registers:
+//     D_q   = sum_d dO[q][d] O[q][d]
+//     dV    = P^T dO            dP = dO V^T           dS = P * (dP - D_q) * scale
+//     dQ    = dS K              dK = dS^T Q
+// A contraction over keys needs "lane = query, registers = keys" (the S^T orientation), one over queries needs
+// "lane = key, registers = queries" (the S orientation); the MFMA accumulator gives whichever is asked for by swapping
+// the operands, so there are two kernels:
+//   attn_bwd_dq_kernel  : wavefront = 32 queries, loops over key blocks:   S^T, dP^T -> dS -> dQ += dS K      (+ writes D_q)
+//   attn_bwd_dkv_kernel : wavefront = 32 keys,    loops over query blocks: S, dP -> P, dS -> dV += P^T dO, dK += dS^T Q
+// Operand images in LDS are the two kinds of the forward: "row" images (lane = row, 8 consecutive d: A/B operands of a
+// contraction over d) and "transposed" images (lane = d, registers = rows in accumulator order: B operands of a
+// contraction over rows).
+// ---------------------------------------------------------------------------------------------------------------------
+// stage NKB*32 rows x 64 d of `src` (row stride `stride` elements) as a row image; rows >= N are zero
+template <int NKB>
+__device__ __forceinline__ void stage_rows(unsigned char* img, const uint16_t* src, long stride, int N, int tid) {
+  for (int c = tid; c < NKB * 32 * (kD / 8); c += 256) {
+    const int k = c >> 3, d8 = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (k < N) v = *reinterpret_cast<const uint4*>(src + k * stride + d8 * 8);
+    *reinterpret_cast<uint4*>(img + ((((k >> 5) * kKS + (d8 >> 1)) * 64) + (d8 & 1) * 32 + (k & 31)) * 16) = v;
+  }
+}
+// the same rows as a transposed image: img[(blk, t, db)][lane = half*32 + d%32][e] = src[blk*32 + (e&3) + 8*(2t + (e>>2)) + 4*half][db*32 + d%32]
+template <int NKB>
+__device__ __forceinline__ void stage_transposed(uint16_t* img, const uint16_t* src, long stride, int N, int tid) {
+  for (int c = tid; c < NKB * 32 * (kD / 8); c += 256) {
+    const int k = c >> 3, d8 = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (k < N) v = *reinterpret_cast<const uint4*>(src + k * stride + d8 * 8);
+    const int blk = k >> 5, kk = k & 31;
+    const int vh = (kk >> 2) & 1, t = kk >> 4, e = (kk & 3) + 4 * ((kk >> 3) & 1);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = d8 * 8 + j;
+      img[((((blk * 2 + t) * kDB + (d >> 5)) * 64) + vh * 32 + (d & 31)) * 8 + e] =
+          static_cast<uint16_t>((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+    }
+  }
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <int NKB>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+                                                             const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             uint16_t* __restrict__ dqkv, float* __restrict__ dvec, int N, int H,
+                                                             float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* kr = lds;                                            // K row image
+  unsigned char* vr = lds + NKB * kKS * 1024;                         // V row image
+  uint16_t* kt = reinterpret_cast<uint16_t*>(lds + 2 * NKB * kKS * 1024);   // K transposed image
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long ts = 3L * H * kD, os = static_cast<long>(H) * kD;
+  const uint16_t* qb = qkv + static_cast<long>(b) * N * ts + h * kD;
+  const uint16_t* kb_ = qb + os;
+  const uint16_t* vb = qb + 2 * os;
+  const uint16_t* ob = o + static_cast<long>(b) * N * os + h * kD;
+  const uint16_t* dob = dout + static_cast<long>(b) * N * os + h * kD;
+  stage_rows<NKB>(kr, kb_, ts, N, tid);
+  stage_rows<NKB>(vr, vb, ts, N, tid);
+  stage_transposed<NKB>(kt, kb_, ts, N, tid);
+  __syncthreads();
+  const float c2 = scale * 1.4426950408889634f;
+  const unsigned char* krf = kr + lane * 16;
+  const unsigned char* vrf = vr + lane * 16;
+  const uint16_t* ktf = kt + lane * 8;
+  const int nqb = (N + 31) / 32;
+  for (int qblk = wave; qblk < nqb; qblk += 4) {
+    asm volatile("" : "+v"(krf), "+v"(vrf), "+v"(ktf));
+    int q = qblk * 32 + l32;
+    const bool q_ok = q < N;
+    if (!q_ok) q = N - 1;
+    bf16x8 qf[kKS], dof[kKS];
+    float dq_part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qb + q * ts + ks * 16 + half * 8);
+      const uint4 dv4 = *reinterpret_cast<const uint4*>(dob + q * os + ks * 16 + half * 8);
+      const uint4 ov4 = *reinterpret_cast<const uint4*>(ob + q * os + ks * 16 + half * 8);
+      dof[ks] = __builtin_bit_cast(bf16x8, dv4);
+      const uint32_t a[4] = {dv4.x, dv4.y, dv4.z, dv4.w}, c[4] = {ov4.x, ov4.y, ov4.z, ov4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dq_part += bf_lo(a[j]) * bf_lo(c[j]) + bf_hi(a[j]) * bf_hi(c[j]);
+    }
+    const float Dq = dq_part + __shfl_xor(dq_part, 32, 64);
+    const float l2 = lse[(static_cast<long>(b) * H + h) * N + q] * 1.4426950408889634f;
+    if (q_ok && half == 0) dvec[(static_cast<long>(b) * H + h) * N + q] = Dq;
+    f32x16 dq[kDB];
+#pragma unroll
+    for (int db = 0; db < kDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+#pragma unroll 1
+    for (int kblk = 0; kblk < NKB; ++kblk) {
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < kKS; ++ks) {
+        const bf16x8 ka = *reinterpret_cast<const bf16x8*>(krf + (kblk * kKS + ks) * 1024);
+        const bf16x8 va = *reinterpret_cast<const bf16x8*>(vrf + (kblk * kKS + ks) * 1024);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpt, 0, 0, 0);
+      }
+      uint32_t pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int key = kblk * 32 + ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * half;
+          const float pv = key < N ? __builtin_amdgcn_exp2f(fmaf(st[r + u], c2, -l2)) : 0.f;
+          ds[u] = pv * (dpt[r + u] - Dq) * scale;
+        }
+        pk[r >> 1] = pack_bf16(ds[0], ds[1]);
+      }
+      const bf16x8 dsf[2] = {__builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3])),
+                             __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]))};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int db = 0; db < kDB; ++db) {
+          const bf16x8 kb8 = *reinterpret_cast<const bf16x8*>(ktf + ((kblk * 2 + t) * kDB + db) * 512);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[t], kb8, dq[db], 0, 0, 0);
+        }
+    }
+    uint16_t* dqb = dqkv + static_cast<long>(b) * N * ts + h * kD;
+#pragma unroll
+    for (int db = 0; db < kDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qr = qblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (qr < N) dqb[static_cast<long>(qr) * ts + db * 32 + l32] = static_cast<uint16_t>(pack_bf16(dq[db][r], 0.f));
+      }
+  }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse, const float* __restrict__ dvec,
+                                                              uint16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int IMG = NKB * kKS * 1024;
+  unsigned char* qr_ = lds;                                           // Q row image
+  unsigned char* dor = lds + IMG;                                     // dO row image
+  uint16_t* qt = reinterpret_cast<uint16_t*>(lds + 2 * IMG);          // Q transposed
+  uint16_t* dot_ = reinterpret_cast<uint16_t*>(lds + 3 * IMG);        // dO transposed
+  float* lse_s = reinterpret_cast<float*>(lds + 4 * IMG);             // [NKB*32] lse * log2(e)
+  float* dv_s = lse_s + NKB * 32;                                     // [NKB*32] D_q
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long ts = 3L * H * kD, os = static_cast<long>(H) * kD;
+  const uint16_t* qb = qkv + static_cast<long>(b) * N * ts + h * kD;
+  const uint16_t* kb_ = qb + os;
+  const uint16_t* vb = qb + 2 * os;
+  const uint16_t* dob = dout + static_cast<long>(b) * N * os + h * kD;
+  stage_rows<NKB>(qr_, qb, ts, N, tid);
+  stage_rows<NKB>(dor, dob, os, N, tid);
+  stage_transposed<NKB>(qt, qb, ts, N, tid);
+  stage_transposed<NKB>(dot_, dob, os, N, tid);
+  for (int i = tid; i < NKB * 32; i += 256) {
+    lse_s[i] = i < N ? lse[(static_cast<long>(b) * H + h) * N + i] * 1.4426950408889634f : INFINITY;   // exp2(-inf) = 0: padded queries
+    dv_s[i] = i < N ? dvec[(static_cast<long>(b) * H + h) * N + i] : 0.f;
+  }
+  __syncthreads();
+  const float c2 = scale * 1.4426950408889634f;
+  const unsigned char* qrf = qr_ + lane * 16;
+  const unsigned char* dorf = dor + lane * 16;
+  const uint16_t* qtf = qt + lane * 8;
+  const uint16_t* dotf = dot_ + lane * 8;
+  const int nkb = (N + 31) / 32;
+  for (int kblk = wave; kblk < nkb; kblk += 4) {
+    asm volatile("" : "+v"(qrf), "+v"(dorf), "+v"(qtf), "+v"(dotf));
+    int k = kblk * 32 + l32;
+    if (k >= N) k = N - 1;                                            // results of padded keys are never stored
+    bf16x8 kf[kKS], vf[kKS];
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kb_ + k * ts + ks * 16 + half * 8);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vb + k * ts + ks * 16 + half * 8);
+    }
+    f32x16 dk[kDB], dv[kDB];
+#pragma unroll
+    for (int db = 0; db < kDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+#pragma unroll 1
+    for (int qblk = 0; qblk < NKB; ++qblk) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < kKS; ++ks) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qrf + (qblk * kKS + ks) * 1024);
+        const bf16x8 da = *reinterpret_cast<const bf16x8*>(dorf + (qblk * kKS + ks) * 1024);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sc, 0, 0, 0);      // D[i = q][j = k]: lane = key
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+      }
+      uint32_t pp[8], pd[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float pv[2], ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int qi = qblk * 32 + ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * half;
+          pv[u] = __builtin_amdgcn_exp2f(fmaf(sc[r + u], c2, -lse_s[qi]));
+          ds[u] = pv[u] * (dp[r + u] - dv_s[qi]) * scale;
+        }
+        pp[r >> 1] = pack_bf16(pv[0], pv[1]);
+        pd[r >> 1] = pack_bf16(ds[0], ds[1]);
+      }
+      const bf16x8 pf[2] = {__builtin_bit_cast(bf16x8, make_uint4(pp[0], pp[1], pp[2], pp[3])),
+                            __builtin_bit_cast(bf16x8, make_uint4(pp[4], pp[5], pp[6], pp[7]))};
+      const bf16x8 dsf[2] = {__builtin_bit_cast(bf16x8, make_uint4(pd[0], pd[1], pd[2], pd[3])),
+                             __builtin_bit_cast(bf16x8, make_uint4(pd[4], pd[5], pd[6], pd[7]))};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int db = 0; db < kDB; ++db) {
+          const bf16x8 dob8 = *reinterpret_cast<const bf16x8*>(dotf + ((qblk * 2 + t) * kDB + db) * 512);
+          const bf16x8 qb8 = *reinterpret_cast<const bf16x8*>(qtf + ((qblk * 2 + t) * kDB + db) * 512);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[t], dob8, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[t], qb8, dk[db], 0, 0, 0);
+        }
+    }
+    uint16_t* dkb = dqkv + static_cast<long>(b) * N * ts + os + h * kD;
+    uint16_t* dvb = dkb + os;
+#pragma unroll
+    for (int db = 0; db < kDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr2 = kblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (kr2 < N) {
+          dkb[static_cast<long>(kr2) * ts + db * 32 + l32] = static_cast<uint16_t>(pack_bf16(dk[db][r], 0.f));
+          dvb[static_cast<long>(kr2) * ts + db * 32 + l32] = static_cast<uint16_t>(pack_bf16(dv[db][r], 0.f));
+        }
+      }
+  }
+}
+
 template <int NKB>
 int launch_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, int N, int H, float scale, hipStream_t s) {
   const size_t lds = static_cast<size_t>(NKB) * (kKS + 2 * kDB) * 1024;
@@ -191,6 +436,36 @@ int cnx_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int32_t
   auto* o = static_cast<uint16_t*>(out);
   if (N <= 224) return launch_attn_fwd<7>(q, o, lse, B, N, H, scale, s);
   return launch_attn_fwd<13>(q, o, lse, B, N, H, scale, s);
+}
+
+int cnx_attention_bwd_supported(int32_t N, int32_t head_dim) { return (head_dim == kD && N >= 1 && N <= 224) ? 1 : 0; }
+
+int cnx_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dvec,
+                      int64_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream) {
+  if (B < 0 || N <= 0 || H <= 0) return APGD_ERR_SIZE;
+  if (B == 0) return APGD_OK;
+  if (!qkv || !out || !dout || !lse || !dqkv || !dvec) return APGD_ERR_NULL;
+  if (!cnx_attention_bwd_supported(N, head_dim)) return APGD_ERR_ARG;
+  if (B * H > 0x7fffffff) return APGD_ERR_SIZE;
+  hipStream_t s = as_stream(stream);
+  constexpr int NKB = 7;
+  const size_t lds_q = static_cast<size_t>(NKB) * (2 * kKS + 2 * kDB) * 1024;
+  const size_t lds_kv = static_cast<size_t>(NKB) * 4 * kKS * 1024 + 2 * NKB * 32 * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds_q));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds_kv));
+    attr_done = true;
+  }
+  const dim3 grid(static_cast<unsigned>(B * H)), block(256);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<NKB>, grid, block, lds_q, s, static_cast<const uint16_t*>(qkv),
+                     static_cast<const uint16_t*>(out), static_cast<const uint16_t*>(dout), lse, static_cast<uint16_t*>(dqkv), dvec, N,
+                     H, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<NKB>, grid, block, lds_kv, s, static_cast<const uint16_t*>(qkv),
+                     static_cast<const uint16_t*>(dout), lse, dvec, static_cast<uint16_t*>(dqkv), N, H, scale);
+  return launch_status();
 }
 
 }  // extern "C"

@@ -451,9 +451,8 @@ def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
 
 class _AttentionFused(torch.autograd.Function):
     """Packed ``[B,N,3C]`` bf16 projection -> ``[B,N,C]`` attention output through ``cnx_attention_fwd`` (one workgroup
-    per (batch, head), K/V in LDS, scores in MFMA accumulators).  Saved for backward: qkv and the per-row log-sum-exp;
-    the backward rebuilds the probabilities from them (library GEMMs for now — the forward is what the 4 no-grad /
-    eval passes of an AT step run)."""
+    per (batch, head), K/V in LDS, scores in MFMA accumulators).  Saved for backward: qkv, the output and the per-row
+    log-sum-exp; ``cnx_attention_bwd`` rebuilds the probabilities from them block by block."""
 
     @staticmethod
     def forward(ctx, qkv, num_heads, scale):
@@ -467,15 +466,25 @@ class _AttentionFused(torch.autograd.Function):
         _lib.check(lib.cnx_attention_fwd(qkv.data_ptr(), out.data_ptr(), _lib.ptr(lse), B, N, num_heads, C // num_heads,
                                          float(scale), _stream()), "cnx_attention_fwd")
         if need_grad:
-            ctx.save_for_backward(qkv, lse)
+            ctx.save_for_backward(qkv, lse, out)
             ctx.num_heads, ctx.scale = num_heads, scale
         return out
 
     @staticmethod
     def backward(ctx, do):
-        qkv, lse = ctx.saved_tensors
+        qkv, lse, out = ctx.saved_tensors
         B, N, C3 = qkv.shape
         C, h = C3 // 3, ctx.num_heads
+        lib = _lib.load()
+        if lib.cnx_attention_bwd_supported(N, C // h):
+            # two streaming kernels (dQ, then dK/dV): P is rebuilt block by block from the saved log-sum-exp
+            dob = do.to(torch.bfloat16).contiguous()
+            dqkv = torch.empty_like(qkv)
+            dvec = torch.empty(B, h, N, device=qkv.device, dtype=torch.float32)
+            _lib.check(lib.cnx_attention_bwd(qkv.data_ptr(), out.data_ptr(), dob.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                             dvec.data_ptr(), B, N, h, C // h, float(ctx.scale), _stream()), "cnx_attention_bwd")
+            return dqkv, None, None
+        # longer sequences (eval-time resolutions): library GEMMs on the rebuilt probabilities
         q, k, v = qkv.reshape(B, N, 3, h, C // h).permute(2, 0, 3, 1, 4).unbind(0)        # [B,h,N,d]
         do_ = do.reshape(B, N, h, C // h).permute(0, 2, 1, 3).to(torch.bfloat16)
         # scores in fp32: a bf16 GEMM output would round them (|s| ~ 10) by ~0.05, i.e. 5 % in the probabilities
