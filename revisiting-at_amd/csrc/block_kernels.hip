@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(co
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
     }                                                                                                      \
   }
-  if ((p.dbg & 16) && (blockIdx.x & 1)) {                 // timing experiment: stagger odd workgroups by ~half a lifetime
-    for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+  if ((p.dbg & 16) && blockIdx.x < 1024) {                // timing experiment: de-phase the co-resident workgroups of the first round
+    const int steps = ((blockIdx.x >> 8) & 3) * (p.dbg >> 8);
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
   }
   DMA_SLICE(0)
   DMA_SLICE(1)
