@@ -7,6 +7,7 @@
 // per-row statistics, deterministic two-stage reductions for parameter gradients.  No MFMA here.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "apgd_hip.h"
 #include "convnext_hip.h"
@@ -362,10 +363,17 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
   const int sc = sidx % n_sc, sr = sidx / n_sc;
   float acc[kDR][kDT];
   const float b0 = bias ? bias[c] : 0.f;
+  const int h_end = min(H, h0 + TH);
+  // the fused "+ add" operand (the residual branch's gradient in the backward) is fetched NOW, so that its HBM latency
+  // hides behind the stencil arithmetic instead of sitting exposed in the epilogue
 #pragma unroll
   for (int oh = 0; oh < kDR; ++oh)
 #pragma unroll
-    for (int t = 0; t < kDT; ++t) acc[oh][t] = b0;
+    for (int t = 0; t < kDT; ++t) {
+      acc[oh][t] = b0;
+      const int h = h0 + sr * kDR + oh, w = sc * kDT + t;
+      if (add && h < h_end && w < W) acc[oh][t] += add[((n * H + h) * static_cast<long>(W) + w) * C + c];
+    }
 
 #pragma unroll
   for (int r = 0; r < kDR + 6; ++r) {
@@ -389,7 +397,6 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
       }
     }
   }
-  const int h_end = min(H, h0 + TH);
 #pragma unroll
   for (int oh = 0; oh < kDR; ++oh) {
     const int h = h0 + sr * kDR + oh;
@@ -398,10 +405,7 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
     for (int t = 0; t < kDT; ++t) {
       const int w = sc * kDT + t;
       if (w >= W) continue;
-      const long off = ((n * H + h) * static_cast<long>(W) + w) * C + c;
-      float v = acc[oh][t];
-      if (add) v += add[off];
-      store1(out + off, v);
+      store1(out + ((n * H + h) * static_cast<long>(W) + w) * C + c, acc[oh][t]);
     }
   }
 }
@@ -413,9 +417,20 @@ inline bool dw_dot2_plan(int H, int W, int C, DwDot* t) {
   if (n_sc > 16) return false;
   int max_sr = 16 / n_sc;                                  // <= 512 threads
   int th = H < kDR * max_sr ? H : kDR * max_sr;
+  // large maps (56x56, 28x28): 4-row tiles - a 40 KiB tile lets 3-4 workgroups share a CU, so one workgroup's staging and
+  // store phases overlap another's arithmetic (measured 508 -> 414 us for the 56x56x96 input gradient); small maps are
+  // taken whole
+  if (H * W >= 784 && th > kDR) th = kDR;
   while (th > kDR && static_cast<size_t>(th + 6) * P2 * kDC * 4 > 64 * 1024) th -= kDR;
   const int n_sr = (th + kDR - 1) / kDR;
-  t->th = th; t->threads = ((n_sr * n_sc * kDC + 63) / 64) * 64; t->lds = static_cast<size_t>(th + 6) * P2 * kDC * 4;
+  t->th = th; t->threads = ((n_sr * n_sc * kDC + 63) / 64) * 64;
+  static const int th_override = getenv("APGD_DW_TH") ? atoi(getenv("APGD_DW_TH")) : 0;     // tuning experiments only
+  if (th_override > 0 && th_override <= th) {
+    t->th = th_override;
+    t->threads = ((((th_override + kDR - 1) / kDR) * n_sc * kDC + 63) / 64) * 64;
+    t->lds = static_cast<size_t>(th_override + 6) * P2 * kDC * 4;
+    return true;
+  } t->lds = static_cast<size_t>(th + 6) * P2 * kDC * 4;
   return t->lds <= 150 * 1024;
 }
 
