@@ -600,21 +600,37 @@ __global__ __launch_bounds__(256) void dwconv7x7_wgrad_dot2_kernel(const TX* __r
   }
 }
 
-// out[j] = sum_p ws[p*len + j]: 64 outputs per block, the parts split over 4 thread groups whose
-// partial sums are combined in a fixed order (deterministic).
+// out[j] = sum_p ws[p*len + j]: 16 outputs x 16 part-groups per block; every thread sums its parts (8 loads in flight)
+// in a fixed order, the 16 group sums are combined by a fixed tree (deterministic).  `len` is a few hundred to a few
+// thousand, `nparts` up to 1024: the old 64-outputs-per-block shape left a dozen blocks walking 256 parts serially.
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ ws, float* __restrict__ out0,
                                                            float* __restrict__ out1, int split, int len, int nparts) {
-  __shared__ float part[4][64];
-  const int jl = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + jl;
+  __shared__ float part[16][17];
+  const int jl = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + jl;
   float s = 0.f;
-  if (j < len)
-    for (int p = pg; p < nparts; p += 4) s += ws[static_cast<long>(p) * len + j];
+  if (j < len) {
+    int p = pg;
+    for (; p + 7 * 16 < nparts; p += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[static_cast<long>(p + u * 16) * len + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < nparts; p += 16) s += ws[static_cast<long>(p) * len + j];
+  }
   part[pg][jl] = s;
   __syncthreads();
   if (pg == 0 && j < len) {
-    s = (part[0][jl] + part[1][jl]) + (part[2][jl] + part[3][jl]);
-    if (j < split) out0[j] = s; else if (out1) out1[j - split] = s;
+    float t[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t[g] = part[g][jl];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int g = 0; g < w; ++g) t[g] += t[g + w];
+    if (j < split) out0[j] = t[0]; else if (out1) out1[j - split] = t[0];
   }
 }
 
@@ -934,7 +950,7 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
     else WGD_LAUNCH(uint16_t, uint16_t)
 #undef WGD_LAUNCH
     const int len = 50 * C;
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 63) / 64), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, nparts);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 15) / 16), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, nparts);
     return launch_status();
   }
   const int cc = C < kCC ? C : kCC;
@@ -952,7 +968,7 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
   else WG_LAUNCH(uint16_t, uint16_t);
 #undef WG_LAUNCH
   const int len = 50 * C;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 63) / 64), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, nb);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 15) / 16), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, nb);
   return launch_status();
 }
 
@@ -1009,7 +1025,7 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
   if (rc != APGD_OK) return rc;
   if (dweight) {
     const int len = 2 * C;
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 63) / 64), dim3(256), 0, s, ws, dweight, dbias, C, len, nb);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 15) / 16), dim3(256), 0, s, ws, dweight, dbias, C, len, nb);
     return launch_status();
   }
   return APGD_OK;

@@ -243,7 +243,7 @@ def _wgrad(x, y):
     the chip) and sum the S partial products in fp32."""
     M = x.shape[0]
     S = 1
-    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 2048:
+    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 512:
         S *= 2
     if S == 1:
         return (x.t() @ y).float()
@@ -255,7 +255,7 @@ def _wgrad_t(xt, y):
     """Same contraction with the left operand already transposed: ``xt`` [N1, M] (K-contiguous), ``y`` [M, N2]."""
     N1, M = xt.shape
     S = 1
-    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 2048:
+    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 512:
         S *= 2
     if S == 1:
         return (xt @ y).float()
@@ -412,6 +412,38 @@ class _BlockFused(torch.autograd.Function):
         return dx, dww, dwb, dlw, dlb, None, dw1, db1, dw2, db2, dgamma
 
 
+class _LinearTallK(torch.autograd.Function):
+    """``F.linear`` whose weight gradient is the split-K batched GEMM of ``_wgrad`` (the library's single GEMM for
+    ``g^T x`` with K = N*H*W = 50 176 rows and a 1536 x 384 result ran at ~200-260 TFLOP/s: too few output tiles)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        dx = (g2 @ w.to(g2.dtype)).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if not _INPUT_GRAD_ONLY:
+            if ctx.needs_input_grad[1]:
+                dw = _wgrad(g2, x.reshape(-1, x.shape[-1]).to(g2.dtype)).to(w.dtype)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = g2.sum(0, dtype=torch.float32)
+        return dx, dw, db
+
+
+def _linear(x, w, b):
+    """fc1 / fc2 of the library path: autocast-cast operands, split-K weight gradient for tall inputs."""
+    if torch.is_autocast_enabled() and x.is_cuda and x.numel() // x.shape[-1] >= 8192:
+        dt = torch.get_autocast_dtype('cuda')
+        return _LinearTallK.apply(x.to(dt), w.to(dt), b.to(dt) if b is not None else None)
+    return F.linear(x, w, b)
+
+
 def block_fused_supported(C):
     return bool(_lib.load().cnx_block_mlp_supported(C))
 
@@ -443,7 +475,7 @@ def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
         if _act_dtype(xr) == torch.bfloat16 and _use_fused_block(x.shape[1]):
             return _BlockFused.apply(xr, dw_w, dw_b, ln_w, ln_b, float(eps), w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
         y = dwconv_ln(xr, dw_w, dw_b, ln_w, ln_b, eps)
-    y = F.linear(F.gelu(F.linear(y, w1, b1)), w2, b2)
+    y = _linear(F.gelu(_linear(y, w1, b1)), w2, b2)
     if gamma is not None:
         y = y * gamma
     return x + y.permute(0, 3, 1, 2)
