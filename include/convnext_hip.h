@@ -56,6 +56,20 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
                       void* dx, int dx_dtype, float* dweight, float* dbias, float* ws,
                       int64_t M, int32_t C, int32_t gelu, void* stream);
 
+/* Element-wise tails of the MLP for widths that run their GEMMs in the library (models/convnext.py:44-49 and their
+ * backward), one pass each, per-channel parameter gradients accumulated on the way (deterministic two-stage sums;
+ * ws = cnx_colsum_ws_floats(n_cols) floats of scratch):
+ *   cnx_scale_residual      out = x + gamma * y                       x, out fp32 or bf16 [M, C]; y bf16; gamma nullable
+ *   cnx_scale_residual_bwd  dos = bf16(g * gamma);  dgamma[c] = sum_m g*y, db2[c] = sum_m dos (both NULL or both set)
+ *   cnx_gelu_bwd_colsum     dhpre = bf16(dh * GELU'(hpre)) on bf16 [M, N];  db1[n] = sum_m dhpre (nullable) */
+int64_t cnx_colsum_ws_floats(int32_t n_cols);
+int cnx_scale_residual(const void* x, int x_dtype, const void* y, const float* gamma, void* out, int out_dtype,
+                       int64_t M, int32_t C, void* stream);
+int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const float* gamma, void* dos,
+                           float* dgamma, float* db2, float* ws, int64_t M, int32_t C, void* stream);
+int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db1, float* ws,
+                        int64_t M, int32_t N, void* stream);
+
 /* Fused block tail (models/convnext.py:40-49): LayerNorm -> fc1 -> GELU -> fc2 -> gamma -> +residual, ONE kernel:
  *     out[m, :] = resid[m, :] + gamma * (GELU(LN(u[m, :]) W1^T + b1) W2^T + b2)
  * u [M, C] bf16 = depthwise-conv output; LN (eps inside the sqrt, fp32 statistics, two-pass) is applied when

@@ -15,6 +15,7 @@ The residual stream stays fp32 exactly as in the reference's autocast run (``gam
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -209,15 +210,19 @@ _wcache = {}
 
 def _cached(params, tag, fn):
     """Derived copies of parameters (bf16 casts, MFMA-fragment packing), rebuilt only when a parameter changes
-    (optimizer steps bump ``_version``); the attack's forwards and the train forward share them."""
+    (optimizer steps bump ``_version``); the attack's forwards and the train forward share them.  Entries hold weak
+    references: ``id()`` and even the storage address of a dead parameter can be handed to a new one."""
     key = tuple(id(q) for q in params) + (tag,)
     ver = tuple((q._version, q.data_ptr()) for q in params)
     hit = _wcache.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and all(r() is q for r, q in zip(hit[2], params)):
         return hit[1]
     with torch.no_grad():
         val = fn(*[q.detach() for q in params])
-    _wcache[key] = (ver, val)
+    if len(_wcache) > 4096:                      # dead entries of models that no longer exist
+        for k in [k for k, v in _wcache.items() if any(r() is None for r in v[2])]:
+            del _wcache[k]
+    _wcache[key] = (ver, val, tuple(weakref.ref(q) for q in params))
     return val
 
 
@@ -412,36 +417,74 @@ class _BlockFused(torch.autograd.Function):
         return dx, dww, dwb, dlw, dlb, None, dw1, db1, dw2, db2, dgamma
 
 
-class _LinearTallK(torch.autograd.Function):
-    """``F.linear`` whose weight gradient is the split-K batched GEMM of ``_wgrad`` (the library's single GEMM for
-    ``g^T x`` with K = N*H*W = 50 176 rows and a 1536 x 384 result ran at ~200-260 TFLOP/s: too few output tiles)."""
+class _MlpTailLib(torch.autograd.Function):
+    """``x + gamma * fc2(GELU(fc1(a)))`` for widths without a fused block kernel (C = 384 in the backward-capable path,
+    768): the four GEMMs per direction stay in hipBLASLt, everything around them is ours —
+
+      forward   ``cnx_scale_residual`` (layer scale + residual, one pass instead of mul + add)
+      backward  ``cnx_scale_residual_bwd`` (dO = bf16(g*gamma) + d(gamma) + d(b2) in one pass instead of 6 launches),
+                ``cnx_gelu_bwd_colsum`` (GELU' + d(b1)), split-K batched GEMMs for the two weight gradients (``_wgrad``:
+                as single GEMMs with K = N*H*W they ran at 200-260 TFLOP/s).
+    """
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return F.linear(x, w, b)
+    def forward(ctx, a, x, w1, b1, w2, b2, gamma):
+        lib = _lib.load()
+        C = a.shape[-1]
+        M = a.numel() // C
+        a2 = a.reshape(M, C)
+        w1b = _cached((w1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+        w2b = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+        hpre = torch.addmm(b1.detach().to(torch.bfloat16), a2, w1b.t())             # [M, 4C]
+        h = F.gelu(hpre)
+        y2 = torch.addmm(b2.detach().to(torch.bfloat16), h, w2b.t())                # [M, C] bf16, pre-gamma
+        gf = _f32(gamma) if gamma is not None else None
+        out = torch.empty(x.shape, device=x.device,
+                          dtype=torch.float32 if (gamma is not None or x.dtype == torch.float32) else x.dtype)
+        _lib.check(lib.cnx_scale_residual(x.data_ptr(), _code(x), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out), M, C,
+                                          _stream()), "cnx_scale_residual")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(a2, hpre, h, y2, w1b, w2b, gf)
+            ctx.x_dtype, ctx.a_shape = x.dtype, a.shape
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        g2 = g.reshape(-1, g.shape[-1])
-        dx = (g2 @ w.to(g2.dtype)).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = db = None
-        if not _INPUT_GRAD_ONLY:
-            if ctx.needs_input_grad[1]:
-                dw = _wgrad(g2, x.reshape(-1, x.shape[-1]).to(g2.dtype)).to(w.dtype)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = g2.sum(0, dtype=torch.float32)
-        return dx, dw, db
+        lib = _lib.load()
+        a2, hpre, h, y2, w1b, w2b, gf = ctx.saved_tensors
+        M, C = a2.shape
+        nig = ctx.needs_input_grad
+        want_p = any(nig[2:]) and not _INPUT_GRAD_ONLY
+        g = g.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        dev = a2.device
+        dos = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        dgamma = db2 = db1 = ws = None
+        if want_p:
+            dgamma = torch.empty(C, device=dev, dtype=torch.float32)
+            db2 = torch.empty(C, device=dev, dtype=torch.float32)
+            db1 = torch.empty(4 * C, device=dev, dtype=torch.float32)
+            ws = torch.empty(lib.cnx_colsum_ws_floats(4 * C), device=dev, dtype=torch.float32)
+        _lib.check(lib.cnx_scale_residual_bwd(g.data_ptr(), _code(g), y2.data_ptr(), _lib.ptr(gf), dos.data_ptr(),
+                                              _lib.ptr(dgamma), _lib.ptr(db2), _lib.ptr(ws), M, C, _stream()),
+                   "cnx_scale_residual_bwd")
+        dh = dos @ w2b                                                              # [M, 4C]
+        dhpre = torch.empty_like(dh)
+        _lib.check(lib.cnx_gelu_bwd_colsum(dh.data_ptr(), hpre.data_ptr(), dhpre.data_ptr(), _lib.ptr(db1), _lib.ptr(ws), M,
+                                           4 * C, _stream()), "cnx_gelu_bwd_colsum")
+        del dh
+        da = (dhpre @ w1b).view(ctx.a_shape) if nig[0] else None
+        dw1 = dw2 = None
+        if want_p:
+            dw2 = _wgrad(dos, h)
+            dw1 = _wgrad(dhpre, a2)
+            if gf is None:
+                dgamma = None
+        dx = g.to(ctx.x_dtype) if nig[1] else None
+        return da, dx, dw1, db1, dw2, db2, dgamma
 
 
-def _linear(x, w, b):
-    """fc1 / fc2 of the library path: autocast-cast operands, split-K weight gradient for tall inputs."""
-    if torch.is_autocast_enabled() and x.is_cuda and x.numel() // x.shape[-1] >= 8192:
-        dt = torch.get_autocast_dtype('cuda')
-        return _LinearTallK.apply(x.to(dt), w.to(dt), b.to(dt) if b is not None else None)
-    return F.linear(x, w, b)
 
 
 def block_fused_supported(C):
@@ -475,7 +518,9 @@ def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
         if _act_dtype(xr) == torch.bfloat16 and _use_fused_block(x.shape[1]):
             return _BlockFused.apply(xr, dw_w, dw_b, ln_w, ln_b, float(eps), w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
         y = dwconv_ln(xr, dw_w, dw_b, ln_w, ln_b, eps)
-    y = _linear(F.gelu(_linear(y, w1, b1)), w2, b2)
+        if y.dtype == torch.bfloat16 and x.shape[1] % 4 == 0:
+            return _MlpTailLib.apply(y, xr, w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
+    y = F.linear(F.gelu(F.linear(y, w1, b1)), w2, b2)
     if gamma is not None:
         y = y * gamma
     return x + y.permute(0, 3, 1, 2)

@@ -378,3 +378,47 @@ def test_fused_attention_forward_and_backward_vs_fp32_reference(R, N, B, H):
     (gd,) = torch.autograd.grad(out, qd, cot.cuda().to(torch.bfloat16))
     assert float((gd.float().cpu() - gr).norm() / gr.norm()) < 1.5e-2
     assert lib.cnx_attention_fwd(qd.data_ptr(), o2.data_ptr(), None, B, 500, H, d, scale, S()) == -4     # N too long
+
+
+@pytest.mark.parametrize("M_,C", [(1, 8), (37, 96), (300, 384), (1000, 768)])
+@pytest.mark.parametrize("gamma", [True, False])
+def test_elementwise_tail_kernels(R, M_, C, gamma):
+    """cnx_scale_residual / cnx_scale_residual_bwd / cnx_gelu_bwd_colsum vs their torch definitions (one-pass element-wise
+    tails of the library-path MLP with the per-channel sums folded in)."""
+    lib = R._lib.load()
+    g_ = torch.Generator().manual_seed(M_ + C)
+    x = torch.randn(M_, C, generator=g_)
+    y = torch.randn(M_, C, generator=g_).to(torch.bfloat16)
+    gm = torch.randn(C, generator=g_) if gamma else None
+    xd, yd = x.cuda(), y.cuda()
+    gmd = gm.cuda() if gamma else None
+    P = R._lib.ptr
+    out = torch.empty(M_, C, device="cuda")
+    assert lib.cnx_scale_residual(xd.data_ptr(), 0, yd.data_ptr(), P(gmd), out.data_ptr(), 0, M_, C, S()) == 0
+    close(out, x + (y.float() * gm if gamma else y.float()), 1e-6, 1e-6)
+    grad = torch.randn(M_, C, generator=g_)
+    gd = grad.cuda()
+    dos = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+    dg, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ws = torch.empty(lib.cnx_colsum_ws_floats(4 * C), device="cuda")
+    assert lib.cnx_scale_residual_bwd(gd.data_ptr(), 0, yd.data_ptr(), P(gmd), dos.data_ptr(), dg.data_ptr(), db2.data_ptr(),
+                                      ws.data_ptr(), M_, C, S()) == 0
+    dref = (grad * gm if gamma else grad).to(torch.bfloat16)
+    assert torch.equal(dos.cpu(), dref)
+    close(db2, dref.float().sum(0), 1e-5, 1e-4)
+    close(dg, (grad * y.float()).sum(0), 1e-5, 1e-4)
+    d2 = torch.empty_like(dos)
+    assert lib.cnx_scale_residual_bwd(gd.data_ptr(), 0, None, P(gmd), d2.data_ptr(), None, None, None, M_, C, S()) == 0
+    assert torch.equal(d2, dos)
+    assert lib.cnx_scale_residual_bwd(gd.data_ptr(), 0, None, P(gmd), d2.data_ptr(), dg.data_ptr(), None, ws.data_ptr(), M_, C, S()) == -1
+    N = 4 * C
+    dh = torch.randn(M_, N, generator=g_).to(torch.bfloat16)
+    hp = (torch.randn(M_, N, generator=g_) * 2).to(torch.bfloat16)
+    hpr = hp.float().requires_grad_()
+    (ref,) = torch.autograd.grad(F.gelu(hpr), hpr, dh.float())
+    dhp = torch.empty(M_, N, device="cuda", dtype=torch.bfloat16)
+    db1 = torch.empty(N, device="cuda")
+    assert lib.cnx_gelu_bwd_colsum(dh.cuda().data_ptr(), hp.cuda().data_ptr(), dhp.data_ptr(), db1.data_ptr(), ws.data_ptr(), M_,
+                                   N, S()) == 0
+    close(dhp, ref, 8e-3, 1e-4)
+    close(db1, dhp.float().sum(0), 1e-5, 1e-4)
