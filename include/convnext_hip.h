@@ -60,7 +60,8 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
  * backward), one pass each, per-channel parameter gradients accumulated on the way (deterministic two-stage sums;
  * ws = cnx_colsum_ws_floats(n_cols) floats of scratch):
  *   cnx_scale_residual      out = x + gamma * y                       x, out fp32 or bf16 [M, C]; y bf16; gamma nullable
- *   cnx_scale_residual_bwd  dos = bf16(g * gamma);  dgamma[c] = sum_m g*y, db2[c] = sum_m dos (both NULL or both set)
+ *   cnx_scale_residual_bwd  dos = bf16(g * gamma) (dos NULL: sums only);  dgamma[c] = sum_m g*y, db2[c] = sum_m dos
+ *                           (both NULL or both set)
  *   cnx_gelu_bwd_colsum     dhpre = bf16(dh * GELU'(hpre)) on bf16 [M, N];  db1[n] = sum_m dhpre (nullable) */
 int64_t cnx_colsum_ws_floats(int32_t n_cols);
 int cnx_scale_residual(const void* x, int x_dtype, const void* y, const float* gamma, void* out, int out_dtype,
@@ -93,13 +94,15 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
  * cnx_layernorm_bwd).  Training backward: pass all four emit pointers to also get the operands of the weight
  * gradients: a_out, do_out [M, C] bf16 and ht_out = GELU(Hpre)^T, dhpt_out = dHpre^T as [4C, M] bf16
  *     dW1 = dHpre^T a,  db1 = rowsum(dHpre^T),  dW2 = (H^T dO)^T,  db2 = colsum(dO).
+ * a_stride (elements, 0 = C, multiple of 8) is the row stride of a_out: with a ones column appended by the caller
+ * (a_out [M, C+8]) the d(b1) sum rides along in the dW1 GEMM.
  * cnx_block_mlp_bwd_supported(C): widths with a kernel (96, 192). */
 int cnx_block_mlp_bwd_supported(int32_t C);
 int64_t cnx_mlp_packed_bwd_elems(int32_t C);
 int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* Wb, int32_t C, void* stream);
 int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                       const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                      void* a_out, void* do_out, void* ht_out, void* dhpt_out,
+                      void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out,
                       int64_t M, int32_t C, void* stream);
 
 /* Fused multi-head softmax attention of the ViT family (timm 0.8 `Attention.forward`, reached through the models of

@@ -468,6 +468,7 @@ struct BlkBwdArgs {
   uint16_t* ht_out;        // emit: [4C, M] bf16 GELU(Hpre)^T
   uint16_t* dhpt_out;      // emit: [4C, M] bf16 dHpre^T
   long M;
+  long a_stride;           // row stride of a_out in elements (>= C; lets the caller append a ones column for d(b1))
 };
 
 template <int C>
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
       }
       const uint4 packed = make_uint4(pk[0], pk[1], pk[2], pk[3]);
       af[ks] = __builtin_bit_cast(bf16x8, packed);
-      if (EMIT && row_ok) reinterpret_cast<uint4*>(p.a_out + row * C + half * (C / 2))[ks] = packed;
+      if (EMIT && row_ok) reinterpret_cast<uint4*>(p.a_out + row * p.a_stride + half * (C / 2))[ks] = packed;
     }
     const float4* gmp = p.gamma ? reinterpret_cast<const float4*>(p.gamma + half * (C / 2)) : nullptr;
 #pragma unroll
@@ -725,7 +726,8 @@ int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* 
 
 int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                       const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                      void* a_out, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C, void* stream) {
+                      void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C,
+                      void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!u || !ln_w || !ln_b || !mean || !rstd || !g || !Wb || !b1 || !da) return APGD_ERR_NULL;
@@ -737,6 +739,8 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
   a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = b1; a.da = static_cast<uint16_t*>(da);
   a.a_out = static_cast<uint16_t*>(a_out); a.do_out = static_cast<uint16_t*>(do_out);
   a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.M = M;
+  if (a_stride != 0 && (a_stride < C || a_stride % 8 != 0)) return APGD_ERR_ARG;
+  a.a_stride = a_stride ? a_stride : C;
   hipStream_t s = as_stream(stream);
   switch (C) {
     case 96: return launch_blk_bwd<96>(a, g_dtype, s);

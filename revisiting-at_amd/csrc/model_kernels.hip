@@ -719,17 +719,41 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict
 //   gelu_bwd_colsum_kernel     dHpre = bf16(dH * GELU'(Hpre));  db1 = sum_m dHpre
 // Thread = 4 consecutive channels; blockIdx.x walks column tiles of 1024, blockIdx.y strides over rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int kColParts = 256;
+constexpr int kColParts = 2048;
 __device__ __forceinline__ float round_bf16(float v) { return __uint_as_float(static_cast<uint32_t>(f2bf(v)) << 16); }
 __device__ __forceinline__ float4 round_bf16(float4 v) { return make_float4(round_bf16(v.x), round_bf16(v.y), round_bf16(v.z), round_bf16(v.w)); }
+
+// thread layout shared by the three kernels: a block is CQ channel-quads x RY rows (CQ = min(C/4, 256), RY = 256 / CQ), so
+// narrow tensors (C = 96: 24 quads) still fill their blocks; "row lane" rl = blockIdx.y*RY + ty walks rows rl, rl+R, ...
+struct ColMap { int c, rl, R; bool active; };
+__device__ __forceinline__ ColMap col_map(int C) {
+  const int cq_all = C / 4, CQ = cq_all < 256 ? cq_all : 256, RY = 256 / CQ;
+  const int tx = threadIdx.x % CQ, ty = threadIdx.x / CQ;
+  ColMap m;
+  m.c = (blockIdx.x * CQ + tx) * 4;
+  m.rl = blockIdx.y * RY + ty;
+  m.R = gridDim.y * RY;
+  m.active = ty < RY && m.c < C;
+  return m;
+}
+inline dim3 col_grid(int C, long M, long max_lanes) {
+  const int cq_all = C / 4, CQ = cq_all < 256 ? cq_all : 256, RY = 256 / CQ;
+  long lanes = M < max_lanes ? M : max_lanes;
+  long gy = (lanes + RY - 1) / RY;
+  if (gy * RY > max_lanes) gy = max_lanes / RY;
+  if (gy < 1) gy = 1;
+  return dim3((cq_all + CQ - 1) / CQ, static_cast<unsigned>(gy));
+}
+inline int col_lanes(int C, const dim3& grid) { const int cq_all = C / 4, CQ = cq_all < 256 ? cq_all : 256; return static_cast<int>(grid.y) * (256 / CQ); }
 
 template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void scale_residual_kernel(const TX* __restrict__ x, const uint16_t* __restrict__ y,
                                                              const float* __restrict__ gamma, TO* __restrict__ out, long M, int C) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c >= C) return;
+  const ColMap cm = col_map(C);
+  if (!cm.active) return;
+  const int c = cm.c;
   const float4 g4 = gamma ? load4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-  for (long m = blockIdx.y; m < M; m += gridDim.y) {
+  for (long m = cm.rl; m < M; m += cm.R) {
     const float4 xv = load4(x + m * C + c), yv = load4(y + m * C + c);
     store4(out + m * C + c, make_float4(fmaf(yv.x, g4.x, xv.x), fmaf(yv.y, g4.y, xv.y), fmaf(yv.z, g4.z, xv.z), fmaf(yv.w, g4.w, xv.w)));
   }
@@ -739,21 +763,22 @@ template <typename TG>
 __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const TG* __restrict__ g, const uint16_t* __restrict__ y,
                                                                  const float* __restrict__ gamma, uint16_t* __restrict__ dos,
                                                                  float* __restrict__ ws, long M, int C) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c >= C) return;
+  const ColMap cm = col_map(C);
+  if (!cm.active) return;
+  const int c = cm.c;
   const float4 g4 = gamma ? load4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
-  for (long m = blockIdx.y; m < M; m += gridDim.y) {
+  for (long m = cm.rl; m < M; m += cm.R) {
     const float4 gv = load4(g + m * C + c);
     const float4 d = round_bf16(make_float4(gv.x * g4.x, gv.y * g4.y, gv.z * g4.z, gv.w * g4.w));
-    store4(dos + m * C + c, d);
+    if (dos) store4(dos + m * C + c, d);
     if (ws) {                                                      // sums of the rounded values, as summing the bf16 tensor would
       ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
       if (y) { const float4 yv = load4(y + m * C + c); ag.x = fmaf(gv.x, yv.x, ag.x); ag.y = fmaf(gv.y, yv.y, ag.y); ag.z = fmaf(gv.z, yv.z, ag.z); ag.w = fmaf(gv.w, yv.w, ag.w); }
     }
   }
   if (ws) {
-    float* p = ws + static_cast<long>(blockIdx.y) * 2 * C;
+    float* p = ws + static_cast<long>(cm.rl) * 2 * C;
     store4(p + c, ag);
     store4(p + C + c, ab);
   }
@@ -761,16 +786,17 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const TG* __res
 
 __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const uint16_t* __restrict__ dh, const uint16_t* __restrict__ hpre,
                                                               uint16_t* __restrict__ dhpre, float* __restrict__ ws, long M, int N) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c >= N) return;
+  const ColMap cm = col_map(N);
+  if (!cm.active) return;
+  const int c = cm.c;
   float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long m = blockIdx.y; m < M; m += gridDim.y) {
+  for (long m = cm.rl; m < M; m += cm.R) {
     const float4 d = load4(dh + m * N + c), z = load4(hpre + m * N + c);
     const float4 o = round_bf16(make_float4(d.x * gelu_grad_f(z.x), d.y * gelu_grad_f(z.y), d.z * gelu_grad_f(z.z), d.w * gelu_grad_f(z.w)));
     store4(dhpre + m * N + c, o);
     if (ws) { ab.x += o.x; ab.y += o.y; ab.z += o.z; ab.w += o.w; }
   }
-  if (ws) store4(ws + static_cast<long>(blockIdx.y) * N + c, ab);
+  if (ws) store4(ws + static_cast<long>(cm.rl) * N + c, ab);
 }
 
 constexpr int kLnBwdBlocks = 1024;
@@ -1101,8 +1127,7 @@ int cnx_scale_residual(const void* x, int x_dtype, const void* y, const float* g
   if (M == 0) return APGD_OK;
   if (!x || !y || !out) return APGD_ERR_NULL;
   if ((x_dtype != APGD_F32 && x_dtype != APGD_BF16) || (out_dtype != APGD_F32 && out_dtype != APGD_BF16)) return APGD_ERR_DTYPE;
-  const long rows = M < 4096 ? M : 4096;
-  const dim3 grid((C / 4 + 255) / 256, static_cast<unsigned>(rows)), block(256);
+  const dim3 grid = col_grid(C, M, 16384), block(256);
   hipStream_t s = as_stream(stream);
   const auto* yy = static_cast<const uint16_t*>(y);
 #define SR(TX, TO) hipLaunchKernelGGL((scale_residual_kernel<TX, TO>), grid, block, 0, s, static_cast<const TX*>(x), yy, gamma, static_cast<TO*>(out), static_cast<long>(M), C)
@@ -1118,13 +1143,13 @@ int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const floa
                            float* ws, int64_t M, int32_t C, void* stream) {
   if (M < 0 || C <= 0 || C % 4 != 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
-  if (!g || !dos) return APGD_ERR_NULL;
+  if (!g || (!dos && !dgamma)) return APGD_ERR_NULL;
   if ((dgamma == nullptr) != (db2 == nullptr)) return APGD_ERR_NULL;          // both sums or neither
   if (dgamma && !ws) return APGD_ERR_NULL;
   if (g_dtype != APGD_F32 && g_dtype != APGD_BF16) return APGD_ERR_DTYPE;
-  const bool sums = dgamma || db2;
-  const long parts = M < kColParts ? M : kColParts;
-  const dim3 grid((C / 4 + 255) / 256, static_cast<unsigned>(sums ? parts : (M < 4096 ? M : 4096))), block(256);
+  const bool sums = dgamma != nullptr;
+  const dim3 grid = col_grid(C, M, sums ? kColParts : 16384), block(256);
+  const int parts = col_lanes(C, grid);
   hipStream_t s = as_stream(stream);
   const auto* yy = static_cast<const uint16_t*>(y);          // NULL: dgamma comes out as zeros
   if (g_dtype == APGD_F32)
@@ -1134,7 +1159,8 @@ int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const floa
     hipLaunchKernelGGL(scale_residual_bwd_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t*>(g), yy, gamma,
                        static_cast<uint16_t*>(dos), sums ? ws : nullptr, static_cast<long>(M), C);
   if (sums)
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, dgamma, db2, C, 2 * C, static_cast<int>(parts));
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, dgamma, db2, C, 2 * C,
+                       static_cast<int>(M < parts ? M : parts));
   return launch_status();
 }
 
@@ -1143,14 +1169,14 @@ int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db
   if (M == 0) return APGD_OK;
   if (!dh || !hpre || !dhpre) return APGD_ERR_NULL;
   if (db1 && !ws) return APGD_ERR_NULL;
-  const long parts = M < kColParts ? M : kColParts;
-  const dim3 grid((N / 4 + 255) / 256, static_cast<unsigned>(db1 ? parts : (M < 4096 ? M : 4096))), block(256);
+  const dim3 grid = col_grid(N, M, db1 ? kColParts : 16384), block(256);
+  const int parts = col_lanes(N, grid);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(gelu_bwd_colsum_kernel, grid, block, 0, s, static_cast<const uint16_t*>(dh), static_cast<const uint16_t*>(hpre),
                      static_cast<uint16_t*>(dhpre), db1 ? ws : nullptr, static_cast<long>(M), N);
   if (db1)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((N + 15) / 16), dim3(256), 0, s, ws, db1, static_cast<float*>(nullptr), N, N,
-                       static_cast<int>(parts));
+                       static_cast<int>(M < parts ? M : parts));
   return launch_status();
 }
 

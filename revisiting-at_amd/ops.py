@@ -208,15 +208,35 @@ def dwconv_ln(x_rows, dw_w, dw_b, ln_w, ln_b, eps):
 _wcache = {}
 
 
+CACHE_STATS = {"miss": 0}
+_WEIGHTS_EPOCH = 0
+
+
+def invalidate_weight_cache(*_):
+    """Drop every derived weight copy.  ``Tensor._version`` is NOT bumped by fused optimizers (``AdamW(fused=True)`` updates
+    parameters in place without touching the counter), so the cache is also keyed on this epoch, advanced by a global
+    optimizer-step hook; call it by hand after any other out-of-band weight update."""
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    register_optimizer_step_post_hook(invalidate_weight_cache)
+except ImportError:                                      # older torch: ATTrainStep calls invalidate_weight_cache() itself
+    pass
+
+
 def _cached(params, tag, fn):
     """Derived copies of parameters (bf16 casts, MFMA-fragment packing), rebuilt only when a parameter changes
     (optimizer steps bump ``_version``); the attack's forwards and the train forward share them.  Entries hold weak
     references: ``id()`` and even the storage address of a dead parameter can be handed to a new one."""
     key = tuple(id(q) for q in params) + (tag,)
-    ver = tuple((q._version, q.data_ptr()) for q in params)
+    ver = (_WEIGHTS_EPOCH,) + tuple((q._version, q.data_ptr()) for q in params)
     hit = _wcache.get(key)
     if hit is not None and hit[0] == ver and all(r() is q for r, q in zip(hit[2], params)):
         return hit[1]
+    CACHE_STATS["miss"] += 1
     with torch.no_grad():
         val = fn(*[q.detach() for q in params])
     if len(_wcache) > 4096:                      # dead entries of models that no longer exist
@@ -266,6 +286,19 @@ def _wgrad_t(xt, y):
         return (xt @ y).float()
     part = torch.bmm(xt.view(N1, S, M // S).transpose(0, 1), y.view(S, M // S, y.shape[1]))
     return part.float().sum(0)
+
+
+_pad_cache = {}
+
+
+def _ones_pad(device):
+    """(1, 0, 0, 0, 0, 0, 0, 0) in bf16: the 8-wide pad whose first entry makes a GEMM also sum its other operand."""
+    t = _pad_cache.get(device)
+    if t is None:
+        t = torch.zeros(8, device=device, dtype=torch.bfloat16)
+        t[0] = 1
+        _pad_cache[device] = t
+    return t
 
 
 def _pack_mlp_bwd(w1, w2):
@@ -353,15 +386,22 @@ class _BlockFused(torch.autograd.Function):
                 g2 = g2.float()
             _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                              g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
-                                             da.data_ptr(), _lib.ptr(a), _lib.ptr(dos), _lib.ptr(ht), _lib.ptr(dhpt), M, C,
+                                             da.data_ptr(), _lib.ptr(a), 0, _lib.ptr(dos), _lib.ptr(ht), _lib.ptr(dhpt), M, C,
                                              _stream()), "cnx_block_mlp_bwd")
             if want_p:
                 dw1 = _wgrad_t(dhpt, a)                                          # [4C, C]
                 db1 = dhpt.sum(1, dtype=torch.float32)
                 dw2 = _wgrad_t(ht, dos).t()                                      # [C, 4C]
-                db2 = dos.sum(0, dtype=torch.float32)
-                if gf is not None:
-                    dgamma = (g2.float() * y2.reshape(M, C).float()).sum(0)
+                # d(gamma) = sum_m g*y2 and d(b2) = sum_m dO in ONE pass over g and y2 (sums-only mode of the tail kernel;
+                # as separate torch reductions they were a cast, a product and two sums: ~390 us per block at 56x56)
+                dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+                db2 = torch.empty(C, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=x.device, dtype=torch.float32)
+                y2p = y2.reshape(M, C).data_ptr() if y2 is not None else None
+                _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2p, _lib.ptr(gf), None, dgamma.data_ptr(),
+                                                      db2.data_ptr(), ws.data_ptr(), M, C, _stream()), "cnx_scale_residual_bwd")
+                if gf is None:
+                    dgamma = None
                 del a, dos, ht, dhpt
         else:
             # ---- library composition on the recomputed activations

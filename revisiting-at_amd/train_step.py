@@ -18,6 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import ops
 from .config import AdvConfig, wrap_model_for_at
 
 
@@ -121,6 +122,7 @@ class ATTrainStep:
             loss = self.loss(output, target)                               # main.py:990
         loss.backward()                                                    # main.py:992 (DDP all-reduce inside)
         self.optimizer.step()                                              # main.py:993
+        ops.invalidate_weight_cache()                                      # packed / bf16 weight copies follow the update
         if self.ema is not None:
             self.ema.update()                                              # main.py:996-997
         return loss.detach()

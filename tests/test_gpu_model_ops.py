@@ -330,7 +330,7 @@ def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt)
         dhpt = torch.empty(4 * C, M_, device="cuda", dtype=torch.bfloat16)
     P = R._lib.ptr
     assert lib.cnx_block_mlp_bwd(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), gd.data_ptr(),
-                                 R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), P(ao), P(dob),
+                                 R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), P(ao), 0, P(dob),
                                  P(ht), P(dhpt), M_, C, S()) == 0
     err = float((da.float().cpu() - da_ref).norm() / da_ref.norm())
     assert err < 8e-3, err                     # bf16 roundings of dHpre and of the stored result
@@ -343,8 +343,14 @@ def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt)
         assert float((dhpt.float().t().cpu() - dhpre).norm() / dhpre.norm()) < 6e-3
     # argument errors
     assert lib.cnx_block_mlp_bwd(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), gd.data_ptr(),
-                                 R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), da.data_ptr(),
+                                 R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), da.data_ptr(), 0,
                                  None, None, None, M_, C, S()) == -1          # emit pointers: all four or none
+    if emit:                                                                  # strided a_out (room for a ones column)
+        a8 = torch.full((M_, C + 8), 7.0, device="cuda", dtype=torch.bfloat16)
+        assert lib.cnx_block_mlp_bwd(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), gd.data_ptr(),
+                                     R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), a8.data_ptr(),
+                                     C + 8, P(dob), P(ht), P(dhpt), M_, C, S()) == 0
+        assert torch.equal(a8[:, :C], ao) and bool((a8[:, C:] == 7).all())
     assert lib.cnx_block_mlp_bwd_supported(384) == 0
 
 
@@ -422,3 +428,32 @@ def test_elementwise_tail_kernels(R, M_, C, gamma):
                                    N, S()) == 0
     close(dhp, ref, 8e-3, 1e-4)
     close(db1, dhp.float().sum(0), 1e-5, 1e-4)
+
+
+def test_derived_weight_copies_follow_a_fused_optimizer_step(R):
+    """AdamW(fused=True) updates parameters in place WITHOUT bumping Tensor._version; the packed / bf16 weight copies of
+    the fused kernels must still be rebuilt (global optimizer-step hook -> ops.invalidate_weight_cache)."""
+    torch.manual_seed(0)
+    blk = R.architecture.ConvNeXtBlock(96, ls_init_value=0.5).cuda()
+    x = torch.randn(2, 96, 14, 14, device="cuda").contiguous(memory_format=torch.channels_last)
+    opt = torch.optim.AdamW(blk.parameters(), lr=0.05, fused=True)
+
+    def both():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            fused = blk(x)
+            saved, R.ops.MODE = R.ops.MODE, "eager"
+            try:
+                eager = blk(x)
+            finally:
+                R.ops.MODE = saved
+        return fused.float(), eager.float()
+
+    f0, e0 = both()
+    assert float((f0 - e0).norm() / (e0 - x).norm()) < 2e-2
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        blk(x).float().square().mean().backward()
+    v = blk.mlp.fc1.weight._version
+    opt.step()
+    f1, e1 = both()
+    assert float((e1 - e0).norm()) > 1e-3 * float(e0.norm())             # the step really moved the block
+    assert float((f1 - e1).norm() / (e1 - x).norm()) < 2e-2, "fused path still uses the pre-step weights"

@@ -157,7 +157,7 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&ddhpt, M * 4 * C * 2));
       rc = cnx_mlp_pack_weights_bwd(dW1, dW2, APGD_F32, dWb, C, nullptr);
       if (rc) { printf("pack bwd rc=%d\n", rc); return 2; }
-      rc = cnx_block_mlp_bwd(du, dlnw, dlnb, dmean, drstd, dg, APGD_F32, dgm, dWb, db1, dda, da_o, ddo_o, dht, ddhpt, M, C, nullptr);
+      rc = cnx_block_mlp_bwd(du, dlnw, dlnb, dmean, drstd, dg, APGD_F32, dgm, dWb, db1, dda, da_o, 0, ddo_o, dht, ddhpt, M, C, nullptr);
       if (rc) { printf("bwd rc=%d\n", rc); return 2; }
       CK(hipDeviceSynchronize());
       std::vector<uint16_t> da(M * C), ht(M * 4 * C), dhpt(M * 4 * C), ao(M * C), doo(M * C);
@@ -206,7 +206,7 @@ int main(int argc, char** argv) {
         std::vector<float> tb;
         for (int it = 0; it < iters + 3; ++it) {
           CK(hipEventRecord(e0));
-          cnx_block_mlp_bwd(du, dlnw, dlnb, dmean, drstd, dg, APGD_F32, dgm, dWb, db1, dda, em ? da_o : nullptr, em ? ddo_o : nullptr,
+          cnx_block_mlp_bwd(du, dlnw, dlnb, dmean, drstd, dg, APGD_F32, dgm, dWb, db1, dda, em ? da_o : nullptr, 0, em ? ddo_o : nullptr,
                             em ? dht : nullptr, em ? ddhpt : nullptr, M, C, nullptr);
           CK(hipEventRecord(e1));
           CK(hipEventSynchronize(e1));
