@@ -726,8 +726,18 @@ __device__ __forceinline__ float4 round_bf16(float4 v) { return make_float4(roun
 // thread layout shared by the three kernels: a block is CQ channel-quads x RY rows (CQ = min(C/4, 256), RY = 256 / CQ), so
 // narrow tensors (C = 96: 24 quads) still fill their blocks; "row lane" rl = blockIdx.y*RY + ty walks rows rl, rl+R, ...
 struct ColMap { int c, rl, R; bool active; };
-__device__ __forceinline__ ColMap col_map(int C) {
-  const int cq_all = C / 4, CQ = cq_all < 256 ? cq_all : 256, RY = 256 / CQ;
+// CQ = the divisor of C/4 (<= 256) that keeps most of the 256 threads busy (C/4 = 384 -> 128 x 2 rows, 24 -> 24 x 10 rows)
+__host__ __device__ inline int col_cq(int cq_all) {
+  int best = 1, best_use = 0;
+  for (int d = 1; d <= 256 && d <= cq_all; ++d) {
+    if (cq_all % d) continue;
+    const int use = d * (256 / d);
+    if (use >= best_use) { best_use = use; best = d; }
+  }
+  return best;
+}
+__device__ __forceinline__ ColMap col_map(int C, int CQ) {
+  const int RY = 256 / CQ;
   const int tx = threadIdx.x % CQ, ty = threadIdx.x / CQ;
   ColMap m;
   m.c = (blockIdx.x * CQ + tx) * 4;
@@ -736,20 +746,22 @@ __device__ __forceinline__ ColMap col_map(int C) {
   m.active = ty < RY && m.c < C;
   return m;
 }
-inline dim3 col_grid(int C, long M, long max_lanes) {
-  const int cq_all = C / 4, CQ = cq_all < 256 ? cq_all : 256, RY = 256 / CQ;
+inline dim3 col_grid(int C, long M, long max_lanes, int* cq_out) {
+  const int cq_all = C / 4, CQ = col_cq(cq_all), RY = 256 / CQ;
+  *cq_out = CQ;
   long lanes = M < max_lanes ? M : max_lanes;
   long gy = (lanes + RY - 1) / RY;
   if (gy * RY > max_lanes) gy = max_lanes / RY;
   if (gy < 1) gy = 1;
-  return dim3((cq_all + CQ - 1) / CQ, static_cast<unsigned>(gy));
+  return dim3(cq_all / CQ, static_cast<unsigned>(gy));
 }
-inline int col_lanes(int C, const dim3& grid) { const int cq_all = C / 4, CQ = cq_all < 256 ? cq_all : 256; return static_cast<int>(grid.y) * (256 / CQ); }
+inline int col_lanes(int CQ, const dim3& grid) { return static_cast<int>(grid.y) * (256 / CQ); }
 
 template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void scale_residual_kernel(const TX* __restrict__ x, const uint16_t* __restrict__ y,
-                                                             const float* __restrict__ gamma, TO* __restrict__ out, long M, int C) {
-  const ColMap cm = col_map(C);
+                                                             const float* __restrict__ gamma, TO* __restrict__ out, long M, int C,
+                                                             int CQ) {
+  const ColMap cm = col_map(C, CQ);
   if (!cm.active) return;
   const int c = cm.c;
   const float4 g4 = gamma ? load4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -762,8 +774,8 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const TX* __restric
 template <typename TG>
 __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const TG* __restrict__ g, const uint16_t* __restrict__ y,
                                                                  const float* __restrict__ gamma, uint16_t* __restrict__ dos,
-                                                                 float* __restrict__ ws, long M, int C) {
-  const ColMap cm = col_map(C);
+                                                                 float* __restrict__ ws, long M, int C, int CQ) {
+  const ColMap cm = col_map(C, CQ);
   if (!cm.active) return;
   const int c = cm.c;
   const float4 g4 = gamma ? load4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -785,8 +797,9 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const TG* __res
 }
 
 __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const uint16_t* __restrict__ dh, const uint16_t* __restrict__ hpre,
-                                                              uint16_t* __restrict__ dhpre, float* __restrict__ ws, long M, int N) {
-  const ColMap cm = col_map(N);
+                                                              uint16_t* __restrict__ dhpre, float* __restrict__ ws, long M, int N,
+                                                              int CQ) {
+  const ColMap cm = col_map(N, CQ);
   if (!cm.active) return;
   const int c = cm.c;
   float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1127,10 +1140,11 @@ int cnx_scale_residual(const void* x, int x_dtype, const void* y, const float* g
   if (M == 0) return APGD_OK;
   if (!x || !y || !out) return APGD_ERR_NULL;
   if ((x_dtype != APGD_F32 && x_dtype != APGD_BF16) || (out_dtype != APGD_F32 && out_dtype != APGD_BF16)) return APGD_ERR_DTYPE;
-  const dim3 grid = col_grid(C, M, 16384), block(256);
+  int cq;
+  const dim3 grid = col_grid(C, M, 16384, &cq), block(256);
   hipStream_t s = as_stream(stream);
   const auto* yy = static_cast<const uint16_t*>(y);
-#define SR(TX, TO) hipLaunchKernelGGL((scale_residual_kernel<TX, TO>), grid, block, 0, s, static_cast<const TX*>(x), yy, gamma, static_cast<TO*>(out), static_cast<long>(M), C)
+#define SR(TX, TO) hipLaunchKernelGGL((scale_residual_kernel<TX, TO>), grid, block, 0, s, static_cast<const TX*>(x), yy, gamma, static_cast<TO*>(out), static_cast<long>(M), C, cq)
   if (x_dtype == APGD_F32 && out_dtype == APGD_F32) SR(float, float);
   else if (x_dtype == APGD_F32) SR(float, uint16_t);
   else if (out_dtype == APGD_F32) SR(uint16_t, float);
@@ -1148,16 +1162,17 @@ int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const floa
   if (dgamma && !ws) return APGD_ERR_NULL;
   if (g_dtype != APGD_F32 && g_dtype != APGD_BF16) return APGD_ERR_DTYPE;
   const bool sums = dgamma != nullptr;
-  const dim3 grid = col_grid(C, M, sums ? kColParts : 16384), block(256);
-  const int parts = col_lanes(C, grid);
+  int cq;
+  const dim3 grid = col_grid(C, M, sums ? kColParts : 16384, &cq), block(256);
+  const int parts = col_lanes(cq, grid);
   hipStream_t s = as_stream(stream);
   const auto* yy = static_cast<const uint16_t*>(y);          // NULL: dgamma comes out as zeros
   if (g_dtype == APGD_F32)
     hipLaunchKernelGGL(scale_residual_bwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(g), yy, gamma,
-                       static_cast<uint16_t*>(dos), sums ? ws : nullptr, static_cast<long>(M), C);
+                       static_cast<uint16_t*>(dos), sums ? ws : nullptr, static_cast<long>(M), C, cq);
   else
     hipLaunchKernelGGL(scale_residual_bwd_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t*>(g), yy, gamma,
-                       static_cast<uint16_t*>(dos), sums ? ws : nullptr, static_cast<long>(M), C);
+                       static_cast<uint16_t*>(dos), sums ? ws : nullptr, static_cast<long>(M), C, cq);
   if (sums)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, dgamma, db2, C, 2 * C,
                        static_cast<int>(M < parts ? M : parts));
@@ -1169,11 +1184,12 @@ int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db
   if (M == 0) return APGD_OK;
   if (!dh || !hpre || !dhpre) return APGD_ERR_NULL;
   if (db1 && !ws) return APGD_ERR_NULL;
-  const dim3 grid = col_grid(N, M, db1 ? kColParts : 16384), block(256);
-  const int parts = col_lanes(N, grid);
+  int cq;
+  const dim3 grid = col_grid(N, M, db1 ? kColParts : 16384, &cq), block(256);
+  const int parts = col_lanes(cq, grid);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(gelu_bwd_colsum_kernel, grid, block, 0, s, static_cast<const uint16_t*>(dh), static_cast<const uint16_t*>(hpre),
-                     static_cast<uint16_t*>(dhpre), db1 ? ws : nullptr, static_cast<long>(M), N);
+                     static_cast<uint16_t*>(dhpre), db1 ? ws : nullptr, static_cast<long>(M), N, cq);
   if (db1)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((N + 15) / 16), dim3(256), 0, s, ws, db1, static_cast<float*>(nullptr), N, N,
                        static_cast<int>(M < parts ? M : parts));

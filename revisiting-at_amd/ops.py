@@ -315,14 +315,16 @@ def _pack_mlp_bwd(w1, w2):
 
 
 class _BlockFused(torch.autograd.Function):
-    """One ConvNeXt block on channels-last rows (``models/convnext.py:37-50``):
+    """One ConvNeXt block on channels-last rows under bf16 autocast (``models/convnext.py:37-50``):
 
         x [N,H,W,C] -> u = dw7x7(x) (bf16)  ->  x + gamma * fc2(GELU(fc1(LN(u))))
 
-    Forward = two kernels: the depthwise stencil and ``cnx_block_mlp_fwd`` (LN prologue, two chained MFMA GEMMs with
-    the 4C-wide hidden activation kept on-chip, bias / layer-scale / residual epilogue).  Saved for backward: x, u and
-    the LN statistics only; the hidden activation is recomputed (M x 4C bf16 per block is the largest tensor of the
-    model and is never materialised in the forward)."""
+    Widths with fused block kernels (96, 192): forward = the depthwise stencil + ``cnx_block_mlp_fwd`` (LN prologue, two
+    chained MFMA GEMMs, hidden activation on-chip, bias / layer-scale / residual epilogue); saved for backward: x, u and the
+    LN statistics only (the hidden activation is recomputed by ``cnx_block_mlp_bwd``).  Other widths (384, 768): the four
+    GEMMs per direction run in hipBLASLt between our one-pass kernels (LN, scale+residual, dO/d(gamma)/d(b2), GELU'/d(b1)),
+    weight gradients as split-K batched GEMMs.  Either way the residual gradient rides into the depthwise input-gradient
+    kernel as its ``add`` operand, and parameter gradients are skipped entirely inside the attack."""
 
     @staticmethod
     def forward(ctx, x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
@@ -333,7 +335,6 @@ class _BlockFused(torch.autograd.Function):
         dwb = _f32(dw_b) if dw_b is not None else None
         lw, lb, b1f, b2f = _f32(ln_w), _f32(ln_b), _f32(b1), _f32(b2)
         gf = _f32(gamma) if gamma is not None else None
-        wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
         u = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
         _lib.check(lib.cnx_dwconv7x7_nhwc(x.data_ptr(), _code(x), w49c.data_ptr(), _lib.ptr(dwb), None, u.data_ptr(),
                                           _code(u), N, H, W, C, 0, _stream()), "cnx_dwconv7x7_nhwc")
@@ -341,31 +342,46 @@ class _BlockFused(torch.autograd.Function):
                           dtype=torch.float32 if (gamma is not None or x.dtype == torch.float32) else x.dtype)
         need_grad = any(ctx.needs_input_grad)        # all False when the caller runs under no_grad
         need_p = need_grad and any(ctx.needs_input_grad[1:])
-        mean = rstd = y2 = None
-        if need_grad:
+        fused = _use_fused_block(C) and bool(lib.cnx_block_mlp_bwd_supported(C))
+        mean = rstd = y2 = a = hpre = h = None
+        if need_grad or not fused:
             mean = torch.empty(M, device=x.device, dtype=torch.float32)
             rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-        if need_p and gamma is not None:
-            y2 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
-        _lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, _lib.ptr(mean), _lib.ptr(rstd),
-                                         wf.data_ptr(), b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), _code(x),
-                                         out.data_ptr(), _code(out), _lib.ptr(y2), M, C, _stream()), "cnx_block_mlp_fwd")
+        if fused:
+            # LN + fc1 + GELU + fc2 + gamma + residual: ONE kernel, hidden activation on-chip (recomputed in the backward)
+            wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
+            if need_p and gamma is not None:
+                y2 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, _lib.ptr(mean), _lib.ptr(rstd),
+                                             wf.data_ptr(), b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), _code(x),
+                                             out.data_ptr(), _code(out), _lib.ptr(y2), M, C, _stream()), "cnx_block_mlp_fwd")
+            wa = _cached((w1, w2), "mlp_packed_bwd", _pack_mlp_bwd) if need_grad else None
+            wb_ = None
+        else:
+            # widths without fused block kernels (384: the weight stream caps it below the library; 768): GEMMs in
+            # hipBLASLt, everything around them in our one-pass kernels
+            a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.cnx_layernorm_fwd(u.data_ptr(), _code(u), lw.data_ptr(), lb.data_ptr(), eps, a.data_ptr(), _code(a),
+                                             mean.data_ptr(), rstd.data_ptr(), M, C, 0, _stream()), "cnx_layernorm_fwd")
+            wa = _cached((w1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+            wb_ = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+            b1b = _cached((b1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+            b2b = _cached((b2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+            hpre = torch.addmm(b1b, a, wa.t())                                   # [M, 4C]
+            h = F.gelu(hpre)
+            y2 = torch.addmm(b2b, h, wb_.t())                                    # [M, C] bf16, pre-gamma
+            _lib.check(lib.cnx_scale_residual(x.data_ptr(), _code(x), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out),
+                                              M, C, _stream()), "cnx_scale_residual")
         if need_grad:
-            ctx.fused_bwd = bool(lib.cnx_block_mlp_bwd_supported(C))
-            if ctx.fused_bwd:
-                w1b = _cached((w1, w2), "mlp_packed_bwd", _pack_mlp_bwd)
-                w2b = None
-            else:
-                w1b = _cached((w1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-                w2b = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-            ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, w1b, w2b, b1f, b2f, gf, y2)
+            ctx.fused = fused
+            ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, wb_, b1f, gf, y2, a, hpre, h)
             ctx.has_dw_bias, ctx.eps = dw_b is not None, eps
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, w49c, u, mean, rstd, lw, lb, w1b, w2b, b1f, b2f, gf, y2 = ctx.saved_tensors
+        x, w49c, u, mean, rstd, lw, lb, w1b, w2b, b1f, gf, y2, a_s, hpre, h = ctx.saved_tensors
         N, H, W, C = x.shape
         M = N * H * W
         nig = ctx.needs_input_grad
@@ -374,7 +390,7 @@ class _BlockFused(torch.autograd.Function):
         g2 = g.reshape(M, C)
         dw1 = db1 = dw2 = db2 = dgamma = None
         da = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)            # gradient w.r.t. LN(u)
-        if ctx.fused_bwd:
+        if ctx.fused:
             # ---- one kernel: LN recompute, dO = g*gamma, Hpre / dH / dHpre per hidden slice on-chip, da
             a = dos = ht = dhpt = None
             if want_p:
@@ -404,26 +420,31 @@ class _BlockFused(torch.autograd.Function):
                     dgamma = None
                 del a, dos, ht, dhpt
         else:
-            # ---- library composition on the recomputed activations
-            a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)         # LN(u), recomputed
-            _lib.check(lib.cnx_layernorm_fwd(u.data_ptr(), _code(u), lw.data_ptr(), lb.data_ptr(), ctx.eps, a.data_ptr(),
-                                             _code(a), None, None, M, C, 0, _stream()), "cnx_layernorm_fwd")
-            dos = (g2 * gf if gf is not None else g2).to(torch.bfloat16)         # d(fc2 out)
-            hpre = torch.addmm(b1f.to(torch.bfloat16), a, w1b.t())               # [M, 4C]
-            dh = dos @ w2b
-            dhpre = torch.ops.aten.gelu_backward(dh, hpre)
+            # ---- library GEMMs between the one-pass tails: dO (+ d(gamma), d(b2)), GELU' (+ d(b1)), split-K weight gradients
+            if g2.dtype not in (torch.float32, torch.bfloat16):
+                g2 = g2.float()
+            dos = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+            ws = None
+            if want_p:
+                dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+                db2 = torch.empty(C, device=x.device, dtype=torch.float32)
+                db1 = torch.empty(4 * C, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.cnx_colsum_ws_floats(4 * C), device=x.device, dtype=torch.float32)
+            _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2.data_ptr(), _lib.ptr(gf), dos.data_ptr(),
+                                                  _lib.ptr(dgamma), _lib.ptr(db2), _lib.ptr(ws), M, C, _stream()),
+                       "cnx_scale_residual_bwd")
+            dh = dos @ w2b                                                       # [M, 4C]
+            dhpre = torch.empty_like(dh)
+            _lib.check(lib.cnx_gelu_bwd_colsum(dh.data_ptr(), hpre.data_ptr(), dhpre.data_ptr(), _lib.ptr(db1), _lib.ptr(ws), M,
+                                               4 * C, _stream()), "cnx_gelu_bwd_colsum")
             del dh
             da = dhpre @ w1b                                                     # [M, C] bf16
             if want_p:
-                h = F.gelu(hpre)
                 dw2 = _wgrad(dos, h)
-                db2 = dos.float().sum(0)
-                dw1 = _wgrad(dhpre, a)
-                db1 = dhpre.float().sum(0)
-                if gf is not None:
-                    dgamma = (g2.float() * y2.reshape(M, C).float()).sum(0)
-                del h
-            del hpre, dhpre
+                dw1 = _wgrad(dhpre, a_s)
+                if gf is None:
+                    dgamma = None
+            del dhpre, dos
         # ---- LayerNorm backward
         d_u = torch.empty_like(u)
         dlw = dlb = ws = None
@@ -457,76 +478,6 @@ class _BlockFused(torch.autograd.Function):
         return dx, dww, dwb, dlw, dlb, None, dw1, db1, dw2, db2, dgamma
 
 
-class _MlpTailLib(torch.autograd.Function):
-    """``x + gamma * fc2(GELU(fc1(a)))`` for widths without a fused block kernel (C = 384 in the backward-capable path,
-    768): the four GEMMs per direction stay in hipBLASLt, everything around them is ours —
-
-      forward   ``cnx_scale_residual`` (layer scale + residual, one pass instead of mul + add)
-      backward  ``cnx_scale_residual_bwd`` (dO = bf16(g*gamma) + d(gamma) + d(b2) in one pass instead of 6 launches),
-                ``cnx_gelu_bwd_colsum`` (GELU' + d(b1)), split-K batched GEMMs for the two weight gradients (``_wgrad``:
-                as single GEMMs with K = N*H*W they ran at 200-260 TFLOP/s).
-    """
-
-    @staticmethod
-    def forward(ctx, a, x, w1, b1, w2, b2, gamma):
-        lib = _lib.load()
-        C = a.shape[-1]
-        M = a.numel() // C
-        a2 = a.reshape(M, C)
-        w1b = _cached((w1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-        w2b = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-        hpre = torch.addmm(b1.detach().to(torch.bfloat16), a2, w1b.t())             # [M, 4C]
-        h = F.gelu(hpre)
-        y2 = torch.addmm(b2.detach().to(torch.bfloat16), h, w2b.t())                # [M, C] bf16, pre-gamma
-        gf = _f32(gamma) if gamma is not None else None
-        out = torch.empty(x.shape, device=x.device,
-                          dtype=torch.float32 if (gamma is not None or x.dtype == torch.float32) else x.dtype)
-        _lib.check(lib.cnx_scale_residual(x.data_ptr(), _code(x), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out), M, C,
-                                          _stream()), "cnx_scale_residual")
-        if any(ctx.needs_input_grad):
-            ctx.save_for_backward(a2, hpre, h, y2, w1b, w2b, gf)
-            ctx.x_dtype, ctx.a_shape = x.dtype, a.shape
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        a2, hpre, h, y2, w1b, w2b, gf = ctx.saved_tensors
-        M, C = a2.shape
-        nig = ctx.needs_input_grad
-        want_p = any(nig[2:]) and not _INPUT_GRAD_ONLY
-        g = g.contiguous()
-        if g.dtype not in (torch.float32, torch.bfloat16):
-            g = g.float()
-        dev = a2.device
-        dos = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
-        dgamma = db2 = db1 = ws = None
-        if want_p:
-            dgamma = torch.empty(C, device=dev, dtype=torch.float32)
-            db2 = torch.empty(C, device=dev, dtype=torch.float32)
-            db1 = torch.empty(4 * C, device=dev, dtype=torch.float32)
-            ws = torch.empty(lib.cnx_colsum_ws_floats(4 * C), device=dev, dtype=torch.float32)
-        _lib.check(lib.cnx_scale_residual_bwd(g.data_ptr(), _code(g), y2.data_ptr(), _lib.ptr(gf), dos.data_ptr(),
-                                              _lib.ptr(dgamma), _lib.ptr(db2), _lib.ptr(ws), M, C, _stream()),
-                   "cnx_scale_residual_bwd")
-        dh = dos @ w2b                                                              # [M, 4C]
-        dhpre = torch.empty_like(dh)
-        _lib.check(lib.cnx_gelu_bwd_colsum(dh.data_ptr(), hpre.data_ptr(), dhpre.data_ptr(), _lib.ptr(db1), _lib.ptr(ws), M,
-                                           4 * C, _stream()), "cnx_gelu_bwd_colsum")
-        del dh
-        da = (dhpre @ w1b).view(ctx.a_shape) if nig[0] else None
-        dw1 = dw2 = None
-        if want_p:
-            dw2 = _wgrad(dos, h)
-            dw1 = _wgrad(dhpre, a2)
-            if gf is None:
-                dgamma = None
-        dx = g.to(ctx.x_dtype) if nig[1] else None
-        return da, dx, dw1, db1, dw2, db2, dgamma
-
-
-
-
 def block_fused_supported(C):
     return bool(_lib.load().cnx_block_mlp_supported(C))
 
@@ -555,11 +506,9 @@ def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
         xr = _rows(x)
         if xr.dtype not in (torch.float32, torch.bfloat16):
             xr = xr.float()
-        if _act_dtype(xr) == torch.bfloat16 and _use_fused_block(x.shape[1]):
+        if _act_dtype(xr) == torch.bfloat16 and x.shape[1] % 4 == 0:
             return _BlockFused.apply(xr, dw_w, dw_b, ln_w, ln_b, float(eps), w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
         y = dwconv_ln(xr, dw_w, dw_b, ln_w, ln_b, eps)
-        if y.dtype == torch.bfloat16 and x.shape[1] % 4 == 0:
-            return _MlpTailLib.apply(y, xr, w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
     y = F.linear(F.gelu(F.linear(y, w1, b1)), w2, b2)
     if gamma is not None:
         y = y * gamma
