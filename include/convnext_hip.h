@@ -56,6 +56,19 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
                       void* dx, int dx_dtype, float* dweight, float* dbias, float* ws,
                       int64_t M, int32_t C, int32_t gelu, void* stream);
 
+/* First ConvStem convolution: Conv2d(3, P, kernel 3, stride 2, padding 1) (utils_architecture.py:127, 180, 205) on the
+ * attack state itself.  x [N, 3, H, W] fp32 NCHW contiguous -> out [N, OH, OW, P] bf16 rows (OH = ceil(H/2)); autocast
+ * numerics (x and the filter rounded to bf16, fp32 accumulation; MFMA).  wq = cnx_stem_conv_pack(weight [P,3,3,3]) is the
+ * filter as MFMA operand fragments for both directions, cnx_stem_conv_packed_bytes(P) bytes.  cnx_stem_conv_dgrad: dy [N, H/2, W/2, P] bf16 -> dx [N, 3, H, W] fp32 NCHW (H, W
+ * even) = the gradient the APGD update consumes.  P in {48, 64, 96}. */
+int cnx_stem_conv_supported(int32_t P);
+int64_t cnx_stem_conv_packed_bytes(int32_t P);
+int cnx_stem_conv_pack(const void* w, int w_dtype, void* wq, int32_t P, void* stream);
+int cnx_stem_conv_fwd(const float* x, const void* wq, const float* bias, void* out,
+                      int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
+int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx,
+                        int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
+
 /* Element-wise tails of the MLP for widths that run their GEMMs in the library (models/convnext.py:44-49 and their
  * backward), one pass each, per-channel parameter gradients accumulated on the way (deterministic two-stage sums;
  * ws = cnx_colsum_ws_floats(n_cols) floats of scratch):

@@ -49,6 +49,11 @@ PROTOTYPES = {
     "cnx_mlp_pack_weights_bwd": (C.c_int, [_p, _p, C.c_int, _p, _i32, _p]),
     "cnx_block_mlp_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p]),
     "cnx_attention_supported": (C.c_int, [_i32, _i32]),
+    "cnx_stem_conv_supported": (C.c_int, [_i32]),
+    "cnx_stem_conv_packed_bytes": (C.c_int64, [_i32]),
+    "cnx_stem_conv_pack": (C.c_int, [_p, C.c_int, _p, _i32, _p]),
+    "cnx_stem_conv_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_stem_conv_dgrad": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_colsum_ws_floats": (C.c_int64, [_i32]),
     "cnx_scale_residual": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int, _i64, _i32, _p]),
     "cnx_scale_residual_bwd": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),

@@ -94,10 +94,22 @@ class _CfLnGelu(nn.Module):
         return ops.layer_norm_cf_gelu(x, self.weight, self.bias, self.eps)
 
 
+class _ImageConv(nn.Conv2d):
+    """The first stem convolution (3 -> P, 3x3, stride 2): a plain ``nn.Conv2d`` for the state dict, routed through the
+    hand-written image-to-NHWC kernel (and its input-gradient kernel, which produces the attack's gradient) when the input
+    is the fp32 NCHW image batch under bf16 autocast."""
+
+    def forward(self, x):
+        if ops.stem_conv_supported(x, self.weight, self.stride, self.padding):
+            return ops.stem_conv(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def _stem(chans, strides, final_1x1=None):
     layers = []
     for cin, cout, s in zip(chans[:-1], chans[1:], strides):
-        layers += [nn.Conv2d(cin, cout, kernel_size=3, stride=s, padding=1), _CfLnGelu(cout), nn.Identity()]
+        conv = _ImageConv if (cin == 3 and s == 2) else nn.Conv2d
+        layers += [conv(cin, cout, kernel_size=3, stride=s, padding=1), _CfLnGelu(cout), nn.Identity()]
     if final_1x1 is not None:
         layers.append(nn.Conv2d(chans[-1], final_1x1, kernel_size=1, stride=1, padding=0))
     return nn.Sequential(*layers)

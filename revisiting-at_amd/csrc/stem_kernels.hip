@@ -1,0 +1,251 @@
+// stem_kernels.hip — first ConvStem convolution (3 -> P channels, 3x3, stride 2, pad 1; utils_architecture.py:127, 180, 205)
+// for gfx950, forward and input gradient.
+//
+// This layer touches the attack state directly: its input is the fp32 NCHW image batch x_adv and its input gradient IS
+// the gradient the APGD update consumes.  Through the library it costs a cast + a layout copy + an implicit-GEMM kernel
+// + a separate bias add in the forward (380 us at batch 256) and a layout copy + CK conv_bwd_data + two more copies in
+// the backward (710 us), for 4.2 GFLOP of work.  Here:
+//   forward   a wavefront = 32 output positions: the 27 taps are read straight from the fp32 NCHW image (rounded to bf16 as
+//             the autocast convolution does) into an MFMA A operand, the filter sits in registers as B fragments, the
+//             result (+bias) goes through a wavefront-private LDS transpose to lane-linear 16-byte NHWC stores;
+//   dgrad     a wavefront = 32 input 2x2 patches (all 3 channels): with stride 2 the four pixels of a patch see the 2x2
+//             neighbouring output positions through fixed (kh, kw) taps - a 12 x 4P matrix times the 4P gradient values
+//             (16-byte NHWC loads), transposed product so that a lane owns a patch and stores float2 runs of fp32 NCHW.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "apgd_hip.h"
+#include "convnext_hip.h"
+
+namespace {
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float round_bf16(float v) { return __uint_as_float(pack_bf16(v, 0.f) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// Both directions are tiny GEMMs per group of 32 positions, on MFMA 32x32x16 (the fp32-FMA form of these kernels was
+// VALU-bound at 420 / 780 us; 1296 MACs per position against 27 loads):
+//   forward  D[pos][co]  = patch[pos][k] W[k][co],  k = (ci, kh, kw) padded 27 -> 32:      2 k-steps x ceil(P/32) blocks
+//   dgrad    D[o][patch] = Wp[o][k] dY[k][patch],   k = (q, co): the 2x2 output positions q around a 2x2 input patch times the
+//            P channels; o = ci*4 + i*2 + j: the 12 values of the patch.  Wp[o][(q, co)] = w[co][ci][kh][kw] with the (kh, kw)
+//            that connects pixel (i, j) to position q (stride 2: at most one), else 0.                  4P/16 k-steps
+// Packed filter (cnx_stem_conv_pack): [NB][2][64][8] bf16 forward B fragments, then [4P/16][64][8] bf16 dgrad A fragments.
+template <int P> struct StemGeo {
+  static constexpr int NB = (P + 31) / 32;            // 32-wide blocks of output channels
+  static constexpr int KD = 4 * P / 16;               // k-steps of the dgrad GEMM
+  static constexpr int FWD_BYTES = NB * 2 * 1024;
+  static constexpr int BYTES = FWD_BYTES + KD * 1024;
+};
+
+template <typename TW>
+__global__ void stem_pack_kernel(const TW* __restrict__ w, uint16_t* __restrict__ wq, int P) {
+  const int NB = (P + 31) / 32, KD = 4 * P / 16;
+  const int i = blockIdx.x * 256 + threadIdx.x;                      // one bf16 element each
+  const int n_fwd = NB * 2 * 512, n_all = n_fwd + KD * 512;
+  if (i >= n_all) return;
+  float v = 0.f;
+  if (i < n_fwd) {
+    const int e = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) & 1, nb = i >> 10;
+    const int co = nb * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + e;
+    if (co < P && k < 27) v = static_cast<float>(w[co * 27 + k]);
+  } else {
+    const int t = i - n_fwd;
+    const int e = t & 7, lane = (t >> 3) & 63, ks = t >> 9;
+    const int o = lane & 31, k = ks * 16 + (lane >> 5) * 8 + e;
+    const int q = k / P, co = k - q * P, qi = q >> 1, qj = q & 1;
+    if (o < 12) {
+      const int ci = o >> 2, pi = (o >> 1) & 1, pj = o & 1;
+      // pixel row 2a+pi <- output row a+qi: pi=0: only qi=0 through kh=1;  pi=1: qi=0 through kh=2, qi=1 through kh=0
+      const int kh = pi == 0 ? (qi == 0 ? 1 : -1) : (qi == 0 ? 2 : 0);
+      const int kw = pj == 0 ? (qj == 0 ? 1 : -1) : (qj == 0 ? 2 : 0);
+      if (kh >= 0 && kw >= 0) v = static_cast<float>(w[co * 27 + (ci * 3 + kh) * 3 + kw]);
+    }
+  }
+  wq[i] = static_cast<uint16_t>(pack_bf16(v, 0.f));
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wq,
+                                                            const float* __restrict__ bias, uint16_t* __restrict__ out, long total,
+                                                            int H, int W, int OH, int OW) {
+  using G = StemGeo<P>;
+  __shared__ __attribute__((aligned(16))) uint16_t stage[4][32 * P];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
+  bf16x8 bw[G::NB][2];
+#pragma unroll
+  for (int nb = 0; nb < G::NB; ++nb)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) bw[nb][ks] = *reinterpret_cast<const bf16x8*>(wq + ((nb * 2 + ks) * 64 + lane) * 8);
+  float bv[G::NB];
+#pragma unroll
+  for (int nb = 0; nb < G::NB; ++nb) bv[nb] = (bias && nb * 32 + l32 < P) ? bias[nb * 32 + l32] : 0.f;
+  const long nblk = (total + 31) / 32;
+  for (long blk = static_cast<long>(blockIdx.x) * 4 + wave; blk < nblk; blk += static_cast<long>(gridDim.x) * 4) {
+    long pos = blk * 32 + l32;
+    const bool ok = pos < total;
+    if (!ok) pos = total - 1;
+    const int ow = static_cast<int>(pos % OW);
+    const long r = pos / OW;
+    const int oh = static_cast<int>(r % OH);
+    const float* xn = x + (r / OH) * 3 * static_cast<long>(H) * W;
+    bf16x8 pa[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = ks * 16 + half * 8 + e;
+        const int ci = k / 9, rem = k - ci * 9, kh = rem / 3, kw = rem - kh * 3;
+        const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+        v[e] = (k < 27 && ih >= 0 && ih < H && iw >= 0 && iw < W) ? xn[(static_cast<long>(ci) * H + ih) * W + iw] : 0.f;
+      }
+      pa[ks] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])));
+    }
+    uint16_t* st = stage[wave];
+#pragma unroll
+    for (int nb = 0; nb < G::NB; ++nb) {
+      f32x16 acc;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc[rr] = bv[nb];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], bw[nb][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], bw[nb][1], acc, 0, 0, 0);
+      const int co = nb * 32 + l32;
+      if (co < P) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) st[((rr & 3) + 8 * (rr >> 2) + 4 * half) * P + co] = static_cast<uint16_t>(pack_bf16(acc[rr], 0.f));
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the region is private to the wavefront
+    // 32 positions x P channels = 64 P contiguous bytes in NHWC memory: P/8 16-byte chunks per position, lane-linear
+    const long base = blk * 32 * P;                                  // element offset of the block
+    const long lim = total * P;
+#pragma unroll
+    for (int c = 0; c < (32 * P / 8 + 63) / 64; ++c) {
+      const int ch = c * 64 + lane;
+      if (ch < 32 * P / 8 && base + static_cast<long>(ch) * 8 < lim)
+        *reinterpret_cast<uint4*>(out + base + static_cast<long>(ch) * 8) = *reinterpret_cast<const uint4*>(st + ch * 8);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void stem_conv_dgrad_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ wq,
+                                                              float* __restrict__ dx, long total, int H, int W, int OH, int OW) {
+  using G = StemGeo<P>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
+  bf16x8 wa[G::KD];
+#pragma unroll
+  for (int ks = 0; ks < G::KD; ++ks) wa[ks] = *reinterpret_cast<const bf16x8*>(wq + G::FWD_BYTES / 2 + (ks * 64 + lane) * 8);
+  const long nblk = (total + 31) / 32;
+  for (long blk = static_cast<long>(blockIdx.x) * 4 + wave; blk < nblk; blk += static_cast<long>(gridDim.x) * 4) {
+    long pt = blk * 32 + l32;
+    const bool ok = pt < total;
+    if (!ok) pt = total - 1;
+    const int b = static_cast<int>(pt % OW);
+    const long r = pt / OW;
+    const int a = static_cast<int>(r % OH);
+    const long n = r / OH;
+    const uint16_t* p00 = dy + ((n * OH + a) * static_cast<long>(OW) + b) * P;
+    f32x16 acc;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) acc[rr] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::KD; ++ks) {
+      const int k = ks * 16 + half * 8;                               // 8 consecutive channels of ONE position q (P % 8 == 0)
+      const int q = k / P, co = k - q * P, qi = q >> 1, qj = q & 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a + qi < OH && b + qj < OW) v = *reinterpret_cast<const uint4*>(p00 + (static_cast<long>(qi) * OW + qj) * P + co);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
+    }
+    // acc[rr] = D[o = (rr&3) + 8*(rr>>2) + 4*half][patch = l32], o = ci*4 + i*2 + j
+    if (ok) {
+      float* xn = dx + n * 3 * static_cast<long>(H) * W;
+      if (half == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          *reinterpret_cast<float2*>(xn + (0L * H + 2 * a + i) * W + 2 * b) = make_float2(acc[2 * i], acc[2 * i + 1]);            // ci = 0: o = 0..3
+          *reinterpret_cast<float2*>(xn + (2L * H + 2 * a + i) * W + 2 * b) = make_float2(acc[4 + 2 * i], acc[4 + 2 * i + 1]);    // ci = 2: o = 8..11
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          *reinterpret_cast<float2*>(xn + (1L * H + 2 * a + i) * W + 2 * b) = make_float2(acc[2 * i], acc[2 * i + 1]);            // ci = 1: o = 4..7
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cnx_stem_conv_supported(int32_t P) { return (P == 48 || P == 64 || P == 96) ? 1 : 0; }
+
+int64_t cnx_stem_conv_packed_bytes(int32_t P) { return (static_cast<int64_t>((P + 31) / 32) * 2 + 4 * P / 16) * 1024; }
+
+int cnx_stem_conv_pack(const void* w, int w_dtype, void* wq, int32_t P, void* stream) {
+  if (!w || !wq) return APGD_ERR_NULL;
+  if (!cnx_stem_conv_supported(P)) return APGD_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  const long n = cnx_stem_conv_packed_bytes(P) / 2;
+  const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
+  auto* q = static_cast<uint16_t*>(wq);
+  if (w_dtype == APGD_F32) hipLaunchKernelGGL(stem_pack_kernel<float>, grid, block, 0, s, static_cast<const float*>(w), q, P);
+  else if (w_dtype == APGD_BF16) hipLaunchKernelGGL(stem_pack_kernel<__bf16>, grid, block, 0, s, static_cast<const __bf16*>(w), q, P);
+  else return APGD_ERR_DTYPE;
+  return launch_status();
+}
+
+int cnx_stem_conv_fwd(const float* x, const void* wq, const float* bias, void* out, int64_t N, int32_t H, int32_t W, int32_t P,
+                      void* stream) {
+  if (N < 0 || H <= 0 || W <= 0) return APGD_ERR_SIZE;
+  if (N == 0) return APGD_OK;
+  if (!x || !wq || !out) return APGD_ERR_NULL;
+  if (!cnx_stem_conv_supported(P)) return APGD_ERR_ARG;
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const long total = N * OH * OW;
+  long nb = (total + 127) / 128;
+  if (nb > 4096) nb = 4096;
+  const dim3 grid(static_cast<unsigned>(nb)), block(256);
+  hipStream_t s = as_stream(stream);
+  auto* o = static_cast<uint16_t*>(out);
+  const auto* q = static_cast<const uint16_t*>(wq);
+  if (P == 48) hipLaunchKernelGGL(stem_conv_fwd_kernel<48>, grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW);
+  else if (P == 64) hipLaunchKernelGGL(stem_conv_fwd_kernel<64>, grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW);
+  else hipLaunchKernelGGL(stem_conv_fwd_kernel<96>, grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW);
+  return launch_status();
+}
+
+int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx, int64_t N, int32_t H, int32_t W, int32_t P, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0) return APGD_ERR_SIZE;
+  if (N == 0) return APGD_OK;
+  if (!dy || !wq || !dx) return APGD_ERR_NULL;
+  if (!cnx_stem_conv_supported(P) || (H & 1) || (W & 1)) return APGD_ERR_ARG;
+  const int OH = H / 2, OW = W / 2;
+  const long total = N * OH * OW;
+  long nb = (total + 127) / 128;
+  if (nb > 4096) nb = 4096;
+  const dim3 grid(static_cast<unsigned>(nb)), block(256);
+  hipStream_t s = as_stream(stream);
+  const auto* d = static_cast<const uint16_t*>(dy);
+  const auto* q = static_cast<const uint16_t*>(wq);
+  if (P == 48) hipLaunchKernelGGL(stem_conv_dgrad_kernel<48>, grid, block, 0, s, d, q, dx, total, H, W, OH, OW);
+  else if (P == 64) hipLaunchKernelGGL(stem_conv_dgrad_kernel<64>, grid, block, 0, s, d, q, dx, total, H, W, OH, OW);
+  else hipLaunchKernelGGL(stem_conv_dgrad_kernel<96>, grid, block, 0, s, d, q, dx, total, H, W, OH, OW);
+  return launch_status();
+}
+
+}  // extern "C"

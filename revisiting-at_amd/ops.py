@@ -132,6 +132,75 @@ def layer_norm_cf_gelu(x, weight, bias, eps):
     return _ln_rows(_rows(x), weight, bias, eps, True).permute(0, 3, 1, 2)
 
 
+# ------------------------------------------------------------------------------ first ConvStem convolution
+class _StemConv(torch.autograd.Function):
+    """``Conv2d(3, P, 3, stride 2, padding 1)`` on the fp32 NCHW image batch -> NCHW-shaped view of NHWC bf16 rows.
+
+    The layer that touches the attack state: its input gradient is what the APGD update consumes.  Forward and input
+    gradient are ``cnx_stem_conv_fwd`` / ``cnx_stem_conv_dgrad`` (no cast, no layout copy, bias fused); the filter / bias
+    gradient (training backward only) stays in the library."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        N, _, H, W = x.shape
+        P = weight.shape[0]
+        wq = _cached((weight,), "stem_wq", _pack_stem)
+        bf = _f32(bias) if bias is not None else None
+        out = torch.empty(N, (H + 1) // 2, (W + 1) // 2, P, device=x.device, dtype=torch.bfloat16)
+        _lib.check(lib.cnx_stem_conv_fwd(x.data_ptr(), wq.data_ptr(), _lib.ptr(bf), out.data_ptr(), N, H, W, P, _stream()),
+                   "cnx_stem_conv_fwd")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, weight, wq)
+            ctx.has_bias = bias is not None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, weight, wq = ctx.saved_tensors
+        N, _, H, W = x.shape
+        P = weight.shape[0]
+        gr = g.permute(0, 2, 3, 1)
+        if gr.dtype != torch.bfloat16 or not gr.is_contiguous():
+            gr = gr.to(torch.bfloat16).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(lib.cnx_stem_conv_dgrad(gr.data_ptr(), wq.data_ptr(), dx.data_ptr(), N, H, W, P, _stream()),
+                       "cnx_stem_conv_dgrad")
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY:
+            xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gb = gr.permute(0, 3, 1, 2)                                    # NCHW view of channels-last memory
+            _, dw, db = torch.ops.aten.convolution_backward(gb, xb, weight.to(torch.bfloat16), [P], [2, 2], [1, 1], [1, 1],
+                                                            False, [0, 0], 1, [False, True, ctx.has_bias])
+            dw = dw.to(weight.dtype)
+            db = db.float() if ctx.has_bias else None
+        return dx, dw, db
+
+
+def _pack_stem(w):
+    lib = _lib.load()
+    P = w.shape[0]
+    w = w.contiguous()
+    if w.dtype not in (torch.float32, torch.bfloat16):
+        w = w.float()
+    wq = torch.empty(lib.cnx_stem_conv_packed_bytes(P), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.cnx_stem_conv_pack(w.data_ptr(), _code(w), wq.data_ptr(), P, _stream()), "cnx_stem_conv_pack")
+    return wq
+
+
+def stem_conv_supported(x, weight, stride, padding):
+    return (MODE != "eager" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and tuple(weight.shape[1:]) == (3, 3, 3)
+            and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype('cuda') == torch.bfloat16 and bool(_lib.load().cnx_stem_conv_supported(weight.shape[0])))
+
+
+def stem_conv(x, weight, bias):
+    return _StemConv.apply(x, weight, bias)
+
+
 # ------------------------------------------------------------------------------ depthwise 7x7 + LayerNorm
 class _DwConvLN(torch.autograd.Function):
     """[N,H,W,C] rows in -> LN(dwconv7x7(x)) rows out (``models/convnext.py:39-41``)."""

@@ -457,3 +457,34 @@ def test_derived_weight_copies_follow_a_fused_optimizer_step(R):
     f1, e1 = both()
     assert float((e1 - e0).norm()) > 1e-3 * float(e0.norm())             # the step really moved the block
     assert float((f1 - e1).norm() / (e1 - x).norm()) < 2e-2, "fused path still uses the pre-step weights"
+
+
+@pytest.mark.parametrize("P,N,H,W", [(48, 2, 32, 32), (64, 1, 16, 24), (96, 3, 8, 8), (48, 1, 224, 224)])
+def test_stem_image_conv_forward_and_input_gradient(R, P, N, H, W):
+    """cnx_stem_conv_fwd / cnx_stem_conv_dgrad (fp32 NCHW image <-> NHWC bf16 rows, stride 2) vs F.conv2d on the bf16-rounded
+    operands (autocast numerics); the autograd wrapper's weight / bias gradients vs fp32 autograd."""
+    g = torch.Generator().manual_seed(P + H)
+    x = torch.rand(N, 3, H, W, generator=g)
+    w = torch.randn(P, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(P, generator=g) * 0.1
+    bf = lambda t: t.to(torch.bfloat16).float()
+    xr, wr, br = bf(x).requires_grad_(), bf(w).requires_grad_(), b.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, br, stride=2, padding=1)
+    xd = x.cuda().requires_grad_()
+    wd, bd = w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert R.ops.stem_conv_supported(xd, wd, (2, 2), (1, 1))
+        out = R.ops.stem_conv(xd, wd, bd)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    close(out, ref, 1e-2, 1e-2)                                   # bf16 output rounding
+    cot = bf(torch.randn(ref.shape, generator=g))
+    gx, gw, gb = torch.autograd.grad(ref, (xr, wr, br), cot)
+    dx, dw, db = torch.autograd.grad(out, (xd, wd, bd), cot.cuda().to(torch.bfloat16))
+    close(dx, gx, 1e-4, 1e-4 * float(gx.abs().max()))            # exact products of bf16 values, fp32 accumulation
+    assert float((dw.float().cpu() - gw).norm() / gw.norm()) < 1e-2
+    assert float((db.float().cpu() - gb).norm() / gb.norm()) < 1e-2
+    with R.ops.input_grad_only():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out2 = R.ops.stem_conv(xd, wd, bd)
+        (dx2,) = torch.autograd.grad(out2, xd, cot.cuda().to(torch.bfloat16))
+    assert torch.equal(dx2, dx)
