@@ -306,7 +306,7 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
                                                              const float* __restrict__ bias, const float* __restrict__ add,
                                                              TO* __restrict__ out, int H, int W, int C, int flip, int TH,
-                                                             int tiles_h) {
+                                                             int tiles_h, int dbg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile2[];       // [TH+6][P2][32]
   const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
   const long n = blockIdx.x / tiles_h;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
   // ---- staging: unit = (row, pair m, 4-channel group): two 4-channel loads (padded cols 2m, 2m+1) -> 4 packed dwords
   constexpr int kSR = 4;
   const int row_units = P2 * (kDC / 4);
-  for (int tr0 = 0; tr0 < TH + 6; tr0 += kSR) {
+  for (int tr0 = 0; tr0 < ((dbg & 2) ? 0 : TH + 6); tr0 += kSR) {       // dbg 2: timing experiment, no staging
     for (int i = tid; i < row_units; i += nthr) {
       const int m = i / (kDC / 4), l4 = i - m * (kDC / 4);
       const int w0 = 2 * m - 3, w1 = w0 + 1;
@@ -359,54 +359,74 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
   __syncthreads();
 
   const int n_sr = (TH + kDR - 1) / kDR;
-  if (sidx >= n_sr * n_sc) return;
-  const int sc = sidx % n_sc, sr = sidx / n_sc;
+  const bool worker = sidx < n_sr * n_sc;                       // the block is rounded up to whole wavefronts
+  const int sc = worker ? sidx % n_sc : 0, sr = worker ? sidx / n_sc : 0;
   float acc[kDR][kDT];
   const float b0 = bias ? bias[c] : 0.f;
   const int h_end = min(H, h0 + TH);
-  // the fused "+ add" operand (the residual branch's gradient in the backward) is fetched NOW, so that its HBM latency
-  // hides behind the stencil arithmetic instead of sitting exposed in the epilogue
 #pragma unroll
   for (int oh = 0; oh < kDR; ++oh)
 #pragma unroll
-    for (int t = 0; t < kDT; ++t) {
-      acc[oh][t] = b0;
-      const int h = h0 + sr * kDR + oh, w = sc * kDT + t;
-      if (add && h < h_end && w < W) acc[oh][t] += add[((n * H + h) * static_cast<long>(W) + w) * C + c];
-    }
+    for (int t = 0; t < kDT; ++t) acc[oh][t] = b0;
 
+  if (worker) {
 #pragma unroll
-  for (int r = 0; r < kDR + 6; ++r) {
-    const int tr = sr * kDR + r;
-    if (tr >= TH + 6) continue;
-    const uint32_t* trow = tile2 + (static_cast<long>(tr) * P2 + sc * (kDT / 2)) * kDC + lc;
-    uint32_t d[kDT / 2 + 3];
+    for (int r = 0; r < kDR + 6; ++r) {
+      const int tr = sr * kDR + r;
+      if (tr >= TH + 6 || (dbg & 1)) continue;                           // dbg 1: timing experiment, no stencil arithmetic
+      const uint32_t* trow = tile2 + (static_cast<long>(tr) * P2 + sc * (kDT / 2)) * kDC + lc;
+      uint32_t d[kDT / 2 + 3];
 #pragma unroll
-    for (int i = 0; i < kDT / 2 + 3; ++i) d[i] = trow[i * kDC];
+      for (int i = 0; i < kDT / 2 + 3; ++i) d[i] = trow[i * kDC];
 #pragma unroll
-    for (int oh = 0; oh < kDR; ++oh) {
-      const int kh = r - oh;
-      if (kh < 0 || kh > 6) continue;
+      for (int oh = 0; oh < kDR; ++oh) {
+        const int kh = r - oh;
+        if (kh < 0 || kh > 6) continue;
 #pragma unroll
-      for (int q = 0; q < kDT / 2; ++q) {
+        for (int q = 0; q < kDT / 2; ++q) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[oh][2 * q] = dot2(d[q + i], we[kh][i], acc[oh][2 * q]);
-          acc[oh][2 * q + 1] = dot2(d[q + i], wo[kh][i], acc[oh][2 * q + 1]);
+          for (int i = 0; i < 4; ++i) {
+            acc[oh][2 * q] = dot2(d[q + i], we[kh][i], acc[oh][2 * q]);
+            acc[oh][2 * q + 1] = dot2(d[q + i], wo[kh][i], acc[oh][2 * q + 1]);
+          }
         }
       }
     }
   }
+  if (dbg & 4) return;                                                   // dbg 4: timing experiment, no stores
+  // ---- epilogue through LDS: lane = channel during the stencil means 2..4-byte accesses per lane (32 channels = one
+  //      64..128-byte run per instruction and position); transposed through the (now dead) input tile every thread moves 16
+  //      bytes of the NHWC tensor per instruction instead - for the result AND for the fused "+ add" operand
+  __syncthreads();
+  TO* ot = reinterpret_cast<TO*>(tile2);                                 // [rows][W][32]
+  if (worker) {
 #pragma unroll
-  for (int oh = 0; oh < kDR; ++oh) {
-    const int h = h0 + sr * kDR + oh;
-    if (h >= h_end) continue;
+    for (int oh = 0; oh < kDR; ++oh) {
+      const int hl = sr * kDR + oh;
 #pragma unroll
-    for (int t = 0; t < kDT; ++t) {
-      const int w = sc * kDT + t;
-      if (w >= W) continue;
-      store1(out + ((n * H + h) * static_cast<long>(W) + w) * C + c, acc[oh][t]);
+      for (int t = 0; t < kDT; ++t) {
+        const int w = sc * kDT + t;
+        if (h0 + hl < h_end && w < W) store1(ot + (static_cast<long>(hl) * W + w) * kDC + lc, acc[oh][t]);
+      }
     }
+  }
+  __syncthreads();
+  constexpr int EPC = 16 / static_cast<int>(sizeof(TO));                 // elements per 16-byte chunk
+  constexpr int CH = kDC / EPC;                                          // chunks per position
+  const int n_chunks = (h_end - h0) * W * CH;
+  for (int i = tid; i < n_chunks; i += nthr) {
+    const int pos = i / CH, ch = i - pos * CH;
+    const long off = ((n * H + h0) * static_cast<long>(W) + pos) * C + cbase + ch * EPC;
+    uint4 v = *reinterpret_cast<const uint4*>(ot + static_cast<long>(pos) * kDC + ch * EPC);
+    if constexpr (sizeof(TO) == 4) {
+      if (add) {
+        const float4 a4 = *reinterpret_cast<const float4*>(add + off);
+        float4 f = __builtin_bit_cast(float4, v);
+        f.x += a4.x; f.y += a4.y; f.z += a4.z; f.w += a4.w;
+        v = __builtin_bit_cast(uint4, f);
+      }
+    }
+    *reinterpret_cast<uint4*>(out + off) = v;
   }
 }
 
@@ -429,6 +449,7 @@ inline bool dw_dot2_plan(int H, int W, int C, DwDot* t) {
     t->th = th_override;
     t->threads = ((((th_override + kDR - 1) / kDR) * n_sc * kDC + 63) / 64) * 64;
     t->lds = static_cast<size_t>(th_override + 6) * P2 * kDC * 4;
+    if (t->lds < static_cast<size_t>(th_override) * W * kDC * 4) t->lds = static_cast<size_t>(th_override) * W * kDC * 4;
     return true;
   } t->lds = static_cast<size_t>(th + 6) * P2 * kDC * 4;
   return t->lds <= 150 * 1024;
@@ -950,6 +971,7 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     return APGD_ERR_DTYPE;
   hipStream_t s = as_stream(stream);
   const bool all_f32 = x_dtype == APGD_F32 && out_dtype == APGD_F32;
+  static const int dw_dbg = getenv("APGD_DW_DBG") ? atoi(getenv("APGD_DW_DBG")) : 0;   // timing experiments only
   if (!all_f32) {
     DwDot dp;
     if (dw_dot2_plan(H, W, C, &dp)) {
@@ -964,7 +986,7 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
       attr_done = true;                                                                                               \
     }                                                                                                                 \
     hipLaunchKernelGGL(kfn, grid, block, dp.lds, s, static_cast<const TI*>(x), w49c, bias, add, static_cast<TO*>(out), H, W, \
-                       C, flip, dp.th, tiles_h);                                                                       \
+                       C, flip, dp.th, tiles_h, dw_dbg);                                                               \
   }
       if (x_dtype == APGD_F32) DWD_LAUNCH(float, uint16_t)
       else if (out_dtype == APGD_F32) DWD_LAUNCH(uint16_t, float)
