@@ -76,6 +76,50 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
   return fmaf(z, pdf, Phi);
 }
 
+// ---- two values per instruction.  The hidden-slice loops are VALU-bound, not MFMA-bound (measured: ~230 VALU + 32
+// v_exp_f32 against 18 MFMAs per slice in the backward), so the activation math runs on v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 (two fp32 lanes per instruction) and with as few quarter-rate transcendentals as possible.
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 exp2_2(f32x2 t) { return (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)}; }
+
+// GELU of a pair (same polynomial as gelu_f), packed to bf16
+__device__ __forceinline__ uint32_t gelu2_bf16(float z0, float z1) {
+  const f32x2 az = {fabsf(z0), fabsf(z1)};
+  f32x2 q = fma2(splat2(-0.00041175442346105595f), az, splat2(0.006678475199902348f));
+  q = fma2(q, az, splat2(-0.050879760394516485f));
+  q = fma2(q, az, splat2(-0.46094072908550926f));
+  q = fma2(q, az, splat2(-1.150400682855232f));
+  q = fma2(q, az, splat2(-8.454223479528131e-05f));
+  const f32x2 e = exp2_2(q);
+  const f32x2 pos = {fmaxf(z0, 0.0f), fmaxf(z1, 0.0f)};
+  const f32x2 g = fma2(az * e, splat2(-0.5f), pos);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(g, bf16x2));
+}
+
+// GELU'(z) with ONE exponential per value:  GELU'(-a) = 0.5 erfc(a/sqrt 2) - a phi(a) = E W(x),  E = exp(-a^2/2) = 2^(-x^2),
+// x = a sqrt(log2(e)/2), W(x) = 0.5 erfcx(a/sqrt 2) - a/sqrt(2 pi) ~ degree-6 polynomial (max |error| 1.6e-5, tools/
+// fit_gelu_grad.py; a = min(|z|, 6): GELU'(-6) = -3e-8), and  GELU'(z) = 0.5 + copysign(0.5 - E W, z).
+// Also returns E (phi(z) = E / sqrt(2 pi)), from which GELU(z) = z (GELU'(z) - z phi(z)) costs three more instructions.
+__device__ __forceinline__ f32x2 gelu_grad2(float z0, float z1, f32x2& E) {
+  const f32x2 a = {fminf(fabsf(z0), 6.0f), fminf(fabsf(z1), 6.0f)};
+  const f32x2 x = a * splat2(0.8493218002880191f);
+  E = exp2_2(-(x * x));
+  f32x2 w = fma2(splat2(1.8761737253e-03f), x, splat2(-1.8196647143e-02f));
+  w = fma2(w, x, splat2(7.6242087502e-02f));
+  w = fma2(w, x, splat2(-1.9087504279e-01f));
+  w = fma2(w, x, splat2(3.3884271219e-01f));
+  w = fma2(w, x, splat2(-9.3857446811e-01f));
+  w = fma2(w, x, splat2(4.9998430368e-01f));
+  const f32x2 h = splat2(0.5f) - E * w;
+  return splat2(0.5f) + (f32x2){copysignf(h.x, z0), copysignf(h.y, z1)};
+}
+__device__ __forceinline__ f32x2 gelu_from_grad2(float z0, float z1, f32x2 gp, f32x2 E) {
+  const f32x2 z = {z0, z1};
+  const f32x2 Phi = fma2(z * E, splat2(-0.3989422804014327f), gp);
+  return z * Phi;
+}
+
 // MFMA with the accumulator pinned in the AGPR half of the register file.  At C = 384 a wavefront's state (96 operand
 // registers + 192 accumulator registers) exceeds the 256 architectural VGPRs; left to itself the register allocator
 // parks OPERANDS in AGPRs and copies them back before every MFMA (273 v_accvgpr_read per slice measured).  Pinning the
@@ -97,7 +141,7 @@ struct Geo {
   static constexpr int FWD_SLICE = FWD_PIECES * 1024;
   static constexpr int FWD_ROUNDS = FWD_PIECES / 4; // DMA instructions per wavefront per slice (4 wavefronts)
   static constexpr int DEPTH = 3;                   // ring slots
-  static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 16 * C;   // + b1 (4C fp32)
+  static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 24 * C;   // + b1 (4C), b2 (C), gamma (C) fp32
   static constexpr int BM = 128;                    // rows per workgroup
   static constexpr bool AGPR_ACC = C >= 384;        // output accumulators pinned in AGPRs (inline-asm MFMA)
   static_assert(FWD_PIECES % 4 == 0, "pieces must divide over 4 wavefronts");
@@ -149,8 +193,11 @@ struct BlkFwdArgs {
   int dbg;                 // timing experiments only (APGD_BLK_DBG): 1 = no weight DMA after the prologue, 2 = no GELU
 };
 
+#ifndef BLK_FWD96_OCC
+#define BLK_FWD96_OCC 2
+#endif
 template <int C, typename TX, typename TO>
-__global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(const BlkFwdArgs p) {
+__global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(const BlkFwdArgs p) {
   using G = Geo<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* ring = lds;
@@ -180,6 +227,10 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(co
   DMA_SLICE(1)
 
   for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  for (int i = tid; i < C; i += 256) {                                  // epilogue constants: b2, gamma (1 when absent)
+    b1s[4 * C + i] = p.b2[i];
+    b1s[5 * C + i] = p.gamma ? p.gamma[i] : 1.0f;
+  }
 
   // ---- this lane's half row of u  ->  (LayerNorm)  ->  GEMM1 B-operand fragments
   long row = m0 + l32;
@@ -324,7 +375,7 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(co
         for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(acc1[r], acc1[r + 1]);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(gelu_f(acc1[r]), gelu_f(acc1[r + 1]));
+        for (int r = 0; r < 16; r += 2) pk[r >> 1] = gelu2_bf16(acc1[r], acc1[r + 1]);
       }
       hf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       hf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
@@ -347,36 +398,65 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(co
   if constexpr (G::AGPR_ACC) MFMA_DRAIN();
 #undef DMA_SLICE
 
-  // ---- epilogue: acc2[cb][r] = O[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]
+  // ---- epilogue: acc2[cb][r] = O[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32].  Straight from the accumulators every
+  //      load / store would move 4 bytes per lane (96 memory instructions per wavefront at C = 96); instead the tile goes
+  //      through the (now dead) weight ring in two passes of 16 rows - registers 0..7 of every accumulator are rows 0..15 -
+  //      and leaves as 16 rows x C contiguous elements: 16 bytes per lane for the residual read and the result.
 #pragma unroll
   for (int i = 0; i < kResPf; ++i) asm volatile("" ::"v"(pf[i]));       // the prefetch loads are complete (and were not dropped)
+  __syncthreads();                                                      // every wavefront is past its last fragment read
+  float* scr = reinterpret_cast<float*>(ring) + wave * (16 * C);        // 16 rows x C fp32 per wavefront (<= 2/3 of the ring)
+  const float4* b2v = reinterpret_cast<const float4*>(b1s + 4 * C);
+  const float4* gav = reinterpret_cast<const float4*>(b1s + 5 * C);
   const TX* resid = static_cast<const TX*>(p.resid);
   TO* out = static_cast<TO*>(p.out);
+  constexpr int C4 = C / 4;                                             // float4 chunks per row
+  constexpr int NCH = 16 * C4 / 64;                                     // chunks per lane and pass
+  constexpr int GRP = 6;                                                // chunks in flight per lane (C/16 is a multiple of 6)
+  static_assert(NCH % GRP == 0, "chunk groups");
 #pragma unroll
-  for (int cb = 0; cb < G::CB; ++cb) {
-    const int c = cb * 32 + l32;
-    const float bb = p.b2[c];
-    const float gg = p.gamma ? p.gamma[c] : 1.0f;
-    float xv[16];
+  for (int pass = 0; pass < 2; ++pass) {
+    const long e0 = (m0 + 16 * pass) * C;                               // first element of this pass
+    const long e_end = p.M * C;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (m >= p.M) m = p.M - 1;
-      xv[r] = 0.f;
-      if (resid) {
-        if constexpr (sizeof(TX) == 4) xv[r] = reinterpret_cast<const float*>(resid)[m * C + c];
-        else xv[r] = __uint_as_float(static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(resid)[m * C + c]) << 16);
+    for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc2[cb][8 * pass + r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g0 = 0; g0 < NCH; g0 += GRP) {
+      float4 xv[GRP];
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        const int idx = (g0 + j) * 64 + lane;
+        const long e = e0 + idx * 4;
+        xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (resid && e < e_end) {
+          if constexpr (sizeof(TX) == 4) {
+            xv[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resid) + e);
+          } else {
+            const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(resid) + e);
+            xv[j] = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+          }
+        }
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (m < p.M) {
-        const float y = acc2[cb][r] + bb;
-        if (p.y2) p.y2[m * C + c] = static_cast<uint16_t>(pack_bf16(y, 0.f));
-        const float o = fmaf(y, gg, xv[r]);
-        if constexpr (sizeof(TO) == 4) reinterpret_cast<float*>(out)[m * C + c] = o;
-        else reinterpret_cast<uint16_t*>(out)[m * C + c] = static_cast<uint16_t>(pack_bf16(o, 0.f));
+      for (int j = 0; j < GRP; ++j) {
+        const int idx = (g0 + j) * 64 + lane;
+        const long e = e0 + idx * 4;
+        const int c4 = idx % C4;
+        const float4 o = reinterpret_cast<const float4*>(scr)[idx];
+        const float4 bb = b2v[c4], gg = gav[c4];
+        const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
+        if (e < e_end) {
+          if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
+          const float o0 = fmaf(y0, gg.x, xv[j].x), o1 = fmaf(y1, gg.y, xv[j].y);
+          const float o2 = fmaf(y2v, gg.z, xv[j].z), o3 = fmaf(y3, gg.w, xv[j].w);
+          if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + e) = make_float4(o0, o1, o2, o3);
+          else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + e) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+        }
       }
     }
   }
@@ -474,14 +554,19 @@ struct BlkBwdArgs {
 template <int C>
 struct GeoB {
   static constexpr int KS = C / 16, CB = C / 32, NHB = C / 8;
-  static constexpr int WAVES = (C <= 96) ? 8 : 4;
+#ifndef BLK_BWD96_WAVES
+#define BLK_BWD96_WAVES 4
+#endif
+  static constexpr int WAVES = (C <= 96) ? BLK_BWD96_WAVES : 4;
   static constexpr int PIECES = 2 * KS + 2 * CB;
   static constexpr int SLICE = PIECES * 1024;
   static constexpr int ROUNDS = (PIECES + WAVES - 1) / WAVES;      // DMA instructions per wavefront per slice (upper bound)
   static constexpr int MIN_ROUNDS = PIECES / WAVES;                // ... lower bound (the counted wait must use this one)
   static constexpr int DEPTH = 3;
-  static constexpr int LDS = DEPTH * SLICE + 16 * C;
+  static constexpr int LDS = DEPTH * SLICE + 16 * C;                // + b1 (4C fp32)
+  static constexpr int LDS_EMIT = LDS + WAVES * 2048;                // + one 32 x 32 bf16 transpose tile per wavefront
   static constexpr int BM = WAVES * 32;
+  static_assert(WAVES * 16 * C * 4 <= DEPTH * SLICE, "the epilogue tile reuses the weight ring");
 };
 
 template <int C, typename TG, bool EMIT>
@@ -583,54 +668,117 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    // one stream of NF = 2 KS + 2 CB operand fragments per slice, read PF fragments ahead of the MFMA that consumes them
+    // (as in the forward): fragment i < 2 KS alternates W1 / W2^T k-steps (two independent accumulation chains), then the
+    // W1 B-fragments of GEMM3 in (t, cb) order so that consecutive MFMAs update different accumulators
+    constexpr int NF = 2 * G::KS + 2 * G::CB, PF = 4;
+    auto piece_of = [](int i) constexpr {
+      if (i < 2 * G::KS) return (i & 1) ? G::KS + (i >> 1) : (i >> 1);
+      const int j = i - 2 * G::KS;                        // j = t * CB + cb  ->  packed piece (cb, t)
+      return 2 * G::KS + (j % G::CB) * 2 + (j / G::CB);
+    };
+    bf16x8 fr[PF];
 #pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {
-      const bf16x8 w1a = *reinterpret_cast<const bf16x8*>(sl + ks * 1024);
-      const bf16x8 w2a = *reinterpret_cast<const bf16x8*>(sl + (G::KS + ks) * 1024);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1a, af[ks], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2a, gf[ks], acc2, 0, 0, 0);
+    for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2 * G::KS; ++i) {
+      if (i & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i >> 1], acc2, 0, 0, 0);
+      else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i >> 1], acc1, 0, 0, 0);
+      if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     bf16x8 dhf[2];
     {
       uint32_t pk[8];
+      uint32_t hk[8];                                     // emit only: GELU(Hpre) pairs
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float d0 = acc2[r] * gelu_grad_f(acc1[r]), d1 = acc2[r + 1] * gelu_grad_f(acc1[r + 1]);
-        pk[r >> 1] = pack_bf16(d0, d1);
+        f32x2 E;
+        const f32x2 gp = gelu_grad2(acc1[r], acc1[r + 1], E);
+        const f32x2 d = (f32x2){acc2[r], acc2[r + 1]} * gp;
+        pk[r >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2));
+        if constexpr (EMIT)
+          hk[r >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(gelu_from_grad2(acc1[r], acc1[r + 1], gp, E), bf16x2));
       }
       dhf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       dhf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
       if constexpr (EMIT) {
-        if (row_ok) {
+        if ((p.M & 7) == 0) {
+          // [4C, M] operands of the weight-gradient GEMMs: a lane holds 16 hidden units of ONE row, the tensors are
+          // contiguous along rows.  2x2 exchange with the neighbouring lane (row m^1) turns the (h, h+1) pairs into
+          // (m, m+1) pairs, the 32 x 32 tile goes through 2 KiB of LDS and leaves as 16 bytes (8 rows of one hidden
+          // unit) per lane: 2 stores per tile instead of 16 two-byte ones.
+          uint32_t* tsc = reinterpret_cast<uint32_t*>(b1s + 4 * C) + wave * 512;
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const uint32_t own = which ? pk[q] : hk[q];
+              const uint32_t nbr = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(own), 0xB1, 0xf, 0xf, true));
+              // even lane: (own.lo, nbr.lo) -> hidden r = 2q;  odd lane: (nbr.hi, own.hi) -> hidden r = 2q + 1
+              const uint32_t v = (lane & 1) ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
+              const int r = 2 * q + (lane & 1);
+              const int hl = (r & 3) + 8 * (r >> 2) + 4 * half;
+              tsc[hl * 16 + (l32 >> 1)] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint16_t* dst = which ? p.dhpt_out : p.ht_out;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const uint4 v = reinterpret_cast<const uint4*>(tsc)[k * 64 + lane];
+              const int hl = k * 16 + (lane >> 2);
+              const long m = m0 + (lane & 3) * 8;
+              if (m < p.M) *reinterpret_cast<uint4*>(dst + (static_cast<long>(s) * 32 + hl) * p.M + m) = v;
+            }
+          }
+        } else if (row_ok) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const long h = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const uint32_t d = pk[r >> 1];
             p.dhpt_out[h * p.M + row] = static_cast<uint16_t>((r & 1) ? (d >> 16) : (d & 0xffffu));
-            p.ht_out[h * p.M + row] = static_cast<uint16_t>(pack_bf16(gelu_f(acc1[r]), 0.f));
+            const uint32_t hv = hk[r >> 1];
+            p.ht_out[h * p.M + row] = static_cast<uint16_t>((r & 1) ? (hv >> 16) : (hv & 0xffffu));
           }
         }
       }
     }
 #pragma unroll
-    for (int cb = 0; cb < G::CB; ++cb) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sl + (2 * G::KS + cb * 2 + t) * 1024);
-        acc3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf[t], wb, acc3[cb], 0, 0, 0);
-      }
+    for (int j = 0; j < 2 * G::CB; ++j) {
+      const int i = 2 * G::KS + j;
+      acc3[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf[j / G::CB], fr[i % PF], acc3[j % G::CB], 0, 0, 0);
+      if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
   }
 #undef DMA_SLICE
 
-  // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]
+  // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]; as in the forward the tile leaves through
+  //      the dead weight ring, 16 rows per pass, so that a lane stores 16 bytes (8 bf16) of a contiguous run instead of 2
+  __syncthreads();
+  float* scr = reinterpret_cast<float*>(ring) + wave * (16 * C);
+  constexpr int NCH = 16 * C / 8 / 64;                                  // 8-element chunks per lane and pass (C / 32)
 #pragma unroll
-  for (int cb = 0; cb < G::CB; ++cb) {
-    const int c = cb * 32 + l32;
+  for (int pass = 0; pass < 2; ++pass) {
+    const long e0 = (m0 + 16 * pass) * C;
+    const long e_end = p.M * C;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (m < p.M) p.da[m * C + c] = static_cast<uint16_t>(pack_bf16(acc3[cb][r], 0.f));
+    for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc3[cb][8 * pass + r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int idx = j * 64 + lane;
+      const long e = e0 + idx * 8;
+      const float4 lo = reinterpret_cast<const float4*>(scr)[2 * idx], hi = reinterpret_cast<const float4*>(scr)[2 * idx + 1];
+      if (e < e_end)
+        *reinterpret_cast<uint4*>(p.da + e) = make_uint4(pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w));
     }
   }
 }
@@ -646,10 +794,10 @@ int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                G::LDS);                                                                         \
+                                (EM) ? G::LDS_EMIT : G::LDS);                                                    \
       attr_done = true;                                                                                          \
     }                                                                                                            \
-    hipLaunchKernelGGL(kfn, grid, block, G::LDS, s, a);                                                          \
+    hipLaunchKernelGGL(kfn, grid, block, (EM) ? G::LDS_EMIT : G::LDS, s, a);                                     \
   }
   if (g_dtype == APGD_F32) { if (emit) BLK_LAUNCH(float, true) else BLK_LAUNCH(float, false) }
   else { if (emit) BLK_LAUNCH(uint16_t, true) else BLK_LAUNCH(uint16_t, false) }

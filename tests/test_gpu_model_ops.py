@@ -293,7 +293,7 @@ def test_fused_block_tail_argument_errors(R):
 
 
 @pytest.mark.parametrize("C", [96, 192])
-@pytest.mark.parametrize("M_", [1, 33, 256, 700])
+@pytest.mark.parametrize("M_", [1, 33, 256, 328, 700])
 @pytest.mark.parametrize("gamma,emit,gdt", [(True, True, torch.float32), (False, False, torch.float32),
                                             (True, False, torch.bfloat16)])
 def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt):

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     const int C = sh.C;
     if (only_c && only_c != C) continue;
     if (!cnx_block_mlp_supported(C)) continue;
-    const long M = static_cast<long>(B) * sh.HW * sh.HW - 5;      // ragged tail on purpose
+    const long M = static_cast<long>(B) * sh.HW * sh.HW - 8;      // ragged tail on purpose (a multiple of 8: the emit path stores 8 rows per lane)
     std::mt19937 rng(C);
     std::normal_distribution<float> nd(0.f, 1.f);
     std::vector<uint16_t> u(M * C);
