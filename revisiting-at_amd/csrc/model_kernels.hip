@@ -6,6 +6,7 @@
 // per-lane accesses coalesced along C, fp32 accumulation, wavefront-64 shuffles + LDS for the
 // per-row statistics, deterministic two-stage reductions for parameter gradients.  No MFMA here.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -309,9 +310,20 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
                                                              int tiles_h, int dbg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile2[];       // [TH+6][P2][32]
   const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
-  const long n = blockIdx.x / tiles_h;
-  const int h0 = static_cast<int>(blockIdx.x % tiles_h) * TH;
-  const int cbase = blockIdx.y * kDC;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so with the plain
+  // blockIdx -> tile map vertically adjacent tiles - which share 6 of their TH + 6 input rows - never meet in one L2 and
+  // every halo row is fetched from HBM up to (TH + 6) / TH times.  Instead XCD x works through the x-th contiguous
+  // eighth of the tile list, ordered (image, channel group, row tile) with the row tile fastest.
+  long tsel;
+  {
+    const long L = blockIdx.x, B = gridDim.x;
+    const long q = B / 8, r = B % 8, xcd = L % 8, k = L / 8;
+    tsel = (dbg & 8) ? L : xcd * q + (xcd < r ? xcd : r) + k;          // dbg 8: timing experiment, plain order
+  }
+  const int n_cg = C / kDC;
+  const int h0 = static_cast<int>(tsel % tiles_h) * TH;
+  const int cbase = static_cast<int>((tsel / tiles_h) % n_cg) * kDC;
+  const long n = tsel / (static_cast<long>(tiles_h) * n_cg);
   const int tid = threadIdx.x, nthr = blockDim.x;
 
   // ---- staging: unit = (row, pair m, 4-channel group): two 4-channel loads (padded cols 2m, 2m+1) -> 4 packed dwords
@@ -428,6 +440,231 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
     }
     *reinterpret_cast<uint4*>(out + off) = v;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rolling-window variant for the large maps (56x56, 28x28).  The tile kernel above stages TH + 6 input rows for TH = 4
+// output rows (2.5x the tensor through the load / pack / LDS-write path, ~1/3 of its time) and sets its 56 filter dwords
+// up once per 4 rows.  Here a workgroup walks DOWN a band of an image: the 10-row window lives in LDS as a ring, each
+// iteration adds only the 4 new rows - loaded into registers BEFORE the arithmetic of the current rows (and so is the
+// fused "+ add" operand), written to the ring after it - and the filter registers are set up once per band.
+//   LDS: ring [10][P2][32] dwords + output tile [4][W][32] TO (transposed epilogue: 16 bytes per lane).
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename TO, int U>
+__global__ __launch_bounds__(256) void dwconv7x7_roll_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
+                                                             const float* __restrict__ bias, const float* __restrict__ add,
+                                                             TO* __restrict__ out, int H, int W, int C, int flip, int RS,
+                                                             int n_seg) {
+  constexpr int TH = kDR, WR = kDR + 6;
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile2[];
+  const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
+  uint32_t* win = tile2;                                                  // [WR][P2][32]
+  TO* ot = reinterpret_cast<TO*>(tile2 + WR * P2 * kDC);                  // [TH][W][32]
+  const int n_cg = C / kDC;
+  long b = blockIdx.x;
+  const int seg = static_cast<int>(b % n_seg);
+  b /= n_seg;
+  const int cbase = static_cast<int>(b % n_cg) * kDC;
+  const long n = b / n_cg;
+  const int r_begin = seg * RS, r_end = min(H, r_begin + RS);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int row_units = P2 * (kDC / 4);
+
+  // staging unit = (pair m, 4-channel group): padded columns 2m, 2m+1 -> 4 packed dwords
+  using Raw = typename std::conditional<sizeof(TI) == 4, float4, uint2>::type;
+  int um[U], ul4[U];
+  bool uok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = min(tid + u * nthr, row_units - 1);
+    uok[u] = tid + u * nthr < row_units;
+    um[u] = i / (kDC / 4);
+    ul4[u] = i - um[u] * (kDC / 4);
+  }
+  // Loads are unconditional (clamped coordinates, zero selected afterwards): a guarded load compiles to a branch with
+  // its own s_waitcnt, which serialises the round trips this kernel exists to overlap.
+  auto load_row = [&](int hh, Raw* v0, Raw* v1) {
+    const int hc = min(max(hh, 0), H - 1);
+    const TI* xrow = x + ((n * H + hc) * static_cast<long>(W)) * C + cbase;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int w0 = 2 * um[u] - 3, w1 = w0 + 1;
+      const TI* xr = xrow + ul4[u] * 4;
+      const Raw r0 = *reinterpret_cast<const Raw*>(xr + static_cast<long>(min(max(w0, 0), W - 1)) * C);
+      const Raw r1 = *reinterpret_cast<const Raw*>(xr + static_cast<long>(min(max(w1, 0), W - 1)) * C);
+      v0[u] = r0;                                       // zeroing of the padding happens in store_row: a select here would
+      v1[u] = r1;                                       // wait for the load on the spot
+    }
+  };
+  auto store_row = [&](int slot, int hh, const Raw* v0, const Raw* v1) {
+    const bool row_in = hh >= 0 && hh < H;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!uok[u]) continue;
+      const int w0 = 2 * um[u] - 3, w1 = w0 + 1;
+      const bool ok0 = row_in && w0 >= 0 && w0 < W, ok1 = row_in && w1 >= 0 && w1 < W;
+      uint4 d;
+      if constexpr (sizeof(TI) == 4) {
+        d.x = pack2_bf16(v0[u].x, v1[u].x); d.y = pack2_bf16(v0[u].y, v1[u].y);
+        d.z = pack2_bf16(v0[u].z, v1[u].z); d.w = pack2_bf16(v0[u].w, v1[u].w);
+      } else {                                                            // bf16 input: interleave the two columns' halves
+        d.x = (v0[u].x & 0xffffu) | (v1[u].x << 16); d.y = (v0[u].x >> 16) | (v1[u].x & 0xffff0000u);
+        d.z = (v0[u].y & 0xffffu) | (v1[u].y << 16); d.w = (v0[u].y >> 16) | (v1[u].y & 0xffff0000u);
+      }
+      const uint32_t k0 = ok0 ? 0x0000ffffu : 0u, k1 = ok1 ? 0xffff0000u : 0u, km = k0 | k1;
+      d.x &= km; d.y &= km; d.z &= km; d.w &= km;
+      *reinterpret_cast<uint4*>(&win[(static_cast<long>(slot) * P2 + um[u]) * kDC + ul4[u] * 4]) = d;
+    }
+  };
+
+  // ---- fill the ring: input rows r_begin-3 .. r_begin+6 -> slots 0..9
+  {
+    Raw v0[TH][U], v1[TH][U];
+#pragma unroll
+    for (int r0 = 0; r0 < WR; r0 += TH) {
+#pragma unroll
+      for (int rr = 0; rr < TH; ++rr)
+        if (r0 + rr < WR) load_row(r_begin - 3 + r0 + rr, v0[rr], v1[rr]);
+#pragma unroll
+      for (int rr = 0; rr < TH; ++rr)
+        if (r0 + rr < WR) store_row(r0 + rr, r_begin - 3 + r0 + rr, v0[rr], v1[rr]);
+    }
+  }
+
+  // ---- this lane's channel: packed filter rows (rotated by 180 degrees when flip)
+  const int lc = tid & (kDC - 1), sidx = tid / kDC;
+  const int c = cbase + lc;
+  uint32_t we[7][4], wo[7][4];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+    float f[7];
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int tap = kh * 7 + kw;
+      f[kw] = w49c[(flip ? 48 - tap : tap) * C + c];
+    }
+    we[kh][0] = pack2_bf16(f[0], f[1]); we[kh][1] = pack2_bf16(f[2], f[3]); we[kh][2] = pack2_bf16(f[4], f[5]); we[kh][3] = pack2_bf16(f[6], 0.f);
+    wo[kh][0] = pack2_bf16(0.f, f[0]); wo[kh][1] = pack2_bf16(f[1], f[2]); wo[kh][2] = pack2_bf16(f[3], f[4]); wo[kh][3] = pack2_bf16(f[5], f[6]);
+  }
+  const float b0 = bias ? bias[c] : 0.f;
+  const bool worker = sidx < n_sc;
+  const int sc = worker ? sidx : 0;
+  constexpr int EPC = 16 / static_cast<int>(sizeof(TO));                 // elements per 16-byte chunk
+  constexpr int CH = kDC / EPC;                                          // chunks per position
+  constexpr int AC = 8;                                                  // "+ add" chunks prefetched per thread (fp32 output)
+  __syncthreads();
+
+  int s0 = 0;                                                            // ring slot of input row h0 - 3
+  for (int h0 = r_begin; h0 < r_end; h0 += TH) {
+    const int h_end = min(r_end, h0 + TH);
+    const bool more = h0 + TH < r_end;
+    // ---- global loads of the NEXT iteration's rows and of this iteration's add operand: in flight during the arithmetic
+    Raw p0[TH][U], p1[TH][U];
+    if (more) {
+#pragma unroll
+      for (int rr = 0; rr < TH; ++rr) load_row(h0 + TH + 3 + rr, p0[rr], p1[rr]);
+    }
+    const int n_chunks = (h_end - h0) * W * CH;
+    const long obase = ((n * H + h0) * static_cast<long>(W)) * C + cbase;
+    float4 a4[AC];
+    if constexpr (sizeof(TO) == 4) {
+      if (add) {
+#pragma unroll
+        for (int k = 0; k < AC; ++k) {
+          const int i = min(tid + k * nthr, n_chunks - 1);                 // clamped: the load stays unconditional
+          const int pos = i / CH, ch = i - pos * CH;
+          a4[k] = *reinterpret_cast<const float4*>(add + obase + static_cast<long>(pos) * C + ch * EPC);
+        }
+      }
+    }
+    // ---- stencil on the ring
+    if (worker) {
+      float acc[kDR][kDT];
+#pragma unroll
+      for (int oh = 0; oh < kDR; ++oh)
+#pragma unroll
+        for (int t = 0; t < kDT; ++t) acc[oh][t] = b0;
+#pragma unroll
+      for (int r = 0; r < kDR + 6; ++r) {
+        int slot = s0 + r;
+        if (slot >= WR) slot -= WR;
+        const uint32_t* trow = win + (static_cast<long>(slot) * P2 + sc * (kDT / 2)) * kDC + lc;
+        uint32_t d[kDT / 2 + 3];
+#pragma unroll
+        for (int i = 0; i < kDT / 2 + 3; ++i) d[i] = trow[i * kDC];
+#pragma unroll
+        for (int oh = 0; oh < kDR; ++oh) {
+          const int kh = r - oh;
+          if (kh < 0 || kh > 6) continue;
+#pragma unroll
+          for (int q = 0; q < kDT / 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              acc[oh][2 * q] = dot2(d[q + i], we[kh][i], acc[oh][2 * q]);
+              acc[oh][2 * q + 1] = dot2(d[q + i], wo[kh][i], acc[oh][2 * q + 1]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int oh = 0; oh < kDR; ++oh)
+#pragma unroll
+        for (int t = 0; t < kDT; ++t) {
+          const int w = sc * kDT + t;
+          if (h0 + oh < h_end && w < W) store1(ot + (static_cast<long>(oh) * W + w) * kDC + lc, acc[oh][t]);
+        }
+    }
+    __syncthreads();                                                     // output tile complete; ring rows free to replace
+    // ---- transposed epilogue: 16 bytes per lane
+#pragma unroll
+    for (int k = 0; k < AC; ++k) {
+      const int i = tid + k * nthr;
+      if (i >= n_chunks) break;
+      const int pos = i / CH, ch = i - pos * CH;
+      uint4 v = *reinterpret_cast<const uint4*>(ot + static_cast<long>(pos) * kDC + ch * EPC);
+      if constexpr (sizeof(TO) == 4) {
+        if (add) {
+          float4 f = __builtin_bit_cast(float4, v);
+          f.x += a4[k].x; f.y += a4[k].y; f.z += a4[k].z; f.w += a4[k].w;
+          v = __builtin_bit_cast(uint4, f);
+        }
+      }
+      *reinterpret_cast<uint4*>(out + obase + static_cast<long>(pos) * C + ch * EPC) = v;
+    }
+    // ---- the prefetched rows replace the 4 oldest ring rows
+    if (more) {
+#pragma unroll
+      for (int rr = 0; rr < TH; ++rr) {
+        int slot = s0 + rr;
+        if (slot >= WR) slot -= WR;
+        store_row(slot, h0 + TH + 3 + rr, p0[rr], p1[rr]);
+      }
+    }
+    s0 += TH;
+    if (s0 >= WR) s0 -= WR;
+    __syncthreads();
+  }
+}
+
+struct DwRoll { int threads, units, rs, n_seg; size_t lds; };
+inline bool dw_roll_plan(int H, int W, int C, int in_bytes, int out_bytes, DwRoll* t) {
+  static const int off = getenv("APGD_DW_ROLL") ? atoi(getenv("APGD_DW_ROLL")) : 1;          // 0: tile kernel everywhere
+  if (!off || C % kDC != 0 || H * W < 784) return false;
+  const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
+  if (n_sc > 8) return false;
+  t->threads = ((n_sc * kDC + 63) / 64) * 64;      // (extra staging-only wavefronts were tried at 28x28: fewer workgroups fit, slower)
+  t->units = (P2 * (kDC / 4) + t->threads - 1) / t->threads;
+  if (t->units > 2) return false;
+  const int chunks = kDR * W * (kDC * out_bytes / 16);
+  if ((chunks + t->threads - 1) / t->threads > 8) return false;                                // AC in the kernel
+  static const int rs_env = getenv("APGD_DW_RS") ? atoi(getenv("APGD_DW_RS")) : 0;            // tuning experiments only
+  // band height, measured (tools/dw_bench.py): 28 rows at 56x56 (two bands per image) and for fp32 tensors at 28x28, 16 for all-bf16 28x28
+  int rs = rs_env > 0 ? rs_env : ((H >= 56 || in_bytes == 4 || out_bytes == 4) ? 28 : 16);
+  rs = ((rs + kDR - 1) / kDR) * kDR;
+  t->rs = rs;
+  t->n_seg = (H + rs - 1) / rs;
+  t->lds = static_cast<size_t>(kDR + 6) * P2 * kDC * 4 + static_cast<size_t>(kDR) * W * kDC * out_bytes;
+  return t->lds <= 150 * 1024;
 }
 
 struct DwDot { int th, threads; size_t lds; };
@@ -973,10 +1210,32 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
   const bool all_f32 = x_dtype == APGD_F32 && out_dtype == APGD_F32;
   static const int dw_dbg = getenv("APGD_DW_DBG") ? atoi(getenv("APGD_DW_DBG")) : 0;   // timing experiments only
   if (!all_f32) {
+    DwRoll rp;
+    if (dw_roll_plan(H, W, C, x_dtype == APGD_F32 ? 4 : 2, out_dtype == APGD_F32 ? 4 : 2, &rp)) {
+      const dim3 grid(static_cast<unsigned>(static_cast<long>(N) * (C / kDC) * rp.n_seg)), block(rp.threads);
+#define DWR_LAUNCH(TI, TO, UU)                                                                                        \
+  {                                                                                                                   \
+    auto kfn = dwconv7x7_roll_kernel<TI, TO, UU>;                                                                     \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, grid, block, rp.lds, s, static_cast<const TI*>(x), w49c, bias, add, static_cast<TO*>(out), H, W, \
+                       C, flip, rp.rs, rp.n_seg);                                                                      \
+  }
+#define DWR_DISPATCH(TI, TO) { if (rp.units == 1) DWR_LAUNCH(TI, TO, 1) else DWR_LAUNCH(TI, TO, 2) }
+      if (x_dtype == APGD_F32) DWR_DISPATCH(float, uint16_t)
+      else if (out_dtype == APGD_F32) DWR_DISPATCH(uint16_t, float)
+      else DWR_DISPATCH(uint16_t, uint16_t)
+#undef DWR_DISPATCH
+#undef DWR_LAUNCH
+      return launch_status();
+    }
     DwDot dp;
     if (dw_dot2_plan(H, W, C, &dp)) {
       const int tiles_h = (H + dp.th - 1) / dp.th;
-      const dim3 grid(static_cast<unsigned>(N * tiles_h), C / kDC), block(dp.threads);
+      const dim3 grid(static_cast<unsigned>(N * tiles_h * (C / kDC))), block(dp.threads);
 #define DWD_LAUNCH(TI, TO)                                                                                            \
   {                                                                                                                   \
     auto kfn = dwconv7x7_dot2_kernel<TI, TO>;                                                                         \

@@ -342,7 +342,7 @@ def _wgrad(x, y):
     if S == 1:
         return (x.t() @ y).float()
     part = torch.bmm(x.view(S, M // S, x.shape[1]).transpose(1, 2), y.view(S, M // S, y.shape[1]))
-    return part.float().sum(0)
+    return part.sum(0, dtype=torch.float32)                   # fp32 accumulation of the bf16 partial products, one pass
 
 
 def _wgrad_t(xt, y):
@@ -354,20 +354,7 @@ def _wgrad_t(xt, y):
     if S == 1:
         return (xt @ y).float()
     part = torch.bmm(xt.view(N1, S, M // S).transpose(0, 1), y.view(S, M // S, y.shape[1]))
-    return part.float().sum(0)
-
-
-_pad_cache = {}
-
-
-def _ones_pad(device):
-    """(1, 0, 0, 0, 0, 0, 0, 0) in bf16: the 8-wide pad whose first entry makes a GEMM also sum its other operand."""
-    t = _pad_cache.get(device)
-    if t is None:
-        t = torch.zeros(8, device=device, dtype=torch.bfloat16)
-        t[0] = 1
-        _pad_cache[device] = t
-    return t
+    return part.sum(0, dtype=torch.float32)                   # fp32 accumulation of the bf16 partial products, one pass
 
 
 def _pack_mlp_bwd(w1, w2):
