@@ -667,6 +667,192 @@ inline bool dw_roll_plan(int H, int W, int C, int in_bytes, int out_bytes, DwRol
   return t->lds <= 150 * 1024;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small maps (14x14, 7x7): the whole zero-padded image x 32 channels is one tile.  A workgroup walks over IPW images of one
+// channel group with the same software pipeline as the rolling kernel: image i+1 (and the add operand of image i) is
+// loaded into registers before the stencil of image i runs, the filter registers are set up once.
+//   LDS: tile [TH+6][P2][32] dwords (border rows / columns zeroed once) + output tile [H][W][32] TO.
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename TO, int UT>
+__global__ __launch_bounds__(256) void dwconv7x7_multi_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
+                                                              const float* __restrict__ bias, const float* __restrict__ add,
+                                                              TO* __restrict__ out, int N, int H, int W, int C, int flip,
+                                                              int n_sr, int ipw) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile2[];
+  using Raw = typename std::conditional<sizeof(TI) == 4, float4, uint2>::type;
+  const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
+  const int TR = n_sr * kDR + 6;                                          // tile rows
+  uint32_t* win = tile2;
+  TO* ot = reinterpret_cast<TO*>(tile2 + TR * P2 * kDC);                  // [H][W][32]
+  const int n_cg = C / kDC;
+  const int cbase = static_cast<int>(blockIdx.x % n_cg) * kDC;
+  const long n_first = static_cast<long>(blockIdx.x / n_cg) * ipw;
+  const long n_last = min(static_cast<long>(N), n_first + ipw);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  // staging unit = (row h, pair m covering columns 2m-3, 2m-2, 4-channel group); only pairs that touch real columns
+  const int m_lo = 1, m_hi = (W + 2) / 2 + 1;                             // pairs m_lo .. m_hi overlap [0, W)
+  const int upr = (m_hi - m_lo + 1) * (kDC / 4), total_units = H * upr;
+  int uh[UT], um[UT], ul4[UT];
+  bool uok[UT];
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    const int i = min(tid + u * nthr, total_units - 1);
+    uok[u] = tid + u * nthr < total_units;
+    uh[u] = i / upr;
+    const int j = i - uh[u] * upr;
+    um[u] = m_lo + j / (kDC / 4);
+    ul4[u] = j % (kDC / 4);
+  }
+  auto load_img = [&](long n, Raw* v0, Raw* v1) {
+    const TI* xi = x + (n * H) * static_cast<long>(W) * C + cbase;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int w0 = 2 * um[u] - 3, w1 = w0 + 1;
+      const TI* xr = xi + (static_cast<long>(uh[u]) * W) * C + ul4[u] * 4;
+      v0[u] = *reinterpret_cast<const Raw*>(xr + static_cast<long>(min(max(w0, 0), W - 1)) * C);
+      v1[u] = *reinterpret_cast<const Raw*>(xr + static_cast<long>(min(max(w1, 0), W - 1)) * C);
+    }
+  };
+  auto store_img = [&](const Raw* v0, const Raw* v1) {
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (!uok[u]) continue;
+      const int w0 = 2 * um[u] - 3, w1 = w0 + 1;
+      uint4 d;
+      if constexpr (sizeof(TI) == 4) {
+        d.x = pack2_bf16(v0[u].x, v1[u].x); d.y = pack2_bf16(v0[u].y, v1[u].y);
+        d.z = pack2_bf16(v0[u].z, v1[u].z); d.w = pack2_bf16(v0[u].w, v1[u].w);
+      } else {
+        d.x = (v0[u].x & 0xffffu) | (v1[u].x << 16); d.y = (v0[u].x >> 16) | (v1[u].x & 0xffff0000u);
+        d.z = (v0[u].y & 0xffffu) | (v1[u].y << 16); d.w = (v0[u].y >> 16) | (v1[u].y & 0xffff0000u);
+      }
+      const uint32_t km = ((w0 >= 0 && w0 < W) ? 0x0000ffffu : 0u) | ((w1 >= 0 && w1 < W) ? 0xffff0000u : 0u);
+      d.x &= km; d.y &= km; d.z &= km; d.w &= km;
+      *reinterpret_cast<uint4*>(&win[(static_cast<long>(uh[u] + 3) * P2 + um[u]) * kDC + ul4[u] * 4]) = d;
+    }
+  };
+
+  // ---- zero the tile once (the staging only ever rewrites the pairs that overlap the image), stage the first image
+  for (int i = tid; i < TR * P2 * kDC / 4; i += nthr) reinterpret_cast<uint4*>(win)[i] = make_uint4(0u, 0u, 0u, 0u);
+  Raw p0[UT], p1[UT];
+  load_img(n_first, p0, p1);
+  const int lc = tid & (kDC - 1), sidx = tid / kDC;
+  const int c = cbase + lc;
+  uint32_t we[7][4], wo[7][4];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+    float f[7];
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int tap = kh * 7 + kw;
+      f[kw] = w49c[(flip ? 48 - tap : tap) * C + c];
+    }
+    we[kh][0] = pack2_bf16(f[0], f[1]); we[kh][1] = pack2_bf16(f[2], f[3]); we[kh][2] = pack2_bf16(f[4], f[5]); we[kh][3] = pack2_bf16(f[6], 0.f);
+    wo[kh][0] = pack2_bf16(0.f, f[0]); wo[kh][1] = pack2_bf16(f[1], f[2]); wo[kh][2] = pack2_bf16(f[3], f[4]); wo[kh][3] = pack2_bf16(f[5], f[6]);
+  }
+  const float b0 = bias ? bias[c] : 0.f;
+  const bool worker = sidx < n_sr * n_sc;
+  const int sc = worker ? sidx % n_sc : 0, sr = worker ? sidx / n_sc : 0;
+  constexpr int EPC = 16 / static_cast<int>(sizeof(TO));
+  constexpr int CH = kDC / EPC;
+  constexpr int AC = 8;
+  const int n_chunks = H * W * CH;
+  __syncthreads();                                                        // zero fill done
+  store_img(p0, p1);
+  __syncthreads();
+
+  for (long n = n_first; n < n_last; ++n) {
+    const bool more = n + 1 < n_last;
+    if (more) load_img(n + 1, p0, p1);
+    const long obase = (n * H) * static_cast<long>(W) * C + cbase;
+    float4 a4[AC];
+    if constexpr (sizeof(TO) == 4) {
+      if (add) {
+#pragma unroll
+        for (int k = 0; k < AC; ++k) {
+          const int i = min(tid + k * nthr, n_chunks - 1);
+          const int pos = i / CH, ch = i - pos * CH;
+          a4[k] = *reinterpret_cast<const float4*>(add + obase + static_cast<long>(pos) * C + ch * EPC);
+        }
+      }
+    }
+    if (worker) {
+      float acc[kDR][kDT];
+#pragma unroll
+      for (int oh = 0; oh < kDR; ++oh)
+#pragma unroll
+        for (int t = 0; t < kDT; ++t) acc[oh][t] = b0;
+#pragma unroll
+      for (int r = 0; r < kDR + 6; ++r) {
+        const uint32_t* trow = win + (static_cast<long>(sr * kDR + r) * P2 + sc * (kDT / 2)) * kDC + lc;
+        uint32_t d[kDT / 2 + 3];
+#pragma unroll
+        for (int i = 0; i < kDT / 2 + 3; ++i) d[i] = trow[i * kDC];
+#pragma unroll
+        for (int oh = 0; oh < kDR; ++oh) {
+          const int kh = r - oh;
+          if (kh < 0 || kh > 6) continue;
+#pragma unroll
+          for (int q = 0; q < kDT / 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              acc[oh][2 * q] = dot2(d[q + i], we[kh][i], acc[oh][2 * q]);
+              acc[oh][2 * q + 1] = dot2(d[q + i], wo[kh][i], acc[oh][2 * q + 1]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int oh = 0; oh < kDR; ++oh)
+#pragma unroll
+        for (int t = 0; t < kDT; ++t) {
+          const int h = sr * kDR + oh, w = sc * kDT + t;
+          if (h < H && w < W) store1(ot + (static_cast<long>(h) * W + w) * kDC + lc, acc[oh][t]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < AC; ++k) {
+      const int i = tid + k * nthr;
+      if (i >= n_chunks) break;
+      const int pos = i / CH, ch = i - pos * CH;
+      uint4 v = *reinterpret_cast<const uint4*>(ot + static_cast<long>(pos) * kDC + ch * EPC);
+      if constexpr (sizeof(TO) == 4) {
+        if (add) {
+          float4 f = __builtin_bit_cast(float4, v);
+          f.x += a4[k].x; f.y += a4[k].y; f.z += a4[k].z; f.w += a4[k].w;
+          v = __builtin_bit_cast(uint4, f);
+        }
+      }
+      *reinterpret_cast<uint4*>(out + obase + static_cast<long>(pos) * C + ch * EPC) = v;
+    }
+    if (more) store_img(p0, p1);
+    __syncthreads();
+  }
+}
+
+struct DwMulti { int threads, n_sr, ut, ipw; size_t lds; };
+inline bool dw_multi_plan(int N, int H, int W, int C, int in_bytes, int out_bytes, DwMulti* t) {
+  static const int on = getenv("APGD_DW_MULTI") ? atoi(getenv("APGD_DW_MULTI")) : 1;          // 0: tile kernel
+  // measured (tools/dw_bench.py, 14x14x384 / 7x7x768): bf16 inputs 74 -> 50 us / 42 -> 31 us, fp32 inputs no better than the
+  // tile kernel (40 prefetch registers per thread at the 256-VGPR limit) - those stay there
+  if (!on || C % kDC != 0 || H * W >= 784 || in_bytes == 4) return false;
+  const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
+  const int n_sr = (H + kDR - 1) / kDR;
+  if (n_sr * n_sc * kDC > 256) return false;
+  t->n_sr = n_sr;
+  t->threads = ((n_sr * n_sc * kDC + 63) / 64) * 64;
+  const int upr = ((W + 2) / 2 + 1) * (kDC / 4);
+  const int ut = (H * upr + t->threads - 1) / t->threads;
+  t->ut = ut <= 5 ? 5 : (ut <= 7 ? 7 : 0);
+  if (!t->ut) return false;
+  if ((H * W * (kDC * out_bytes / 16) + t->threads - 1) / t->threads > 8) return false;        // AC in the kernel
+  static const int ipw_env = getenv("APGD_DW_IPW") ? atoi(getenv("APGD_DW_IPW")) : 0;         // tuning experiments only
+  t->ipw = ipw_env > 0 ? ipw_env : (H * W <= 64 ? 2 : 4);
+  t->lds = static_cast<size_t>(n_sr * kDR + 6) * P2 * kDC * 4 + static_cast<size_t>(H) * W * kDC * out_bytes;
+  return t->lds <= 150 * 1024;
+}
+
 struct DwDot { int th, threads; size_t lds; };
 inline bool dw_dot2_plan(int H, int W, int C, DwDot* t) {
   if (C % kDC != 0) return false;
@@ -1230,6 +1416,27 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
       else DWR_DISPATCH(uint16_t, uint16_t)
 #undef DWR_DISPATCH
 #undef DWR_LAUNCH
+      return launch_status();
+    }
+    DwMulti mp;
+    if (dw_multi_plan(N, H, W, C, x_dtype == APGD_F32 ? 4 : 2, out_dtype == APGD_F32 ? 4 : 2, &mp)) {
+      const dim3 grid(static_cast<unsigned>(static_cast<long>((N + mp.ipw - 1) / mp.ipw) * (C / kDC))), block(mp.threads);
+#define DWM_LAUNCH(TI, TO, UU)                                                                                        \
+  {                                                                                                                   \
+    auto kfn = dwconv7x7_multi_kernel<TI, TO, UU>;                                                                    \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, grid, block, mp.lds, s, static_cast<const TI*>(x), w49c, bias, add, static_cast<TO*>(out), N, H, \
+                       W, C, flip, mp.n_sr, mp.ipw);                                                                   \
+  }
+#define DWM_DISPATCH(TI, TO) { if (mp.ut == 5) DWM_LAUNCH(TI, TO, 5) else DWM_LAUNCH(TI, TO, 7) }
+      if (out_dtype == APGD_F32) DWM_DISPATCH(uint16_t, float)       // the plan only accepts bf16 inputs
+      else DWM_DISPATCH(uint16_t, uint16_t)
+#undef DWM_DISPATCH
+#undef DWM_LAUNCH
       return launch_status();
     }
     DwDot dp;
