@@ -1044,6 +1044,160 @@ __global__ __launch_bounds__(256) void dwconv7x7_wgrad_dot2_kernel(const TX* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Rolling-window variant of the filter gradient (same pipeline as dwconv7x7_roll_kernel): a workgroup walks down a band
+// of `imgs` images x 32 channels with the 10-row x window as a ring in LDS and 4 dy rows per iteration; the rows of the
+// next iteration are loaded into registers before the dot products of the current one run.  Every x row is staged once
+// per band instead of 2.5 times, the global latency hides behind the arithmetic, and the 49 x 32 partial sums stay in
+// registers over the whole band.  ws[part][50][C], part = blockIdx / (C/32).
+// ------------------------------------------------------------------------------------------------
+template <typename TX>
+__global__ __launch_bounds__(256) void dwconv7x7_wgrad_roll_kernel(const TX* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                                   float* __restrict__ ws, long N, int H, int W, int C,
+                                                                   int RS, int n_seg, int imgs) {
+  constexpr int TH = 4, WR = TH + 6;
+  extern __shared__ __attribute__((aligned(16))) uint32_t wg_lds[];
+  using Raw = typename std::conditional<sizeof(TX) == 4, float4, uint2>::type;
+  const int D2 = (W + 1) / 2, P2 = D2 + 3;
+  uint32_t* win = wg_lds;                                        // [WR][P2][32]
+  uint32_t* dt = wg_lds + static_cast<long>(WR) * P2 * kDC;      // [TH][D2][32]
+  const int n_cg = C / kDC;
+  const int cbase = static_cast<int>(blockIdx.x % n_cg) * kDC;
+  const long part = blockIdx.x / n_cg;
+  const int seg = static_cast<int>(part % n_seg);
+  const long n_begin = (part / n_seg) * imgs;
+  const long n_end = n_begin + imgs < N ? n_begin + imgs : N;
+  const int r_begin = seg * RS, r_end = min(H, r_begin + RS);
+  const int tid = threadIdx.x;
+  const int lc = tid & (kDC - 1), kh = tid / kDC;                // kh == 7: staging helper only
+
+  // staging units (one per thread and row): x pair m covers padded columns 2m-3, 2m-2; dy pair m covers 2m, 2m+1
+  const int xu = P2 * (kDC / 4), du = D2 * (kDC / 4);
+  const bool xok = tid < xu, dok = tid < du;
+  const int xi = min(tid, xu - 1), di = min(tid, du - 1);
+  const int xm = xi / (kDC / 4), xl4 = xi % (kDC / 4), dm = di / (kDC / 4), dl4 = di % (kDC / 4);
+  const int xw0 = 2 * xm - 3, xw1 = xw0 + 1, dw0 = 2 * dm, dw1 = dw0 + 1;
+  const uint32_t xmask = ((xw0 >= 0 && xw0 < W) ? 0x0000ffffu : 0u) | ((xw1 >= 0 && xw1 < W) ? 0xffff0000u : 0u);
+  const uint32_t dmask = 0x0000ffffu | (dw1 < W ? 0xffff0000u : 0u);
+  const long xoff0 = static_cast<long>(min(max(xw0, 0), W - 1)) * C + cbase + xl4 * 4;
+  const long xoff1 = static_cast<long>(min(max(xw1, 0), W - 1)) * C + cbase + xl4 * 4;
+  const long doff0 = static_cast<long>(dw0) * C + cbase + dl4 * 4;
+  const long doff1 = static_cast<long>(min(dw1, W - 1)) * C + cbase + dl4 * 4;
+
+  auto load_x = [&](long n, int hh, Raw& v0, Raw& v1) {
+    const TX* xr = x + ((n * H + min(max(hh, 0), H - 1)) * static_cast<long>(W)) * C;
+    v0 = *reinterpret_cast<const Raw*>(xr + xoff0);
+    v1 = *reinterpret_cast<const Raw*>(xr + xoff1);
+  };
+  auto store_x = [&](int slot, int hh, const Raw& v0, const Raw& v1) {
+    if (!xok) return;
+    uint4 d;
+    if constexpr (sizeof(TX) == 4) {
+      d.x = pack2_bf16(v0.x, v1.x); d.y = pack2_bf16(v0.y, v1.y); d.z = pack2_bf16(v0.z, v1.z); d.w = pack2_bf16(v0.w, v1.w);
+    } else {
+      d.x = (v0.x & 0xffffu) | (v1.x << 16); d.y = (v0.x >> 16) | (v1.x & 0xffff0000u);
+      d.z = (v0.y & 0xffffu) | (v1.y << 16); d.w = (v0.y >> 16) | (v1.y & 0xffff0000u);
+    }
+    const uint32_t km = (hh >= 0 && hh < H) ? xmask : 0u;
+    d.x &= km; d.y &= km; d.z &= km; d.w &= km;
+    *reinterpret_cast<uint4*>(&win[(static_cast<long>(slot) * P2 + xm) * kDC + xl4 * 4]) = d;
+  };
+  auto load_d = [&](long n, int hh, uint2& v0, uint2& v1) {
+    const uint16_t* dr = dy + ((n * H + min(hh, H - 1)) * static_cast<long>(W)) * C;
+    v0 = *reinterpret_cast<const uint2*>(dr + doff0);
+    v1 = *reinterpret_cast<const uint2*>(dr + doff1);
+  };
+  auto store_d = [&](int r, int hh, const uint2& v0, const uint2& v1) {
+    if (!dok) return;
+    uint4 d;
+    d.x = (v0.x & 0xffffu) | (v1.x << 16); d.y = (v0.x >> 16) | (v1.x & 0xffff0000u);
+    d.z = (v0.y & 0xffffu) | (v1.y << 16); d.w = (v0.y >> 16) | (v1.y & 0xffff0000u);
+    const uint32_t km = hh < r_end ? dmask : 0u;                 // rows past the band contribute nothing
+    d.x &= km; d.y &= km; d.z &= km; d.w &= km;
+    *reinterpret_cast<uint4*>(&dt[(static_cast<long>(r) * D2 + dm) * kDC + dl4 * 4]) = d;
+  };
+
+  float acc[7], accb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc[k] = 0.f;
+  const uint32_t ones = 0x3f803f80u;                             // (1.0bf16, 1.0bf16)
+
+  for (long n = n_begin; n < n_end; ++n) {
+    // ---- fill: x rows r_begin-3 .. r_begin+6 -> slots 0..9, dy rows r_begin .. r_begin+3
+    {
+      Raw a0[5], a1[5];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int rr = 0; rr < 5; ++rr) load_x(n, r_begin - 3 + half * 5 + rr, a0[rr], a1[rr]);
+#pragma unroll
+        for (int rr = 0; rr < 5; ++rr) store_x(half * 5 + rr, r_begin - 3 + half * 5 + rr, a0[rr], a1[rr]);
+      }
+      uint2 b0[TH], b1[TH];
+#pragma unroll
+      for (int rr = 0; rr < TH; ++rr) load_d(n, r_begin + rr, b0[rr], b1[rr]);
+#pragma unroll
+      for (int rr = 0; rr < TH; ++rr) store_d(rr, r_begin + rr, b0[rr], b1[rr]);
+    }
+    __syncthreads();
+    int s0 = 0;
+    for (int h0 = r_begin; h0 < r_end; h0 += TH) {
+      const bool more = h0 + TH < r_end;
+      Raw px0[TH], px1[TH];
+      uint2 pd0[TH], pd1[TH];
+      if (more) {
+#pragma unroll
+        for (int rr = 0; rr < TH; ++rr) {
+          load_x(n, h0 + TH + 3 + rr, px0[rr], px1[rr]);
+          load_d(n, h0 + TH + rr, pd0[rr], pd1[rr]);
+        }
+      }
+      if (kh < 7) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+          int slot = s0 + r + kh;
+          if (slot >= WR) slot -= WR;
+          if (slot >= WR) slot -= WR;
+          const uint32_t* xrow = win + static_cast<long>(slot) * P2 * kDC + lc;
+          const uint32_t* drow = dt + static_cast<long>(r) * D2 * kDC + lc;
+          uint32_t e0 = xrow[0], e1 = xrow[kDC], e2 = xrow[2 * kDC], e3 = xrow[3 * kDC];
+#pragma unroll 2
+          for (int m = 0; m < D2; ++m) {
+            const uint32_t d = drow[m * kDC];
+            const uint32_t e4 = xrow[(m + 4) * kDC];             // m + 4 <= D2 + 3 = P2: one dword past the row at most (stays inside the ring / dy tile)
+            const uint32_t o0 = __builtin_amdgcn_alignbit(e1, e0, 16), o1 = __builtin_amdgcn_alignbit(e2, e1, 16),
+                           o2 = __builtin_amdgcn_alignbit(e3, e2, 16);
+            acc[0] = dot2(d, e0, acc[0]); acc[1] = dot2(d, o0, acc[1]); acc[2] = dot2(d, e1, acc[2]);
+            acc[3] = dot2(d, o1, acc[3]); acc[4] = dot2(d, e2, acc[4]); acc[5] = dot2(d, o2, acc[5]);
+            acc[6] = dot2(d, e3, acc[6]);
+            if (kh == 3) accb = dot2(d, ones, accb);
+            e0 = e1; e1 = e2; e2 = e3; e3 = e4;
+          }
+        }
+      }
+      __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int rr = 0; rr < TH; ++rr) {
+          int slot = s0 + rr;
+          if (slot >= WR) slot -= WR;
+          store_x(slot, h0 + TH + 3 + rr, px0[rr], px1[rr]);
+          store_d(rr, h0 + TH + rr, pd0[rr], pd1[rr]);
+        }
+      }
+      s0 += TH;
+      if (s0 >= WR) s0 -= WR;
+      __syncthreads();
+    }
+  }
+  if (kh < 7) {
+    float* pw = ws + part * 50 * C + cbase + lc;
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) pw[(kh * 7 + kw) * C] = acc[kw];
+    if (kh == 3) pw[49 * C] = accb;
+  }
+}
+
 // out[j] = sum_p ws[p*len + j]: 16 outputs x 16 part-groups per block; every thread sums its parts (8 loads in flight)
 // in a fixed order, the 16 group sums are combined by a fixed tree (deterministic).  `len` is a few hundred to a few
 // thousand, `nparts` up to 1024: the old 64-outputs-per-block shape left a dozen blocks walking 256 parts serially.
@@ -1516,6 +1670,36 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
   if (dy_dtype == APGD_BF16 && C % kDC == 0 && W <= 128) {
     // autocast path: bf16 output gradient; an fp32 x is rounded to bf16 (as the convolution itself did); packed dot products
     const int D2 = (W + 1) / 2, P2 = D2 + 3;
+    static const int wroll = getenv("APGD_DW_WROLL") ? atoi(getenv("APGD_DW_WROLL")) : 1;        // 0: tile kernel
+    if (wroll && P2 * (kDC / 4) <= 256) {
+      static const int rs_env = getenv("APGD_DW_WRS") ? atoi(getenv("APGD_DW_WRS")) : 0;         // tuning experiments only
+      static const int im_env = getenv("APGD_DW_WIMGS") ? atoi(getenv("APGD_DW_WIMGS")) : 0;
+      int rs = rs_env > 0 ? rs_env : (H >= 56 ? 28 : H);
+      rs = ((rs + 3) / 4) * 4;
+      const int n_seg = (H + rs - 1) / rs;
+      int imgs = im_env > 0 ? im_env : (H * W >= 784 ? 1 : (H * W >= 196 ? 2 : 4));
+      while (((N + imgs - 1) / imgs) * n_seg > kWgradBlocks) ++imgs;
+      const int nparts = static_cast<int>((N + imgs - 1) / imgs) * n_seg;
+      const size_t lds = (static_cast<size_t>(10) * P2 + static_cast<size_t>(4) * D2 + 1) * kDC * 4;   // + 1 pair: the look-ahead read
+      const dim3 grid(static_cast<unsigned>(nparts) * (C / kDC)), block(256);
+#define WGR_LAUNCH(TX)                                                                                                \
+  {                                                                                                                   \
+    auto kfn = dwconv7x7_wgrad_roll_kernel<TX>;                                                                       \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, static_cast<const TX*>(x), static_cast<const uint16_t*>(dy), ws,     \
+                       static_cast<long>(N), H, W, C, rs, n_seg, imgs);                                                \
+  }
+      if (x_dtype == APGD_F32) WGR_LAUNCH(float)
+      else WGR_LAUNCH(uint16_t)
+#undef WGR_LAUNCH
+      const int len = 50 * C;
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 15) / 16), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, nparts);
+      return launch_status();
+    }
     int th = H < 8 ? H : 8;
     auto lds_of = [&](int rows) { return (static_cast<size_t>(rows + 6) * P2 + static_cast<size_t>(rows) * D2) * kDC * 4; };
     while (th > 1 && lds_of(th) > 56 * 1024) --th;
