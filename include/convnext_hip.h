@@ -117,6 +117,14 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                       void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out,
                       int64_t M, int32_t C, void* stream);
+/* Input-gradient-only variant (the attack's backward, models/convnext.py:41-49 including the LayerNorm): the same kernel
+ * with the LayerNorm backward in its epilogue,
+ *     du = rstd * (t - mean_c(t) - xh * mean_c(t * xh)),   t = ln_w * da,  xh = (u - mean) * rstd,
+ * so the [M, C] gradient is written once, as du [M, C] bf16 = gradient w.r.t. the depthwise-conv output (feed it to
+ * cnx_dwconv7x7_nhwc(flip = 1)); no parameter gradients. */
+int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                            const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
+                            int64_t M, int32_t C, void* stream);
 
 /* Fused multi-head softmax attention of the ViT family (timm 0.8 `Attention.forward`, reached through the models of
  * /root/reference/utils_architecture.py:272-301):

@@ -542,7 +542,7 @@ struct BlkBwdArgs {
   const float* gamma;      // [C] or NULL
   const uint16_t* Wb;      // packed backward weights
   const float* b1;         // [4C]
-  uint16_t* da;            // [M, C] bf16: gradient w.r.t. LN(u)
+  uint16_t* da;            // [M, C] bf16: gradient w.r.t. LN(u)  (LNB kernels: w.r.t. u itself)
   uint16_t* a_out;         // emit: [M, C] bf16 LN(u)           (all four NULL or all four set)
   uint16_t* do_out;        // emit: [M, C] bf16 g * gamma
   uint16_t* ht_out;        // emit: [4C, M] bf16 GELU(Hpre)^T
@@ -569,7 +569,7 @@ struct GeoB {
   static_assert(WAVES * 16 * C * 4 <= DEPTH * SLICE, "the epilogue tile reuses the weight ring");
 };
 
-template <int C, typename TG, bool EMIT>
+template <int C, typename TG, bool EMIT, bool LNB>
 __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_mlp_bwd_kernel(const BlkBwdArgs p) {
   using G = GeoB<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -759,38 +759,104 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
   // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]; as in the forward the tile leaves through
   //      the dead weight ring, 16 rows per pass, so that a lane stores 16 bytes (8 bf16) of a contiguous run instead of 2
   __syncthreads();
-  float* scr = reinterpret_cast<float*>(ring) + wave * (16 * C);
-  constexpr int NCH = 16 * C / 8 / 64;                                  // 8-element chunks per lane and pass (C / 32)
+  if constexpr (LNB) {
+    // ---- ... and the LayerNorm backward rides along (input-gradient-only calls): with t = ln_w * da and
+    //      xh = (u - mean) * rstd,   du = rstd * (t - mean_c(t) - xh * mean_c(t * xh)).
+    //      16 rows per pass, 4 lanes per row (lane = row*4 + q; q takes the 8-channel chunks q, q+4, ...): the row sums
+    //      are two quad exchanges, a row's four lanes store 64 contiguous bytes per chunk step.
+    constexpr int CP = C + 4;                                             // padded row: the 4 lanes x 16 rows spread over the banks
+    static_assert(G::WAVES * 16 * CP * 4 <= G::DEPTH * G::SLICE, "the epilogue tile reuses the weight ring");
+    float* scr = reinterpret_cast<float*>(ring) + wave * (16 * CP);
+    constexpr int NJ = C / 32;                                            // 8-channel chunks per lane
+    const int rl = lane >> 2, q = lane & 3;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const long e0 = (m0 + 16 * pass) * C;
-    const long e_end = p.M * C;
-    __builtin_amdgcn_wave_barrier();
+    for (int pass = 0; pass < 2; ++pass) {
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int cb = 0; cb < G::CB; ++cb)
+      for (int cb = 0; cb < G::CB; ++cb)
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc3[cb][8 * pass + r];
-    __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 8; ++r)
+          scr[((r & 3) + 8 * (r >> 2) + 4 * half) * CP + cb * 32 + l32] = acc3[cb][8 * pass + r];
+      __builtin_amdgcn_wave_barrier();
+      const long m = m0 + 16 * pass + rl;
+      const long mc = m < p.M ? m : p.M - 1;
+      const float mean = p.mean[mc], rstd = p.rstd[mc];
+      uint4 ur[NJ];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const int idx = j * 64 + lane;
-      const long e = e0 + idx * 8;
-      const float4 lo = reinterpret_cast<const float4*>(scr)[2 * idx], hi = reinterpret_cast<const float4*>(scr)[2 * idx + 1];
-      if (e < e_end)
-        *reinterpret_cast<uint4*>(p.da + e) = make_uint4(pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w));
+      for (int j = 0; j < NJ; ++j) ur[j] = *reinterpret_cast<const uint4*>(p.u + mc * C + (q + 4 * j) * 8);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c0 = (q + 4 * j) * 8;
+        const float4 d0 = *reinterpret_cast<const float4*>(scr + rl * CP + c0), d1 = *reinterpret_cast<const float4*>(scr + rl * CP + c0 + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + c0), w1 = *reinterpret_cast<const float4*>(p.ln_w + c0 + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const uint32_t uw[4] = {ur[j].x, ur[j].y, ur[j].z, ur[j].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float uv = (e & 1) ? bf16_hi(uw[e >> 1]) : bf16_lo(uw[e >> 1]);
+          const float t = wv[e] * dv[e], xh = (uv - mean) * rstd;
+          s1 += t;
+          s2 = fmaf(t, xh, s2);
+        }
+      }
+      s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+      s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+      s1 *= (1.0f / C); s2 *= (1.0f / C);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c0 = (q + 4 * j) * 8;
+        const float4 d0 = *reinterpret_cast<const float4*>(scr + rl * CP + c0), d1 = *reinterpret_cast<const float4*>(scr + rl * CP + c0 + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + c0), w1 = *reinterpret_cast<const float4*>(p.ln_w + c0 + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const uint32_t uw[4] = {ur[j].x, ur[j].y, ur[j].z, ur[j].w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float uv = (e & 1) ? bf16_hi(uw[e >> 1]) : bf16_lo(uw[e >> 1]);
+          const float t = wv[e] * dv[e], xh = (uv - mean) * rstd;
+          o[e] = rstd * (t - s1 - xh * s2);
+        }
+        if (m < p.M)
+          *reinterpret_cast<uint4*>(p.da + m * C + c0) = make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+      }
+    }
+  } else {
+    float* scr = reinterpret_cast<float*>(ring) + wave * (16 * C);
+    constexpr int NCH = 16 * C / 8 / 64;                                  // 8-element chunks per lane and pass (C / 32)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const long e0 = (m0 + 16 * pass) * C;
+      const long e_end = p.M * C;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc3[cb][8 * pass + r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int idx = j * 64 + lane;
+        const long e = e0 + idx * 8;
+        const float4 lo = reinterpret_cast<const float4*>(scr)[2 * idx], hi = reinterpret_cast<const float4*>(scr)[2 * idx + 1];
+        if (e < e_end)
+          *reinterpret_cast<uint4*>(p.da + e) = make_uint4(pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w));
+      }
     }
   }
 }
 
 template <int C>
-int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
+int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, bool ln_bwd, hipStream_t s) {
   using G = GeoB<C>;
   const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(G::WAVES * 64);
   const bool emit = a.a_out != nullptr;
-#define BLK_LAUNCH(TG, EM)                                                                                       \
+#define BLK_LAUNCH(TG, EM, LN)                                                                                   \
   {                                                                                                              \
-    auto kfn = blk_mlp_bwd_kernel<C, TG, EM>;                                                                    \
+    auto kfn = blk_mlp_bwd_kernel<C, TG, EM, LN>;                                                                \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
@@ -799,8 +865,11 @@ int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
     }                                                                                                            \
     hipLaunchKernelGGL(kfn, grid, block, (EM) ? G::LDS_EMIT : G::LDS, s, a);                                     \
   }
-  if (g_dtype == APGD_F32) { if (emit) BLK_LAUNCH(float, true) else BLK_LAUNCH(float, false) }
-  else { if (emit) BLK_LAUNCH(uint16_t, true) else BLK_LAUNCH(uint16_t, false) }
+  if (g_dtype == APGD_F32) {
+    if (emit) BLK_LAUNCH(float, true, false) else if (ln_bwd) BLK_LAUNCH(float, false, true) else BLK_LAUNCH(float, false, false)
+  } else {
+    if (emit) BLK_LAUNCH(uint16_t, true, false) else if (ln_bwd) BLK_LAUNCH(uint16_t, false, true) else BLK_LAUNCH(uint16_t, false, false)
+  }
 #undef BLK_LAUNCH
   return launch_status();
 }
@@ -872,10 +941,10 @@ int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* 
   return launch_status();
 }
 
-int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
-                      const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                      void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C,
-                      void* stream) {
+static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                              const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
+                              void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, bool ln_bwd,
+                              int64_t M, int32_t C, void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!u || !ln_w || !ln_b || !mean || !rstd || !g || !Wb || !b1 || !da) return APGD_ERR_NULL;
@@ -891,10 +960,25 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
   a.a_stride = a_stride ? a_stride : C;
   hipStream_t s = as_stream(stream);
   switch (C) {
-    case 96: return launch_blk_bwd<96>(a, g_dtype, s);
-    case 192: return launch_blk_bwd<192>(a, g_dtype, s);
+    case 96: return launch_blk_bwd<96>(a, g_dtype, ln_bwd, s);
+    case 192: return launch_blk_bwd<192>(a, g_dtype, ln_bwd, s);
     default: return APGD_ERR_ARG;
   }
+}
+
+int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                      const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
+                      void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C,
+                      void* stream) {
+  return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, a_stride, do_out, ht_out, dhpt_out,
+                            false, M, C, stream);
+}
+
+int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                            const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
+                            int64_t M, int32_t C, void* stream) {
+  return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, du, nullptr, 0, nullptr, nullptr, nullptr,
+                            true, M, C, stream);
 }
 
 int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 192) ? 1 : 0; }

@@ -446,7 +446,16 @@ class _BlockFused(torch.autograd.Function):
         g2 = g.reshape(M, C)
         dw1 = db1 = dw2 = db2 = dgamma = None
         da = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)            # gradient w.r.t. LN(u)
-        if ctx.fused:
+        d_u = None
+        if ctx.fused and not want_p:
+            # ---- attack backward: ONE kernel down to the depthwise-conv output (LayerNorm backward in its epilogue)
+            if g2.dtype not in (torch.float32, torch.bfloat16):
+                g2 = g2.float()
+            d_u = da.view(u.shape)
+            _lib.check(lib.cnx_block_mlp_bwd_input(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
+                                                   d_u.data_ptr(), M, C, _stream()), "cnx_block_mlp_bwd_input")
+        elif ctx.fused:
             # ---- one kernel: LN recompute, dO = g*gamma, Hpre / dH / dHpre per hidden slice on-chip, da
             a = dos = ht = dhpt = None
             if want_p:
@@ -501,17 +510,18 @@ class _BlockFused(torch.autograd.Function):
                 if gf is None:
                     dgamma = None
             del dhpre, dos
-        # ---- LayerNorm backward
-        d_u = torch.empty_like(u)
+        # ---- LayerNorm backward (already done by the fused input-gradient kernel)
         dlw = dlb = ws = None
-        if want_p:
-            dlw = torch.empty(C, device=x.device, dtype=torch.float32)
-            dlb = torch.empty(C, device=x.device, dtype=torch.float32)
-            ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device=x.device, dtype=torch.float32)
-        _lib.check(lib.cnx_layernorm_bwd(da.data_ptr(), _code(da), u.data_ptr(), _code(u), lw.data_ptr(), None,
-                                         mean.data_ptr(), rstd.data_ptr(), d_u.data_ptr(), _code(d_u),
-                                         _lib.ptr(dlw), _lib.ptr(dlb), _lib.ptr(ws), M, C, 0, _stream()),
-                   "cnx_layernorm_bwd")
+        if d_u is None:
+            d_u = torch.empty_like(u)
+            if want_p:
+                dlw = torch.empty(C, device=x.device, dtype=torch.float32)
+                dlb = torch.empty(C, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device=x.device, dtype=torch.float32)
+            _lib.check(lib.cnx_layernorm_bwd(da.data_ptr(), _code(da), u.data_ptr(), _code(u), lw.data_ptr(), None,
+                                             mean.data_ptr(), rstd.data_ptr(), d_u.data_ptr(), _code(d_u),
+                                             _lib.ptr(dlw), _lib.ptr(dlb), _lib.ptr(ws), M, C, 0, _stream()),
+                       "cnx_layernorm_bwd")
         # ---- depthwise conv backward; the residual branch's gradient rides along as the stencil's `add` input
         dx = None
         if nig[0]:

@@ -342,6 +342,20 @@ def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt)
         hp2 = hpre.detach().clone().requires_grad_()
         (dhpre,) = torch.autograd.grad(F.gelu(hp2), hp2, dh)
         assert float((dhpt.float().t().cpu() - dhpre).norm() / dhpre.norm()) < 6e-3
+    if not emit:
+        # input-gradient-only entry: LayerNorm backward in the epilogue -> gradient w.r.t. u, vs fp32 autograd through LN
+        u32 = u.float().requires_grad_()
+        a2 = F.layer_norm(u32, (C,), lw, lb, 1e-6)
+        (du_ref,) = torch.autograd.grad(a2, u32, da_ref)
+        du = torch.full((M_, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+        assert lib.cnx_block_mlp_bwd_input(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(),
+                                           gd.data_ptr(), R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(),
+                                           du.data_ptr(), M_, C, S()) == 0
+        err = float((du.float().cpu() - du_ref).norm() / du_ref.norm())
+        assert err < 1e-2, err                 # + the cancellation in t - mean(t) - xh mean(t xh) on bf16-accurate da
+        assert lib.cnx_block_mlp_bwd_input(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(),
+                                           gd.data_ptr(), R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(),
+                                           None, M_, C, S()) == -1
     # argument errors
     assert lib.cnx_block_mlp_bwd(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), gd.data_ptr(),
                                  R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), da.data_ptr(), 0,
