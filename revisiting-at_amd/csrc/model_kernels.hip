@@ -1317,7 +1317,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict
 //   gelu_bwd_colsum_kernel     dHpre = bf16(dH * GELU'(Hpre));  db1 = sum_m dHpre
 // Thread = 4 consecutive channels; blockIdx.x walks column tiles of 1024, blockIdx.y strides over rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int kColParts = 2048;
+// row lanes (= partial sums per column) of the column-sum passes: enough threads to fill the chip also for narrow tensors
+// (C = 96: 24 threads per row lane; 2048 lanes were 192 blocks and ran the 462 MB d(gamma)/d(b2) pass at 1.1 TB/s)
+inline int col_parts(int n_cols) {
+  const int p = (1 << 19) / n_cols;
+  return p < 2048 ? 2048 : (p > 8192 ? 8192 : p);
+}
 __device__ __forceinline__ float round_bf16(float v) { return __uint_as_float(static_cast<uint32_t>(f2bf(v)) << 16); }
 __device__ __forceinline__ float4 round_bf16(float4 v) { return make_float4(round_bf16(v.x), round_bf16(v.y), round_bf16(v.z), round_bf16(v.w)); }
 
@@ -1378,13 +1383,28 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const TG* __res
   const int c = cm.c;
   const float4 g4 = gamma ? load4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
-  for (long m = cm.rl; m < M; m += cm.R) {
-    const float4 gv = load4(g + m * C + c);
-    const float4 d = round_bf16(make_float4(gv.x * g4.x, gv.y * g4.y, gv.z * g4.z, gv.w * g4.w));
-    if (dos) store4(dos + m * C + c, d);
-    if (ws) {                                                      // sums of the rounded values, as summing the bf16 tensor would
-      ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
-      if (y) { const float4 yv = load4(y + m * C + c); ag.x = fmaf(gv.x, yv.x, ag.x); ag.y = fmaf(gv.y, yv.y, ag.y); ag.z = fmaf(gv.z, yv.z, ag.z); ag.w = fmaf(gv.w, yv.w, ag.w); }
+  // 4 rows per trip: the loads of a trip are independent (one load in flight per thread left this pass latency-bound at
+  // ~2 TB/s on cache-resident tensors); the sums keep their row order
+  constexpr int UR = 4;
+  for (long m0 = cm.rl; m0 < M; m0 += static_cast<long>(UR) * cm.R) {
+    float4 gv[UR], yv[UR];
+#pragma unroll
+    for (int k = 0; k < UR; ++k) {
+      const long m = m0 + static_cast<long>(k) * cm.R;
+      const long mc = m < M ? m : M - 1;
+      gv[k] = load4(g + mc * C + c);
+      if (ws && y) yv[k] = load4(y + mc * C + c);
+    }
+#pragma unroll
+    for (int k = 0; k < UR; ++k) {
+      const long m = m0 + static_cast<long>(k) * cm.R;
+      if (m >= M) break;
+      const float4 d = round_bf16(make_float4(gv[k].x * g4.x, gv[k].y * g4.y, gv[k].z * g4.z, gv[k].w * g4.w));
+      if (dos) store4(dos + m * C + c, d);
+      if (ws) {                                                    // sums of the rounded values, as summing the bf16 tensor would
+        ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+        if (y) { ag.x = fmaf(gv[k].x, yv[k].x, ag.x); ag.y = fmaf(gv[k].y, yv[k].y, ag.y); ag.z = fmaf(gv[k].z, yv[k].z, ag.z); ag.w = fmaf(gv[k].w, yv[k].w, ag.w); }
+      }
     }
   }
   if (ws) {
@@ -1804,7 +1824,7 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
   return APGD_OK;
 }
 
-int64_t cnx_colsum_ws_floats(int32_t n_cols) { return static_cast<int64_t>(kColParts) * 2 * n_cols; }
+int64_t cnx_colsum_ws_floats(int32_t n_cols) { return n_cols > 0 ? static_cast<int64_t>(col_parts(n_cols)) * 2 * n_cols : 0; }
 
 int cnx_scale_residual(const void* x, int x_dtype, const void* y, const float* gamma, void* out, int out_dtype, int64_t M,
                        int32_t C, void* stream) {
@@ -1835,7 +1855,7 @@ int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const floa
   if (g_dtype != APGD_F32 && g_dtype != APGD_BF16) return APGD_ERR_DTYPE;
   const bool sums = dgamma != nullptr;
   int cq;
-  const dim3 grid = col_grid(C, M, sums ? kColParts : 16384, &cq), block(256);
+  const dim3 grid = col_grid(C, M, sums ? col_parts(C) : 16384, &cq), block(256);
   const int parts = col_lanes(cq, grid);
   hipStream_t s = as_stream(stream);
   const auto* yy = static_cast<const uint16_t*>(y);          // NULL: dgamma comes out as zeros
@@ -1857,7 +1877,7 @@ int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db
   if (!dh || !hpre || !dhpre) return APGD_ERR_NULL;
   if (db1 && !ws) return APGD_ERR_NULL;
   int cq;
-  const dim3 grid = col_grid(N, M, db1 ? kColParts : 16384, &cq), block(256);
+  const dim3 grid = col_grid(N, M, db1 ? col_parts(N) : 16384, &cq), block(256);
   const int parts = col_lanes(cq, grid);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(gelu_bwd_colsum_kernel, grid, block, 0, s, static_cast<const uint16_t*>(dh), static_cast<const uint16_t*>(hpre),
