@@ -1510,6 +1510,150 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide variants for the widths of the model (C = 48 * 2^k: 48 ... 768): G = C/24 lanes per row, three 8-channel chunks
+// (16 bytes of bf16, 32 of fp32) per lane, 64/G rows per wavefront.  The 4-channel kernels above keep one row of <= 1.5 KB in
+// flight per wavefront and two 6-step reductions per row: latency-bound at ~3 TB/s on tensors that sit in the MALL.
+// ------------------------------------------------------------------------------------------------
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 load8(const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  return F8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ F8 load8(const uint16_t* p) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p);
+  return F8{{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u),
+             __uint_as_float(t.z << 16), __uint_as_float(t.z & 0xffff0000u), __uint_as_float(t.w << 16), __uint_as_float(t.w & 0xffff0000u)}};
+}
+__device__ __forceinline__ void store8(float* p, const F8& o) {
+  *reinterpret_cast<float4*>(p) = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(o.v[4], o.v[5], o.v[6], o.v[7]);
+}
+__device__ __forceinline__ void store8(uint16_t* p, const F8& o) {
+  uint4 t;
+  t.x = static_cast<uint32_t>(f2bf(o.v[0])) | (static_cast<uint32_t>(f2bf(o.v[1])) << 16);
+  t.y = static_cast<uint32_t>(f2bf(o.v[2])) | (static_cast<uint32_t>(f2bf(o.v[3])) << 16);
+  t.z = static_cast<uint32_t>(f2bf(o.v[4])) | (static_cast<uint32_t>(f2bf(o.v[5])) << 16);
+  t.w = static_cast<uint32_t>(f2bf(o.v[6])) | (static_cast<uint32_t>(f2bf(o.v[7])) << 16);
+  *reinterpret_cast<uint4*>(p) = t;
+}
+
+template <typename TX, typename TY, int G>
+__global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const TX* __restrict__ x, const float* __restrict__ weight,
+                                                                 const float* __restrict__ bias, float eps,
+                                                                 TY* __restrict__ y, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd, long M, int C, int gelu) {
+  constexpr int RPB = 256 / G;
+  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  const float invC = 1.0f / static_cast<float>(C);
+  F8 w8[3], b8[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { w8[k] = load8(weight + (gl + k * G) * 8); b8[k] = load8(bias + (gl + k * G) * 8); }
+  for (long row = static_cast<long>(blockIdx.x) * RPB + gr; row < M; row += static_cast<long>(gridDim.x) * RPB) {
+    const TX* xr = x + row * C;
+    F8 v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = load8(xr + (gl + k * G) * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[k].v[e];
+    const float mu = group_sum<G>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[k].v[e] - mu; q += d * d; }
+    const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
+    if (gl == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    TY* yr = y + row * C;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      F8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o.v[e] = (v[k].v[e] - mu) * rs * w8[k].v[e] + b8[k].v[e];
+        if (gelu) o.v[e] = gelu_f(o.v[e]);
+      }
+      store8(yr + (gl + k * G) * 8, o);
+    }
+  }
+}
+
+template <typename TD, typename TX, typename TO, int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __restrict__ dy, const TX* __restrict__ x,
+                                                                 const float* __restrict__ weight,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, TO* __restrict__ dx,
+                                                                 float* __restrict__ ws, long M, int C, int gelu) {
+  constexpr int RPB = 256 / G;
+  __shared__ float red[2][RPB][G * 8];                // per row-group partial parameter gradients (one chunk)
+  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  const float invC = 1.0f / static_cast<float>(C);
+  F8 w8[3], b8[3], aw[3], ab[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    w8[k] = load8(weight + (gl + k * G) * 8);
+    if (gelu && bias) b8[k] = load8(bias + (gl + k * G) * 8);
+    else b8[k] = F8{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    aw[k] = ab[k] = F8{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+  }
+  for (long row = static_cast<long>(blockIdx.x) * RPB + gr; row < M; row += static_cast<long>(gridDim.x) * RPB) {
+    const float mu = mean[row], rs = rstd[row];
+    F8 xh[3], g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { xh[k] = load8(x + row * C + (gl + k * G) * 8); g[k] = load8(dy + row * C + (gl + k * G) * 8); }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float h = (xh[k].v[e] - mu) * rs;
+        float d = g[k].v[e];
+        if (gelu) d *= gelu_grad_f(h * w8[k].v[e] + b8[k].v[e]);
+        if (ws) { aw[k].v[e] += d * h; ab[k].v[e] += d; }
+        const float t = d * w8[k].v[e];
+        xh[k].v[e] = h;
+        g[k].v[e] = t;
+        s1 += t;
+        s2 += t * h;
+      }
+    const float c1 = group_sum<G>(s1) * invC, c2 = group_sum<G>(s2) * invC;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      F8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.v[e] = rs * (g[k].v[e] - c1 - xh[k].v[e] * c2);
+      store8(dx + row * C + (gl + k * G) * 8, o);
+    }
+  }
+  if (!ws) return;
+  float* pw = ws + static_cast<long>(blockIdx.x) * 2 * C;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][gr][gl * 8 + e] = aw[k].v[e]; red[1][gr][gl * 8 + e] = ab[k].v[e]; }
+    __syncthreads();
+    // G*8 channels of this chunk x 2 sums, combined over the RPB row-groups in a fixed order
+    for (int j = threadIdx.x; j < 2 * G * 8; j += 256) {
+      const int which = j / (G * 8), cc = j % (G * 8);
+      float t = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < RPB; ++r) t += red[which][r][cc];
+      pw[which * C + k * G * 8 + cc] = t;
+    }
+  }
+}
+
+inline int ln_wide_group(int C) {              // C = 24 * G with G a power of two in [2, 32]
+  if (C % 24 != 0) return 0;
+  const int g = C / 24;
+  return (g >= 2 && g <= 32 && (g & (g - 1)) == 0) ? g : 0;
+}
+
 template <typename TX, typename TY>
 int launch_ln_fwd(const TX* x, const float* w, const float* b, float eps, TY* y, float* mean, float* rstd, long M, int C,
                   int gelu, hipStream_t s) {
@@ -1520,6 +1664,23 @@ int launch_ln_fwd(const TX* x, const float* w, const float* b, float eps, TY* y,
     hipLaunchKernelGGL((layernorm_fwd_kernel<TX, TY, G, NV>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, x, w, \
                        b, eps, y, mean, rstd, M, C, gelu);                                                     \
     return launch_status();                                                                                    \
+  }
+  static const int wide_on = getenv("APGD_LN_WIDE") ? atoi(getenv("APGD_LN_WIDE")) : 1;     // 0: 4-channel kernels everywhere
+  if (const int g = wide_on ? ln_wide_group(C) : 0) {
+#define LN_FWD_W(G)                                                                                            \
+  {                                                                                                            \
+    const long rpb = 256 / G;                                                                                  \
+    long nb = (M + rpb - 1) / rpb; if (nb > 16384) nb = 16384;                                                 \
+    hipLaunchKernelGGL((layernorm_fwd_wide_kernel<TX, TY, G>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, x, w, \
+                       b, eps, y, mean, rstd, M, C, gelu);                                                     \
+    return launch_status();                                                                                    \
+  }
+    if (g == 2) LN_FWD_W(2)
+    if (g == 4) LN_FWD_W(4)
+    if (g == 8) LN_FWD_W(8)
+    if (g == 16) LN_FWD_W(16)
+    if (g == 32) LN_FWD_W(32)
+#undef LN_FWD_W
   }
   if (C <= 64) LN_FWD(16, 1)
   if (C <= 128) LN_FWD(32, 1)
@@ -1542,6 +1703,24 @@ int launch_ln_bwd(const TD* dy, const TX* x, const float* w, const float* b, con
     hipLaunchKernelGGL((layernorm_bwd_kernel<TD, TX, TO, G, NV>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dy, \
                        x, w, b, mean, rstd, dx, ws, M, C, gelu);                                               \
     return launch_status();                                                                                    \
+  }
+  static const int wide_on = getenv("APGD_LN_WIDE") ? atoi(getenv("APGD_LN_WIDE")) : 1;
+  if (const int g = wide_on ? ln_wide_group(C) : 0) {
+#define LN_BWD_W(G)                                                                                            \
+  {                                                                                                            \
+    const long rpb = 256 / G;                                                                                  \
+    long nb = (M + rpb - 1) / rpb; if (nb > kLnBwdBlocks) nb = kLnBwdBlocks;                                   \
+    *nblocks = static_cast<int>(nb);                                                                           \
+    hipLaunchKernelGGL((layernorm_bwd_wide_kernel<TD, TX, TO, G>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dy, \
+                       x, w, b, mean, rstd, dx, ws, M, C, gelu);                                               \
+    return launch_status();                                                                                    \
+  }
+    if (g == 2) LN_BWD_W(2)
+    if (g == 4) LN_BWD_W(4)
+    if (g == 8) LN_BWD_W(8)
+    if (g == 16) LN_BWD_W(16)
+    if (g == 32) LN_BWD_W(32)
+#undef LN_BWD_W
   }
   if (C <= 64) LN_BWD(16, 1)
   if (C <= 128) LN_BWD(32, 1)

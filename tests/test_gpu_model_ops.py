@@ -92,7 +92,8 @@ def test_dwconv7x7_fwd_bwd_data_wgrad(R, N, C, H, W, xdt, odt):
     close(db, gb, 1e-4, 1e-4 * float(gb.abs().max()) + 1e-5)
 
 
-@pytest.mark.parametrize("M_,C", [(5, 48), (37, 96), (64, 64), (10, 144), (33, 192), (21, 384), (9, 768), (4, 1536), (3, 8)])
+@pytest.mark.parametrize("M_,C", [(5, 48), (37, 96), (64, 64), (10, 144), (33, 192), (21, 384), (9, 768), (4, 1536), (3, 8),
+                                  (1000, 48), (3000, 96), (700, 384), (300, 768)])
 @pytest.mark.parametrize("gelu", [0, 1])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_layernorm_rows_fwd_bwd(R, M_, C, gelu, dt):
