@@ -296,6 +296,30 @@ except ImportError:                                      # older torch: ATTrainS
     pass
 
 
+def load_gemm_table(path=None):
+    """Point PyTorch's TunableOp at the shipped hipBLASLt / rocBLAS solution table for the GEMM shapes of the benchmark
+    configuration (``gemm_tuning_gfx950.csv``, recorded on MI355X with ``PYTORCH_TUNABLEOP_TUNING=1 python bench.py``; about
+    0.5 ms of a 67 ms step).  Lookup only: no tuning at run time, shapes that are not in the table (and library builds other
+    than the ones in its ``Validator`` lines) use the default heuristic.  ``APGD_GEMM_TABLE=0`` disables it."""
+    if os.environ.get("APGD_GEMM_TABLE", "1") == "0" or not torch.cuda.is_available():
+        return False
+    if os.environ.get("PYTORCH_TUNABLEOP_ENABLED"):          # the user drives TunableOp themselves
+        return False
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.csv")
+    if not os.path.exists(path):
+        return False
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.record_untuned_enable(False)
+        tunable.write_file_on_exit(False)                    # the shipped table is read-only
+        tunable.set_filename(path)
+        return bool(tunable.read_file(path))
+    except Exception:                                        # an older / different PyTorch build: default GEMM selection
+        return False
+
+
 def _cached(params, tag, fn):
     """Derived copies of parameters (bf16 casts, MFMA-fragment packing), rebuilt only when a parameter changes
     (optimizer steps bump ``_version``); the attack's forwards and the train forward share them.  Entries hold weak

@@ -87,6 +87,8 @@ class ATTrainStep:
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ema: bool = True, mixup=None,
                  soft_targets: bool = False, perturb=None):
         self.device = torch.device(device)
+        if self.device.type == 'cuda':
+            ops.load_gemm_table()                                          # tuned library-GEMM selection for the known shapes
         if channels_last:
             model = model.to(memory_format=torch.channels_last)            # main.py:815-817
         if perturb is not None:                                            # any callable(model, x, y), as main.py:844
