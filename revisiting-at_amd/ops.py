@@ -313,9 +313,7 @@ def load_gemm_table(path=None):
         tunable.enable(True)
         tunable.tuning_enable(False)
         tunable.record_untuned_enable(False)
-        tunable.write_file_on_exit(False)                    # the shipped table is read-only
-        tunable.set_filename(path)
-        return bool(tunable.read_file(path))
+        return bool(tunable.read_file(path))                 # read only: the shipped table is never written
     except Exception:                                        # an older / different PyTorch build: default GEMM selection
         return False
 
