@@ -77,6 +77,11 @@ int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx,
  *                           (both NULL or both set)
  *   cnx_gelu_bwd_colsum     dhpre = bf16(dh * GELU'(hpre)) on bf16 [M, N];  db1[n] = sum_m dhpre (nullable) */
 int64_t cnx_colsum_ws_floats(int32_t n_cols);
+
+/* out[j] = sum_s parts[s][j]: fp32 sum (fixed order) of the S bf16 partial products [S, L] of a split-K batched GEMM - the
+ * weight gradients dW = X^T dY of models/convnext.py:42-46 contract over N*H*W rows (up to 802 816), which the product runs as
+ * S batches of a library GEMM.  L % 8 == 0. */
+int cnx_sum_parts_bf16(const void* parts, float* out, int64_t S, int64_t L, void* stream);
 int cnx_scale_residual(const void* x, int x_dtype, const void* y, const float* gamma, void* out, int out_dtype,
                        int64_t M, int32_t C, void* stream);
 int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const float* gamma, void* dos,

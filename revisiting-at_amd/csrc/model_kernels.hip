@@ -1257,6 +1257,50 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
   const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.7213475204444817f * z * z);
   return fmaf(z, pdf, cdf);
 }
+// out[j] = sum_s parts[s][j] for bf16 partial products of a split-K batched GEMM (fp32 accumulation, fixed order):
+// block = 64 column chunks (8 columns = 16 bytes per lane) x 4 part groups; a thread walks parts pg, pg+4, ... with four
+// loads in flight, the 4 group sums are combined through LDS.  (ATen's sum over dim 0 read the 75 MB of a 64 x 1536 x 384
+// stack at 2.1 TB/s.)
+__global__ __launch_bounds__(256) void sum_parts_bf16_kernel(const uint16_t* __restrict__ parts, float* __restrict__ out,
+                                                             long S, long L) {
+  __shared__ float red[4][64][9];
+  const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const long j = (static_cast<long>(blockIdx.x) * 64 + cl) * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (j < L) {
+    long sidx = pg;
+    for (; sidx + 12 < S; sidx += 16) {
+      uint4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const uint4*>(parts + (sidx + 4 * u) * L + j);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t w[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(w[e] << 16); acc[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+      }
+    }
+    for (; sidx < S; sidx += 4) {
+      const uint4 t = *reinterpret_cast<const uint4*>(parts + sidx * L + j);
+      const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(w[e] << 16); acc[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[pg][cl][e] = acc[e];
+  __syncthreads();
+  if (pg == 0 && j < L) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ((red[0][cl][e] + red[1][cl][e]) + red[2][cl][e]) + red[3][cl][e];
+    *reinterpret_cast<float4*>(out + j) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(out + j + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
 template <int GROUP>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -2001,6 +2045,15 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
     return launch_status();
   }
   return APGD_OK;
+}
+
+int cnx_sum_parts_bf16(const void* parts, float* out, int64_t S, int64_t L, void* stream) {
+  if (S < 0 || L < 0 || L % 8 != 0) return APGD_ERR_SIZE;
+  if (L == 0) return APGD_OK;
+  if (!parts || !out) return APGD_ERR_NULL;
+  hipLaunchKernelGGL(sum_parts_bf16_kernel, dim3(static_cast<unsigned>((L / 8 + 63) / 64)), dim3(256), 0, as_stream(stream),
+                     static_cast<const uint16_t*>(parts), out, static_cast<long>(S), static_cast<long>(L));
+  return launch_status();
 }
 
 int64_t cnx_colsum_ws_floats(int32_t n_cols) { return n_cols > 0 ? static_cast<int64_t>(col_parts(n_cols)) * 2 * n_cols : 0; }

@@ -350,6 +350,16 @@ def _pack_mlp(w1, w2):
     return wf
 
 
+def _sum_parts(part):
+    """fp32 sum over the leading (split-K) dimension of the bf16 partial products, one pass (``cnx_sum_parts_bf16``)."""
+    S, L = part.shape[0], part[0].numel()
+    if part.dtype != torch.bfloat16 or not part.is_cuda or L % 8 != 0 or not part.is_contiguous():
+        return part.sum(0, dtype=torch.float32)
+    out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
+    _lib.check(_lib.load().cnx_sum_parts_bf16(part.data_ptr(), out.data_ptr(), S, L, _stream()), "cnx_sum_parts_bf16")
+    return out
+
+
 def _wgrad(x, y):
     """``x^T y`` for tall operands (``x`` [M, N1], ``y`` [M, N2], M >> N) -> fp32 [N1, N2].
 
@@ -364,7 +374,7 @@ def _wgrad(x, y):
     if S == 1:
         return (x.t() @ y).float()
     part = torch.bmm(x.view(S, M // S, x.shape[1]).transpose(1, 2), y.view(S, M // S, y.shape[1]))
-    return part.sum(0, dtype=torch.float32)                   # fp32 accumulation of the bf16 partial products, one pass
+    return _sum_parts(part)
 
 
 def _wgrad_t(xt, y):
@@ -376,7 +386,7 @@ def _wgrad_t(xt, y):
     if S == 1:
         return (xt @ y).float()
     part = torch.bmm(xt.view(N1, S, M // S).transpose(0, 1), y.view(S, M // S, y.shape[1]))
-    return part.sum(0, dtype=torch.float32)                   # fp32 accumulation of the bf16 partial products, one pass
+    return _sum_parts(part)
 
 
 def _pack_mlp_bwd(w1, w2):

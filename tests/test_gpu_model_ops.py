@@ -504,3 +504,21 @@ def test_stem_image_conv_forward_and_input_gradient(R, P, N, H, W):
             out2 = R.ops.stem_conv(xd, wd, bd)
         (dx2,) = torch.autograd.grad(out2, xd, cot.cuda().to(torch.bfloat16))
     assert torch.equal(dx2, dx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,shape", [(1, (8,)), (3, (5, 8)), (64, (96, 40)), (17, (384, 96)), (512, (24, 16))])
+def test_sum_parts_bf16_is_the_fp32_sum_of_the_partials(R, S, shape):
+    """cnx_sum_parts_bf16 (split-K partial products of the weight-gradient GEMMs) vs torch's fp32-accumulated sum; the wrapper
+    falls back to torch for layouts the kernel does not take."""
+    g = torch.Generator().manual_seed(S)
+    part = torch.randn(S, *shape, generator=g).to(torch.bfloat16).cuda()
+    out = R.ops._sum_parts(part)
+    assert out.dtype == torch.float32 and out.shape == part.shape[1:]
+    ref = part.double().sum(0)
+    close(out, ref, 1e-6, 1e-5)
+    lib = R._lib.load()
+    assert lib.cnx_sum_parts_bf16(None, out.data_ptr(), S, 8, torch.cuda.current_stream().cuda_stream) == -1
+    assert lib.cnx_sum_parts_bf16(part.data_ptr(), out.data_ptr(), S, 12, torch.cuda.current_stream().cuda_stream) != 0
+    odd = torch.randn(4, 3, 5).to(torch.bfloat16).cuda()                  # 15 elements per part: torch path
+    close(R.ops._sum_parts(odd), odd.double().sum(0), 1e-6, 1e-5)
