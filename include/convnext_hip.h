@@ -56,6 +56,18 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
                       void* dx, int dx_dtype, float* dweight, float* dbias, float* ws,
                       int64_t M, int32_t C, int32_t gelu, void* stream);
 
+/* The downsample layers of the stages (models/convnext.py:76-83: LayerNorm over C, then Conv2d(C, C', kernel 2, stride 2)) as
+ * LayerNorm + GEMM: cnx_layernorm_fwd_patch2 writes LN(x) of an [N, H, W, C] tensor in 2x2-patch form
+ *     y [N*H/2*W/2, 4C],  y[(n, h/2, w/2)][((h&1)*2 + (w&1))*C + c] = LN(x)[n, h, w, c]
+ * so that the convolution is  y @ Wp^T + b  with Wp [C', 4C] = weight.permute(0, 2, 3, 1) (a library GEMM with the bias in its
+ * epilogue); cnx_layernorm_bwd_patch2 reads the GEMM's input gradient dy in the same form.  mean / rstd [N*H*W] in row order.
+ * H, W even; C in {48, 96, 192, 384, 768} (the wide kernels); otherwise APGD_ERR_ARG. */
+int cnx_layernorm_fwd_patch2(const void* x, int x_dtype, const float* weight, const float* bias, float eps, void* y,
+                             int y_dtype, float* mean, float* rstd, int64_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int cnx_layernorm_bwd_patch2(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight, const float* mean,
+                             const float* rstd, void* dx, int dx_dtype, float* dweight, float* dbias, float* ws, int64_t N,
+                             int32_t H, int32_t W, int32_t C, void* stream);
+
 /* First ConvStem convolution: Conv2d(3, P, kernel 3, stride 2, padding 1) (utils_architecture.py:127, 180, 205) on the
  * attack state itself.  x [N, 3, H, W] fp32 NCHW contiguous -> out [N, OH, OW, P] bf16 rows (OH = ceil(H/2)); autocast
  * numerics (x and the filter rounded to bf16, fp32 accumulation; MFMA).  wq = cnx_stem_conv_pack(weight [P,3,3,3]) is the

@@ -65,6 +65,9 @@ PROTOTYPES = {
     "cnx_attention_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _f, _p]),
     "cnx_layernorm_bwd": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32,
                                     _i32, _p]),
+    "cnx_layernorm_fwd_patch2": (C.c_int, [_p, C.c_int, _p, _p, C.c_float, _p, C.c_int, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_layernorm_bwd_patch2": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32,
+                                           _p]),
 }
 
 

@@ -205,7 +205,13 @@ class ConvNeXtStage(nn.Module):
         self.blocks = nn.Sequential(*[ConvNeXtBlock(out_chs, ls_init_value) for _ in range(depth)])
 
     def forward(self, x):
-        return self.blocks(self.downsample(x))
+        ds = self.downsample
+        if isinstance(ds, nn.Sequential) and ops.downsample_supported(x, ds[0].weight, ds[1]):
+            # LayerNorm written in 2x2-patch form + one library GEMM with the bias in its epilogue
+            x = ops.downsample_ln_conv(x, ds[0].weight, ds[0].bias, ds[0].eps, ds[1].weight, ds[1].bias)
+        else:
+            x = ds(x)
+        return self.blocks(x)
 
 
 class _Head(nn.Module):

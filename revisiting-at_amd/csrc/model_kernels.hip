@@ -1582,11 +1582,23 @@ __device__ __forceinline__ void store8(uint16_t* p, const F8& o) {
   *reinterpret_cast<uint4*>(p) = t;
 }
 
+// Element offset of row (n, h, w) of an [N, pH, pW, C] tensor in its 2x2-patch form [N, pH/2, pW/2, (h&1, w&1, C)] - the
+// left operand of the downsample "convolution" (kernel 2, stride 2 = a GEMM over patches); pW == 0: plain rows.
+__device__ __forceinline__ long patch2_offset(long row, int C, int pH, int pW) {
+  if (pW == 0) return row * C;
+  const int w = static_cast<int>(row % pW);
+  const long t = row / pW;
+  const int h = static_cast<int>(t % pH);
+  const long n = t / pH;
+  return (((n * (pH >> 1) + (h >> 1)) * (pW >> 1) + (w >> 1)) * 4 + (h & 1) * 2 + (w & 1)) * C;
+}
+
 template <typename TX, typename TY, int G>
 __global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const TX* __restrict__ x, const float* __restrict__ weight,
                                                                  const float* __restrict__ bias, float eps,
                                                                  TY* __restrict__ y, float* __restrict__ mean,
-                                                                 float* __restrict__ rstd, long M, int C, int gelu) {
+                                                                 float* __restrict__ rstd, long M, int C, int gelu, int pH,
+                                                                 int pW) {
   constexpr int RPB = 256 / G;
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
   const float invC = 1.0f / static_cast<float>(C);
@@ -1611,7 +1623,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const TX* __res
       for (int e = 0; e < 8; ++e) { const float d = v[k].v[e] - mu; q += d * d; }
     const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
     if (gl == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
-    TY* yr = y + row * C;
+    TY* yr = y + patch2_offset(row, C, pH, pW);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       F8 o;
@@ -1631,7 +1643,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, TO* __restrict__ dx,
-                                                                 float* __restrict__ ws, long M, int C, int gelu) {
+                                                                 float* __restrict__ ws, long M, int C, int gelu, int pH,
+                                                                 int pW) {
   constexpr int RPB = 256 / G;
   __shared__ float red[2][RPB][G * 8];                // per row-group partial parameter gradients (one chunk)
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
@@ -1647,8 +1660,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
   for (long row = static_cast<long>(blockIdx.x) * RPB + gr; row < M; row += static_cast<long>(gridDim.x) * RPB) {
     const float mu = mean[row], rs = rstd[row];
     F8 xh[3], g[3];
+    const TD* dyr = dy + patch2_offset(row, C, pH, pW);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { xh[k] = load8(x + row * C + (gl + k * G) * 8); g[k] = load8(dy + row * C + (gl + k * G) * 8); }
+    for (int k = 0; k < 3; ++k) { xh[k] = load8(x + row * C + (gl + k * G) * 8); g[k] = load8(dyr + (gl + k * G) * 8); }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -1700,7 +1714,7 @@ inline int ln_wide_group(int C) {              // C = 24 * G with G a power of t
 
 template <typename TX, typename TY>
 int launch_ln_fwd(const TX* x, const float* w, const float* b, float eps, TY* y, float* mean, float* rstd, long M, int C,
-                  int gelu, hipStream_t s) {
+                  int gelu, hipStream_t s, int pH = 0, int pW = 0) {
 #define LN_FWD(G, NV)                                                                                          \
   {                                                                                                            \
     const long rpb = 256 / G;                                                                                  \
@@ -1716,7 +1730,7 @@ int launch_ln_fwd(const TX* x, const float* w, const float* b, float eps, TY* y,
     const long rpb = 256 / G;                                                                                  \
     long nb = (M + rpb - 1) / rpb; if (nb > 16384) nb = 16384;                                                 \
     hipLaunchKernelGGL((layernorm_fwd_wide_kernel<TX, TY, G>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, x, w, \
-                       b, eps, y, mean, rstd, M, C, gelu);                                                     \
+                       b, eps, y, mean, rstd, M, C, gelu, pH, pW);                                             \
     return launch_status();                                                                                    \
   }
     if (g == 2) LN_FWD_W(2)
@@ -1726,6 +1740,7 @@ int launch_ln_fwd(const TX* x, const float* w, const float* b, float eps, TY* y,
     if (g == 32) LN_FWD_W(32)
 #undef LN_FWD_W
   }
+  if (pW) return APGD_ERR_ARG;                              // the patch form exists for the wide kernels only
   if (C <= 64) LN_FWD(16, 1)
   if (C <= 128) LN_FWD(32, 1)
   if (C <= 256) LN_FWD(64, 1)
@@ -1738,7 +1753,7 @@ int launch_ln_fwd(const TX* x, const float* w, const float* b, float eps, TY* y,
 
 template <typename TD, typename TX, typename TO>
 int launch_ln_bwd(const TD* dy, const TX* x, const float* w, const float* b, const float* mean, const float* rstd, TO* dx,
-                  float* ws, long M, int C, int gelu, int* nblocks, hipStream_t s) {
+                  float* ws, long M, int C, int gelu, int* nblocks, hipStream_t s, int pH = 0, int pW = 0) {
 #define LN_BWD(G, NV)                                                                                          \
   {                                                                                                            \
     const long rpb = 256 / G;                                                                                  \
@@ -1756,7 +1771,7 @@ int launch_ln_bwd(const TD* dy, const TX* x, const float* w, const float* b, con
     long nb = (M + rpb - 1) / rpb; if (nb > kLnBwdBlocks) nb = kLnBwdBlocks;                                   \
     *nblocks = static_cast<int>(nb);                                                                           \
     hipLaunchKernelGGL((layernorm_bwd_wide_kernel<TD, TX, TO, G>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dy, \
-                       x, w, b, mean, rstd, dx, ws, M, C, gelu);                                               \
+                       x, w, b, mean, rstd, dx, ws, M, C, gelu, pH, pW);                                       \
     return launch_status();                                                                                    \
   }
     if (g == 2) LN_BWD_W(2)
@@ -1766,6 +1781,7 @@ int launch_ln_bwd(const TD* dy, const TX* x, const float* w, const float* b, con
     if (g == 32) LN_BWD_W(32)
 #undef LN_BWD_W
   }
+  if (pW) return APGD_ERR_ARG;
   if (C <= 64) LN_BWD(16, 1)
   if (C <= 128) LN_BWD(32, 1)
   if (C <= 256) LN_BWD(64, 1)
@@ -1988,8 +2004,9 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
   return launch_status();
 }
 
-int cnx_layernorm_fwd(const void* x, int x_dtype, const float* weight, const float* bias, float eps, void* y,
-                      int y_dtype, float* mean, float* rstd, int64_t M, int32_t C, int32_t gelu, void* stream) {
+static int layernorm_fwd_impl(const void* x, int x_dtype, const float* weight, const float* bias, float eps, void* y,
+                              int y_dtype, float* mean, float* rstd, int64_t M, int32_t C, int32_t gelu, int pH, int pW,
+                              void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!x || !weight || !bias || !y) return APGD_ERR_NULL;
@@ -1997,21 +2014,34 @@ int cnx_layernorm_fwd(const void* x, int x_dtype, const float* weight, const flo
   if (C % 4 != 0) return APGD_ERR_ARG;
   hipStream_t s = as_stream(stream);
   if (x_dtype == APGD_F32 && y_dtype == APGD_F32)
-    return launch_ln_fwd(static_cast<const float*>(x), weight, bias, eps, static_cast<float*>(y), mean, rstd, M, C, gelu, s);
+    return launch_ln_fwd(static_cast<const float*>(x), weight, bias, eps, static_cast<float*>(y), mean, rstd, M, C, gelu, s, pH, pW);
   if (x_dtype == APGD_F32 && y_dtype == APGD_BF16)
-    return launch_ln_fwd(static_cast<const float*>(x), weight, bias, eps, static_cast<uint16_t*>(y), mean, rstd, M, C, gelu, s);
+    return launch_ln_fwd(static_cast<const float*>(x), weight, bias, eps, static_cast<uint16_t*>(y), mean, rstd, M, C, gelu, s, pH, pW);
   if (x_dtype == APGD_BF16 && y_dtype == APGD_F32)
-    return launch_ln_fwd(static_cast<const uint16_t*>(x), weight, bias, eps, static_cast<float*>(y), mean, rstd, M, C, gelu, s);
+    return launch_ln_fwd(static_cast<const uint16_t*>(x), weight, bias, eps, static_cast<float*>(y), mean, rstd, M, C, gelu, s, pH, pW);
   if (x_dtype == APGD_BF16 && y_dtype == APGD_BF16)
-    return launch_ln_fwd(static_cast<const uint16_t*>(x), weight, bias, eps, static_cast<uint16_t*>(y), mean, rstd, M, C, gelu, s);
+    return launch_ln_fwd(static_cast<const uint16_t*>(x), weight, bias, eps, static_cast<uint16_t*>(y), mean, rstd, M, C, gelu, s, pH, pW);
   return APGD_ERR_DTYPE;
+}
+
+int cnx_layernorm_fwd(const void* x, int x_dtype, const float* weight, const float* bias, float eps, void* y,
+                      int y_dtype, float* mean, float* rstd, int64_t M, int32_t C, int32_t gelu, void* stream) {
+  return layernorm_fwd_impl(x, x_dtype, weight, bias, eps, y, y_dtype, mean, rstd, M, C, gelu, 0, 0, stream);
+}
+
+int cnx_layernorm_fwd_patch2(const void* x, int x_dtype, const float* weight, const float* bias, float eps, void* y,
+                             int y_dtype, float* mean, float* rstd, int64_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0) return APGD_ERR_SIZE;
+  if ((H | W) & 1) return APGD_ERR_ARG;
+  if (!ln_wide_group(C)) return APGD_ERR_ARG;
+  return layernorm_fwd_impl(x, x_dtype, weight, bias, eps, y, y_dtype, mean, rstd, N * H * W, C, 0, H, W, stream);
 }
 
 int64_t cnx_layernorm_bwd_ws_floats(int32_t C) { return static_cast<int64_t>(kLnBwdBlocks) * 2 * C; }
 
-int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight, const float* bias,
-                      const float* mean, const float* rstd, void* dx, int dx_dtype, float* dweight, float* dbias,
-                      float* ws, int64_t M, int32_t C, int32_t gelu, void* stream) {
+static int layernorm_bwd_impl(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight, const float* bias,
+                              const float* mean, const float* rstd, void* dx, int dx_dtype, float* dweight, float* dbias,
+                              float* ws, int64_t M, int32_t C, int32_t gelu, int pH, int pW, void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!dy || !x || !weight || !mean || !rstd || !dx) return APGD_ERR_NULL;
@@ -2024,7 +2054,7 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
   int nb = 0, rc = APGD_ERR_DTYPE;
 #define LNB(TD, TX, TO)                                                                                          \
   rc = launch_ln_bwd(static_cast<const TD*>(dy), static_cast<const TX*>(x), weight, bias, mean, rstd,            \
-                     static_cast<TO*>(dx), wsp, M, C, gelu, &nb, s)
+                     static_cast<TO*>(dx), wsp, M, C, gelu, &nb, s, pH, pW)
   const int key = dy_dtype * 4 + x_dtype * 2 + dx_dtype;
   switch (key) {
     case 0: LNB(float, float, float); break;
@@ -2045,6 +2075,23 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
     return launch_status();
   }
   return APGD_OK;
+}
+
+int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight, const float* bias,
+                      const float* mean, const float* rstd, void* dx, int dx_dtype, float* dweight, float* dbias,
+                      float* ws, int64_t M, int32_t C, int32_t gelu, void* stream) {
+  return layernorm_bwd_impl(dy, dy_dtype, x, x_dtype, weight, bias, mean, rstd, dx, dx_dtype, dweight, dbias, ws, M, C, gelu, 0, 0,
+                            stream);
+}
+
+int cnx_layernorm_bwd_patch2(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight, const float* mean,
+                             const float* rstd, void* dx, int dx_dtype, float* dweight, float* dbias, float* ws, int64_t N,
+                             int32_t H, int32_t W, int32_t C, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0) return APGD_ERR_SIZE;
+  if ((H | W) & 1) return APGD_ERR_ARG;
+  if (!ln_wide_group(C)) return APGD_ERR_ARG;
+  return layernorm_bwd_impl(dy, dy_dtype, x, x_dtype, weight, nullptr, mean, rstd, dx, dx_dtype, dweight, dbias, ws, N * H * W, C, 0,
+                            H, W, stream);
 }
 
 int cnx_sum_parts_bf16(const void* parts, float* out, int64_t S, int64_t L, void* stream) {

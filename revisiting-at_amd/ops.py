@@ -132,6 +132,84 @@ def layer_norm_cf_gelu(x, weight, bias, eps):
     return _ln_rows(_rows(x), weight, bias, eps, True).permute(0, 3, 1, 2)
 
 
+# ------------------------------------------------------------------------------ stage downsample: LN + 2x2/2 convolution
+class _DownsampleLnConv(torch.autograd.Function):
+    """``Conv2d(C, C', 2, stride 2)(LayerNorm2d(x))`` (``models/convnext.py:76-83``) on channels-last rows:
+    ``cnx_layernorm_fwd_patch2`` writes LN(x) directly in 2x2-patch form ``[N*H/2*W/2, 4C]``, the convolution is one library
+    GEMM with the bias in its epilogue (instead of an implicit-GEMM convolution + a separate bias add), its input gradient a
+    GEMM whose result ``cnx_layernorm_bwd_patch2`` reads in the same form; filter gradient = split-K batched GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, weight, bias):
+        lib = _lib.load()
+        N, H, W, C = x.shape
+        Co = weight.shape[0]
+        Mo = N * (H // 2) * (W // 2)
+        yp = torch.empty(Mo, 4 * C, device=x.device, dtype=torch.bfloat16)
+        mean = torch.empty(N * H * W, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        lw, lb = _f32(ln_w), _f32(ln_b)
+        _lib.check(lib.cnx_layernorm_fwd_patch2(x.data_ptr(), _code(x), lw.data_ptr(), lb.data_ptr(), eps, yp.data_ptr(), _code(yp),
+                                                mean.data_ptr(), rstd.data_ptr(), N, H, W, C, _stream()), "cnx_layernorm_fwd_patch2")
+        wp = _cached((weight,), "patch2_bf16", lambda w: w.permute(0, 2, 3, 1).reshape(Co, 4 * C).to(torch.bfloat16).contiguous())
+        if bias is not None:
+            bb = _cached((bias,), "bf16", lambda b: b.to(torch.bfloat16).contiguous())
+            out = torch.addmm(bb, yp, wp.t())
+        else:
+            out = yp @ wp.t()
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, lw, mean, rstd, yp, wp)
+            ctx.has_bias = bias is not None
+        return out.view(N, H // 2, W // 2, Co)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, lw, mean, rstd, yp, wp = ctx.saved_tensors
+        N, H, W, C = x.shape
+        Co = wp.shape[0]
+        nig = ctx.needs_input_grad
+        want_p = any(nig[1:]) and not _INPUT_GRAD_ONLY
+        g2 = g.reshape(-1, Co)
+        gb = g2 if g2.dtype == torch.bfloat16 else g2.to(torch.bfloat16)
+        gb = gb.contiguous()
+        dx = dlw = dlb = dwt = db = None
+        dyp = gb @ wp                                                            # [Mo, 4C] in patch form
+        dx = torch.empty_like(x)
+        ws = None
+        if want_p:
+            dlw = torch.empty(C, device=x.device, dtype=torch.float32)
+            dlb = torch.empty(C, device=x.device, dtype=torch.float32)
+            ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device=x.device, dtype=torch.float32)
+        _lib.check(lib.cnx_layernorm_bwd_patch2(dyp.data_ptr(), _code(dyp), x.data_ptr(), _code(x), lw.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), dx.data_ptr(), _code(dx), _lib.ptr(dlw), _lib.ptr(dlb), _lib.ptr(ws),
+                                                N, H, W, C, _stream()), "cnx_layernorm_bwd_patch2")
+        if want_p:
+            dwt = _wgrad(gb, yp).view(Co, 2, 2, C).permute(0, 3, 1, 2)          # [Co, C, 2, 2] like the parameter
+            if ctx.has_bias:
+                db = g2.sum(0, dtype=torch.float32)
+        return dx, dlw, dlb, None, dwt, db
+
+
+def downsample_supported(x, ln_w, conv):
+    """LayerNorm2d + Conv2d(kernel 2, stride 2, no padding / dilation / groups) on a CUDA tensor under bf16 activations with
+    even H, W and a width the wide LayerNorm kernels take."""
+    if MODE == "eager" or not x.is_cuda or x.dim() != 4:
+        return False
+    C = x.shape[1]
+    ok_conv = (conv.kernel_size == (2, 2) and conv.stride == (2, 2) and conv.padding == (0, 0) and conv.dilation == (1, 1)
+               and conv.groups == 1 and conv.in_channels == C)
+    g = C // 24
+    ok_c = C % 24 == 0 and 2 <= g <= 32 and (g & (g - 1)) == 0
+    return bool(ok_conv and ok_c and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and _act_dtype(x) == torch.bfloat16
+                and x.dtype in (torch.float32, torch.bfloat16))
+
+
+def downsample_ln_conv(x, ln_w, ln_b, eps, weight, bias):
+    """[N,C,H,W] -> [N,C',H/2,W/2] (NCHW-shaped view of channels-last rows)."""
+    return _DownsampleLnConv.apply(_rows(x), ln_w, ln_b, float(eps), weight, bias).permute(0, 3, 1, 2)
+
+
 # ------------------------------------------------------------------------------ first ConvStem convolution
 class _StemConv(torch.autograd.Function):
     """``Conv2d(3, P, 3, stride 2, padding 1)`` on the fp32 NCHW image batch -> NCHW-shaped view of NHWC bf16 rows.

@@ -522,3 +522,43 @@ def test_sum_parts_bf16_is_the_fp32_sum_of_the_partials(R, S, shape):
     assert lib.cnx_sum_parts_bf16(part.data_ptr(), out.data_ptr(), S, 12, torch.cuda.current_stream().cuda_stream) != 0
     odd = torch.randn(4, 3, 5).to(torch.bfloat16).cuda()                  # 15 elements per part: torch path
     close(R.ops._sum_parts(odd), odd.double().sum(0), 1e-6, 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,Co,H,W,xdt", [(2, 96, 192, 8, 12, torch.float32), (3, 192, 384, 6, 6, torch.float32),
+                                            (1, 384, 768, 14, 14, torch.bfloat16), (2, 48, 64, 4, 2, torch.float32)])
+def test_downsample_ln_patch_gemm_vs_fp32_reference(R, N, C, Co, H, W, xdt):
+    """LayerNorm2d + Conv2d(k=2, s=2) as cnx_layernorm_fwd_patch2 + GEMM (+ cnx_layernorm_bwd_patch2) vs the fp32 eager pair:
+    output, input gradient and all four parameter gradients; bf16 bar 1e-2 relative (Frobenius)."""
+    g = torch.Generator().manual_seed(C + H)
+    ln = torch.nn.LayerNorm(C, eps=1e-6)
+    conv = torch.nn.Conv2d(C, Co, 2, 2)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(C, generator=g)); ln.bias.copy_(0.2 * torch.randn(C, generator=g))
+    x = torch.randn(N, C, H, W, generator=g).to(xdt).float()
+    gy = torch.randn(N, Co, H // 2, W // 2, generator=g)
+    xr = x.clone().requires_grad_()
+    ref = conv(ln(xr.permute(0, 2, 3, 1)).permute(0, 3, 1, 2))
+    ref.backward(gy)
+    refs = [ref.detach(), xr.grad, ln.weight.grad.clone(), ln.bias.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()]
+    for p in list(ln.parameters()) + list(conv.parameters()):
+        p.grad = None
+    ln, conv = ln.cuda(), conv.cuda()
+    xd = x.to(xdt).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    if xdt == torch.float32:
+        assert R.ops.downsample_supported(xd, ln.weight, conv) is False    # no autocast: fp32 activations stay in the library
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert R.ops.downsample_supported(xd, ln.weight, conv)
+        out = R.ops.downsample_ln_conv(xd, ln.weight, ln.bias, 1e-6, conv.weight, conv.bias)
+    assert out.shape == ref.shape and out.dtype == torch.bfloat16
+    out.backward(gy.cuda().to(out.dtype))
+    got = [out.detach(), xd.grad, ln.weight.grad, ln.bias.grad, conv.weight.grad, conv.bias.grad]
+    for a, b in zip(got, refs):
+        err = float((a.float().cpu() - b).norm() / b.norm())
+        assert err < 1e-2, err
+    lib = R._lib.load()
+    t = torch.zeros(64, device="cuda")
+    assert lib.cnx_layernorm_fwd_patch2(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), 1e-6, t.data_ptr(), 1, None, None, 1, 3, 2, 96,
+                                        torch.cuda.current_stream().cuda_stream) != 0          # odd H
+    assert lib.cnx_layernorm_fwd_patch2(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), 1e-6, t.data_ptr(), 1, None, None, 1, 2, 2, 100,
+                                        torch.cuda.current_stream().cuda_stream) != 0          # width without a wide kernel
