@@ -14,6 +14,7 @@ The residual stream stays fp32 exactly as in the reference's autocast run (``gam
 """
 from __future__ import annotations
 
+import math
 import os
 import weakref
 
@@ -438,17 +439,30 @@ def _sum_parts(part):
     return out
 
 
+# split-K factor of the weight-gradient GEMMs.  Measured on MI355X (tools/wgrad_bench.py, bmm + partial sum): the optimum puts
+# about one 192 x 192 output tile on every CU, S * N1 * N2 ~ 256 * 192 * 192, over the whole range of shapes of the model
+# (S = 4 for 768 x 3072 at M = 12 544 ... S = 256 for 384 x 96 at M = 802 816); two shapes sit one step below the rule.
+_SPLIT_K_TARGET = 256 * 192 * 192
+_SPLIT_K_MEASURED = {(768, 192, 200704): 32}
+
+
+def _split_k(M, N1, N2):
+    S = _SPLIT_K_MEASURED.get((N1, N2, M))
+    if S is None:
+        S = 1 << max(0, round(math.log2(max(1.0, _SPLIT_K_TARGET / float(N1 * N2)))))
+    while S > 1 and (M % S != 0 or M // S < 256):
+        S //= 2
+    return S
+
+
 def _wgrad(x, y):
     """``x^T y`` for tall operands (``x`` [M, N1], ``y`` [M, N2], M >> N) -> fp32 [N1, N2].
 
-    The weight gradients of the early stages contract over M = N*H*W (802 816 rows at 56x56, batch 256) into a
-    384x96 result: as one GEMM that is a handful of output tiles with an enormous K and runs at ~45 TFLOP/s in
-    hipBLASLt.  Split K into S batches of a batched GEMM (every batch fills its own output tiles, S of them fill
-    the chip) and sum the S partial products in fp32."""
+    The weight gradients contract over M = N*H*W (802 816 rows at 56x56, batch 256) into a small result: as one GEMM that
+    is a handful of output tiles with an enormous K (45 TFLOP/s in hipBLASLt at 384x96).  Split K into S batches of a batched
+    GEMM (every batch fills its own output tiles, S of them fill the chip) and sum the S bf16 partial products in fp32."""
     M = x.shape[0]
-    S = 1
-    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 512:
-        S *= 2
+    S = _split_k(M, x.shape[1], y.shape[1])
     if S == 1:
         return (x.t() @ y).float()
     part = torch.bmm(x.view(S, M // S, x.shape[1]).transpose(1, 2), y.view(S, M // S, y.shape[1]))
@@ -458,9 +472,7 @@ def _wgrad(x, y):
 def _wgrad_t(xt, y):
     """Same contraction with the left operand already transposed: ``xt`` [N1, M] (K-contiguous), ``y`` [M, N2]."""
     N1, M = xt.shape
-    S = 1
-    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 512:
-        S *= 2
+    S = _split_k(M, N1, y.shape[1])
     if S == 1:
         return (xt @ y).float()
     part = torch.bmm(xt.view(N1, S, M // S).transpose(0, 1), y.view(S, M // S, y.shape[1]))
