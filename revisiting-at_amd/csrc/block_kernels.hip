@@ -140,7 +140,10 @@ struct Geo {
   static constexpr int FWD_PIECES = KS + 2 * CB;    // 1 KiB operand fragments per slice: W1 (KS) + W2 (2 CB)
   static constexpr int FWD_SLICE = FWD_PIECES * 1024;
   static constexpr int FWD_ROUNDS = FWD_PIECES / 4; // DMA instructions per wavefront per slice (4 wavefronts)
-  static constexpr int DEPTH = 3;                   // ring slots
+#ifndef BLK_FWD96_DEPTH
+#define BLK_FWD96_DEPTH 3
+#endif
+  static constexpr int DEPTH = (C <= 96) ? BLK_FWD96_DEPTH : 3;   // ring slots (DEPTH - 1 slices in flight ahead of the one being read)
   static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 24 * C;   // + b1 (4C), b2 (C), gamma (C) fp32
   static constexpr int BM = 128;                    // rows per workgroup
   static constexpr bool AGPR_ACC = C >= 384;        // output accumulators pinned in AGPRs (inline-asm MFMA)
@@ -223,8 +226,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     const int steps = ((blockIdx.x >> 8) & 3) * (p.dbg >> 8);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
   }
-  DMA_SLICE(0)
-  DMA_SLICE(1)
+#pragma unroll
+  for (int s0 = 0; s0 < G::DEPTH - 1; ++s0) DMA_SLICE(s0)
 
   for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
   for (int i = tid; i < C; i += 256) {                                  // epilogue constants: b2, gamma (1 when absent)
@@ -324,11 +327,12 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     // slice s has landed once this wavefront's own pieces are in (counted wait: slice s+1 may stay in flight) and
     // every wavefront has passed the barrier; the slot of slice s+2 held slice s-1, which nobody reads any more
     if (!(p.dbg & 4)) {
-      if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");
+      if (G::DEPTH > 3 && s + 2 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::FWD_ROUNDS) : "memory");
+      else if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if (s + 2 < G::NHB && !(p.dbg & 1)) DMA_SLICE(s + 2)
+    if (s + G::DEPTH - 1 < G::NHB && !(p.dbg & 1)) DMA_SLICE(s + G::DEPTH - 1)
     const unsigned char* sl = ring + (s % G::DEPTH) * G::FWD_SLICE + lane * 16;
 
     // One stream of NF = KS + 2 CB operand fragments per slice (1 KiB each, fragment i feeds MFMA i).  The reads run
