@@ -306,8 +306,8 @@ __device__ __forceinline__ void store1(uint16_t* p, float v) { *p = static_cast<
 template <typename TI, typename TO>
 __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
                                                              const float* __restrict__ bias, const float* __restrict__ add,
-                                                             TO* __restrict__ out, int H, int W, int C, int flip, int TH,
-                                                             int tiles_h, int dbg) {
+                                                             TO* __restrict__ out, long N, int H, int W, int C, int flip,
+                                                             int TH, int tiles_h, int ipw, int dbg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile2[];       // [TH+6][P2][32]
   const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so with the plain
@@ -323,9 +323,28 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
   const int n_cg = C / kDC;
   const int h0 = static_cast<int>(tsel % tiles_h) * TH;
   const int cbase = static_cast<int>((tsel / tiles_h) % n_cg) * kDC;
-  const long n = tsel / (static_cast<long>(tiles_h) * n_cg);
+  const long ng = tsel / (static_cast<long>(tiles_h) * n_cg);     // group of ipw images
   const int tid = threadIdx.x, nthr = blockDim.x;
 
+  // ---- this lane's channel: packed filter rows (rotated by 180 degrees when flip)
+  const int lc = tid & (kDC - 1), sidx = tid / kDC;
+  const int c = cbase + lc;
+  uint32_t we[7][4], wo[7][4];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+    float f[7];
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int tap = kh * 7 + kw;
+      f[kw] = w49c[(flip ? 48 - tap : tap) * C + c];
+    }
+    we[kh][0] = pack2_bf16(f[0], f[1]); we[kh][1] = pack2_bf16(f[2], f[3]); we[kh][2] = pack2_bf16(f[4], f[5]); we[kh][3] = pack2_bf16(f[6], 0.f);
+    wo[kh][0] = pack2_bf16(0.f, f[0]); wo[kh][1] = pack2_bf16(f[1], f[2]); wo[kh][2] = pack2_bf16(f[3], f[4]); wo[kh][3] = pack2_bf16(f[5], f[6]);
+  }
+  // ---- ipw images per workgroup (whole-image tiles of the smallest maps; the filter registers above are set up once)
+  for (int ii = 0; ii < ipw; ++ii) {
+  const long n = ng * ipw + ii;
+  if (n >= N) break;
   // ---- staging: unit = (row, pair m, 4-channel group): two 4-channel loads (padded cols 2m, 2m+1) -> 4 packed dwords
   constexpr int kSR = 4;
   const int row_units = P2 * (kDC / 4);
@@ -353,21 +372,6 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
     }
   }
 
-  // ---- this lane's channel: packed filter rows (rotated by 180 degrees when flip)
-  const int lc = tid & (kDC - 1), sidx = tid / kDC;
-  const int c = cbase + lc;
-  uint32_t we[7][4], wo[7][4];
-#pragma unroll
-  for (int kh = 0; kh < 7; ++kh) {
-    float f[7];
-#pragma unroll
-    for (int kw = 0; kw < 7; ++kw) {
-      const int tap = kh * 7 + kw;
-      f[kw] = w49c[(flip ? 48 - tap : tap) * C + c];
-    }
-    we[kh][0] = pack2_bf16(f[0], f[1]); we[kh][1] = pack2_bf16(f[2], f[3]); we[kh][2] = pack2_bf16(f[4], f[5]); we[kh][3] = pack2_bf16(f[6], 0.f);
-    wo[kh][0] = pack2_bf16(0.f, f[0]); wo[kh][1] = pack2_bf16(f[1], f[2]); wo[kh][2] = pack2_bf16(f[3], f[4]); wo[kh][3] = pack2_bf16(f[5], f[6]);
-  }
   __syncthreads();
 
   const int n_sr = (TH + kDR - 1) / kDR;
@@ -405,7 +409,6 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
       }
     }
   }
-  if (dbg & 4) return;                                                   // dbg 4: timing experiment, no stores
   // ---- epilogue through LDS: lane = channel during the stencil means 2..4-byte accesses per lane (32 channels = one
   //      64..128-byte run per instruction and position); transposed through the (now dead) input tile every thread moves 16
   //      bytes of the NHWC tensor per instruction instead - for the result AND for the fused "+ add" operand
@@ -439,6 +442,8 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
       }
     }
     *reinterpret_cast<uint4*>(out + off) = v;
+  }
+  __syncthreads();                                                       // the output tile aliases the next image's input tile
   }
 }
 
@@ -1855,7 +1860,9 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     DwDot dp;
     if (dw_dot2_plan(H, W, C, &dp)) {
       const int tiles_h = (H + dp.th - 1) / dp.th;
-      const dim3 grid(static_cast<unsigned>(N * tiles_h * (C / kDC))), block(dp.threads);
+      static const int ipw_env = getenv("APGD_DW_TIPW") ? atoi(getenv("APGD_DW_TIPW")) : 0;     // tuning experiments only
+      const int ipw = tiles_h == 1 ? (ipw_env > 0 ? ipw_env : (H * W <= 64 ? 2 : 1)) : 1;     // measured: 7x7 40 -> 36 us, 14x14 no gain
+      const dim3 grid(static_cast<unsigned>(((N + ipw - 1) / ipw) * tiles_h * (C / kDC))), block(dp.threads);
 #define DWD_LAUNCH(TI, TO)                                                                                            \
   {                                                                                                                   \
     auto kfn = dwconv7x7_dot2_kernel<TI, TO>;                                                                         \
@@ -1864,8 +1871,8 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       attr_done = true;                                                                                               \
     }                                                                                                                 \
-    hipLaunchKernelGGL(kfn, grid, block, dp.lds, s, static_cast<const TI*>(x), w49c, bias, add, static_cast<TO*>(out), H, W, \
-                       C, flip, dp.th, tiles_h, dw_dbg);                                                               \
+    hipLaunchKernelGGL(kfn, grid, block, dp.lds, s, static_cast<const TI*>(x), w49c, bias, add, static_cast<TO*>(out),    \
+                       static_cast<long>(N), H, W, C, flip, dp.th, tiles_h, ipw, dw_dbg);                              \
   }
       if (x_dtype == APGD_F32) DWD_LAUNCH(float, uint16_t)
       else if (out_dtype == APGD_F32) DWD_LAUNCH(uint16_t, float)
