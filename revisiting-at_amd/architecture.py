@@ -316,13 +316,20 @@ class _LayerScale(nn.Module):
         return x * self.gamma
 
 
+class _RowLayerNorm(nn.LayerNorm):
+    """``nn.LayerNorm`` (same parameters / state-dict keys) on the hand-written row kernel."""
+
+    def forward(self, x):
+        return ops.layer_norm_last(x, self.weight, self.bias, self.eps)
+
+
 class VitBlock(nn.Module):
     def __init__(self, dim, num_heads, init_values=None):
         super().__init__()
-        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.norm1 = _RowLayerNorm(dim, eps=1e-6)
         self.attn = Attention(dim, num_heads)
         self.ls1 = _LayerScale(dim, init_values) if init_values else nn.Identity()
-        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.norm2 = _RowLayerNorm(dim, eps=1e-6)
         self.mlp = _Mlp(dim, 4 * dim)
         self.ls2 = _LayerScale(dim, init_values) if init_values else nn.Identity()
 
@@ -358,7 +365,7 @@ class VisionTransformer(nn.Module):
         n_pos = self.patch_embed.num_patches + (0 if no_embed_class else 1)
         self.pos_embed = nn.Parameter(torch.randn(1, n_pos, embed_dim) * .02)
         self.blocks = nn.Sequential(*[VitBlock(embed_dim, num_heads, init_values) for _ in range(depth)])
-        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.norm = _RowLayerNorm(embed_dim, eps=1e-6)
         self.head = nn.Linear(embed_dim, num_classes)
         nn.init.trunc_normal_(self.pos_embed, std=.02)
         nn.init.normal_(self.cls_token, std=1e-6)

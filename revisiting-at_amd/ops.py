@@ -119,6 +119,14 @@ def _ln_rows(x_rows, weight, bias, eps, gelu):
     return _LayerNormRows.apply(x_rows, weight, bias, float(eps), bool(gelu), _act_dtype(x_rows))
 
 
+def layer_norm_last(x, weight, bias, eps):
+    """LayerNorm over the last dim of ``[..., C]`` (the ViT blocks' ``nn.LayerNorm``, timm ``vision_transformer.Block``): one
+    kernel, output already in the autocast activation dtype (the eager pair is an fp32 LayerNorm + a cast in the next Linear)."""
+    if MODE == "eager" or not x.is_cuda or x.shape[-1] % 4 != 0:
+        return F.layer_norm(x, weight.shape, weight, bias, eps)
+    return _ln_rows(x.contiguous(), weight, bias, eps, False)
+
+
 def layer_norm_cf(x, weight, bias, eps):
     """LayerNorm over dim 1 of ``[N,C,H,W]`` (``utils_architecture.py:76-81``; timm LayerNorm2d)."""
     if MODE == "eager":
