@@ -334,8 +334,10 @@ class VitBlock(nn.Module):
         self.ls2 = _LayerScale(dim, init_values) if init_values else nn.Identity()
 
     def forward(self, x):
-        x = x + self.ls1(self.attn(self.norm1(x)))
-        return x + self.ls2(self.mlp(self.norm2(x)))
+        g1 = self.ls1.gamma if isinstance(self.ls1, _LayerScale) else None
+        g2 = self.ls2.gamma if isinstance(self.ls2, _LayerScale) else None
+        x = ops.scale_residual(x, self.attn(self.norm1(x)), g1)            # x + ls1(attn(norm1(x)))
+        return ops.scale_residual(x, self.mlp(self.norm2(x)), g2)          # x + ls2(mlp(norm2(x)))
 
 
 class PatchEmbed(nn.Module):

@@ -119,6 +119,57 @@ def _ln_rows(x_rows, weight, bias, eps, gelu):
     return _LayerNormRows.apply(x_rows, weight, bias, float(eps), bool(gelu), _act_dtype(x_rows))
 
 
+class _ScaleResidual(torch.autograd.Function):
+    """``x + gamma * y`` over rows (``x`` fp32 or bf16 residual stream, ``y`` bf16 branch output, ``gamma`` [C] or None) ->
+    fp32: the residual connections of the ViT blocks (timm ``Block.forward``: ``x + ls(attn(norm(x)))``).  One kernel each way
+    instead of cast + multiply + add (and their autograd counterparts)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma):
+        lib = _lib.load()
+        C = x.shape[-1]
+        M = x.numel() // C
+        gf = _f32(gamma) if gamma is not None else None
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        _lib.check(lib.cnx_scale_residual(x.data_ptr(), _code(x), y.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out), M, C,
+                                          _stream()), "cnx_scale_residual")
+        ctx.save_for_backward(y if (gamma is not None and ctx.needs_input_grad[2]) else None, gf)
+        ctx.x_dtype, ctx.C, ctx.M = x.dtype, C, M
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y, gf = ctx.saved_tensors
+        C, M = ctx.C, ctx.M
+        g = g.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        want_p = gf is not None and ctx.needs_input_grad[2] and not _INPUT_GRAD_ONLY
+        dy = torch.empty(g.shape, device=g.device, dtype=torch.bfloat16) if ctx.needs_input_grad[1] else None
+        dgamma = db = ws = None
+        if want_p:
+            dgamma = torch.empty(C, device=g.device, dtype=torch.float32)
+            db = torch.empty(C, device=g.device, dtype=torch.float32)
+            ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=g.device, dtype=torch.float32)
+        if dy is not None or want_p:
+            _lib.check(lib.cnx_scale_residual_bwd(g.data_ptr(), _code(g), _lib.ptr(y) if want_p else None, _lib.ptr(gf), _lib.ptr(dy),
+                                                  _lib.ptr(dgamma), _lib.ptr(db), _lib.ptr(ws), M, C, _stream()),
+                       "cnx_scale_residual_bwd")
+        dx = g if ctx.needs_input_grad[0] else None
+        if dx is not None and dx.dtype != ctx.x_dtype:
+            dx = dx.to(ctx.x_dtype)
+        return dx, dy, dgamma
+
+
+def scale_residual(x, y, gamma=None):
+    """``x + gamma * y`` (fp32 result) for a bf16 branch output ``y``; eager composition off the device / for other dtypes."""
+    if (MODE == "eager" or not x.is_cuda or y.dtype != torch.bfloat16 or x.dtype not in (torch.float32, torch.bfloat16)
+            or x.shape != y.shape or x.shape[-1] % 4 != 0):
+        return x + (y * gamma if gamma is not None else y)
+    return _ScaleResidual.apply(x.contiguous(), y.contiguous(), gamma)
+
+
 def layer_norm_last(x, weight, bias, eps):
     """LayerNorm over the last dim of ``[..., C]`` (the ViT blocks' ``nn.LayerNorm``, timm ``vision_transformer.Block``): one
     kernel, output already in the autocast activation dtype (the eager pair is an fp32 LayerNorm + a cast in the next Linear)."""

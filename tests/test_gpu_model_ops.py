@@ -562,3 +562,30 @@ def test_downsample_ln_patch_gemm_vs_fp32_reference(R, N, C, Co, H, W, xdt):
                                         torch.cuda.current_stream().cuda_stream) != 0          # odd H
     assert lib.cnx_layernorm_fwd_patch2(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), 1e-6, t.data_ptr(), 1, None, None, 1, 2, 2, 100,
                                         torch.cuda.current_stream().cuda_stream) != 0          # width without a wide kernel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,gamma,xdt", [((3, 7, 96), True, torch.float32), ((2, 197, 768), False, torch.float32),
+                                             ((5, 64), True, torch.bfloat16)])
+def test_scale_residual_autograd_vs_eager(R, shape, gamma, xdt):
+    """ops.scale_residual (cnx_scale_residual / cnx_scale_residual_bwd behind autograd): x + gamma*y and its three gradients
+    vs the fp32 eager expression on the same bf16-rounded branch."""
+    g = torch.Generator().manual_seed(shape[-1])
+    x = torch.randn(*shape, generator=g).to(xdt)
+    y = torch.randn(*shape, generator=g).to(torch.bfloat16)
+    gm = torch.randn(shape[-1], generator=g) if gamma else None
+    go = torch.randn(*shape, generator=g)
+    xr, yr = x.float().clone().requires_grad_(), y.float().clone().requires_grad_()
+    gr = gm.clone().requires_grad_() if gamma else None
+    ref = xr + (yr * gr if gamma else yr)
+    ref.backward(go)
+    xd, yd = x.detach().cuda().requires_grad_(), y.detach().cuda().requires_grad_()
+    gd = gm.cuda().requires_grad_() if gamma else None
+    out = R.ops.scale_residual(xd, yd, gd)
+    assert out.dtype == torch.float32
+    out.backward(go.cuda())
+    close(out, ref, 1e-6, 1e-6)
+    close(xd.grad, xr.grad, 1e-2 if xdt == torch.bfloat16 else 1e-6, 1e-2 if xdt == torch.bfloat16 else 1e-6)
+    close(yd.grad, yr.grad, 8e-3, 1e-3)                                    # branch gradient leaves as bf16
+    if gamma:
+        close(gd.grad, gr.grad, 2e-3, 2e-3 * float(gr.grad.abs().max()))
