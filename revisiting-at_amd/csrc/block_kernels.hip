@@ -562,6 +562,10 @@ struct GeoB {
 #define BLK_BWD96_WAVES 4
 #endif
   static constexpr int WAVES = (C <= 96) ? BLK_BWD96_WAVES : 4;
+#ifndef BLK_BWD192_AGPR
+#define BLK_BWD192_AGPR 0
+#endif
+  static constexpr bool AGPR_ACC = (C >= 192) && BLK_BWD192_AGPR;   // da accumulators pinned in AGPRs (inline-asm MFMA)
   static constexpr int PIECES = 2 * KS + 2 * CB;
   static constexpr int SLICE = PIECES * 1024;
   static constexpr int ROUNDS = (PIECES + WAVES - 1) / WAVES;      // DMA instructions per wavefront per slice (upper bound)
@@ -752,12 +756,20 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
 #pragma unroll
     for (int j = 0; j < 2 * G::CB; ++j) {
       const int i = 2 * G::KS + j;
-      acc3[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf[j / G::CB], fr[i % PF], acc3[j % G::CB], 0, 0, 0);
-      if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if constexpr (G::AGPR_ACC) {
+        // experiment (BLK_BWD192_AGPR=1): da accumulators pinned in AGPRs.  The allocator then parks the a / dO operand
+        // fragments in AGPRs instead (96 v_accvgpr moves per slice instead of 128): measured 418 vs 408 us, left off
+        MFMA_AGPR(acc3[j % G::CB], dhf[j / G::CB], fr[i % PF]);
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
+      } else {
+        acc3[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf[j / G::CB], fr[i % PF], acc3[j % G::CB], 0, 0, 0);
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
     }
   }
+  if constexpr (G::AGPR_ACC) MFMA_DRAIN();
 #undef DMA_SLICE
 
   // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]; as in the forward the tile leaves through
