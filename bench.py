@@ -95,6 +95,63 @@ def cpu_baseline(args):
                       f"{cores} of {avail} host threads, {dt:.1f} s"}
 
 
+def model_kernel_rooflines(R, dev, B, iters=10):
+    """Live HIP-event timing (after the timed region) of the two hand-written model kernels that lead the step profile, on
+    synthetic stage-0 tensors of this batch, against their algorithmic bytes / flops:
+    fused LN+MLP forward at C = 96 and the rolling-window depthwise 7x7 forward at 56x56x96.  Back-to-back launches of one
+    kernel run slower than the same kernel inside the step (profiles/: 271 / 148 us there), so avg_us is conservative; min_us is
+    the fastest single launch."""
+    import torch
+    lib = R._lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    out, best = [], []
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        best.append(min(ts))
+        return sum(ts) / len(ts)
+
+    C, HW = 96, 56
+    M = B * HW * HW
+    g = torch.Generator(device=dev).manual_seed(0)
+    u = torch.randn(M, C, device=dev, generator=g).to(torch.bfloat16)
+    x = torch.randn(M, C, device=dev, generator=g)
+    w1 = torch.randn(4 * C, C, device=dev, generator=g) * C ** -0.5
+    w2 = torch.randn(C, 4 * C, device=dev, generator=g) * (4 * C) ** -0.5
+    lw, lb, b1, b2, gm = (torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.zeros(4 * C, device=dev),
+                          torch.zeros(C, device=dev), torch.ones(C, device=dev))
+    wf = R.ops._pack_mlp(w1, w2)
+    o = torch.empty(M, C, device=dev)
+    t = timed(lambda: R._lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, None, None, wf.data_ptr(),
+                                                          b1.data_ptr(), b2.data_ptr(), gm.data_ptr(), x.data_ptr(), 0, o.data_ptr(), 0,
+                                                          None, M, C, stream), "cnx_block_mlp_fwd"))
+    nbytes, flops = M * C * (2 + 4 + 4), 16.0 * M * C * C
+    out.append({"kernel": "blk_mlp_fwd_kernel<96> (cnx_block_mlp_fwd, M=%d)" % M, "avg_us": round(t * 1e6, 1),
+                "min_us": round(best[-1] * 1e6, 1),
+                "hbm": {"achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
+                        "algorithmic_bytes_per_launch": nbytes},
+                "mfma": {"achieved": round(flops / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4)}})
+    w49 = torch.randn(49, C, device=dev, generator=g) * 0.1
+    xo = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+    t = timed(lambda: R._lib.check(lib.cnx_dwconv7x7_nhwc(x.data_ptr(), 0, w49.data_ptr(), b2.data_ptr(), None, xo.data_ptr(), 1, B, HW,
+                                                           HW, C, 0, stream), "cnx_dwconv7x7_nhwc"))
+    nbytes = M * C * (4 + 2)
+    out.append({"kernel": "dwconv7x7_roll_kernel<float, bf16> (cnx_dwconv7x7_nhwc, %dx%dx%dx%d)" % (B, HW, HW, C),
+                "avg_us": round(t * 1e6, 1), "min_us": round(best[-1] * 1e6, 1),
+                "hbm": {"achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
+                        "algorithmic_bytes_per_launch": nbytes}})
+    return out
+
+
 def main():
     args = parse()
     import revisiting_at_amd as R
@@ -183,6 +240,11 @@ def main():
             sync()
             extra["attack_only_img_s"] = round(world * B * reps / (time.perf_counter() - ta), 1)
         base.train()
+        if rank == 0 and world == 1 and args.arch.startswith("convnext") and R.ops.MODE != "eager":
+            try:
+                extra["model_kernel_rooflines"] = model_kernel_rooflines(R, dev, B)
+            except Exception as e:                       # informational only: never fail the bench line over it
+                extra["model_kernel_rooflines"] = "unavailable: %r" % (e,)
         extra["ops_mode"] = R.ops.MODE
         extra["device"] = torch.cuda.get_device_name(dev)
 
