@@ -94,6 +94,8 @@ int64_t cnx_colsum_ws_floats(int32_t n_cols);
  * weight gradients dW = X^T dY of models/convnext.py:42-46 contract over N*H*W rows (up to 802 816), which the product runs as
  * S batches of a library GEMM.  L % 8 == 0. */
 int cnx_sum_parts_bf16(const void* parts, float* out, int64_t S, int64_t L, void* stream);
+/* out[j] = sum_p parts[p][j] (fp32, fixed order): the second stage of the deterministic per-workgroup column sums. */
+int cnx_reduce_parts(const float* parts, float* out, int64_t nparts, int64_t len, void* stream);
 int cnx_scale_residual(const void* x, int x_dtype, const void* y, const float* gamma, void* out, int out_dtype,
                        int64_t M, int32_t C, void* stream);
 int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const float* gamma, void* dos,
@@ -134,6 +136,15 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                       void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out,
                       int64_t M, int32_t C, void* stream);
+/* Training backward: cnx_block_mlp_bwd with all four emit outputs plus the d(b1) partials - db1_parts
+ * [cnx_block_mlp_bwd_parts(M, C), 4C] fp32 = per-workgroup column sums of dHpre (the values dhpt_out holds), summed by
+ * cnx_reduce_parts; spares a pass over the [4C, M] operand. */
+int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C);
+int cnx_block_mlp_bwd_train(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                            const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
+                            void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, int64_t M, int32_t C,
+                            void* stream);
+
 /* Input-gradient-only variant (the attack's backward, models/convnext.py:41-49 including the LayerNorm): the same kernel
  * with the LayerNorm backward in its epilogue,
  *     du = rstd * (t - mean_c(t) - xh * mean_c(t * xh)),   t = ln_w * da,  xh = (u - mean) * rstd,

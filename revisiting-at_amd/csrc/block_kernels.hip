@@ -551,6 +551,7 @@ struct BlkBwdArgs {
   uint16_t* do_out;        // emit: [M, C] bf16 g * gamma
   uint16_t* ht_out;        // emit: [4C, M] bf16 GELU(Hpre)^T
   uint16_t* dhpt_out;      // emit: [4C, M] bf16 dHpre^T
+  float* db1_parts;        // emit, optional: [ceil(M / BM), 4C] per-workgroup column sums of dHpre (d(b1) partials)
   long M;
   long a_stride;           // row stride of a_out in elements (>= C; lets the caller append a ones column for d(b1))
 };
@@ -572,7 +573,7 @@ struct GeoB {
   static constexpr int MIN_ROUNDS = PIECES / WAVES;                // ... lower bound (the counted wait must use this one)
   static constexpr int DEPTH = 3;
   static constexpr int LDS = DEPTH * SLICE + 16 * C;                // + b1 (4C fp32)
-  static constexpr int LDS_EMIT = LDS + WAVES * 2048;                // + one 32 x 32 bf16 transpose tile per wavefront
+  static constexpr int LDS_EMIT = LDS + WAVES * 2048 + WAVES * 16 * C; // + one 32 x 32 bf16 transpose tile and 4C column sums per wavefront
   static constexpr int BM = WAVES * 32;
   static_assert(WAVES * 16 * C * 4 <= DEPTH * SLICE, "the epilogue tile reuses the weight ring");
 };
@@ -712,6 +713,22 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
       dhf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       dhf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
       if constexpr (EMIT) {
+        if (p.db1_parts) {
+          // d(b1) = column sums of dHpre (of the bf16 values the GEMM operand holds): for a fixed register the 32 lanes of a
+          // half-wave are 32 rows of ONE hidden unit -> 4 DPP steps inside the 16-lane rows + one exchange across them
+          float* cs = b1s + 4 * C + G::WAVES * 512 + wave * (4 * C);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t d = pk[r >> 1];
+            float v = row_ok ? ((r & 1) ? bf16_hi(d) : bf16_lo(d)) : 0.f;
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+            v += __shfl_xor(v, 16, 64);
+            if (l32 == 0) cs[s * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+          }
+        }
         if ((p.M & 7) == 0) {
           // [4C, M] operands of the weight-gradient GEMMs: a lane holds 16 hidden units of ONE row, the tensors are
           // contiguous along rows.  2x2 exchange with the neighbouring lane (row m^1) turns the (h, h+1) pairs into
@@ -775,6 +792,17 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
   // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]; as in the forward the tile leaves through
   //      the dead weight ring, 16 rows per pass, so that a lane stores 16 bytes (8 bf16) of a contiguous run instead of 2
   __syncthreads();
+  if constexpr (EMIT) {
+    if (p.db1_parts) {                                                   // combine the wavefronts' column sums in a fixed order
+      const float* cs = b1s + 4 * C + G::WAVES * 512;
+      for (int i = tid; i < 4 * C; i += G::WAVES * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < G::WAVES; ++w) t += cs[w * (4 * C) + i];
+        p.db1_parts[static_cast<long>(blockIdx.x) * (4 * C) + i] = t;
+      }
+    }
+  }
   if constexpr (LNB) {
     // ---- ... and the LayerNorm backward rides along (input-gradient-only calls): with t = ln_w * da and
     //      xh = (u - mean) * rstd,   du = rstd * (t - mean_c(t) - xh * mean_c(t * xh)).
@@ -959,8 +987,8 @@ int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* 
 
 static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                               const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                              void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, bool ln_bwd,
-                              int64_t M, int32_t C, void* stream) {
+                              void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts,
+                              bool ln_bwd, int64_t M, int32_t C, void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!u || !ln_w || !ln_b || !mean || !rstd || !g || !Wb || !b1 || !da) return APGD_ERR_NULL;
@@ -972,6 +1000,8 @@ static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_
   a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = b1; a.da = static_cast<uint16_t*>(da);
   a.a_out = static_cast<uint16_t*>(a_out); a.do_out = static_cast<uint16_t*>(do_out);
   a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.M = M;
+  if (db1_parts && n_emit != 4) return APGD_ERR_NULL;
+  a.db1_parts = db1_parts;
   if (a_stride != 0 && (a_stride < C || a_stride % 8 != 0)) return APGD_ERR_ARG;
   a.a_stride = a_stride ? a_stride : C;
   hipStream_t s = as_stream(stream);
@@ -987,6 +1017,23 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C,
                       void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, a_stride, do_out, ht_out, dhpt_out,
+                            nullptr, false, M, C, stream);
+}
+
+int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C) {
+  switch (C) {
+    case 96: return (M + GeoB<96>::BM - 1) / GeoB<96>::BM;
+    case 192: return (M + GeoB<192>::BM - 1) / GeoB<192>::BM;
+    default: return 0;
+  }
+}
+
+int cnx_block_mlp_bwd_train(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                            const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
+                            void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, int64_t M, int32_t C,
+                            void* stream) {
+  if (!db1_parts) return APGD_ERR_NULL;
+  return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, 0, do_out, ht_out, dhpt_out, db1_parts,
                             false, M, C, stream);
 }
 
@@ -994,7 +1041,7 @@ int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
                             int64_t M, int32_t C, void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, du, nullptr, 0, nullptr, nullptr, nullptr,
-                            true, M, C, stream);
+                            nullptr, true, M, C, stream);
 }
 
 int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 192) ? 1 : 0; }

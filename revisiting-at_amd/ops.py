@@ -646,13 +646,22 @@ class _BlockFused(torch.autograd.Function):
                 dhpt = torch.empty(4 * C, M, device=x.device, dtype=torch.bfloat16)
             if g2.dtype not in (torch.float32, torch.bfloat16):
                 g2 = g2.float()
-            _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                             g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
-                                             da.data_ptr(), _lib.ptr(a), 0, _lib.ptr(dos), _lib.ptr(ht), _lib.ptr(dhpt), M, C,
-                                             _stream()), "cnx_block_mlp_bwd")
+            if want_p:
+                # training backward: the kernel also emits the operands of the weight-gradient GEMMs and the d(b1) partials
+                nparts = lib.cnx_block_mlp_bwd_parts(M, C)
+                parts = torch.empty(nparts, 4 * C, device=x.device, dtype=torch.float32)
+                _lib.check(lib.cnx_block_mlp_bwd_train(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                       g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
+                                                       da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
+                                                       parts.data_ptr(), M, C, _stream()), "cnx_block_mlp_bwd_train")
+                db1 = torch.empty(4 * C, device=x.device, dtype=torch.float32)
+                _lib.check(lib.cnx_reduce_parts(parts.data_ptr(), db1.data_ptr(), nparts, 4 * C, _stream()), "cnx_reduce_parts")
+            else:
+                _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                 g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
+                                                 da.data_ptr(), None, 0, None, None, None, M, C, _stream()), "cnx_block_mlp_bwd")
             if want_p:
                 dw1 = _wgrad_t(dhpt, a)                                          # [4C, C]
-                db1 = dhpt.sum(1, dtype=torch.float32)
                 dw2 = _wgrad_t(ht, dos).t()                                      # [C, 4C]
                 # d(gamma) = sum_m g*y2 and d(b2) = sum_m dO in ONE pass over g and y2 (sums-only mode of the tail kernel;
                 # as separate torch reductions they were a cast, a product and two sums: ~390 us per block at 56x56)

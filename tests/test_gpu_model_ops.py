@@ -357,6 +357,21 @@ def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt)
         assert lib.cnx_block_mlp_bwd_input(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(),
                                            gd.data_ptr(), R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(),
                                            None, M_, C, S()) == -1
+    if emit:
+        # training entry: same outputs + per-workgroup d(b1) partials = column sums of the emitted dHpre operand
+        nparts = lib.cnx_block_mlp_bwd_parts(M_, C)
+        assert nparts >= 1
+        parts = torch.full((nparts, 4 * C), float("nan"), device="cuda")
+        da2, ao2, dob2, ht2, dhpt2 = (torch.empty_like(t) for t in (da, ao, dob, ht, dhpt))
+        assert lib.cnx_block_mlp_bwd_train(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(),
+                                           gd.data_ptr(), R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(),
+                                           da2.data_ptr(), ao2.data_ptr(), dob2.data_ptr(), ht2.data_ptr(), dhpt2.data_ptr(),
+                                           parts.data_ptr(), M_, C, S()) == 0
+        assert torch.equal(da2, da) and torch.equal(dhpt2, dhpt) and torch.equal(ht2, ht)
+        db1 = torch.empty(4 * C, device="cuda")
+        assert lib.cnx_reduce_parts(parts.data_ptr(), db1.data_ptr(), nparts, 4 * C, S()) == 0
+        ref_db1 = dhpt.float().sum(1)
+        close(db1, ref_db1, 1e-5, 1e-5 * float(ref_db1.abs().max()) + 1e-6)
     # argument errors
     assert lib.cnx_block_mlp_bwd(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), gd.data_ptr(),
                                  R._lib.dtype_code(gdt), P(gmd), wb.data_ptr(), b1d.data_ptr(), da.data_ptr(), da.data_ptr(), 0,
