@@ -136,14 +136,17 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                       void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out,
                       int64_t M, int32_t C, void* stream);
-/* Training backward: cnx_block_mlp_bwd with all four emit outputs plus the d(b1) partials - db1_parts
- * [cnx_block_mlp_bwd_parts(M, C), 4C] fp32 = per-workgroup column sums of dHpre (the values dhpt_out holds), summed by
- * cnx_reduce_parts; spares a pass over the [4C, M] operand. */
+/* Training backward: cnx_block_mlp_bwd with all four emit outputs plus per-workgroup partial sums (P =
+ * cnx_block_mlp_bwd_parts(M, C) workgroups; cnx_reduce_parts adds them up in a fixed order):
+ *   db1_parts [P, 4C]  column sums of dHpre (the values dhpt_out holds)                 -> d(b1)
+ *   dgb_parts [P, 2C]  column sums of g * y2 (y2 [M, C] bf16 = pre-gamma fc2 output of the forward, NULL: zeros) and of dO
+ *                      (the values do_out holds)                                        -> d(gamma), d(b2)
+ * spares a pass over the [4C, M] operand and one over g and y2. */
 int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C);
 int cnx_block_mlp_bwd_train(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                            void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, int64_t M, int32_t C,
-                            void* stream);
+                            void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, const void* y2,
+                            float* dgb_parts, int64_t M, int32_t C, void* stream);
 
 /* Input-gradient-only variant (the attack's backward, models/convnext.py:41-49 including the LayerNorm): the same kernel
  * with the LayerNorm backward in its epilogue,

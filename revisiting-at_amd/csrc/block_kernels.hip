@@ -120,6 +120,16 @@ __device__ __forceinline__ f32x2 gelu_from_grad2(float z0, float z1, f32x2 gp, f
   return z * Phi;
 }
 
+// sum over the 32 lanes of a half-wave (every lane of the half gets the total): 4 DPP steps inside the 16-lane rows, one
+// exchange across them
+__device__ __forceinline__ float half_sum32(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm 1,0,3,2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm 2,3,0,1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v + __shfl_xor(v, 16, 64);
+}
+
 // MFMA with the accumulator pinned in the AGPR half of the register file.  At C = 384 a wavefront's state (96 operand
 // registers + 192 accumulator registers) exceeds the 256 architectural VGPRs; left to itself the register allocator
 // parks OPERANDS in AGPRs and copies them back before every MFMA (273 v_accvgpr_read per slice measured).  Pinning the
@@ -552,6 +562,8 @@ struct BlkBwdArgs {
   uint16_t* ht_out;        // emit: [4C, M] bf16 GELU(Hpre)^T
   uint16_t* dhpt_out;      // emit: [4C, M] bf16 dHpre^T
   float* db1_parts;        // emit, optional: [ceil(M / BM), 4C] per-workgroup column sums of dHpre (d(b1) partials)
+  const uint16_t* y2;      // emit, optional: [M, C] bf16 pre-gamma fc2 output of the forward (for d(gamma))
+  float* dgb_parts;        // emit, optional: [ceil(M / BM), 2C]: column sums of g * y2 (d(gamma)) and of dO (d(b2))
   long M;
   long a_stride;           // row stride of a_out in elements (>= C; lets the caller append a ones column for d(b1))
 };
@@ -573,7 +585,7 @@ struct GeoB {
   static constexpr int MIN_ROUNDS = PIECES / WAVES;                // ... lower bound (the counted wait must use this one)
   static constexpr int DEPTH = 3;
   static constexpr int LDS = DEPTH * SLICE + 16 * C;                // + b1 (4C fp32)
-  static constexpr int LDS_EMIT = LDS + WAVES * 2048 + WAVES * 16 * C; // + one 32 x 32 bf16 transpose tile and 4C column sums per wavefront
+  static constexpr int LDS_EMIT = LDS + WAVES * 2048 + WAVES * 24 * C; // + one 32 x 32 bf16 transpose tile and 4C + 2C column sums per wavefront
   static constexpr int BM = WAVES * 32;
   static_assert(WAVES * 16 * C * 4 <= DEPTH * SLICE, "the epilogue tile reuses the weight ring");
 };
@@ -646,6 +658,9 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
         v[0] = bf16_lo(raw.x); v[1] = bf16_hi(raw.x); v[2] = bf16_lo(raw.y); v[3] = bf16_hi(raw.y);
         v[4] = bf16_lo(raw.z); v[5] = bf16_hi(raw.z); v[6] = bf16_lo(raw.w); v[7] = bf16_hi(raw.w);
       }
+      float graw[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) graw[e] = v[e];
       if (gmp) {
         const float4 m0v = gmp[2 * ks], m1v = gmp[2 * ks + 1];
         v[0] *= m0v.x; v[1] *= m0v.y; v[2] *= m0v.z; v[3] *= m0v.w; v[4] *= m1v.x; v[5] *= m1v.y; v[6] *= m1v.z; v[7] *= m1v.w;
@@ -653,6 +668,27 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
       const uint4 packed = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
       gf[ks] = __builtin_bit_cast(bf16x8, packed);
       if (EMIT && row_ok) reinterpret_cast<uint4*>(p.do_out + row * C + half * (C / 2))[ks] = packed;
+      if constexpr (EMIT) {
+        if (p.dgb_parts) {
+          // d(gamma) = sum_m g * y2 and d(b2) = sum_m dO (of the rounded values): for a fixed (k-step, element) the 32 lanes of
+          // a half-wave are 32 rows of one channel
+          float* cs2 = b1s + 4 * C + G::WAVES * 512 + G::WAVES * (4 * C) + wave * (2 * C);
+          uint4 yr = make_uint4(0u, 0u, 0u, 0u);
+          if (p.y2) yr = reinterpret_cast<const uint4*>(p.y2 + row * C + half * (C / 2))[ks];
+          const uint32_t yw[4] = {yr.x, yr.y, yr.z, yr.w}, dw[4] = {packed.x, packed.y, packed.z, packed.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float yv = (e & 1) ? bf16_hi(yw[e >> 1]) : bf16_lo(yw[e >> 1]);
+            const float dv = (e & 1) ? bf16_hi(dw[e >> 1]) : bf16_lo(dw[e >> 1]);
+            const float sg = half_sum32(row_ok ? graw[e] * yv : 0.f), sd = half_sum32(row_ok ? dv : 0.f);
+            if (l32 == 0) {
+              const int c = half * (C / 2) + ks * 8 + e;
+              cs2[c] = sg;
+              cs2[C + c] = sd;
+            }
+          }
+        }
+      }
     }
   }
 
@@ -720,12 +756,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const uint32_t d = pk[r >> 1];
-            float v = row_ok ? ((r & 1) ? bf16_hi(d) : bf16_lo(d)) : 0.f;
-            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
-            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
-            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
-            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
-            v += __shfl_xor(v, 16, 64);
+            const float v = half_sum32(row_ok ? ((r & 1) ? bf16_hi(d) : bf16_lo(d)) : 0.f);
             if (l32 == 0) cs[s * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
           }
         }
@@ -800,6 +831,15 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
 #pragma unroll
         for (int w = 0; w < G::WAVES; ++w) t += cs[w * (4 * C) + i];
         p.db1_parts[static_cast<long>(blockIdx.x) * (4 * C) + i] = t;
+      }
+    }
+    if (p.dgb_parts) {
+      const float* cs2 = b1s + 4 * C + G::WAVES * 512 + G::WAVES * (4 * C);
+      for (int i = tid; i < 2 * C; i += G::WAVES * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < G::WAVES; ++w) t += cs2[w * (2 * C) + i];
+        p.dgb_parts[static_cast<long>(blockIdx.x) * (2 * C) + i] = t;
       }
     }
   }
@@ -988,7 +1028,7 @@ int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* 
 static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                               const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                               void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts,
-                              bool ln_bwd, int64_t M, int32_t C, void* stream) {
+                              const void* y2, float* dgb_parts, bool ln_bwd, int64_t M, int32_t C, void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!u || !ln_w || !ln_b || !mean || !rstd || !g || !Wb || !b1 || !da) return APGD_ERR_NULL;
@@ -1000,8 +1040,10 @@ static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_
   a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = b1; a.da = static_cast<uint16_t*>(da);
   a.a_out = static_cast<uint16_t*>(a_out); a.do_out = static_cast<uint16_t*>(do_out);
   a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.M = M;
-  if (db1_parts && n_emit != 4) return APGD_ERR_NULL;
+  if ((db1_parts || dgb_parts) && n_emit != 4) return APGD_ERR_NULL;
   a.db1_parts = db1_parts;
+  a.y2 = static_cast<const uint16_t*>(y2);
+  a.dgb_parts = dgb_parts;
   if (a_stride != 0 && (a_stride < C || a_stride % 8 != 0)) return APGD_ERR_ARG;
   a.a_stride = a_stride ? a_stride : C;
   hipStream_t s = as_stream(stream);
@@ -1017,7 +1059,7 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C,
                       void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, a_stride, do_out, ht_out, dhpt_out,
-                            nullptr, false, M, C, stream);
+                            nullptr, nullptr, nullptr, false, M, C, stream);
 }
 
 int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C) {
@@ -1030,18 +1072,18 @@ int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C) {
 
 int cnx_block_mlp_bwd_train(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                            void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, int64_t M, int32_t C,
-                            void* stream) {
-  if (!db1_parts) return APGD_ERR_NULL;
+                            void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, const void* y2,
+                            float* dgb_parts, int64_t M, int32_t C, void* stream) {
+  if (!db1_parts || !dgb_parts) return APGD_ERR_NULL;
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, 0, do_out, ht_out, dhpt_out, db1_parts,
-                            false, M, C, stream);
+                            y2, dgb_parts, false, M, C, stream);
 }
 
 int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
                             int64_t M, int32_t C, void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, du, nullptr, 0, nullptr, nullptr, nullptr,
-                            nullptr, true, M, C, stream);
+                            nullptr, nullptr, nullptr, true, M, C, stream);
 }
 
 int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 192) ? 1 : 0; }

@@ -648,14 +648,21 @@ class _BlockFused(torch.autograd.Function):
                 g2 = g2.float()
             if want_p:
                 # training backward: the kernel also emits the operands of the weight-gradient GEMMs and the d(b1) partials
+                # (d(b1), d(gamma), d(b2) as per-workgroup column sums: no extra pass over dHpre^T or over g and y2)
                 nparts = lib.cnx_block_mlp_bwd_parts(M, C)
                 parts = torch.empty(nparts, 4 * C, device=x.device, dtype=torch.float32)
+                parts2 = torch.empty(nparts, 2 * C, device=x.device, dtype=torch.float32)
+                y2p = y2.reshape(M, C).data_ptr() if y2 is not None else None
                 _lib.check(lib.cnx_block_mlp_bwd_train(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                        g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
                                                        da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
-                                                       parts.data_ptr(), M, C, _stream()), "cnx_block_mlp_bwd_train")
+                                                       parts.data_ptr(), y2p, parts2.data_ptr(), M, C, _stream()),
+                           "cnx_block_mlp_bwd_train")
                 db1 = torch.empty(4 * C, device=x.device, dtype=torch.float32)
                 _lib.check(lib.cnx_reduce_parts(parts.data_ptr(), db1.data_ptr(), nparts, 4 * C, _stream()), "cnx_reduce_parts")
+                dgb = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+                _lib.check(lib.cnx_reduce_parts(parts2.data_ptr(), dgb.data_ptr(), nparts, 2 * C, _stream()), "cnx_reduce_parts")
+                dgamma, db2 = (dgb[:C] if gf is not None else None), dgb[C:]
             else:
                 _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                  g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
@@ -663,16 +670,6 @@ class _BlockFused(torch.autograd.Function):
             if want_p:
                 dw1 = _wgrad_t(dhpt, a)                                          # [4C, C]
                 dw2 = _wgrad_t(ht, dos).t()                                      # [C, 4C]
-                # d(gamma) = sum_m g*y2 and d(b2) = sum_m dO in ONE pass over g and y2 (sums-only mode of the tail kernel;
-                # as separate torch reductions they were a cast, a product and two sums: ~390 us per block at 56x56)
-                dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
-                db2 = torch.empty(C, device=x.device, dtype=torch.float32)
-                ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=x.device, dtype=torch.float32)
-                y2p = y2.reshape(M, C).data_ptr() if y2 is not None else None
-                _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2p, _lib.ptr(gf), None, dgamma.data_ptr(),
-                                                      db2.data_ptr(), ws.data_ptr(), M, C, _stream()), "cnx_scale_residual_bwd")
-                if gf is None:
-                    dgamma = None
                 del a, dos, ht, dhpt
         else:
             # ---- library GEMMs between the one-pass tails: dO (+ d(gamma), d(b2)), GELU' (+ d(b1)), split-K weight gradients
