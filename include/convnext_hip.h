@@ -141,12 +141,14 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
  *   db1_parts [P, 4C]  column sums of dHpre (the values dhpt_out holds)                 -> d(b1)
  *   dgb_parts [P, 2C]  column sums of g * y2 (y2 [M, C] bf16 = pre-gamma fc2 output of the forward, NULL: zeros) and of dO
  *                      (the values do_out holds)                                        -> d(gamma), d(b2)
- * spares a pass over the [4C, M] operand and one over g and y2. */
+ *   dln_parts [P, 2C]  (nullable) column sums of da * xh and of da                      -> d(ln_w), d(ln_b);  when given, the
+ *                      LayerNorm backward runs in the epilogue as in cnx_block_mlp_bwd_input and `da` receives d loss / d u
+ * spares a pass over the [4C, M] operand, one over g and y2 and the separate LayerNorm backward. */
 int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C);
 int cnx_block_mlp_bwd_train(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                             void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, const void* y2,
-                            float* dgb_parts, int64_t M, int32_t C, void* stream);
+                            float* dgb_parts, float* dln_parts, int64_t M, int32_t C, void* stream);
 
 /* Input-gradient-only variant (the attack's backward, models/convnext.py:41-49 including the LayerNorm): the same kernel
  * with the LayerNorm backward in its epilogue,

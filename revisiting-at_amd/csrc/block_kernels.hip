@@ -564,6 +564,7 @@ struct BlkBwdArgs {
   float* db1_parts;        // emit, optional: [ceil(M / BM), 4C] per-workgroup column sums of dHpre (d(b1) partials)
   const uint16_t* y2;      // emit, optional: [M, C] bf16 pre-gamma fc2 output of the forward (for d(gamma))
   float* dgb_parts;        // emit, optional: [ceil(M / BM), 2C]: column sums of g * y2 (d(gamma)) and of dO (d(b2))
+  float* dln_parts;        // emit + LNB, optional: [ceil(M / BM), 2C]: column sums of da * xh (d(ln_w)) and of da (d(ln_b))
   long M;
   long a_stride;           // row stride of a_out in elements (>= C; lets the caller append a ones column for d(b1))
 };
@@ -585,7 +586,7 @@ struct GeoB {
   static constexpr int MIN_ROUNDS = PIECES / WAVES;                // ... lower bound (the counted wait must use this one)
   static constexpr int DEPTH = 3;
   static constexpr int LDS = DEPTH * SLICE + 16 * C;                // + b1 (4C fp32)
-  static constexpr int LDS_EMIT = LDS + WAVES * 2048 + WAVES * 24 * C; // + one 32 x 32 bf16 transpose tile and 4C + 2C column sums per wavefront
+  static constexpr int LDS_EMIT = LDS + WAVES * 2048 + WAVES * 32 * C; // + one 32 x 32 bf16 transpose tile and 4C + 2C + 2C column sums per wavefront
   static constexpr int BM = WAVES * 32;
   static_assert(WAVES * 16 * C * 4 <= DEPTH * SLICE, "the epilogue tile reuses the weight ring");
 };
@@ -853,6 +854,11 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     float* scr = reinterpret_cast<float*>(ring) + wave * (16 * CP);
     constexpr int NJ = C / 32;                                            // 8-channel chunks per lane
     const int rl = lane >> 2, q = lane & 3;
+    float aw[EMIT ? NJ : 1][8], ab[EMIT ? NJ : 1][8];                     // training: d(ln_w), d(ln_b) partials of this lane's channels
+#pragma unroll
+    for (int j = 0; j < (EMIT ? NJ : 1); ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) aw[j][e] = ab[j][e] = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       __builtin_amdgcn_wave_barrier();
@@ -902,9 +908,36 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
           const float uv = (e & 1) ? bf16_hi(uw[e >> 1]) : bf16_lo(uw[e >> 1]);
           const float t = wv[e] * dv[e], xh = (uv - mean) * rstd;
           o[e] = rstd * (t - s1 - xh * s2);
+          if constexpr (EMIT) {
+            if (m < p.M) { aw[j][e] = fmaf(dv[e], xh, aw[j][e]); ab[j][e] += dv[e]; }
+          }
         }
         if (m < p.M)
           *reinterpret_cast<uint4*>(p.da + m * C + c0) = make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+      }
+    }
+    if constexpr (EMIT) {
+      if (p.dln_parts) {
+        // the 16 lanes with the same q hold the same channels for 16 different rows: butterfly over lane bits 2..5, then the
+        // wavefronts are combined through LDS in a fixed order
+        float* cs3 = b1s + 4 * C + G::WAVES * 512 + G::WAVES * (6 * C) + wave * (2 * C);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = aw[j][e], b = ab[j][e];
+#pragma unroll
+            for (int sft = 4; sft < 64; sft <<= 1) { a += __shfl_xor(a, sft, 64); b += __shfl_xor(b, sft, 64); }
+            if (rl == 0) { cs3[(q + 4 * j) * 8 + e] = a; cs3[C + (q + 4 * j) * 8 + e] = b; }
+          }
+        __syncthreads();
+        const float* call = b1s + 4 * C + G::WAVES * 512 + G::WAVES * (6 * C);
+        for (int i = tid; i < 2 * C; i += G::WAVES * 64) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < G::WAVES; ++w) t += call[w * (2 * C) + i];
+          p.dln_parts[static_cast<long>(blockIdx.x) * (2 * C) + i] = t;
+        }
       }
     }
   } else {
@@ -950,9 +983,11 @@ int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, bool ln_bwd, hipStream_t s)
     hipLaunchKernelGGL(kfn, grid, block, (EM) ? G::LDS_EMIT : G::LDS, s, a);                                     \
   }
   if (g_dtype == APGD_F32) {
-    if (emit) BLK_LAUNCH(float, true, false) else if (ln_bwd) BLK_LAUNCH(float, false, true) else BLK_LAUNCH(float, false, false)
+    if (emit) { if (ln_bwd) BLK_LAUNCH(float, true, true) else BLK_LAUNCH(float, true, false) }
+    else if (ln_bwd) BLK_LAUNCH(float, false, true) else BLK_LAUNCH(float, false, false)
   } else {
-    if (emit) BLK_LAUNCH(uint16_t, true, false) else if (ln_bwd) BLK_LAUNCH(uint16_t, false, true) else BLK_LAUNCH(uint16_t, false, false)
+    if (emit) { if (ln_bwd) BLK_LAUNCH(uint16_t, true, true) else BLK_LAUNCH(uint16_t, true, false) }
+    else if (ln_bwd) BLK_LAUNCH(uint16_t, false, true) else BLK_LAUNCH(uint16_t, false, false)
   }
 #undef BLK_LAUNCH
   return launch_status();
@@ -1028,7 +1063,8 @@ int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* 
 static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                               const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                               void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts,
-                              const void* y2, float* dgb_parts, bool ln_bwd, int64_t M, int32_t C, void* stream) {
+                              const void* y2, float* dgb_parts, float* dln_parts, bool ln_bwd, int64_t M, int32_t C,
+                              void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!u || !ln_w || !ln_b || !mean || !rstd || !g || !Wb || !b1 || !da) return APGD_ERR_NULL;
@@ -1044,6 +1080,8 @@ static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_
   a.db1_parts = db1_parts;
   a.y2 = static_cast<const uint16_t*>(y2);
   a.dgb_parts = dgb_parts;
+  if (dln_parts && (n_emit != 4 || !ln_bwd)) return APGD_ERR_ARG;
+  a.dln_parts = dln_parts;
   if (a_stride != 0 && (a_stride < C || a_stride % 8 != 0)) return APGD_ERR_ARG;
   a.a_stride = a_stride ? a_stride : C;
   hipStream_t s = as_stream(stream);
@@ -1059,7 +1097,7 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C,
                       void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, a_stride, do_out, ht_out, dhpt_out,
-                            nullptr, nullptr, nullptr, false, M, C, stream);
+                            nullptr, nullptr, nullptr, nullptr, false, M, C, stream);
 }
 
 int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C) {
@@ -1073,17 +1111,17 @@ int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C) {
 int cnx_block_mlp_bwd_train(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                             void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, const void* y2,
-                            float* dgb_parts, int64_t M, int32_t C, void* stream) {
+                            float* dgb_parts, float* dln_parts, int64_t M, int32_t C, void* stream) {
   if (!db1_parts || !dgb_parts) return APGD_ERR_NULL;
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, 0, do_out, ht_out, dhpt_out, db1_parts,
-                            y2, dgb_parts, false, M, C, stream);
+                            y2, dgb_parts, dln_parts, dln_parts != nullptr, M, C, stream);
 }
 
 int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
                             int64_t M, int32_t C, void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, du, nullptr, 0, nullptr, nullptr, nullptr,
-                            nullptr, nullptr, nullptr, true, M, C, stream);
+                            nullptr, nullptr, nullptr, nullptr, true, M, C, stream);
 }
 
 int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 192) ? 1 : 0; }

@@ -652,12 +652,20 @@ class _BlockFused(torch.autograd.Function):
                 nparts = lib.cnx_block_mlp_bwd_parts(M, C)
                 parts = torch.empty(nparts, 4 * C, device=x.device, dtype=torch.float32)
                 parts2 = torch.empty(nparts, 2 * C, device=x.device, dtype=torch.float32)
+                parts3 = torch.empty(nparts, 2 * C, device=x.device, dtype=torch.float32)
                 y2p = y2.reshape(M, C).data_ptr() if y2 is not None else None
+                if _TRAIN_LN_FUSED:
+                    d_u = da.view(u.shape)                                       # LayerNorm backward in the kernel's epilogue
                 _lib.check(lib.cnx_block_mlp_bwd_train(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                        g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
                                                        da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
-                                                       parts.data_ptr(), y2p, parts2.data_ptr(), M, C, _stream()),
+                                                       parts.data_ptr(), y2p, parts2.data_ptr(),
+                                                       parts3.data_ptr() if _TRAIN_LN_FUSED else None, M, C, _stream()),
                            "cnx_block_mlp_bwd_train")
+                if _TRAIN_LN_FUSED:
+                    dln = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+                    _lib.check(lib.cnx_reduce_parts(parts3.data_ptr(), dln.data_ptr(), nparts, 2 * C, _stream()), "cnx_reduce_parts")
+                    dlw_f, dlb_f = dln[:C], dln[C:]
                 db1 = torch.empty(4 * C, device=x.device, dtype=torch.float32)
                 _lib.check(lib.cnx_reduce_parts(parts.data_ptr(), db1.data_ptr(), nparts, 4 * C, _stream()), "cnx_reduce_parts")
                 dgb = torch.empty(2 * C, device=x.device, dtype=torch.float32)
@@ -697,8 +705,10 @@ class _BlockFused(torch.autograd.Function):
                 if gf is None:
                     dgamma = None
             del dhpre, dos
-        # ---- LayerNorm backward (already done by the fused input-gradient kernel)
+        # ---- LayerNorm backward (already done by the fused kernels of the fused stages)
         dlw = dlb = ws = None
+        if d_u is not None and want_p:
+            dlw, dlb = dlw_f, dlb_f
         if d_u is None:
             d_u = torch.empty_like(u)
             if want_p:
@@ -738,6 +748,7 @@ def block_fused_supported(C):
 # Widths routed through the fused LN+MLP kernel.  Measured on MI355X (tools/block_bench.py, batch 256): a clear win
 # where the unfused block is HBM-bound (C = 96, 192); at C = 384 the weight stream (128 rows per workgroup) caps it
 # below the hipBLASLt composition, so that width stays on the library path for now.  APGD_BLOCK_FUSED overrides.
+_TRAIN_LN_FUSED = os.environ.get("APGD_TRAIN_LN_FUSED", "0") != "0"       # LayerNorm backward inside the training backward kernel (measured: no gain over the separate pass, off)
 _FUSED_WIDTHS = os.environ.get("APGD_BLOCK_FUSED", "96,192")
 _FUSED_WIDTHS = {int(v) for v in _FUSED_WIDTHS.split(",") if v.strip()}
 
