@@ -78,6 +78,13 @@ int64_t cnx_stem_conv_packed_bytes(int32_t P);
 int cnx_stem_conv_pack(const void* w, int w_dtype, void* wq, int32_t P, void* stream);
 int cnx_stem_conv_fwd(const float* x, const void* wq, const float* bias, void* out,
                       int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
+/* The same convolution with the ConvStem's LayerNorm(channels_first) + GELU (utils_architecture.py:76-81, 128-129) applied to
+ * the output tile while it is still on chip: act [N, H/2, W/2, P] bf16 = GELU(LN(conv(x) rounded to bf16)); y (nullable: a
+ * gradient-free forward does not need it) = the convolution output, mean / rstd (nullable pair) [N*H/2*W/2] the LayerNorm
+ * statistics - what cnx_layernorm_bwd(gelu = 1) takes in the backward. */
+int cnx_stem_conv_ln_gelu_fwd(const float* x, const void* wq, const float* bias, const float* ln_w, const float* ln_b, float eps,
+                              void* y, void* act, float* mean, float* rstd, int64_t N, int32_t H, int32_t W, int32_t P,
+                              void* stream);
 int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx,
                         int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
 

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "cnx_stem_conv_packed_bytes": (C.c_int64, [_i32]),
     "cnx_stem_conv_pack": (C.c_int, [_p, C.c_int, _p, _i32, _p]),
     "cnx_stem_conv_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_stem_conv_ln_gelu_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_dgrad": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_colsum_ws_floats": (C.c_int64, [_i32]),
     "cnx_sum_parts_bf16": (C.c_int, [_p, _p, _i64, _i64, _p]),

@@ -105,6 +105,26 @@ class _ImageConv(nn.Conv2d):
         return super().forward(x)
 
 
+class _StemSequential(nn.Sequential):
+    """``nn.Sequential`` (same indices / state-dict keys) that runs the first convolution and its LayerNorm + GELU as one
+    kernel when the input is the fp32 image batch under bf16 autocast."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, _ImageConv) and i + 1 < len(mods) and isinstance(mods[i + 1], _CfLnGelu)
+                    and ops.stem_conv_supported(x, m.weight, m.stride, m.padding) and ops.stem_fused_ln()):
+                n = mods[i + 1]
+                x = ops.stem_conv_ln_gelu(x, m.weight, m.bias, n.weight, n.bias, n.eps)
+                i += 2
+                continue
+            x = m(x)
+            i += 1
+        return x
+
+
 def _stem(chans, strides, final_1x1=None):
     layers = []
     for cin, cout, s in zip(chans[:-1], chans[1:], strides):
@@ -112,7 +132,7 @@ def _stem(chans, strides, final_1x1=None):
         layers += [conv(cin, cout, kernel_size=3, stride=s, padding=1), _CfLnGelu(cout), nn.Identity()]
     if final_1x1 is not None:
         layers.append(nn.Conv2d(chans[-1], final_1x1, kernel_size=1, stride=1, padding=0))
-    return nn.Sequential(*layers)
+    return _StemSequential(*layers)
 
 
 class ConvBlock(nn.Module):

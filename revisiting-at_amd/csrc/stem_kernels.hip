@@ -29,6 +29,16 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 __device__ __forceinline__ float round_bf16(float v) { return __uint_as_float(pack_bf16(v, 0.f) << 16); }
+// exact-erf GELU, the evaluation shared by all kernels of the library (tools/fit_gelu.py: |error| <= 1.2e-6)
+__device__ __forceinline__ float gelu_f(float z) {
+  const float az = fabsf(z);
+  float q = fmaf(-0.00041175442346105595f, az, 0.006678475199902348f);
+  q = fmaf(q, az, -0.050879760394516485f);
+  q = fmaf(q, az, -0.46094072908550926f);
+  q = fmaf(q, az, -1.150400682855232f);
+  q = fmaf(q, az, -8.454223479528131e-05f);
+  return fmaf(az * __builtin_amdgcn_exp2f(q), -0.5f, fmaxf(z, 0.0f));
+}
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -76,12 +86,24 @@ __global__ void stem_pack_kernel(const TW* __restrict__ w, uint16_t* __restrict_
   wq[i] = static_cast<uint16_t>(pack_bf16(v, 0.f));
 }
 
-template <int P>
+template <int P, bool LNG>
 __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wq,
                                                             const float* __restrict__ bias, uint16_t* __restrict__ out, long total,
-                                                            int H, int W, int OH, int OW) {
+                                                            int H, int W, int OH, int OW, const float* __restrict__ ln_w,
+                                                            const float* __restrict__ ln_b, float eps, uint16_t* __restrict__ act,
+                                                            float* __restrict__ mean, float* __restrict__ rstd) {
   using G = StemGeo<P>;
   __shared__ __attribute__((aligned(16))) uint16_t stage[4][32 * P];
+  __shared__ __attribute__((aligned(16))) uint16_t stage2[LNG ? 4 : 1][LNG ? 32 * P : 8];
+  // LNG: the ConvStem's LayerNorm(channels) + GELU on the 32 x P tile while it sits in LDS (two lanes per position, P/2 channels
+  // each): the activation leaves next to (or, for a gradient-free forward, instead of) the convolution output
+  constexpr int NCH = P / 16;                                       // 8-channel chunks per lane in the LN phase
+  float lw[LNG ? NCH * 8 : 1], lb[LNG ? NCH * 8 : 1];
+  if constexpr (LNG) {
+    const int h2 = threadIdx.x & 1;
+#pragma unroll
+    for (int i = 0; i < NCH * 8; ++i) { lw[i] = ln_w[h2 * (P / 2) + i]; lb[i] = ln_b[h2 * (P / 2) + i]; }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
   bf16x8 bw[G::NB][2];
 #pragma unroll
@@ -128,14 +150,50 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the region is private to the wavefront
+    uint16_t* st2 = stage2[LNG ? wave : 0];
+    if constexpr (LNG) {
+      const int pl = lane >> 1, h2 = lane & 1;
+      const uint16_t* src = st + pl * P + h2 * (P / 2);
+      float v[NCH * 8];
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const uint4 t = *reinterpret_cast<const uint4*>(src + k * 8);
+        const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[k * 8 + 2 * e] = __uint_as_float(w4[e] << 16); v[k * 8 + 2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
+      }
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH * 8; ++i) sm += v[i];
+      sm += __shfl_xor(sm, 1, 64);
+      const float mu = sm * (1.0f / P);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH * 8; ++i) { const float d = v[i] - mu; q += d * d; }
+      q += __shfl_xor(q, 1, 64);
+      const float rs = rsqrtf(q * (1.0f / P) + eps);
+      const long posl = blk * 32 + pl;
+      if (h2 == 0 && mean && posl < total) { mean[posl] = mu; rstd[posl] = rs; }
+      uint16_t* dst = st2 + pl * P + h2 * (P / 2);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gelu_f((v[k * 8 + e] - mu) * rs * lw[k * 8 + e] + lb[k * 8 + e]);
+        *reinterpret_cast<uint4*>(dst + k * 8) = make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
     // 32 positions x P channels = 64 P contiguous bytes in NHWC memory: P/8 16-byte chunks per position, lane-linear
     const long base = blk * 32 * P;                                  // element offset of the block
     const long lim = total * P;
 #pragma unroll
     for (int c = 0; c < (32 * P / 8 + 63) / 64; ++c) {
       const int ch = c * 64 + lane;
-      if (ch < 32 * P / 8 && base + static_cast<long>(ch) * 8 < lim)
-        *reinterpret_cast<uint4*>(out + base + static_cast<long>(ch) * 8) = *reinterpret_cast<const uint4*>(st + ch * 8);
+      if (ch < 32 * P / 8 && base + static_cast<long>(ch) * 8 < lim) {
+        if (out) *reinterpret_cast<uint4*>(out + base + static_cast<long>(ch) * 8) = *reinterpret_cast<const uint4*>(st + ch * 8);
+        if constexpr (LNG) *reinterpret_cast<uint4*>(act + base + static_cast<long>(ch) * 8) = *reinterpret_cast<const uint4*>(st2 + ch * 8);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
   }
@@ -223,9 +281,35 @@ int cnx_stem_conv_fwd(const float* x, const void* wq, const float* bias, void* o
   hipStream_t s = as_stream(stream);
   auto* o = static_cast<uint16_t*>(out);
   const auto* q = static_cast<const uint16_t*>(wq);
-  if (P == 48) hipLaunchKernelGGL(stem_conv_fwd_kernel<48>, grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW);
-  else if (P == 64) hipLaunchKernelGGL(stem_conv_fwd_kernel<64>, grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW);
-  else hipLaunchKernelGGL(stem_conv_fwd_kernel<96>, grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW);
+  const float* nf = nullptr;
+  uint16_t* nu = nullptr;
+  float* nm = nullptr;
+  if (P == 48) hipLaunchKernelGGL((stem_conv_fwd_kernel<48, false>), grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW, nf, nf, 0.f, nu, nm, nm);
+  else if (P == 64) hipLaunchKernelGGL((stem_conv_fwd_kernel<64, false>), grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW, nf, nf, 0.f, nu, nm, nm);
+  else hipLaunchKernelGGL((stem_conv_fwd_kernel<96, false>), grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW, nf, nf, 0.f, nu, nm, nm);
+  return launch_status();
+}
+
+int cnx_stem_conv_ln_gelu_fwd(const float* x, const void* wq, const float* bias, const float* ln_w, const float* ln_b, float eps,
+                              void* y, void* act, float* mean, float* rstd, int64_t N, int32_t H, int32_t W, int32_t P,
+                              void* stream) {
+  if (N < 0 || H <= 0 || W <= 0) return APGD_ERR_SIZE;
+  if (N == 0) return APGD_OK;
+  if (!x || !wq || !ln_w || !ln_b || !act) return APGD_ERR_NULL;
+  if ((mean == nullptr) != (rstd == nullptr)) return APGD_ERR_ARG;
+  if (!cnx_stem_conv_supported(P)) return APGD_ERR_ARG;
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const long total = N * OH * OW;
+  long nb = (total + 127) / 128;
+  if (nb > 4096) nb = 4096;
+  const dim3 grid(static_cast<unsigned>(nb)), block(256);
+  hipStream_t s = as_stream(stream);
+  auto* o = static_cast<uint16_t*>(y);
+  auto* a = static_cast<uint16_t*>(act);
+  const auto* q = static_cast<const uint16_t*>(wq);
+  if (P == 48) hipLaunchKernelGGL((stem_conv_fwd_kernel<48, true>), grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW, ln_w, ln_b, eps, a, mean, rstd);
+  else if (P == 64) hipLaunchKernelGGL((stem_conv_fwd_kernel<64, true>), grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW, ln_w, ln_b, eps, a, mean, rstd);
+  else hipLaunchKernelGGL((stem_conv_fwd_kernel<96, true>), grid, block, 0, s, x, q, bias, o, total, H, W, OH, OW, ln_w, ln_b, eps, a, mean, rstd);
   return launch_status();
 }
 

@@ -317,6 +317,83 @@ class _StemConv(torch.autograd.Function):
         return dx, dw, db
 
 
+class _StemConvLnGelu(torch.autograd.Function):
+    """First ConvStem convolution + LayerNorm(channels) + GELU in ONE forward kernel (``cnx_stem_conv_ln_gelu_fwd``): the
+    [N,112,112,P] convolution output is normalised while it sits in LDS instead of being written, re-read and re-written by a
+    separate LayerNorm pass; a gradient-free forward does not write it at all.  Backward: ``cnx_layernorm_bwd(gelu=1)`` on the
+    saved convolution output, then ``_StemConv``'s input / filter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ln_w, ln_b, eps):
+        lib = _lib.load()
+        N, _, H, W = x.shape
+        P = weight.shape[0]
+        wq = _cached((weight,), "stem_wq", _pack_stem)
+        bf = _f32(bias) if bias is not None else None
+        lw, lb = _f32(ln_w), _f32(ln_b)
+        need_grad = any(ctx.needs_input_grad)
+        OH, OW = (H + 1) // 2, (W + 1) // 2
+        act = torch.empty(N, OH, OW, P, device=x.device, dtype=torch.bfloat16)
+        y = mean = rstd = None
+        if need_grad:
+            y = torch.empty(N, OH, OW, P, device=x.device, dtype=torch.bfloat16)
+            mean = torch.empty(N * OH * OW, device=x.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+        _lib.check(lib.cnx_stem_conv_ln_gelu_fwd(x.data_ptr(), wq.data_ptr(), _lib.ptr(bf), lw.data_ptr(), lb.data_ptr(), eps,
+                                                 _lib.ptr(y), act.data_ptr(), _lib.ptr(mean), _lib.ptr(rstd), N, H, W, P, _stream()),
+                   "cnx_stem_conv_ln_gelu_fwd")
+        if need_grad:
+            ctx.save_for_backward(x, weight, wq, y, mean, rstd, lw, lb)
+            ctx.has_bias = bias is not None
+        return act.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, weight, wq, y, mean, rstd, lw, lb = ctx.saved_tensors
+        N, _, H, W = x.shape
+        P = weight.shape[0]
+        M = y.numel() // P
+        nig = ctx.needs_input_grad
+        gr = g.permute(0, 2, 3, 1)
+        if gr.dtype not in (torch.float32, torch.bfloat16) or not gr.is_contiguous():
+            gr = gr.to(torch.bfloat16).contiguous()
+        want_ln = (nig[3] or nig[4]) and not _INPUT_GRAD_ONLY
+        dlw = dlb = ws = None
+        if want_ln:
+            dlw = torch.empty(P, device=x.device, dtype=torch.float32)
+            dlb = torch.empty(P, device=x.device, dtype=torch.float32)
+            ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(P), device=x.device, dtype=torch.float32)
+        dy = torch.empty_like(y)                                             # gradient w.r.t. the convolution output, bf16 NHWC
+        _lib.check(lib.cnx_layernorm_bwd(gr.data_ptr(), _code(gr), y.data_ptr(), _code(y), lw.data_ptr(), lb.data_ptr(),
+                                         mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), _code(dy), _lib.ptr(dlw), _lib.ptr(dlb),
+                                         _lib.ptr(ws), M, P, 1, _stream()), "cnx_layernorm_bwd")
+        dx = dw = db = None
+        if nig[0]:
+            dx = torch.empty_like(x)
+            _lib.check(lib.cnx_stem_conv_dgrad(dy.data_ptr(), wq.data_ptr(), dx.data_ptr(), N, H, W, P, _stream()),
+                       "cnx_stem_conv_dgrad")
+        if (nig[1] or nig[2]) and not _INPUT_GRAD_ONLY:
+            xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gb = dy.permute(0, 3, 1, 2)                                    # NCHW view of channels-last memory
+            _, dw, db = torch.ops.aten.convolution_backward(gb, xb, weight.to(torch.bfloat16), [P], [2, 2], [1, 1], [1, 1],
+                                                            False, [0, 0], 1, [False, True, ctx.has_bias])
+            dw = dw.to(weight.dtype)
+            db = db.float() if ctx.has_bias else None
+        return dx, dw, db, dlw, dlb, None
+
+
+def stem_fused_ln():
+    """Measured on MI355X (batch 256, 224x224): the one-kernel stem (162 + 147 us as two kernels) is not faster - the GELU of
+    154 M activations makes the convolution kernel VALU-bound - so the two-kernel composition stays the default;
+    ``APGD_STEM_FUSED_LN=1`` selects the fused kernel (it writes 308 MB less per gradient-free forward)."""
+    return os.environ.get("APGD_STEM_FUSED_LN", "0") != "0"
+
+
+def stem_conv_ln_gelu(x, weight, bias, ln_w, ln_b, eps):
+    return _StemConvLnGelu.apply(x, weight, bias, ln_w, ln_b, float(eps))
+
+
 def _pack_stem(w):
     lib = _lib.load()
     P = w.shape[0]

@@ -629,3 +629,38 @@ def test_scale_residual_autograd_vs_eager(R, shape, gamma, xdt):
     close(yd.grad, yr.grad, 8e-3, 1e-3)                                    # branch gradient leaves as bf16
     if gamma:
         close(gd.grad, gr.grad, 2e-3, 2e-3 * float(gr.grad.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,N,H,W", [(48, 2, 32, 32), (64, 1, 16, 24), (96, 3, 8, 8), (48, 1, 224, 224)])
+def test_stem_conv_ln_gelu_fused_equals_the_two_kernel_composition(R, P, N, H, W):
+    """cnx_stem_conv_ln_gelu_fwd (LayerNorm + GELU on the convolution tile in LDS) vs stem_conv followed by the LayerNorm+GELU
+    kernel: same activation up to one bf16 ulp, same gradients w.r.t. image, filter, bias and LayerNorm parameters; a
+    gradient-free forward (no convolution output written) gives the same activation."""
+    g = torch.Generator().manual_seed(P * 3 + H)
+    x = torch.rand(N, 3, H, W, generator=g).cuda()
+    w = (torch.randn(P, 3, 3, 3, generator=g) * 0.3).cuda()
+    b = (torch.randn(P, generator=g) * 0.1).cuda()
+    lw = (1 + 0.2 * torch.randn(P, generator=g)).cuda()
+    lb = (0.2 * torch.randn(P, generator=g)).cuda()
+    cot = torch.randn(N, P, H // 2, W // 2, generator=g).to(torch.bfloat16).cuda()
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_() for t in (x, w, b, lw, lb)]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if fused:
+                out = R.ops.stem_conv_ln_gelu(*leaves, 1e-6)
+            else:
+                out = R.ops.layer_norm_cf_gelu(R.ops.stem_conv(leaves[0], leaves[1], leaves[2]), leaves[3], leaves[4], 1e-6)
+        grads = torch.autograd.grad(out, leaves, cot)
+        return out.detach(), grads
+
+    o_f, g_f = run(True)
+    o_r, g_r = run(False)
+    assert o_f.dtype == torch.bfloat16 and o_f.shape == o_r.shape
+    close(o_f, o_r, 8e-3, 2e-3)
+    for a, r in zip(g_f, g_r):
+        assert float((a.float() - r.float()).norm() / r.float().norm()) < 5e-3
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        o_n = R.ops.stem_conv_ln_gelu(x, w, b, lw, lb, 1e-6)
+    assert torch.equal(o_n, o_f)
