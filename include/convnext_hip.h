@@ -101,8 +101,6 @@ int64_t cnx_colsum_ws_floats(int32_t n_cols);
  * weight gradients dW = X^T dY of models/convnext.py:42-46 contract over N*H*W rows (up to 802 816), which the product runs as
  * S batches of a library GEMM.  L % 8 == 0. */
 int cnx_sum_parts_bf16(const void* parts, float* out, int64_t S, int64_t L, void* stream);
-/* out[j] = sum_p parts[p][j] (fp32, fixed order): the second stage of the deterministic per-workgroup column sums. */
-int cnx_reduce_parts(const float* parts, float* out, int64_t nparts, int64_t len, void* stream);
 int cnx_scale_residual(const void* x, int x_dtype, const void* y, const float* gamma, void* out, int out_dtype,
                        int64_t M, int32_t C, void* stream);
 int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const float* gamma, void* dos,
@@ -143,20 +141,6 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                       void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out,
                       int64_t M, int32_t C, void* stream);
-/* Training backward: cnx_block_mlp_bwd with all four emit outputs plus per-workgroup partial sums (P =
- * cnx_block_mlp_bwd_parts(M, C) workgroups; cnx_reduce_parts adds them up in a fixed order):
- *   db1_parts [P, 4C]  column sums of dHpre (the values dhpt_out holds)                 -> d(b1)
- *   dgb_parts [P, 2C]  column sums of g * y2 (y2 [M, C] bf16 = pre-gamma fc2 output of the forward, NULL: zeros) and of dO
- *                      (the values do_out holds)                                        -> d(gamma), d(b2)
- *   dln_parts [P, 2C]  (nullable) column sums of da * xh and of da                      -> d(ln_w), d(ln_b);  when given, the
- *                      LayerNorm backward runs in the epilogue as in cnx_block_mlp_bwd_input and `da` receives d loss / d u
- * spares a pass over the [4C, M] operand, one over g and y2 and the separate LayerNorm backward. */
-int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C);
-int cnx_block_mlp_bwd_train(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
-                            const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                            void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, const void* y2,
-                            float* dgb_parts, float* dln_parts, int64_t M, int32_t C, void* stream);
-
 /* Input-gradient-only variant (the attack's backward, models/convnext.py:41-49 including the LayerNorm): the same kernel
  * with the LayerNorm backward in its epilogue,
  *     du = rstd * (t - mean_c(t) - xh * mean_c(t * xh)),   t = ln_w * da,  xh = (u - mean) * rstd,

@@ -120,16 +120,6 @@ __device__ __forceinline__ f32x2 gelu_from_grad2(float z0, float z1, f32x2 gp, f
   return z * Phi;
 }
 
-// sum over the 32 lanes of a half-wave (every lane of the half gets the total): 4 DPP steps inside the 16-lane rows, one
-// exchange across them
-__device__ __forceinline__ float half_sum32(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm 1,0,3,2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm 2,3,0,1
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
-  return v + __shfl_xor(v, 16, 64);
-}
-
 // MFMA with the accumulator pinned in the AGPR half of the register file.  At C = 384 a wavefront's state (96 operand
 // registers + 192 accumulator registers) exceeds the 256 architectural VGPRs; left to itself the register allocator
 // parks OPERANDS in AGPRs and copies them back before every MFMA (273 v_accvgpr_read per slice measured).  Pinning the
@@ -561,10 +551,6 @@ struct BlkBwdArgs {
   uint16_t* do_out;        // emit: [M, C] bf16 g * gamma
   uint16_t* ht_out;        // emit: [4C, M] bf16 GELU(Hpre)^T
   uint16_t* dhpt_out;      // emit: [4C, M] bf16 dHpre^T
-  float* db1_parts;        // emit, optional: [ceil(M / BM), 4C] per-workgroup column sums of dHpre (d(b1) partials)
-  const uint16_t* y2;      // emit, optional: [M, C] bf16 pre-gamma fc2 output of the forward (for d(gamma))
-  float* dgb_parts;        // emit, optional: [ceil(M / BM), 2C]: column sums of g * y2 (d(gamma)) and of dO (d(b2))
-  float* dln_parts;        // emit + LNB, optional: [ceil(M / BM), 2C]: column sums of da * xh (d(ln_w)) and of da (d(ln_b))
   long M;
   long a_stride;           // row stride of a_out in elements (>= C; lets the caller append a ones column for d(b1))
 };
@@ -586,7 +572,7 @@ struct GeoB {
   static constexpr int MIN_ROUNDS = PIECES / WAVES;                // ... lower bound (the counted wait must use this one)
   static constexpr int DEPTH = 3;
   static constexpr int LDS = DEPTH * SLICE + 16 * C;                // + b1 (4C fp32)
-  static constexpr int LDS_EMIT = LDS + WAVES * 2048 + WAVES * 32 * C; // + one 32 x 32 bf16 transpose tile and 4C + 2C + 2C column sums per wavefront
+  static constexpr int LDS_EMIT = LDS + WAVES * 2048;                // + one 32 x 32 bf16 transpose tile per wavefront
   static constexpr int BM = WAVES * 32;
   static_assert(WAVES * 16 * C * 4 <= DEPTH * SLICE, "the epilogue tile reuses the weight ring");
 };
@@ -659,9 +645,6 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
         v[0] = bf16_lo(raw.x); v[1] = bf16_hi(raw.x); v[2] = bf16_lo(raw.y); v[3] = bf16_hi(raw.y);
         v[4] = bf16_lo(raw.z); v[5] = bf16_hi(raw.z); v[6] = bf16_lo(raw.w); v[7] = bf16_hi(raw.w);
       }
-      float graw[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) graw[e] = v[e];
       if (gmp) {
         const float4 m0v = gmp[2 * ks], m1v = gmp[2 * ks + 1];
         v[0] *= m0v.x; v[1] *= m0v.y; v[2] *= m0v.z; v[3] *= m0v.w; v[4] *= m1v.x; v[5] *= m1v.y; v[6] *= m1v.z; v[7] *= m1v.w;
@@ -669,27 +652,6 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
       const uint4 packed = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
       gf[ks] = __builtin_bit_cast(bf16x8, packed);
       if (EMIT && row_ok) reinterpret_cast<uint4*>(p.do_out + row * C + half * (C / 2))[ks] = packed;
-      if constexpr (EMIT) {
-        if (p.dgb_parts) {
-          // d(gamma) = sum_m g * y2 and d(b2) = sum_m dO (of the rounded values): for a fixed (k-step, element) the 32 lanes of
-          // a half-wave are 32 rows of one channel
-          float* cs2 = b1s + 4 * C + G::WAVES * 512 + G::WAVES * (4 * C) + wave * (2 * C);
-          uint4 yr = make_uint4(0u, 0u, 0u, 0u);
-          if (p.y2) yr = reinterpret_cast<const uint4*>(p.y2 + row * C + half * (C / 2))[ks];
-          const uint32_t yw[4] = {yr.x, yr.y, yr.z, yr.w}, dw[4] = {packed.x, packed.y, packed.z, packed.w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float yv = (e & 1) ? bf16_hi(yw[e >> 1]) : bf16_lo(yw[e >> 1]);
-            const float dv = (e & 1) ? bf16_hi(dw[e >> 1]) : bf16_lo(dw[e >> 1]);
-            const float sg = half_sum32(row_ok ? graw[e] * yv : 0.f), sd = half_sum32(row_ok ? dv : 0.f);
-            if (l32 == 0) {
-              const int c = half * (C / 2) + ks * 8 + e;
-              cs2[c] = sg;
-              cs2[C + c] = sd;
-            }
-          }
-        }
-      }
     }
   }
 
@@ -750,17 +712,6 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
       dhf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       dhf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
       if constexpr (EMIT) {
-        if (p.db1_parts) {
-          // d(b1) = column sums of dHpre (of the bf16 values the GEMM operand holds): for a fixed register the 32 lanes of a
-          // half-wave are 32 rows of ONE hidden unit -> 4 DPP steps inside the 16-lane rows + one exchange across them
-          float* cs = b1s + 4 * C + G::WAVES * 512 + wave * (4 * C);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const uint32_t d = pk[r >> 1];
-            const float v = half_sum32(row_ok ? ((r & 1) ? bf16_hi(d) : bf16_lo(d)) : 0.f);
-            if (l32 == 0) cs[s * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
-          }
-        }
         if ((p.M & 7) == 0) {
           // [4C, M] operands of the weight-gradient GEMMs: a lane holds 16 hidden units of ONE row, the tensors are
           // contiguous along rows.  2x2 exchange with the neighbouring lane (row m^1) turns the (h, h+1) pairs into
@@ -824,26 +775,6 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
   // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]; as in the forward the tile leaves through
   //      the dead weight ring, 16 rows per pass, so that a lane stores 16 bytes (8 bf16) of a contiguous run instead of 2
   __syncthreads();
-  if constexpr (EMIT) {
-    if (p.db1_parts) {                                                   // combine the wavefronts' column sums in a fixed order
-      const float* cs = b1s + 4 * C + G::WAVES * 512;
-      for (int i = tid; i < 4 * C; i += G::WAVES * 64) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < G::WAVES; ++w) t += cs[w * (4 * C) + i];
-        p.db1_parts[static_cast<long>(blockIdx.x) * (4 * C) + i] = t;
-      }
-    }
-    if (p.dgb_parts) {
-      const float* cs2 = b1s + 4 * C + G::WAVES * 512 + G::WAVES * (4 * C);
-      for (int i = tid; i < 2 * C; i += G::WAVES * 64) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < G::WAVES; ++w) t += cs2[w * (2 * C) + i];
-        p.dgb_parts[static_cast<long>(blockIdx.x) * (2 * C) + i] = t;
-      }
-    }
-  }
   if constexpr (LNB) {
     // ---- ... and the LayerNorm backward rides along (input-gradient-only calls): with t = ln_w * da and
     //      xh = (u - mean) * rstd,   du = rstd * (t - mean_c(t) - xh * mean_c(t * xh)).
@@ -854,11 +785,6 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     float* scr = reinterpret_cast<float*>(ring) + wave * (16 * CP);
     constexpr int NJ = C / 32;                                            // 8-channel chunks per lane
     const int rl = lane >> 2, q = lane & 3;
-    float aw[EMIT ? NJ : 1][8], ab[EMIT ? NJ : 1][8];                     // training: d(ln_w), d(ln_b) partials of this lane's channels
-#pragma unroll
-    for (int j = 0; j < (EMIT ? NJ : 1); ++j)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) aw[j][e] = ab[j][e] = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       __builtin_amdgcn_wave_barrier();
@@ -908,36 +834,9 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
           const float uv = (e & 1) ? bf16_hi(uw[e >> 1]) : bf16_lo(uw[e >> 1]);
           const float t = wv[e] * dv[e], xh = (uv - mean) * rstd;
           o[e] = rstd * (t - s1 - xh * s2);
-          if constexpr (EMIT) {
-            if (m < p.M) { aw[j][e] = fmaf(dv[e], xh, aw[j][e]); ab[j][e] += dv[e]; }
-          }
         }
         if (m < p.M)
           *reinterpret_cast<uint4*>(p.da + m * C + c0) = make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
-      }
-    }
-    if constexpr (EMIT) {
-      if (p.dln_parts) {
-        // the 16 lanes with the same q hold the same channels for 16 different rows: butterfly over lane bits 2..5, then the
-        // wavefronts are combined through LDS in a fixed order
-        float* cs3 = b1s + 4 * C + G::WAVES * 512 + G::WAVES * (6 * C) + wave * (2 * C);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float a = aw[j][e], b = ab[j][e];
-#pragma unroll
-            for (int sft = 4; sft < 64; sft <<= 1) { a += __shfl_xor(a, sft, 64); b += __shfl_xor(b, sft, 64); }
-            if (rl == 0) { cs3[(q + 4 * j) * 8 + e] = a; cs3[C + (q + 4 * j) * 8 + e] = b; }
-          }
-        __syncthreads();
-        const float* call = b1s + 4 * C + G::WAVES * 512 + G::WAVES * (6 * C);
-        for (int i = tid; i < 2 * C; i += G::WAVES * 64) {
-          float t = 0.f;
-#pragma unroll
-          for (int w = 0; w < G::WAVES; ++w) t += call[w * (2 * C) + i];
-          p.dln_parts[static_cast<long>(blockIdx.x) * (2 * C) + i] = t;
-        }
       }
     }
   } else {
@@ -983,11 +882,9 @@ int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, bool ln_bwd, hipStream_t s)
     hipLaunchKernelGGL(kfn, grid, block, (EM) ? G::LDS_EMIT : G::LDS, s, a);                                     \
   }
   if (g_dtype == APGD_F32) {
-    if (emit) { if (ln_bwd) BLK_LAUNCH(float, true, true) else BLK_LAUNCH(float, true, false) }
-    else if (ln_bwd) BLK_LAUNCH(float, false, true) else BLK_LAUNCH(float, false, false)
+    if (emit) BLK_LAUNCH(float, true, false) else if (ln_bwd) BLK_LAUNCH(float, false, true) else BLK_LAUNCH(float, false, false)
   } else {
-    if (emit) { if (ln_bwd) BLK_LAUNCH(uint16_t, true, true) else BLK_LAUNCH(uint16_t, true, false) }
-    else if (ln_bwd) BLK_LAUNCH(uint16_t, false, true) else BLK_LAUNCH(uint16_t, false, false)
+    if (emit) BLK_LAUNCH(uint16_t, true, false) else if (ln_bwd) BLK_LAUNCH(uint16_t, false, true) else BLK_LAUNCH(uint16_t, false, false)
   }
 #undef BLK_LAUNCH
   return launch_status();
@@ -1062,9 +959,8 @@ int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* 
 
 static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                               const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                              void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts,
-                              const void* y2, float* dgb_parts, float* dln_parts, bool ln_bwd, int64_t M, int32_t C,
-                              void* stream) {
+                              void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, bool ln_bwd,
+                              int64_t M, int32_t C, void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!u || !ln_w || !ln_b || !mean || !rstd || !g || !Wb || !b1 || !da) return APGD_ERR_NULL;
@@ -1076,12 +972,6 @@ static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_
   a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = b1; a.da = static_cast<uint16_t*>(da);
   a.a_out = static_cast<uint16_t*>(a_out); a.do_out = static_cast<uint16_t*>(do_out);
   a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.M = M;
-  if ((db1_parts || dgb_parts) && n_emit != 4) return APGD_ERR_NULL;
-  a.db1_parts = db1_parts;
-  a.y2 = static_cast<const uint16_t*>(y2);
-  a.dgb_parts = dgb_parts;
-  if (dln_parts && (n_emit != 4 || !ln_bwd)) return APGD_ERR_ARG;
-  a.dln_parts = dln_parts;
   if (a_stride != 0 && (a_stride < C || a_stride % 8 != 0)) return APGD_ERR_ARG;
   a.a_stride = a_stride ? a_stride : C;
   hipStream_t s = as_stream(stream);
@@ -1097,31 +987,14 @@ int cnx_block_mlp_bwd(const void* u, const float* ln_w, const float* ln_b, const
                       void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, int64_t M, int32_t C,
                       void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, a_stride, do_out, ht_out, dhpt_out,
-                            nullptr, nullptr, nullptr, nullptr, false, M, C, stream);
-}
-
-int64_t cnx_block_mlp_bwd_parts(int64_t M, int32_t C) {
-  switch (C) {
-    case 96: return (M + GeoB<96>::BM - 1) / GeoB<96>::BM;
-    case 192: return (M + GeoB<192>::BM - 1) / GeoB<192>::BM;
-    default: return 0;
-  }
-}
-
-int cnx_block_mlp_bwd_train(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
-                            const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
-                            void* a_out, void* do_out, void* ht_out, void* dhpt_out, float* db1_parts, const void* y2,
-                            float* dgb_parts, float* dln_parts, int64_t M, int32_t C, void* stream) {
-  if (!db1_parts || !dgb_parts) return APGD_ERR_NULL;
-  return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_out, 0, do_out, ht_out, dhpt_out, db1_parts,
-                            y2, dgb_parts, dln_parts, dln_parts != nullptr, M, C, stream);
+                            false, M, C, stream);
 }
 
 int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
                             int64_t M, int32_t C, void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, du, nullptr, 0, nullptr, nullptr, nullptr,
-                            nullptr, nullptr, nullptr, nullptr, true, M, C, stream);
+                            true, M, C, stream);
 }
 
 int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 192) ? 1 : 0; }

@@ -2101,15 +2101,6 @@ int cnx_layernorm_bwd_patch2(const void* dy, int dy_dtype, const void* x, int x_
                             H, W, stream);
 }
 
-int cnx_reduce_parts(const float* parts, float* out, int64_t nparts, int64_t len, void* stream) {
-  if (nparts < 0 || len < 0) return APGD_ERR_SIZE;
-  if (len == 0) return APGD_OK;
-  if (!parts || !out) return APGD_ERR_NULL;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(static_cast<unsigned>((len + 15) / 16)), dim3(256), 0, as_stream(stream), parts, out,
-                     static_cast<float*>(nullptr), static_cast<int>(len), static_cast<int>(len), static_cast<int>(nparts));
-  return launch_status();
-}
-
 int cnx_sum_parts_bf16(const void* parts, float* out, int64_t S, int64_t L, void* stream) {
   if (S < 0 || L < 0 || L % 8 != 0) return APGD_ERR_SIZE;
   if (L == 0) return APGD_OK;

@@ -723,38 +723,24 @@ class _BlockFused(torch.autograd.Function):
                 dhpt = torch.empty(4 * C, M, device=x.device, dtype=torch.bfloat16)
             if g2.dtype not in (torch.float32, torch.bfloat16):
                 g2 = g2.float()
-            if want_p:
-                # training backward: the kernel also emits the operands of the weight-gradient GEMMs and the d(b1) partials
-                # (d(b1), d(gamma), d(b2) as per-workgroup column sums: no extra pass over dHpre^T or over g and y2)
-                nparts = lib.cnx_block_mlp_bwd_parts(M, C)
-                parts = torch.empty(nparts, 4 * C, device=x.device, dtype=torch.float32)
-                parts2 = torch.empty(nparts, 2 * C, device=x.device, dtype=torch.float32)
-                parts3 = torch.empty(nparts, 2 * C, device=x.device, dtype=torch.float32)
-                y2p = y2.reshape(M, C).data_ptr() if y2 is not None else None
-                if _TRAIN_LN_FUSED:
-                    d_u = da.view(u.shape)                                       # LayerNorm backward in the kernel's epilogue
-                _lib.check(lib.cnx_block_mlp_bwd_train(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                       g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
-                                                       da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
-                                                       parts.data_ptr(), y2p, parts2.data_ptr(),
-                                                       parts3.data_ptr() if _TRAIN_LN_FUSED else None, M, C, _stream()),
-                           "cnx_block_mlp_bwd_train")
-                if _TRAIN_LN_FUSED:
-                    dln = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-                    _lib.check(lib.cnx_reduce_parts(parts3.data_ptr(), dln.data_ptr(), nparts, 2 * C, _stream()), "cnx_reduce_parts")
-                    dlw_f, dlb_f = dln[:C], dln[C:]
-                db1 = torch.empty(4 * C, device=x.device, dtype=torch.float32)
-                _lib.check(lib.cnx_reduce_parts(parts.data_ptr(), db1.data_ptr(), nparts, 4 * C, _stream()), "cnx_reduce_parts")
-                dgb = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-                _lib.check(lib.cnx_reduce_parts(parts2.data_ptr(), dgb.data_ptr(), nparts, 2 * C, _stream()), "cnx_reduce_parts")
-                dgamma, db2 = (dgb[:C] if gf is not None else None), dgb[C:]
-            else:
-                _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                 g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
-                                                 da.data_ptr(), None, 0, None, None, None, M, C, _stream()), "cnx_block_mlp_bwd")
+            _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
+                                             da.data_ptr(), _lib.ptr(a), 0, _lib.ptr(dos), _lib.ptr(ht), _lib.ptr(dhpt), M, C,
+                                             _stream()), "cnx_block_mlp_bwd")
             if want_p:
                 dw1 = _wgrad_t(dhpt, a)                                          # [4C, C]
+                db1 = dhpt.sum(1, dtype=torch.float32)
                 dw2 = _wgrad_t(ht, dos).t()                                      # [C, 4C]
+                # d(gamma) = sum_m g*y2 and d(b2) = sum_m dO in ONE pass over g and y2 (sums-only mode of the tail kernel;
+                # as separate torch reductions they were a cast, a product and two sums: ~390 us per block at 56x56)
+                dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+                db2 = torch.empty(C, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=x.device, dtype=torch.float32)
+                y2p = y2.reshape(M, C).data_ptr() if y2 is not None else None
+                _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2p, _lib.ptr(gf), None, dgamma.data_ptr(),
+                                                      db2.data_ptr(), ws.data_ptr(), M, C, _stream()), "cnx_scale_residual_bwd")
+                if gf is None:
+                    dgamma = None
                 del a, dos, ht, dhpt
         else:
             # ---- library GEMMs between the one-pass tails: dO (+ d(gamma), d(b2)), GELU' (+ d(b1)), split-K weight gradients
@@ -782,10 +768,8 @@ class _BlockFused(torch.autograd.Function):
                 if gf is None:
                     dgamma = None
             del dhpre, dos
-        # ---- LayerNorm backward (already done by the fused kernels of the fused stages)
+        # ---- LayerNorm backward (already done by the fused input-gradient kernel)
         dlw = dlb = ws = None
-        if d_u is not None and want_p:
-            dlw, dlb = dlw_f, dlb_f
         if d_u is None:
             d_u = torch.empty_like(u)
             if want_p:
@@ -825,7 +809,6 @@ def block_fused_supported(C):
 # Widths routed through the fused LN+MLP kernel.  Measured on MI355X (tools/block_bench.py, batch 256): a clear win
 # where the unfused block is HBM-bound (C = 96, 192); at C = 384 the weight stream (128 rows per workgroup) caps it
 # below the hipBLASLt composition, so that width stays on the library path for now.  APGD_BLOCK_FUSED overrides.
-_TRAIN_LN_FUSED = os.environ.get("APGD_TRAIN_LN_FUSED", "0") != "0"       # LayerNorm backward inside the training backward kernel (measured: no gain over the separate pass, off)
 _FUSED_WIDTHS = os.environ.get("APGD_BLOCK_FUSED", "96,192")
 _FUSED_WIDTHS = {int(v) for v in _FUSED_WIDTHS.split(",") if v.strip()}
 
