@@ -1813,7 +1813,11 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
   hipStream_t s = as_stream(stream);
   const bool all_f32 = x_dtype == APGD_F32 && out_dtype == APGD_F32;
   static const int dw_dbg = getenv("APGD_DW_DBG") ? atoi(getenv("APGD_DW_DBG")) : 0;   // timing experiments only
-  if (!all_f32) {
+  // The packed-dot kernels fuse "+ add" only into an fp32 result.  A bf16 result with an add operand (the residual gradient
+  // of a block whose input is bf16) goes to the strip kernel below, which honours it for every output type - never silently
+  // dropped.
+  const bool add_into_bf16 = add != nullptr && out_dtype == APGD_BF16;
+  if (!all_f32 && !add_into_bf16) {
     DwRoll rp;
     if (dw_roll_plan(H, W, C, x_dtype == APGD_F32 ? 4 : 2, out_dtype == APGD_F32 ? 4 : 2, &rp)) {
       const dim3 grid(static_cast<unsigned>(static_cast<long>(N) * (C / kDC) * rp.n_seg)), block(rp.threads);

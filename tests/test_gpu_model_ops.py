@@ -624,3 +624,62 @@ def test_stem_conv_ln_gelu_fused_equals_the_two_kernel_composition(R, P, N, H, W
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         o_n = R.ops.stem_conv_ln_gelu(x, w, b, lw, lb, 1e-6)
     assert torch.equal(o_n, o_f)
+
+
+@pytest.mark.gpu
+def test_convnext_tiny_train_step_gradients_hip_vs_library_composition(R, monkeypatch):
+    """End to end at the benchmark's shapes (ConvNeXt-T-CvSt, 224x224, bf16 autocast, batch 2): logits, input gradient and
+    EVERY parameter gradient of the hand-written path (rolling / tile depthwise kernels, fused LN+MLP blocks and their emit
+    backward, library-GEMM blocks with the one-pass tails, patch-form downsample, split-K weight gradients, stem kernels)
+    against the same model run as the plain library composition (ops.MODE = "eager") on the same weights and input."""
+    torch.manual_seed(0)
+    model = R.get_new_model("convnext_tiny", pretrained=False, not_original=True).cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():                                   # layer-scale at its init (1e-6) would hide the block branches
+        for n_, p in model.named_parameters():
+            if n_.endswith("gamma"):
+                p.fill_(0.5)
+    model.train()
+    x = torch.rand(2, 3, 224, 224, device="cuda")
+    y = torch.tensor([3, 7], device="cuda")
+
+    def run(mode):
+        monkeypatch.setattr(R.ops, "MODE", mode)
+        R.ops.invalidate_weight_cache()
+        for p in model.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_()
+        torch.clear_autocast_cache()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = model(xi)
+            loss = F.cross_entropy(logits.float(), y)
+        loss.backward()
+        return logits.detach().float(), xi.grad.clone(), {n_: p.grad.detach().float().clone() for n_, p in model.named_parameters()}
+
+    lo_h, gx_h, gp_h = run("hip")
+    lo_e, gx_e, gp_e = run("eager")
+    assert float((lo_h - lo_e).norm() / lo_e.norm()) < 3e-2
+    assert float((gx_h - gx_e).norm() / gx_e.norm()) < 6e-2
+    worst = max((float((gp_h[k] - gp_e[k]).norm() / (gp_e[k].norm() + 1e-12)), k) for k in gp_e if float(gp_e[k].norm()) > 0)
+    assert worst[0] < 8e-2, worst                           # two bf16 executions of a 60-kernel-deep chain
+    assert set(gp_h) == set(gp_e) and all(torch.isfinite(v).all() for v in gp_h.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,C", [(2, 14, 14, 64), (1, 56, 56, 32), (3, 7, 7, 96), (2, 28, 28, 64)])
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+def test_dwconv_add_operand_is_never_dropped_for_a_bf16_result(R, N, H, W, C, xdt):
+    """The fused "+ add" operand of cnx_dwconv7x7_nhwc (the residual gradient riding into the input-gradient call) with a bf16
+    result - the gradient of a block whose input is bf16, i.e. the first block of every stage - must equal the fp32 result
+    rounded once.  (The packed-dot kernels fuse the add only into fp32 results; this combination used to lose the operand.)"""
+    lib = R._lib.load()
+    g = torch.Generator().manual_seed(N * H + C)
+    d_u = torch.randn(N, H, W, C, generator=g).to(xdt).cuda()
+    add = torch.randn(N, H, W, C, generator=g).cuda()
+    w49 = (torch.randn(49, C, generator=g) * 0.1).cuda()
+    o16 = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    o32 = torch.empty(N, H, W, C, device="cuda")
+    code = R._lib.dtype_code(xdt)
+    assert lib.cnx_dwconv7x7_nhwc(d_u.data_ptr(), code, w49.data_ptr(), None, add.data_ptr(), o16.data_ptr(), 1, N, H, W, C, 1, S()) == 0
+    assert lib.cnx_dwconv7x7_nhwc(d_u.data_ptr(), code, w49.data_ptr(), None, add.data_ptr(), o32.data_ptr(), 0, N, H, W, C, 1, S()) == 0
+    assert float((o32 - add).norm()) > 0.1 * float(add.norm())            # the stencil part is not negligible ...
+    close(o16, o32, 8e-3, 8e-3)                                             # ... and the sum is only rounded
