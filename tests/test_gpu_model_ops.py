@@ -627,13 +627,14 @@ def test_stem_conv_ln_gelu_fused_equals_the_two_kernel_composition(R, P, N, H, W
 
 
 @pytest.mark.gpu
-def test_convnext_tiny_train_step_gradients_hip_vs_library_composition(R, monkeypatch):
+@pytest.mark.parametrize("arch", ["convnext_tiny", "vit_s", "deit_s"])
+def test_train_step_gradients_hip_vs_library_composition(R, monkeypatch, arch):
     """End to end at the benchmark's shapes (ConvNeXt-T-CvSt, 224x224, bf16 autocast, batch 2): logits, input gradient and
     EVERY parameter gradient of the hand-written path (rolling / tile depthwise kernels, fused LN+MLP blocks and their emit
     backward, library-GEMM blocks with the one-pass tails, patch-form downsample, split-K weight gradients, stem kernels)
     against the same model run as the plain library composition (ops.MODE = "eager") on the same weights and input."""
     torch.manual_seed(0)
-    model = R.get_new_model("convnext_tiny", pretrained=False, not_original=True).cuda().to(memory_format=torch.channels_last)
+    model = R.get_new_model(arch, pretrained=False, not_original=True).cuda().to(memory_format=torch.channels_last)
     with torch.no_grad():                                   # layer-scale at its init (1e-6) would hide the block branches
         for n_, p in model.named_parameters():
             if n_.endswith("gamma"):
@@ -683,3 +684,30 @@ def test_dwconv_add_operand_is_never_dropped_for_a_bf16_result(R, N, H, W, C, xd
     assert lib.cnx_dwconv7x7_nhwc(d_u.data_ptr(), code, w49.data_ptr(), None, add.data_ptr(), o32.data_ptr(), 0, N, H, W, C, 1, S()) == 0
     assert float((o32 - add).norm()) > 0.1 * float(add.norm())            # the stencil part is not negligible ...
     close(o16, o32, 8e-3, 8e-3)                                             # ... and the sum is only rounded
+
+
+@pytest.mark.gpu
+def test_apgd_on_the_hip_model_agrees_with_apgd_on_the_library_composition(R, monkeypatch):
+    """The attack consumes only sign(gradient), so a wrongly scaled or partially missing input gradient does not show in the
+    APGD state machine tests.  Here the same ConvNeXt-T-CvSt weights are attacked through the hand-written model path and through
+    the plain library composition (bf16 autocast both): the adversarial images must agree except where the gradient is within
+    bf16 noise of zero."""
+    torch.manual_seed(1)
+    model = R.get_new_model("convnext_tiny", pretrained=False, not_original=True).cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("gamma"):
+                p.fill_(0.5)
+    model.eval()
+    x = torch.rand(4, 3, 224, 224, device="cuda")
+    y = torch.tensor([1, 2, 3, 4], device="cuda")
+    outs = {}
+    for mode in ("hip", "eager"):
+        monkeypatch.setattr(R.ops, "MODE", mode)
+        R.ops.invalidate_weight_cache()
+        torch.clear_autocast_cache()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outs[mode] = R.apgd_train(model, x, y, norm="Linf", eps=4 / 255, n_iter=2)[0]
+    same = (outs["hip"] == outs["eager"]).float().mean().item()
+    assert same > 0.9, same
+    assert float((outs["hip"] - x).abs().max()) <= 4 / 255 + 1e-6
