@@ -627,7 +627,7 @@ def test_stem_conv_ln_gelu_fused_equals_the_two_kernel_composition(R, P, N, H, W
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arch", ["convnext_tiny", "vit_s", "deit_s"])
+@pytest.mark.parametrize("arch", ["convnext_tiny", "convnext_base", "vit_s", "deit_s", "vit_b"])
 def test_train_step_gradients_hip_vs_library_composition(R, monkeypatch, arch):
     """End to end at the benchmark's shapes (ConvNeXt-T-CvSt, 224x224, bf16 autocast, batch 2): logits, input gradient and
     EVERY parameter gradient of the hand-written path (rolling / tile depthwise kernels, fused LN+MLP blocks and their emit
