@@ -627,8 +627,9 @@ def test_stem_conv_ln_gelu_fused_equals_the_two_kernel_composition(R, P, N, H, W
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arch", ["convnext_tiny", "convnext_base", "vit_s", "deit_s", "vit_b"])
-def test_train_step_gradients_hip_vs_library_composition(R, monkeypatch, arch):
+@pytest.mark.parametrize("arch,nb,res", [("convnext_tiny", 2, 224), ("convnext_tiny", 3, 160), ("convnext_tiny", 1, 96),
+                                         ("convnext_base", 2, 224), ("vit_s", 2, 224), ("deit_s", 2, 224), ("vit_b", 2, 224)])
+def test_train_step_gradients_hip_vs_library_composition(R, monkeypatch, arch, nb, res):
     """End to end at the benchmark's shapes (ConvNeXt-T-CvSt, 224x224, bf16 autocast, batch 2): logits, input gradient and
     EVERY parameter gradient of the hand-written path (rolling / tile depthwise kernels, fused LN+MLP blocks and their emit
     backward, library-GEMM blocks with the one-pass tails, patch-form downsample, split-K weight gradients, stem kernels)
@@ -640,8 +641,8 @@ def test_train_step_gradients_hip_vs_library_composition(R, monkeypatch, arch):
             if n_.endswith("gamma"):
                 p.fill_(0.5)
     model.train()
-    x = torch.rand(2, 3, 224, 224, device="cuda")
-    y = torch.tensor([3, 7], device="cuda")
+    x = torch.rand(nb, 3, res, res, device="cuda")
+    y = torch.tensor([3, 7, 11][:nb], device="cuda")
 
     def run(mode):
         monkeypatch.setattr(R.ops, "MODE", mode)
