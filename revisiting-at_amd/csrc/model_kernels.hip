@@ -455,7 +455,7 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
 // fused "+ add" operand), written to the ring after it - and the filter registers are set up once per band.
 //   LDS: ring [10][P2][32] dwords + output tile [4][W][32] TO (transposed epilogue: 16 bytes per lane).
 // ------------------------------------------------------------------------------------------------
-template <typename TI, typename TO, int U>
+template <typename TI, typename TO, int U, bool FA = false>
 __global__ __launch_bounds__(256) void dwconv7x7_roll_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
                                                              const float* __restrict__ bias, const float* __restrict__ add,
                                                              TO* __restrict__ out, int H, int W, int C, int flip, int RS,
@@ -464,7 +464,8 @@ __global__ __launch_bounds__(256) void dwconv7x7_roll_kernel(const TI* __restric
   extern __shared__ __attribute__((aligned(16))) uint32_t tile2[];
   const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
   uint32_t* win = tile2;                                                  // [WR][P2][32]
-  TO* ot = reinterpret_cast<TO*>(tile2 + WR * P2 * kDC);                  // [TH][W][32]
+  using TS = typename std::conditional<FA, float, TO>::type;              // FA: fp32 staging so that "+ add" is summed before the one rounding to bf16
+  TS* ot = reinterpret_cast<TS*>(tile2 + WR * P2 * kDC);                  // [TH][W][32]
   const int n_cg = C / kDC;
   long b = blockIdx.x;
   const int seg = static_cast<int>(b % n_seg);
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_roll_kernel(const TI* __restric
   const float b0 = bias ? bias[c] : 0.f;
   const bool worker = sidx < n_sc;
   const int sc = worker ? sidx : 0;
-  constexpr int EPC = 16 / static_cast<int>(sizeof(TO));                 // elements per 16-byte chunk
+  constexpr int EPC = 16 / static_cast<int>(sizeof(TS));                 // elements per 16-byte chunk
   constexpr int CH = kDC / EPC;                                          // chunks per position
   constexpr int AC = 8;                                                  // "+ add" chunks prefetched per thread (fp32 output)
   __syncthreads();
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_roll_kernel(const TI* __restric
     const int n_chunks = (h_end - h0) * W * CH;
     const long obase = ((n * H + h0) * static_cast<long>(W)) * C + cbase;
     float4 a4[AC];
-    if constexpr (sizeof(TO) == 4) {
+    if constexpr (sizeof(TS) == 4) {
       if (add) {
 #pragma unroll
         for (int k = 0; k < AC; ++k) {
@@ -627,14 +628,19 @@ __global__ __launch_bounds__(256) void dwconv7x7_roll_kernel(const TI* __restric
       if (i >= n_chunks) break;
       const int pos = i / CH, ch = i - pos * CH;
       uint4 v = *reinterpret_cast<const uint4*>(ot + static_cast<long>(pos) * kDC + ch * EPC);
-      if constexpr (sizeof(TO) == 4) {
+      if constexpr (sizeof(TS) == 4) {
         if (add) {
           float4 f = __builtin_bit_cast(float4, v);
           f.x += a4[k].x; f.y += a4[k].y; f.z += a4[k].z; f.w += a4[k].w;
           v = __builtin_bit_cast(uint4, f);
         }
       }
-      *reinterpret_cast<uint4*>(out + obase + static_cast<long>(pos) * C + ch * EPC) = v;
+      if constexpr (sizeof(TS) == sizeof(TO)) {
+        *reinterpret_cast<uint4*>(out + obase + static_cast<long>(pos) * C + ch * EPC) = v;
+      } else {                                                           // fp32 sum -> bf16 result, rounded once
+        const float4 f = __builtin_bit_cast(float4, v);
+        *reinterpret_cast<uint2*>(out + obase + static_cast<long>(pos) * C + ch * EPC) = make_uint2(pack2_bf16(f.x, f.y), pack2_bf16(f.z, f.w));
+      }
     }
     // ---- the prefetched rows replace the 4 oldest ring rows
     if (more) {
@@ -678,7 +684,7 @@ inline bool dw_roll_plan(int H, int W, int C, int in_bytes, int out_bytes, DwRol
 // loaded into registers before the stencil of image i runs, the filter registers are set up once.
 //   LDS: tile [TH+6][P2][32] dwords (border rows / columns zeroed once) + output tile [H][W][32] TO.
 // ------------------------------------------------------------------------------------------------
-template <typename TI, typename TO, int UT>
+template <typename TI, typename TO, int UT, bool FA = false>
 __global__ __launch_bounds__(256) void dwconv7x7_multi_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
                                                               const float* __restrict__ bias, const float* __restrict__ add,
                                                               TO* __restrict__ out, int N, int H, int W, int C, int flip,
@@ -688,7 +694,8 @@ __global__ __launch_bounds__(256) void dwconv7x7_multi_kernel(const TI* __restri
   const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
   const int TR = n_sr * kDR + 6;                                          // tile rows
   uint32_t* win = tile2;
-  TO* ot = reinterpret_cast<TO*>(tile2 + TR * P2 * kDC);                  // [H][W][32]
+  using TS = typename std::conditional<FA, float, TO>::type;              // FA: fp32 staging so that "+ add" is summed before the one rounding to bf16
+  TS* ot = reinterpret_cast<TS*>(tile2 + TR * P2 * kDC);                  // [H][W][32]
   const int n_cg = C / kDC;
   const int cbase = static_cast<int>(blockIdx.x % n_cg) * kDC;
   const long n_first = static_cast<long>(blockIdx.x / n_cg) * ipw;
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_multi_kernel(const TI* __restri
   const float b0 = bias ? bias[c] : 0.f;
   const bool worker = sidx < n_sr * n_sc;
   const int sc = worker ? sidx % n_sc : 0, sr = worker ? sidx / n_sc : 0;
-  constexpr int EPC = 16 / static_cast<int>(sizeof(TO));
+  constexpr int EPC = 16 / static_cast<int>(sizeof(TS));
   constexpr int CH = kDC / EPC;
   constexpr int AC = 8;
   const int n_chunks = H * W * CH;
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_multi_kernel(const TI* __restri
     if (more) load_img(n + 1, p0, p1);
     const long obase = (n * H) * static_cast<long>(W) * C + cbase;
     float4 a4[AC];
-    if constexpr (sizeof(TO) == 4) {
+    if constexpr (sizeof(TS) == 4) {
       if (add) {
 #pragma unroll
         for (int k = 0; k < AC; ++k) {
@@ -822,14 +829,19 @@ __global__ __launch_bounds__(256) void dwconv7x7_multi_kernel(const TI* __restri
       if (i >= n_chunks) break;
       const int pos = i / CH, ch = i - pos * CH;
       uint4 v = *reinterpret_cast<const uint4*>(ot + static_cast<long>(pos) * kDC + ch * EPC);
-      if constexpr (sizeof(TO) == 4) {
+      if constexpr (sizeof(TS) == 4) {
         if (add) {
           float4 f = __builtin_bit_cast(float4, v);
           f.x += a4[k].x; f.y += a4[k].y; f.z += a4[k].z; f.w += a4[k].w;
           v = __builtin_bit_cast(uint4, f);
         }
       }
-      *reinterpret_cast<uint4*>(out + obase + static_cast<long>(pos) * C + ch * EPC) = v;
+      if constexpr (sizeof(TS) == sizeof(TO)) {
+        *reinterpret_cast<uint4*>(out + obase + static_cast<long>(pos) * C + ch * EPC) = v;
+      } else {                                                           // fp32 sum -> bf16 result, rounded once
+        const float4 f = __builtin_bit_cast(float4, v);
+        *reinterpret_cast<uint2*>(out + obase + static_cast<long>(pos) * C + ch * EPC) = make_uint2(pack2_bf16(f.x, f.y), pack2_bf16(f.z, f.w));
+      }
     }
     if (more) store_img(p0, p1);
     __syncthreads();
@@ -1817,6 +1829,46 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
   // of a block whose input is bf16) goes to the strip kernel below, which honours it for every output type - never silently
   // dropped.
   const bool add_into_bf16 = add != nullptr && out_dtype == APGD_BF16;
+  if (add_into_bf16 && x_dtype == APGD_BF16) {
+    // input-gradient call of a block whose input is bf16 (first block of a stage): fp32 staging of the result tile, the sum with
+    // the residual gradient rounded once
+    DwRoll rp;
+    DwMulti mp;
+    if (dw_roll_plan(H, W, C, 2, 4, &rp)) {
+      const dim3 grid(static_cast<unsigned>(static_cast<long>(N) * (C / kDC) * rp.n_seg)), block(rp.threads);
+#define DWRA_LAUNCH(UU)                                                                                               \
+  {                                                                                                                   \
+    auto kfn = dwconv7x7_roll_kernel<uint16_t, uint16_t, UU, true>;                                                   \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, grid, block, rp.lds, s, static_cast<const uint16_t*>(x), w49c, bias, add,                 \
+                       static_cast<uint16_t*>(out), H, W, C, flip, rp.rs, rp.n_seg);                                   \
+  }
+      if (rp.units == 1) DWRA_LAUNCH(1) else DWRA_LAUNCH(2)
+#undef DWRA_LAUNCH
+      return launch_status();
+    }
+    if (dw_multi_plan(N, H, W, C, 2, 4, &mp)) {
+      const dim3 grid(static_cast<unsigned>(static_cast<long>((N + mp.ipw - 1) / mp.ipw) * (C / kDC))), block(mp.threads);
+#define DWMA_LAUNCH(UU)                                                                                               \
+  {                                                                                                                   \
+    auto kfn = dwconv7x7_multi_kernel<uint16_t, uint16_t, UU, true>;                                                  \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, grid, block, mp.lds, s, static_cast<const uint16_t*>(x), w49c, bias, add,                 \
+                       static_cast<uint16_t*>(out), N, H, W, C, flip, mp.n_sr, mp.ipw);                                \
+  }
+      if (mp.ut == 5) DWMA_LAUNCH(5) else DWMA_LAUNCH(7)
+#undef DWMA_LAUNCH
+      return launch_status();
+    }
+  }
   if (!all_f32 && !add_into_bf16) {
     DwRoll rp;
     if (dw_roll_plan(H, W, C, x_dtype == APGD_F32 ? 4 : 2, out_dtype == APGD_F32 ? 4 : 2, &rp)) {

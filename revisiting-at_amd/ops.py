@@ -783,15 +783,13 @@ class _BlockFused(torch.autograd.Function):
         # ---- depthwise conv backward; the residual branch's gradient rides along as the stencil's `add` input
         dx = None
         if nig[0]:
-            # always an fp32 result: the packed-dot kernels fuse "+ add" (the residual gradient) only into fp32; a bf16 block
-            # input (first block of a stage) gets its gradient rounded once, after the sum
-            dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+            # "+ add" (the residual gradient) is summed in fp32 inside the kernel; a bf16 block input (first block of a stage)
+            # gets the sum rounded once
+            dx = torch.empty_like(x)
             gadd = g if g.dtype == torch.float32 else g.float()
             _lib.check(lib.cnx_dwconv7x7_nhwc(d_u.data_ptr(), _code(d_u), w49c.data_ptr(), None, gadd.data_ptr(),
                                               dx.data_ptr(), _code(dx), N, H, W, C, 1, _stream()),
                        "cnx_dwconv7x7_nhwc(flip)")
-            if x.dtype != torch.float32:
-                dx = dx.to(x.dtype)
         dww = dwb = None
         if want_p:
             g49 = torch.empty(49, C, device=x.device, dtype=torch.float32)
