@@ -688,7 +688,8 @@ def test_dwconv_add_operand_is_never_dropped_for_a_bf16_result(R, N, H, W, C, xd
 
 
 @pytest.mark.gpu
-def test_apgd_on_the_hip_model_agrees_with_apgd_on_the_library_composition(R, monkeypatch):
+@pytest.mark.parametrize("norm,eps", [("Linf", 4 / 255), ("L2", 2.0)])
+def test_apgd_on_the_hip_model_agrees_with_apgd_on_the_library_composition(R, monkeypatch, norm, eps):
     """The attack consumes only sign(gradient), so a wrongly scaled or partially missing input gradient does not show in the
     APGD state machine tests.  Here the same ConvNeXt-T-CvSt weights are attacked through the hand-written model path and through
     the plain library composition (bf16 autocast both): the adversarial images must agree except where the gradient is within
@@ -708,7 +709,13 @@ def test_apgd_on_the_hip_model_agrees_with_apgd_on_the_library_composition(R, mo
         R.ops.invalidate_weight_cache()
         torch.clear_autocast_cache()
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            outs[mode] = R.apgd_train(model, x, y, norm="Linf", eps=4 / 255, n_iter=2)[0]
-    same = (outs["hip"] == outs["eager"]).float().mean().item()
-    assert same > 0.9, same
-    assert float((outs["hip"] - x).abs().max()) <= 4 / 255 + 1e-6
+            outs[mode] = R.apgd_train(model, x, y, norm=norm, eps=eps, n_iter=2)[0]
+    if norm == "Linf":
+        same = (outs["hip"] == outs["eager"]).float().mean().item()
+        assert same > 0.9, same
+        assert float((outs["hip"] - x).abs().max()) <= eps + 1e-6
+    else:                                                   # L2: the normalised gradient direction must agree
+        d_h, d_e = (outs["hip"] - x).flatten(1), (outs["eager"] - x).flatten(1)
+        cos = F.cosine_similarity(d_h, d_e, dim=1)
+        assert float(cos.min()) > 0.95, cos
+        assert float(d_h.norm(dim=1).max()) <= eps * (1 + 1e-4)
