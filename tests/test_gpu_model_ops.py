@@ -719,3 +719,40 @@ def test_apgd_on_the_hip_model_agrees_with_apgd_on_the_library_composition(R, mo
         cos = F.cosine_similarity(d_h, d_e, dim=1)
         assert float(cos.min()) > 0.95, cos
         assert float(d_h.norm(dim=1).max()) <= eps * (1 + 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss,n_iter", [("ce", 10), ("dlr", 1)])
+def test_eval_attack_on_the_hip_model_agrees_with_the_library_composition(R, monkeypatch, loss, n_iter):
+    """aa_eval.apgd_attack (no random start) through the hand-written model path vs the library composition: the adversarial
+    images agree except where the gradient is within bf16 noise of zero.  DLR divides by the top-1 - top-3 logit gap and picks
+    classes by rank, both at the bf16 resolution of a random-init head: it is compared after one iteration and only on samples
+    whose top-3 ranking is the same in the two executions."""
+    torch.manual_seed(2)
+    model = R.get_new_model("convnext_tiny", pretrained=False, not_original=True).cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("gamma"):
+                p.fill_(0.5)
+    model.eval()
+    x = torch.rand(8, 3, 224, 224, device="cuda")
+    outs, top3 = {}, {}
+    for mode in ("hip", "eager"):
+        monkeypatch.setattr(R.ops, "MODE", mode)
+        R.ops.invalidate_weight_cache()
+        torch.clear_autocast_cache()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            top3[mode] = model(x).float().topk(3).indices
+    y = top3["eager"][:, 0]                                     # attack the predicted class: every point starts robust
+    for mode in ("hip", "eager"):
+        monkeypatch.setattr(R.ops, "MODE", mode)
+        R.ops.invalidate_weight_cache()
+        torch.clear_autocast_cache()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outs[mode] = R.aa_eval.apgd_attack(model, x, y, "Linf", 4 / 255, n_iter, loss, None, False)
+    keep = (top3["hip"] == top3["eager"]).all(1) if loss == "dlr" else torch.ones(8, dtype=torch.bool, device="cuda")
+    assert int(keep.sum()) >= 2
+    xa_h, xa_e = outs["hip"][3][keep], outs["eager"][3][keep]   # x_best
+    same = (xa_h == xa_e).float().mean().item()
+    assert same > 0.8, same                                     # sign flips of near-zero gradients compound over the iterations
+    assert float((outs["hip"][3] - x).abs().max()) <= 4 / 255 + 1e-6
