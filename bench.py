@@ -19,6 +19,8 @@ plain-torch model) on a bounded sample of the same workload on this host's cores
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -152,15 +154,67 @@ def model_kernel_rooflines(R, dev, B, iters=10):
     return out
 
 
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a torchrun environment: start N fresh rank processes (one per GPU, RCCL over
+    xGMI; the reference's ``mp.spawn`` of ``main.py:1128-1152``), relay rank 0's JSON line, and fail if the job that ran is
+    not an N-rank job.  The parent never touches the GPU (``torch.cuda.device_count()`` does not initialise HIP on this
+    image) and never re-execs itself: the ranks are plain child processes."""
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if ndev < n:
+        print(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    threads = os.environ.get("OMP_NUM_THREADS") or str(max(1, min(8, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=threads,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()                                         # the exact child we started, by handle
+            codes.append(-9)
+    if any(codes):
+        sys.stdout.write(out0)
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            try:
+                line = json.loads(ln)
+            except ValueError:
+                pass
+    if line is None or line.get("n_gpus") != n:
+        sys.stdout.write(out0)
+        print(f"bench.py: expected one JSON line with n_gpus == {n}, got {None if line is None else line.get('n_gpus')}",
+              file=sys.stderr)
+        return 1
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import revisiting_at_amd as R
     from revisiting_at_amd import apgd as apgd_mod
     import torch.distributed as dist
 
     rank, local, world = R.setup_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (spawns "
+                         f"the ranks itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback for the product path"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -172,7 +226,7 @@ def main():
     adv = R.AdvConfig(attack="apgd", norm="Linf", eps=args.eps, n_iter=args.n_iter)
     trainer = R.ATTrainStep(model, args.arch, adv, dev, lr=1e-3, distributed=world > 1, channels_last=True,
                             amp_dtype=torch.bfloat16, ema=True, mixup=object() if args.soft_labels else None,
-                            soft_targets=args.soft_labels)
+                            soft_targets=args.soft_labels, gemm_table=True)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch
     x = torch.rand(B, 3, args.res, args.res, device=dev, generator=g)        # synthetic 224x224x3 batch in [0,1)

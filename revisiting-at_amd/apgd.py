@@ -118,7 +118,7 @@ class ApgdWorkspace:
         self.loss_best = torch.empty(B, **f32)
         self.loss_best_last = torch.empty(B, **f32)
         self.reduced_last = torch.ones(B, **f32)                    # :201
-        self.loss_steps = torch.zeros(n_iter, B, **f32)             # :144
+        self.loss_steps = torch.zeros(max(n_iter, 1), B, **f32)     # :144
         self.pred = torch.empty(B, device=dev, dtype=torch.uint8)
         self.acc = torch.empty(B, device=dev, dtype=torch.uint8)
         self.flags = torch.empty(B, device=dev, dtype=torch.uint8)
@@ -191,9 +191,10 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
         raise _lib.ApgdHipError(f"attack state is fp32 (got {x.dtype})")
     lib = _lib.load()
     n_iter = int(n_iter)
-    if n_iter < 1:
-        # range(0) in the reference: returns the clamped clean point after one forward; keep it simple
-        raise ValueError("n_iter must be >= 1")
+    if n_iter < 0:
+        raise ValueError("n_iter must be >= 0")
+    # n_iter == 0: `range(0)` in the reference (:209) - one forward/backward, then the clamped clean point with its
+    # acc / loss is returned; the loop below simply does not run
 
     x = x.detach()
     if not _dense_rows(x):

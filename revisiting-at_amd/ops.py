@@ -57,6 +57,13 @@ def _act_dtype(x):
     return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
 
+def _hip_dtype_ok(x):
+    """The hand-written operators compute in fp32 / bf16.  Under any other activation dtype - e.g. the reference's own
+    ``autocast(enabled=True)``, which is fp16 (``main.py:985``) - the operator dispatchers below run the plain library
+    composition instead of failing inside a kernel with APGD_ERR_DTYPE."""
+    return _act_dtype(x) in (torch.float32, torch.bfloat16)
+
+
 def _code(t):
     return _lib.dtype_code(t.dtype)
 
@@ -173,21 +180,21 @@ def scale_residual(x, y, gamma=None):
 def layer_norm_last(x, weight, bias, eps):
     """LayerNorm over the last dim of ``[..., C]`` (the ViT blocks' ``nn.LayerNorm``, timm ``vision_transformer.Block``): one
     kernel, output already in the autocast activation dtype (the eager pair is an fp32 LayerNorm + a cast in the next Linear)."""
-    if MODE == "eager" or not x.is_cuda or x.shape[-1] % 4 != 0:
+    if MODE == "eager" or not x.is_cuda or x.shape[-1] % 4 != 0 or not _hip_dtype_ok(x):
         return F.layer_norm(x, weight.shape, weight, bias, eps)
     return _ln_rows(x.contiguous(), weight, bias, eps, False)
 
 
 def layer_norm_cf(x, weight, bias, eps):
     """LayerNorm over dim 1 of ``[N,C,H,W]`` (``utils_architecture.py:76-81``; timm LayerNorm2d)."""
-    if MODE == "eager":
+    if MODE == "eager" or (x.is_cuda and not _hip_dtype_ok(x)):
         return F.layer_norm(x.permute(0, 2, 3, 1), weight.shape, weight, bias, eps).permute(0, 3, 1, 2)
     return _ln_rows(_rows(x), weight, bias, eps, False).permute(0, 3, 1, 2)
 
 
 def layer_norm_cf_gelu(x, weight, bias, eps):
     """``GELU(LN_cf(x))`` — the ConvStem pair (``utils_architecture.py:128-129`` etc.), one kernel."""
-    if MODE == "eager":
+    if MODE == "eager" or (x.is_cuda and not _hip_dtype_ok(x)):
         return F.gelu(F.layer_norm(x.permute(0, 2, 3, 1), weight.shape, weight, bias, eps).permute(0, 3, 1, 2))
     return _ln_rows(_rows(x), weight, bias, eps, True).permute(0, 3, 1, 2)
 
@@ -823,7 +830,7 @@ def _use_fused_block(C):
 
 def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
     """``x + gamma * fc2(GELU(fc1(LN(dw7x7(x)))))`` on ``[N,C,H,W]`` (``models/convnext.py:37-50``)."""
-    if MODE == "eager":
+    if MODE == "eager" or (x.is_cuda and not _hip_dtype_ok(x)):
         y = F.conv2d(x, dw_w, dw_b, padding=3, groups=x.shape[1]).permute(0, 2, 3, 1)
         y = F.layer_norm(y, ln_w.shape, ln_w, ln_b, eps)
     else:

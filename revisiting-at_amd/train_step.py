@@ -52,17 +52,44 @@ def create_optimizer(model: nn.Module, arch: str, weight_decay: float = 0.05):
 
 
 class DeviceEma:
-    """``ModelEmaV2(decay)`` semantics (``ema = decay*ema + (1-decay)*model`` over the whole
-    state dict) kept on the device and updated by one ``_foreach_lerp_``."""
+    """``ModelEmaV2(decay)`` semantics (``ema = decay*ema + (1-decay)*model`` over the whole state dict,
+    ``main.py:882-887, 996-997``) kept on the device and updated by one multi-tensor lerp.
+
+    The copy keeps the model's state-dict keys (``base_model.*`` under ``WrappedModel``), which is what the
+    reference saves as ``weights_ema_{epoch}.pt`` / ``state_dict_ema`` via ``get_state_dict(model_ema)``
+    (``main.py:739-747``).  Non-floating entries (none in the LayerNorm models of this path, but e.g.
+    ``num_batches_tracked`` elsewhere) are copied verbatim at every update."""
 
     def __init__(self, model: nn.Module, decay: float = 0.9999):
         self.decay = decay
-        self.src = [t for t in model.state_dict().values() if t.is_floating_point()]
-        self.ema = [t.detach().clone() for t in self.src]
+        sd = model.state_dict()
+        self.keys = list(sd.keys())
+        self._model_sd = sd                                   # live views of the parameters / buffers
+        self._ema_sd = {k: v.detach().clone() for k, v in sd.items()}
+        self._fkeys = [k for k in self.keys if sd[k].is_floating_point()]
+        self._ikeys = [k for k in self.keys if not sd[k].is_floating_point()]
+        self.src = [sd[k] for k in self._fkeys]
+        self.ema = [self._ema_sd[k] for k in self._fkeys]
 
     @torch.no_grad()
     def update(self):
         torch._foreach_lerp_(self.ema, [s.detach() for s in self.src], 1.0 - self.decay)
+        for k in self._ikeys:
+            self._ema_sd[k].copy_(self._model_sd[k])
+
+    def state_dict(self):
+        """``{key: ema tensor}`` with the wrapped model's own keys (timm ``get_state_dict(model_ema)``)."""
+        return {k: self._ema_sd[k] for k in self.keys}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd, strict: bool = True):
+        missing = [k for k in self.keys if k not in sd]
+        extra = [k for k in sd if k not in self._ema_sd]
+        if strict and (missing or extra):
+            raise KeyError(f"EMA state dict mismatch: missing {missing[:4]}, unexpected {extra[:4]}")
+        for k in self.keys:
+            if k in sd:
+                self._ema_sd[k].copy_(sd[k])
 
 
 def setup_distributed():
@@ -85,10 +112,11 @@ class ATTrainStep:
     def __init__(self, model: nn.Module, arch: str, adv: AdvConfig, device, lr: float = 1e-3,
                  weight_decay: float = 0.05, distributed: bool = False, channels_last: bool = True,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ema: bool = True, mixup=None,
-                 soft_targets: bool = False, perturb=None):
+                 soft_targets: bool = False, perturb=None, gemm_table: bool = False, ema_decay: float = 0.9999):
         self.device = torch.device(device)
-        if self.device.type == 'cuda':
-            ops.load_gemm_table()                                          # tuned library-GEMM selection for the known shapes
+        if gemm_table and self.device.type == 'cuda':
+            # opt-in: points PyTorch's process-wide TunableOp at the shipped, read-only hipBLASLt solution table
+            ops.load_gemm_table()
         if channels_last:
             model = model.to(memory_format=torch.channels_last)            # main.py:815-817
         if perturb is not None:                                            # any callable(model, x, y), as main.py:844
@@ -96,7 +124,7 @@ class ATTrainStep:
             wrapped = WrappedModel(model, perturb).to(self.device)
         else:
             wrapped = wrap_model_for_at(model, adv, mixup=mixup).to(self.device)  # main.py:831-844, 881
-        self.ema = DeviceEma(wrapped) if ema else None                     # before DDP (main.py:882-887)
+        self.ema = DeviceEma(wrapped, ema_decay) if ema else None                     # before DDP (main.py:882-887)
         self.perturb = adv.attack != 'none' or perturb is not None
         self.inner = wrapped
         if distributed:

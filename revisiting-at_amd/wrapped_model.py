@@ -6,8 +6,6 @@ state-dict prefix, so checkpoints and the trainer's call ``self.model(images, ta
 ``perturb(model, x, y) -> tensor | tuple``; the MI355X path injects
 ``functools.partial(apgd_train, ...)`` from ``revisiting_at_amd.config.build_perturb``.
 """
-import time
-
 import torch.nn as nn
 
 
@@ -15,6 +13,8 @@ class WrappedModel(nn.Module):
     """Generates the adversarial perturbation inside the forward pass."""
 
     def __init__(self, base_model, perturb, verbose=False):
+        # `verbose` is kept for signature compatibility; the reference's un-synchronised wall-clock prints
+        # (main.py:280-287) are diagnostics, not interface, and are not reproduced
         super().__init__()
         self.base_model = base_model
         self.perturb = perturb
@@ -25,18 +25,11 @@ class WrappedModel(nn.Module):
         if self.perturb_input:
             assert y is not None                               # main.py:276
             self.base_model.eval()                             # attack runs in eval mode (main.py:279)
-            if self.verbose:
-                print('perturb input')
-                startt = time.time()
             z = self.perturb(self.base_model, x, y)            # main.py:283
-            if self.verbose:
-                print(f'inference time={time.time() - startt:.5f}')
             self.base_model.train()                            # main.py:289
             if isinstance(z, (tuple, list)):
                 z = z[0]                                       # x_best (main.py:291-292)
             return self.base_model(z)
-        if self.verbose:
-            print('clean inference')
         return self.base_model(x)
 
     def set_perturb(self, mode):

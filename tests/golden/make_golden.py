@@ -122,7 +122,7 @@ def run_case(name, model, x, y, norm, eps, n_iter, soft=False, keep_fed=False, l
     rec = Recorder(model).eval()
     mixup = object() if soft else None
     xb, acc, lb, xba = ref.apgd_train(rec, x, y, norm=norm, eps=eps, n_iter=n_iter, mixup=mixup, loss=loss)
-    assert len(rec.logits) == n_iter + 1 and len(rec.grads) == n_iter, (len(rec.logits), len(rec.grads))
+    assert len(rec.logits) == n_iter + 1 and len(rec.grads) == max(n_iter, 1), (len(rec.logits), len(rec.grads))   # K = 0 still runs fwd/bwd #0
     logits = torch.stack(rec.logits)
     losses = torch.stack([ref.criterion_dict[loss](l, y) for l in rec.logits])   # the reference's own criterion
     out = dict(
@@ -166,6 +166,13 @@ def main():
         x = torch.rand(6, 3, 12, 12, generator=g)
         y = labels_for(m, x, 10, g)
         run_case(f"linf_k{k}", m, x, y, "Linf", 4 / 255, k, keep_fed=(k <= 3))
+    # --- n_iter = 0: `range(0)` (:209) - one forward/backward, the clamped clean point comes back (inputs partly outside [0,1])
+    g = torch.Generator().manual_seed(99)
+    torch.manual_seed(99)
+    m = ToyConv()
+    x = torch.rand(5, 3, 12, 12, generator=g) * 1.2 - 0.1
+    y = labels_for(m, x.clamp(0, 1), 10, g)
+    run_case("linf_k0", m, x, y, "Linf", 4 / 255, 0, keep_fed=True)
     for k, eps in ((25, 8 / 255), (100, 8 / 255)):
         g = torch.Generator().manual_seed(200 + k)
         torch.manual_seed(50 + k)

@@ -132,5 +132,21 @@ def main():
     record("normalize_model", nm, torch.rand(1, 3, 8, 8, generator=g))
 
 
+def pos_embed_fixture():
+    """``interpolate_pos_encoding`` (utils_architecture.py:22-53): a 14x14(+cls) table resized for 320, 256 and 224."""
+    g = torch.Generator().manual_seed(7)
+    pe = torch.randn(1, 197, 12, generator=g)
+    blob = dict(pos_embed=pe.numpy())
+    for res in (320, 256, 224):
+        blob[f"out_{res}"] = ua.interpolate_pos_encoding(pe, res, old_img_size=224, patch_size=16).numpy()
+    path = os.path.join(HERE, "model_pos_embed.npz")
+    np.savez_compressed(path, **blob)
+    print("pos_embed", {k: v.shape for k, v in blob.items()}, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["pos_embed"]:
+        pos_embed_fixture()
+    else:
+        main()
+        pos_embed_fixture()

@@ -48,11 +48,36 @@ def _worker(rank, world, port, q):
     torch.set_num_threads(1)
     r, l, w = R.setup_distributed()
     assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
-    n_coll = {"n": 0}
-    real_ar = dist.all_reduce
+    # Count every exchange and where it happens: DDP's bucket reductions go through a comm hook (the C++ reducer does not
+    # call the Python-level collectives), the Python-level collectives are wrapped.  `in_attack` is raised by the perturb
+    # callable, i.e. exactly for the span WrappedModel spends inside the attack (main.py:283).
+    st = {"in_attack": False, "hook_in_attack": 0, "hook_total": 0, "py_in_attack": 0}
+
+    def attack(model, x, y):
+        st["in_attack"] = True
+        try:
+            return _sign_attack(model, x, y)
+        finally:
+            st["in_attack"] = False
+
+    for name in ("all_reduce", "broadcast", "all_gather", "reduce_scatter", "barrier", "all_to_all", "reduce"):
+        real = getattr(dist, name)
+
+        def counted(*a, _real=real, **kw):
+            if st["in_attack"]:
+                st["py_in_attack"] += 1
+            return _real(*a, **kw)
+        setattr(dist, name, counted)
 
     tr = R.ATTrainStep(_model(), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=True, channels_last=False,
-                       amp_dtype=None, ema=True, perturb=_sign_attack)
+                       amp_dtype=None, ema=True, perturb=attack)
+
+    def hook(_, bucket):
+        st["hook_total"] += 1
+        st["hook_in_attack"] += int(st["in_attack"])
+        fut = dist.all_reduce(bucket.buffer().div_(world), async_op=True).get_future()
+        return fut.then(lambda f: f.value()[0])
+    tr.model.register_comm_hook(None, hook)
     x, y = _data(8)
     xs, ys = x[rank::world], y[rank::world]                 # DistributedSampler-style disjoint shards (main.py:567)
     losses = [float(tr.step(xs, ys)) for _ in range(3)]
@@ -63,7 +88,7 @@ def _worker(rank, world, port, q):
     if rank == 0:
         q.put(dict(params=flat, same=bool(all(torch.equal(gathered[0], t) for t in gathered)), losses=losses,
                    ema_moved=bool(not torch.equal(ema0, tr.inner.state_dict()[list(tr.inner.state_dict())[0]])),
-                   training=tr.model.training, keys=list(tr.model.state_dict())[:2]))
+                   training=tr.model.training, keys=list(tr.model.state_dict())[:2], coll=dict(st)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,6 +107,10 @@ def test_ddp_world2_matches_single_process():
     assert res["same"], "ranks diverged: gradients were not all-reduced"
     assert res["training"] and res["keys"][0].startswith("module.base_model.")      # DDP(WrappedModel(model))
     assert res["ema_moved"]
+    # no inter-rank traffic inside the attack; the only exchange is the gradient all-reduce of the
+    # outer backward (>= 1 bucket per step, 3 steps)
+    assert res["coll"]["hook_in_attack"] == 0 and res["coll"]["py_in_attack"] == 0, res["coll"]
+    assert res["coll"]["hook_total"] >= 3, res["coll"]
     # single process, whole batch: DDP averages per-rank mean losses == mean over the full batch (equal shards)
     torch.set_num_threads(1)
     tr = R.ATTrainStep(_model(), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=False, channels_last=False,

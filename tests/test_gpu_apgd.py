@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 LINF = [c for c in golden_cases() if c.startswith("linf")]
 L2 = [c for c in golden_cases() if c.startswith("l2")]
-TIE_FREE = ["linf_k1", "linf_k2", "linf_k3", "linf_cl_k3", "linf_flat_k5", "linf_scripted_k4", "linf_soft_k2",
+TIE_FREE = ["linf_k0", "linf_k1", "linf_k2", "linf_k3", "linf_cl_k3", "linf_flat_k5", "linf_scripted_k4", "linf_soft_k2",
             "linf_dlr_k5"]
 
 

@@ -1,0 +1,97 @@
+"""N > 1 on real GPUs: one process per GPU over RCCL (backend "nccl"), as ``main.py:351-359, 889-890, 1128-1152``.
+Skipped on a 1-GPU box (the round's GPU box has one); the CPU twin with gloo is tests/test_ddp_gloo.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_on_one_gpu_box_refuses_two_ranks():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs: covered by the two-rank test")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_bench_spawns_two_rccl_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["scaling"] == "weak"
+
+
+_WORKER = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import revisiting_at_amd as R
+rank, local, world = R.setup_distributed()
+assert dist.get_backend() == "nccl" and world == 2
+dev = torch.device("cuda", local)
+torch.manual_seed(0)
+A = R.architecture
+m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
+m.stem = A.ConvBlock1(48)
+st = {"in_attack": False, "hook_in_attack": 0, "hook_total": 0}
+real_attack = R.build_perturb(R.AdvConfig(attack="apgd", n_iter=2))
+def attack(model, x, y):
+    st["in_attack"] = True
+    try:
+        return real_attack(model, x, y)
+    finally:
+        st["in_attack"] = False
+tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2), dev, lr=1e-3, distributed=True, ema=True,
+                   perturb=attack)
+def hook(_, bucket):
+    st["hook_total"] += 1
+    st["hook_in_attack"] += int(st["in_attack"])
+    fut = dist.all_reduce(bucket.buffer().div_(world), async_op=True).get_future()
+    return fut.then(lambda f: f.value()[0])
+tr.model.register_comm_hook(None, hook)
+g = torch.Generator(device=dev).manual_seed(100 + rank)
+x = torch.rand(4, 3, 64, 64, device=dev, generator=g)
+y = torch.randint(0, 10, (4,), device=dev, generator=g)
+for _ in range(2):
+    tr.step(x, y)
+flat = torch.cat([p.detach().flatten() for p in tr.inner.parameters()])
+other = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(other, flat)
+ok = all(torch.equal(other[0], t) for t in other)
+if rank == 0:
+    print(json.dumps(dict(same=bool(ok), **st)))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_two_rccl_ranks_keep_identical_parameters_and_no_collective_inside_the_attack(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, text=True))
+    out = procs[0].communicate(timeout=900)[0]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["same"] and res["hook_in_attack"] == 0 and res["hook_total"] >= 2, res
