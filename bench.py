@@ -256,26 +256,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    # roofline of the dominant hand-written kernel (APGD Linf update)
-    k1 = [(i, a.elapsed_time(b)) for (name, i, a, b) in events if name == "apgd_linf_step_f32"]
-    k1_ms = [t for _, t in k1]
+    # roofline of the dominant hand-written kernel (APGD Linf update), its two forms reported separately:
+    #   general (i >= 1): 20 algorithmic B/elem - the `roofline` object;
+    #   first   (i == 0): x_adv_old aliases x_adv, 16 algorithmic B/elem - `roofline.first_iter`.
+    # `achieved` = algorithmic bytes / HIP-event time measured here; `traffic` = HBM bytes per launch of the same kernel
+    # form from the PMC passes (profiles/k1_traffic.json).  With int8 gradient signs the kernel moves 17 / 13 B/elem, i.e.
+    # LESS than the algorithmic figure: `bytes_moved` and `moved_GBs` state that side by side.
     n_elem = B * 3 * args.res * args.res
-    roof = None
-    if k1_ms:
-        avg_ms = sum(k1_ms) / len(k1_ms)
-        alg_bytes = sum((K1_BYTES_PER_ELEM_IT0 if i == 0 else K1_BYTES_PER_ELEM) * n_elem for i, _ in k1)
-        ach = alg_bytes / (sum(k1_ms) * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    traffic_tab = {}
+    try:
+        traffic_tab = json.load(open(os.path.join(ROOT, "profiles", "k1_traffic.json"))).get("variants", {})
+    except Exception:
+        pass
+
+    def k1_entry(sel, alg_bpe, form):
+        ev = [(a.elapsed_time(b), gb) for (name, i, a, b, gb) in events if name == "apgd_linf_step_f32" and sel(i)]
+        if not ev:
+            return None
+        avg_ms = sum(t for t, _ in ev) / len(ev)
+        gbytes = ev[0][1]
+        moved_bpe = alg_bpe - 4 + gbytes
+        ach = alg_bpe * n_elem / (avg_ms * 1e-3) / 1e9
+        tr = traffic_tab.get(f"{form}_{'i8' if gbytes == 1 else 'f32'}", {})
+        traffic = tr.get("hbm_bytes_per_launch") if n_elem * alg_bpe == tr.get("algorithmic_bytes_per_launch") else None
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "linf_step_vec4_kernel (apgd_linf_step_f32)", "launches": len(k1_ms),
-                "avg_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bytes / len(k1_ms)}
+                "kernel": ("linf_step_vec4_kernel" if form == "general" else "linf_step_first_vec4_kernel")
+                          + f" (apgd_linf_step_f32, {'int8 sign' if gbytes == 1 else 'fp32'} gradient)",
+                "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bpe * n_elem,
+                "bytes_moved": moved_bpe * n_elem, "moved_GBs": round(moved_bpe * n_elem / (avg_ms * 1e-3) / 1e9, 1)}
+
+    roof = k1_entry(lambda i: i > 0, K1_BYTES_PER_ELEM, "general")
+    first = k1_entry(lambda i: i == 0, K1_BYTES_PER_ELEM_IT0, "first")
+    if roof is None:
+        roof, first = first, None
+    if roof is not None and first is not None:
+        roof["first_iter"] = first
 
     extra = {}
     if args.attack_only or True:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define APGD_HIP_VERSION 10100 /* major*10000 + minor*100 + patch */
+#define APGD_HIP_VERSION 10200 /* major*10000 + minor*100 + patch */
 
 #define APGD_OK 0
 #define APGD_ERR_NULL (-1)    /* required pointer is NULL */
@@ -43,6 +43,7 @@ extern "C" {
 #define APGD_F32 0
 #define APGD_BF16 1
 #define APGD_F16 2
+#define APGD_I8 3 /* gradient SIGNS {-1, 0, +1} as int8: all the Linf step uses of the gradient (autopgd_train_clean.py:221) */
 
 /* bits of the per-sample flag byte produced by apgd_state_update */
 #define APGD_FLAG_NEW_BEST 1u  /* loss_indiv > loss_best          (autopgd_train_clean.py:321)      */
@@ -63,7 +64,8 @@ int apgd_init_f32(const float* x, float* x_adv, float* x_best, float* x_best_adv
  *   x1    = P(x_adv + step[b]*sign(grad))                      P(t)=clamp(min(max(t,x-eps),x+eps),0,1)
  *   out   = P((x_adv + (x1 - x_adv)*a) + grad2*(1-a))
  * `x_adv_old = x_adv.clone()` (:215) is a buffer rotation on the host: out must not alias an input.
- * grad is fp32 or bf16 (grad_dtype; only its sign is used).  out_bf16 (nullable) receives
+ * grad is fp32, bf16 or APGD_I8 signs (grad_dtype; only its sign is used: with int8 signs the kernel moves 17
+ * instead of 20 bytes per element, 13 instead of 16 at i = 0).  out_bf16 (nullable) receives
  * round-to-nearest-even bf16(out) for a bf16 model input.  step_size is [B]. */
 int apgd_linf_step_f32(const float* x, const float* x_adv, const float* x_adv_old,
                        const void* grad, int grad_dtype, const float* step_size,
@@ -132,7 +134,7 @@ int apgd_state_update(const float* loss, const uint8_t* pred,
  * `final` != 0 (last iteration): only the copies that reach the return tuple are done
  * (grad is stale there, :281-283, and x_adv/grad are never read again).
  * grad / grad_best may be NULL together (no gradient tracked).  grad_elt = bytes per grad
- * element (4 fp32, 2 bf16). */
+ * element (4 fp32, 2 bf16, 1 int8 signs). */
 int apgd_track_rows(const uint8_t* flags, float* x_adv, void* grad, float* x_best,
                     void* grad_best, float* x_best_adv, int32_t grad_elt,
                     int64_t B, int64_t E, int32_t final, void* stream);

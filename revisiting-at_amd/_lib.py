@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libapgd_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, I8 = 0, 1, 2, 3
 FLAG_NEW_BEST, FLAG_MISCLS, FLAG_HALVE = 1, 2, 4
 
 _p, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -56,6 +56,7 @@ PROTOTYPES = {
     "cnx_stem_conv_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_ln_gelu_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_dgrad": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_stem_conv_dgrad_sign": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_colsum_ws_floats": (C.c_int64, [_i32]),
     "cnx_sum_parts_bf16": (C.c_int, [_p, _p, _i64, _i64, _p]),
     "cnx_scale_residual": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int, _i64, _i32, _p]),
@@ -122,6 +123,8 @@ def dtype_code(t) -> int:
         return BF16
     if t == torch.float16:
         return F16
+    if t == torch.int8:
+        return I8                                   # gradient signs (apgd_linf_step_f32 / cnx_stem_conv_dgrad_sign)
     raise ApgdHipError(f"unsupported dtype {t}")
 
 

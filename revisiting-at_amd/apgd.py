@@ -18,6 +18,7 @@ There is no CPU fallback: CPU tensors or a missing ``libapgd_hip.so`` raise.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import List, Optional, Tuple
 
@@ -28,8 +29,12 @@ from . import _lib, ops
 __all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "ApgdWorkspace"]
 
 # bench.py sets this to a list to have every Linf-update launch bracketed by HIP events recorded on
-# the stream the kernel runs on: entries are (name, iteration, start_event, end_event).
+# the stream the kernel runs on: entries are (name, iteration, start_event, end_event, gradient element bytes).
 PROFILE_EVENTS = None
+
+# Linf only reads sign(grad) (:221): let our own stem kernel hand the attack int8 signs instead of the fp32 gradient
+# (ops.grad_sign_sink).  Same decisions bit for bit; 17 instead of 20 bytes per element in the update kernel.
+USE_SIGN_SINK = True
 
 # losses the reference's criterion_dict names (autopgd_train_clean.py:113-114)
 criterion_names = ("ce", "softloss", "dlr", "dlr-targeted")
@@ -125,7 +130,7 @@ class ApgdWorkspace:
 
 
 def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace, loss_out, pred_out,
-                   need_grad: bool, kind: int = 0, y_target=None):
+                   need_grad: bool, kind: int = 0, y_target=None, sign_ok: bool = False):
     """One model call of the attack: forward, K2, and (optionally) the input gradient.
 
     ``autopgd_train_clean.py:174-192`` (first call) and ``:266-287`` (in-loop calls; the last
@@ -138,9 +143,13 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
         dl = _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, True, kind, *(() if y_target is None else (y_target,)))
         if dl.shape != logits.shape or dl.dtype != logits.dtype:
             raise _lib.ApgdHipError("dlogits/logits mismatch")
-        with ops.input_grad_only():
+        # the sink is opened for Linf only: the L2 step needs the gradient's values
+        sink = ops.grad_sign_sink(x_in) if (sign_ok and USE_SIGN_SINK) else contextlib.nullcontext()
+        with ops.input_grad_only(), sink:
             grad = torch.autograd.grad([logits], [x_in], grad_outputs=[dl.view_as(logits)])[0].detach()
         x_in.requires_grad_(False)
+        if getattr(sink, "signs", None) is not None:
+            return sink.signs                                # int8 sign(grad), x_in's shape and (contiguous) layout
         if grad.stride() != x_in.stride():
             g2 = torch.empty_like(x_in, dtype=grad.dtype)
             g2.copy_(grad)
@@ -226,7 +235,8 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
         l2_ws = torch.empty(3 * B * lib.apgd_l2_parts(), device=x.device, dtype=torch.float32)
 
     # first forward/backward: acc, loss_best are written directly by the loss kernel (:194-200)
-    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target)
+    sign_ok = norm == 'Linf'
+    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok)
     grad_best = torch.empty_like(grad)                                       # :189
     grad_best.copy_(grad)
     ws.loss_best_last.copy_(ws.loss_best)                                    # :200
@@ -247,7 +257,7 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
             if PROFILE_EVENTS is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
-                PROFILE_EVENTS.append(("apgd_linf_step_f32", i, ev0, ev1))
+                PROFILE_EVENTS.append(("apgd_linf_step_f32", i, ev0, ev1, grad.element_size()))
         else:
             _lib.check(lib.apgd_l2_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(),
                                             step_size.data_ptr(), out.data_ptr(), l2_ws.data_ptr(), B, E, eps, a,
@@ -257,8 +267,10 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
         old, cur = cur, out                                                  # :215, 260 (buffer rotation)
 
         last = i == n_iter - 1
-        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind, y_target)   # :266-287
+        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind, y_target, sign_ok)   # :266-287
         if g_new is not None:
+            if g_new.dtype != grad_best.dtype:               # a model that switches gradient form mid-attack
+                g_new = torch.sign(g_new).to(grad_best.dtype) if grad_best.dtype == torch.int8 else g_new.to(grad_best.dtype)
             grad = g_new
 
         do_check = i in sched                                                # :329

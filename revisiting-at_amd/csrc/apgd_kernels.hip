@@ -144,6 +144,13 @@ __device__ __forceinline__ G4 ldg4(const float* p, int64_t v, bool nt) {
   const float4 t = ld4(p, v, nt);
   return {t.x, t.y, t.z, t.w};
 }
+// int8 signs {-1, 0, +1} (4 per dword): what the Linf step consumes of the gradient (:221, torch.sign)
+__device__ __forceinline__ G4 ldg4(const int8_t* p, int64_t v, bool nt) {
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p) + v;
+  const uint32_t t = nt ? __builtin_nontemporal_load(q) : *q;
+  return {static_cast<float>(static_cast<int8_t>(t & 0xffu)), static_cast<float>(static_cast<int8_t>((t >> 8) & 0xffu)),
+          static_cast<float>(static_cast<int8_t>((t >> 16) & 0xffu)), static_cast<float>(static_cast<int8_t>(t >> 24))};
+}
 __device__ __forceinline__ G4 ldg4(const uint16_t* p, int64_t v, bool nt) {
   const u32x2* q = reinterpret_cast<const u32x2*>(p) + v;     // 4 bf16 = 8 bytes
   const u32x2 t = nt ? __builtin_nontemporal_load(q) : *q;
@@ -663,31 +670,22 @@ int apgd_init_f32(const float* x, float* x_adv, float* x_best, float* x_best_adv
   return launch_status();
 }
 
-// Tunable form (used by bench/microbench sweeps): blocks_per_sample <= 0 and unroll <= 0 pick defaults.
-int apgd_linf_step_f32_ex(const float* x, const float* x_adv, const float* x_adv_old, const void* grad,
-                          int grad_dtype, const float* step_size, float* out, uint16_t* out_bf16, int64_t B,
-                          int64_t E, float eps, float a, int32_t blocks_per_sample, int32_t unroll,
-                          int32_t nontemporal, void* stream) {
-  if (B < 0 || E < 0) return APGD_ERR_SIZE;
-  if (B == 0 || E == 0) return APGD_OK;
-  if (!x || !x_adv || !x_adv_old || !grad || !step_size || !out) return APGD_ERR_NULL;
-  if (grad_dtype != APGD_F32 && grad_dtype != APGD_BF16) return APGD_ERR_DTYPE;
-  if (B > 65535) return APGD_ERR_SIZE;
-  if (out == x || out == x_adv || out == x_adv_old || out == grad) return APGD_ERR_ARG;
-  hipStream_t s = as_stream(stream);
-  const bool g16 = grad_dtype == APGD_BF16;
-  const bool vec = (E % 4 == 0) && aligned16(x) && aligned16(x_adv) && aligned16(x_adv_old) && aligned16(out) &&
-                   (reinterpret_cast<uintptr_t>(grad) % (g16 ? 8 : 16) == 0) &&
-                   (!out_bf16 || reinterpret_cast<uintptr_t>(out_bf16) % 8 == 0);
+}  // extern "C"
+
+namespace {
+template <> struct Elt<int8_t> {    // gradient signs
+  static __device__ __forceinline__ float load(const int8_t* p, int64_t i) { return static_cast<float>(p[i]); }
+};
+
+template <typename GT>
+int linf_dispatch(const float* x, const float* x_adv, const float* x_adv_old, const GT* g, const float* step_size,
+                  float* out, uint16_t* out_bf16, int64_t B, int64_t E, float eps, float a, int32_t blocks_per_sample,
+                  int32_t unroll, int32_t nontemporal, bool vec, hipStream_t s) {
   if (!vec) {
     const dim3 grid(blocks_for(E, kBlock * 4, 64), static_cast<unsigned>(B));
     const float oma = static_cast<float>(1.0 - static_cast<double>(a));
-    if (g16)
-      hipLaunchKernelGGL(linf_step_scalar_kernel<uint16_t>, grid, dim3(kBlock), 0, s, x, x_adv, x_adv_old,
-                         static_cast<const uint16_t*>(grad), step_size, out, out_bf16, E, eps, a, oma);
-    else
-      hipLaunchKernelGGL(linf_step_scalar_kernel<float>, grid, dim3(kBlock), 0, s, x, x_adv, x_adv_old,
-                         static_cast<const float*>(grad), step_size, out, out_bf16, E, eps, a, oma);
+    hipLaunchKernelGGL(linf_step_scalar_kernel<GT>, grid, dim3(kBlock), 0, s, x, x_adv, x_adv_old, g, step_size, out,
+                       out_bf16, E, eps, a, oma);
     return launch_status();
   }
   const int U = unroll > 0 ? unroll : 1;
@@ -698,33 +696,54 @@ int apgd_linf_step_f32_ex(const float* x, const float* x_adv, const float* x_adv
     // as many workgroups as that takes (147 x 256 = 37632 here) beats block-stride loops by ~8 %
     bps = blocks_for(E4, static_cast<int64_t>(kBlock) * U, 65535);
   }
-  const float* gf = static_cast<const float*>(grad);
-  const uint16_t* gh = static_cast<const uint16_t*>(grad);
   if (x_adv_old == x_adv && a == 1.0f && blocks_per_sample <= 0 && unroll <= 0 && !nontemporal) {
     const dim3 grid(bps, static_cast<unsigned>(B));
-#define APGD_FIRST(GT, GP, BO)                                                                                   \
-  hipLaunchKernelGGL((linf_step_first_vec4_kernel<GT, BO>), grid, dim3(kBlock), 0, s, x, x_adv, GP, step_size, out, \
-                     out_bf16, E, eps)
-    if (g16) { if (out_bf16) APGD_FIRST(uint16_t, gh, true); else APGD_FIRST(uint16_t, gh, false); }
-    else { if (out_bf16) APGD_FIRST(float, gf, true); else APGD_FIRST(float, gf, false); }
-#undef APGD_FIRST
+    if (out_bf16)
+      hipLaunchKernelGGL((linf_step_first_vec4_kernel<GT, true>), grid, dim3(kBlock), 0, s, x, x_adv, g, step_size, out,
+                         out_bf16, E, eps);
+    else
+      hipLaunchKernelGGL((linf_step_first_vec4_kernel<GT, false>), grid, dim3(kBlock), 0, s, x, x_adv, g, step_size, out,
+                         out_bf16, E, eps);
     return launch_status();
   }
-#define APGD_DISPATCH_U(UU)                                                                                          \
-  if (U == UU) {                                                                                                     \
-    if (nontemporal)                                                                                                 \
-      return g16 ? launch_linf_vec4<uint16_t, UU, true>(x, x_adv, x_adv_old, gh, step_size, out, out_bf16, B, E, eps, \
-                                                        a, bps, s)                                                   \
-                 : launch_linf_vec4<float, UU, true>(x, x_adv, x_adv_old, gf, step_size, out, out_bf16, B, E, eps, a, \
-                                                     bps, s);                                                        \
-    return g16 ? launch_linf_vec4<uint16_t, UU, false>(x, x_adv, x_adv_old, gh, step_size, out, out_bf16, B, E, eps, \
-                                                       a, bps, s)                                                    \
-               : launch_linf_vec4<float, UU, false>(x, x_adv, x_adv_old, gf, step_size, out, out_bf16, B, E, eps, a, \
-                                                    bps, s);                                                         \
+#define APGD_DISPATCH_U(UU)                                                                                              \
+  if (U == UU) {                                                                                                         \
+    if (nontemporal)                                                                                                     \
+      return launch_linf_vec4<GT, UU, true>(x, x_adv, x_adv_old, g, step_size, out, out_bf16, B, E, eps, a, bps, s);    \
+    return launch_linf_vec4<GT, UU, false>(x, x_adv, x_adv_old, g, step_size, out, out_bf16, B, E, eps, a, bps, s);     \
   }
   APGD_DISPATCH_U(1) APGD_DISPATCH_U(2) APGD_DISPATCH_U(4)
 #undef APGD_DISPATCH_U
   return APGD_ERR_ARG;
+}
+}  // namespace
+
+extern "C" {
+
+// Tunable form (used by bench/microbench sweeps): blocks_per_sample <= 0 and unroll <= 0 pick defaults.
+int apgd_linf_step_f32_ex(const float* x, const float* x_adv, const float* x_adv_old, const void* grad,
+                          int grad_dtype, const float* step_size, float* out, uint16_t* out_bf16, int64_t B,
+                          int64_t E, float eps, float a, int32_t blocks_per_sample, int32_t unroll,
+                          int32_t nontemporal, void* stream) {
+  if (B < 0 || E < 0) return APGD_ERR_SIZE;
+  if (B == 0 || E == 0) return APGD_OK;
+  if (!x || !x_adv || !x_adv_old || !grad || !step_size || !out) return APGD_ERR_NULL;
+  if (grad_dtype != APGD_F32 && grad_dtype != APGD_BF16 && grad_dtype != APGD_I8) return APGD_ERR_DTYPE;
+  if (B > 65535) return APGD_ERR_SIZE;
+  if (out == x || out == x_adv || out == x_adv_old || out == grad) return APGD_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  const int galign = grad_dtype == APGD_F32 ? 16 : (grad_dtype == APGD_BF16 ? 8 : 4);
+  const bool vec = (E % 4 == 0) && aligned16(x) && aligned16(x_adv) && aligned16(x_adv_old) && aligned16(out) &&
+                   (reinterpret_cast<uintptr_t>(grad) % galign == 0) &&
+                   (!out_bf16 || reinterpret_cast<uintptr_t>(out_bf16) % 8 == 0);
+  if (grad_dtype == APGD_F32)
+    return linf_dispatch(x, x_adv, x_adv_old, static_cast<const float*>(grad), step_size, out, out_bf16, B, E, eps, a,
+                         blocks_per_sample, unroll, nontemporal, vec, s);
+  if (grad_dtype == APGD_BF16)
+    return linf_dispatch(x, x_adv, x_adv_old, static_cast<const uint16_t*>(grad), step_size, out, out_bf16, B, E, eps, a,
+                         blocks_per_sample, unroll, nontemporal, vec, s);
+  return linf_dispatch(x, x_adv, x_adv_old, static_cast<const int8_t*>(grad), step_size, out, out_bf16, B, E, eps, a,
+                       blocks_per_sample, unroll, nontemporal, vec, s);
 }
 
 int apgd_linf_step_f32(const float* x, const float* x_adv, const float* x_adv_old, const void* grad, int grad_dtype,
@@ -848,7 +867,7 @@ int apgd_track_rows(const uint8_t* flags, float* x_adv, void* grad, float* x_bes
   if (B == 0 || E == 0) return APGD_OK;
   if (!flags || !x_adv || !x_best || !x_best_adv) return APGD_ERR_NULL;
   if ((grad == nullptr) != (grad_best == nullptr)) return APGD_ERR_ARG;
-  if (grad && grad_elt != 4 && grad_elt != 2) return APGD_ERR_DTYPE;
+  if (grad && grad_elt != 4 && grad_elt != 2 && grad_elt != 1) return APGD_ERR_DTYPE;
   if (B > 65535) return APGD_ERR_SIZE;
   const int ge = grad ? grad_elt : 4;
   const bool vec16 = ((E * 4) % 16 == 0) && ((E * ge) % 16 == 0) && aligned16(x_adv) && aligned16(x_best) &&

@@ -199,9 +199,21 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
   }
 }
 
-template <int P>
+// TO = float: the input gradient itself;  TO = int8_t: its SIGN {-1, 0, +1} (sign(NaN) = 0, as torch.sign on the
+// reference's path) - all the Linf update reads of the gradient (autopgd_train_clean.py:221), a quarter of the bytes.
+template <typename TO>
+__device__ __forceinline__ void st_pair(TO* p, float a, float b) {
+  if constexpr (sizeof(TO) == 4) {
+    *reinterpret_cast<float2*>(p) = make_float2(a, b);
+  } else {
+    const int sa = (a > 0.f) - (a < 0.f), sb = (b > 0.f) - (b < 0.f);
+    *reinterpret_cast<uint16_t*>(p) = static_cast<uint16_t>((sa & 0xff) | ((sb & 0xff) << 8));
+  }
+}
+
+template <int P, typename TO>
 __global__ __launch_bounds__(256) void stem_conv_dgrad_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ wq,
-                                                              float* __restrict__ dx, long total, int H, int W, int OH, int OW) {
+                                                              TO* __restrict__ dx, long total, int H, int W, int OH, int OW) {
   using G = StemGeo<P>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
   bf16x8 wa[G::KD];
@@ -230,17 +242,17 @@ __global__ __launch_bounds__(256) void stem_conv_dgrad_kernel(const uint16_t* __
     }
     // acc[rr] = D[o = (rr&3) + 8*(rr>>2) + 4*half][patch = l32], o = ci*4 + i*2 + j
     if (ok) {
-      float* xn = dx + n * 3 * static_cast<long>(H) * W;
+      TO* xn = dx + n * 3 * static_cast<long>(H) * W;
       if (half == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          *reinterpret_cast<float2*>(xn + (0L * H + 2 * a + i) * W + 2 * b) = make_float2(acc[2 * i], acc[2 * i + 1]);            // ci = 0: o = 0..3
-          *reinterpret_cast<float2*>(xn + (2L * H + 2 * a + i) * W + 2 * b) = make_float2(acc[4 + 2 * i], acc[4 + 2 * i + 1]);    // ci = 2: o = 8..11
+          st_pair(xn + (0L * H + 2 * a + i) * W + 2 * b, acc[2 * i], acc[2 * i + 1]);            // ci = 0: o = 0..3
+          st_pair(xn + (2L * H + 2 * a + i) * W + 2 * b, acc[4 + 2 * i], acc[4 + 2 * i + 1]);    // ci = 2: o = 8..11
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          *reinterpret_cast<float2*>(xn + (1L * H + 2 * a + i) * W + 2 * b) = make_float2(acc[2 * i], acc[2 * i + 1]);            // ci = 1: o = 4..7
+          st_pair(xn + (1L * H + 2 * a + i) * W + 2 * b, acc[2 * i], acc[2 * i + 1]);            // ci = 1: o = 4..7
       }
     }
   }
@@ -313,7 +325,7 @@ int cnx_stem_conv_ln_gelu_fwd(const float* x, const void* wq, const float* bias,
   return launch_status();
 }
 
-int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx, int64_t N, int32_t H, int32_t W, int32_t P, void* stream) {
+static int stem_dgrad_impl(const void* dy, const void* wq, void* dx, bool sign, int64_t N, int32_t H, int32_t W, int32_t P, void* stream) {
   if (N < 0 || H <= 0 || W <= 0) return APGD_ERR_SIZE;
   if (N == 0) return APGD_OK;
   if (!dy || !wq || !dx) return APGD_ERR_NULL;
@@ -326,10 +338,27 @@ int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx, int64_t N, in
   hipStream_t s = as_stream(stream);
   const auto* d = static_cast<const uint16_t*>(dy);
   const auto* q = static_cast<const uint16_t*>(wq);
-  if (P == 48) hipLaunchKernelGGL(stem_conv_dgrad_kernel<48>, grid, block, 0, s, d, q, dx, total, H, W, OH, OW);
-  else if (P == 64) hipLaunchKernelGGL(stem_conv_dgrad_kernel<64>, grid, block, 0, s, d, q, dx, total, H, W, OH, OW);
-  else hipLaunchKernelGGL(stem_conv_dgrad_kernel<96>, grid, block, 0, s, d, q, dx, total, H, W, OH, OW);
+  if (sign) {
+    auto* o = static_cast<int8_t*>(dx);
+    if (P == 48) hipLaunchKernelGGL((stem_conv_dgrad_kernel<48, int8_t>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+    else if (P == 64) hipLaunchKernelGGL((stem_conv_dgrad_kernel<64, int8_t>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+    else hipLaunchKernelGGL((stem_conv_dgrad_kernel<96, int8_t>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+  } else {
+    auto* o = static_cast<float*>(dx);
+    if (P == 48) hipLaunchKernelGGL((stem_conv_dgrad_kernel<48, float>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+    else if (P == 64) hipLaunchKernelGGL((stem_conv_dgrad_kernel<64, float>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+    else hipLaunchKernelGGL((stem_conv_dgrad_kernel<96, float>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+  }
   return launch_status();
+}
+
+int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx, int64_t N, int32_t H, int32_t W, int32_t P, void* stream) {
+  return stem_dgrad_impl(dy, wq, dx, false, N, H, W, P, stream);
+}
+
+int cnx_stem_conv_dgrad_sign(const void* dy, const void* wq, int8_t* sign_out, int64_t N, int32_t H, int32_t W, int32_t P,
+                             void* stream) {
+  return stem_dgrad_impl(dy, wq, sign_out, true, N, H, W, P, stream);
 }
 
 }  // extern "C"

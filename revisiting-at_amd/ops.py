@@ -47,6 +47,61 @@ class input_grad_only:
         return False
 
 
+# Gradient-sign sink of the Linf attack.  ``step_size * sign(grad)`` (autopgd_train_clean.py:221) is the only use the Linf
+# update makes of the input gradient, so when the layer that produces it is our own first stem convolution AND its input
+# is the attack iterate itself, the attack hands it an int8 buffer: the kernel stores sign(dx) (a quarter of the bytes)
+# taken from the same fp32 accumulator it would have stored, and autograd gets a stride-0 zero in place of dx.
+_SIGN_SINK = None
+
+
+class grad_sign_sink:
+    """``with grad_sign_sink(x_in) as sink: autograd.grad(...)`` - afterwards ``sink.signs`` is the int8 sign tensor
+    (same shape / layout as ``x_in``) if the stem kernel produced it, else None (the caller uses autograd's gradient)."""
+
+    def __init__(self, x_in):
+        self.x_in, self.signs, self._buf = x_in, None, None
+
+    def buffer(self):
+        if self._buf is None:
+            self._buf = torch.empty(self.x_in.shape, device=self.x_in.device, dtype=torch.int8)
+        return self._buf
+
+    def __enter__(self):
+        global _SIGN_SINK
+        self._prev = _SIGN_SINK
+        _SIGN_SINK = self
+        return self
+
+    def __exit__(self, *exc):
+        global _SIGN_SINK
+        _SIGN_SINK = self._prev
+        return False
+
+
+def _sink_for(x):
+    """The active sink if ``x`` (the stem convolution's saved input) is the attack iterate it was opened for."""
+    sk = _SIGN_SINK
+    if (sk is not None and _INPUT_GRAD_ONLY and x.data_ptr() == sk.x_in.data_ptr() and x.shape == sk.x_in.shape
+            and x.is_contiguous() and sk.x_in.is_contiguous()):
+        return sk
+    return None
+
+
+def _stem_dgrad(lib, x, gr, wq, N, H, W, P):
+    """Input gradient of the first stem convolution: int8 signs into the attack's sink, or fp32 dx."""
+    sk = _sink_for(x)
+    if sk is not None:
+        buf = sk.buffer()
+        _lib.check(lib.cnx_stem_conv_dgrad_sign(gr.data_ptr(), wq.data_ptr(), buf.data_ptr(), N, H, W, P, _stream()),
+                   "cnx_stem_conv_dgrad_sign")
+        sk.signs = buf
+        return torch.zeros((), device=x.device, dtype=x.dtype).expand(x.shape)
+    dx = torch.empty_like(x)
+    _lib.check(lib.cnx_stem_conv_dgrad(gr.data_ptr(), wq.data_ptr(), dx.data_ptr(), N, H, W, P, _stream()),
+               "cnx_stem_conv_dgrad")
+    return dx
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -311,9 +366,7 @@ class _StemConv(torch.autograd.Function):
             gr = gr.to(torch.bfloat16).contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            _lib.check(lib.cnx_stem_conv_dgrad(gr.data_ptr(), wq.data_ptr(), dx.data_ptr(), N, H, W, P, _stream()),
-                       "cnx_stem_conv_dgrad")
+            dx = _stem_dgrad(lib, x, gr, wq, N, H, W, P)
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY:
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             gb = gr.permute(0, 3, 1, 2)                                    # NCHW view of channels-last memory
@@ -377,9 +430,7 @@ class _StemConvLnGelu(torch.autograd.Function):
                                          _lib.ptr(ws), M, P, 1, _stream()), "cnx_layernorm_bwd")
         dx = dw = db = None
         if nig[0]:
-            dx = torch.empty_like(x)
-            _lib.check(lib.cnx_stem_conv_dgrad(dy.data_ptr(), wq.data_ptr(), dx.data_ptr(), N, H, W, P, _stream()),
-                       "cnx_stem_conv_dgrad")
+            dx = _stem_dgrad(lib, x, dy, wq, N, H, W, P)
         if (nig[1] or nig[2]) and not _INPUT_GRAD_ONLY:
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             gb = dy.permute(0, 3, 1, 2)                                    # NCHW view of channels-last memory

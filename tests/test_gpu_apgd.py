@@ -121,6 +121,54 @@ def test_linf_step_bit_exact(lib, B, E, a):
     assert torch.equal(ob, o3.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("B,E", [(3, 50), (2, 3 * 64 * 64), (7, 1021), (4, 3 * 224 * 224)])
+@pytest.mark.parametrize("a", [1.0, 0.75])
+def test_linf_step_with_int8_gradient_signs_is_bit_identical(lib, B, E, a):
+    """grad_dtype = APGD_I8: sign(grad) as int8 {-1, 0, +1} (sign(+-0) = sign(NaN) = 0) gives the bits of the fp32 call -
+    the update reads nothing else of the gradient (autopgd_train_clean.py:221) - in every launch form."""
+    eps = 4 / 255
+    x, xa, xo, g, step = _step_inputs(B, E, B * 77 + E, eps)
+    if a == 1.0:
+        xo = xa.copy()
+    want = O.linf_step(x, xa, xo, g, step, eps, a)
+    sg = np.zeros(g.shape, np.int8)
+    sg[g > 0] = 1
+    sg[g < 0] = -1
+    xd, xad, xod, sd = map(dev, (x, xa, xo, step))
+    sgd = torch.from_numpy(sg).cuda()
+    out = torch.zeros_like(xd)
+    xo_ptr = xad.data_ptr() if a == 1.0 else xod.data_ptr()                    # a == 1: the 3-stream first-iteration form
+    assert lib.apgd_linf_step_f32(xd.data_ptr(), xad.data_ptr(), xo_ptr, sgd.data_ptr(), 3, sd.data_ptr(),
+                                  out.data_ptr(), None, B, E, eps, a, S()) == 0
+    assert bits_equal(out.cpu().numpy(), want)
+    for bps, un, nt in [(1, 1, 0), (3, 2, 1), (8, 4, 0)]:
+        o2 = torch.zeros_like(xd)
+        assert lib.apgd_linf_step_f32_ex(xd.data_ptr(), xad.data_ptr(), xod.data_ptr(), sgd.data_ptr(), 3,
+                                         sd.data_ptr(), o2.data_ptr(), None, B, E, eps, a, bps, un, nt, S()) == 0
+        assert bits_equal(o2.cpu().numpy(), want), (bps, un, nt)
+    assert lib.apgd_linf_step_f32(xd.data_ptr(), xad.data_ptr(), xod.data_ptr(), sgd.data_ptr(), 7, sd.data_ptr(),
+                                  out.data_ptr(), None, B, E, eps, a, S()) == -3     # unknown dtype code
+
+
+def test_track_rows_moves_int8_sign_rows(lib):
+    B, E = 6, 3 * 16 * 16
+    g = torch.Generator(device="cuda").manual_seed(0)
+    flags = torch.tensor([0, 1, 2, 4, 5, 7], device="cuda", dtype=torch.uint8)
+    xa = torch.rand(B, E, device="cuda", generator=g)
+    xb, xba = torch.rand(B, E, device="cuda", generator=g), torch.rand(B, E, device="cuda", generator=g)
+    gr = torch.randint(-1, 2, (B, E), device="cuda", generator=g, dtype=torch.int8)
+    gb = torch.randint(-1, 2, (B, E), device="cuda", generator=g, dtype=torch.int8)
+    xa0, xb0, gr0, gb0 = xa.clone(), xb.clone(), gr.clone(), gb.clone()
+    assert lib.apgd_track_rows(flags.data_ptr(), xa.data_ptr(), gr.data_ptr(), xb.data_ptr(), gb.data_ptr(), xba.data_ptr(), 1, B, E,
+                               0, S()) == 0
+    for b, f in enumerate(flags.tolist()):
+        nb, rs = bool(f & 1), bool(f & 4) and not bool(f & 1)
+        assert torch.equal(gb[b], gr0[b] if nb else gb0[b])
+        assert torch.equal(gr[b], gb0[b] if rs else gr0[b])
+        assert torch.equal(xb[b], xa0[b] if nb else xb0[b])
+        assert torch.equal(xa[b], xb0[b] if rs else xa0[b])
+
+
 def test_linf_step_unaligned_rows(lib):
     eps, B, E = 8 / 255, 3, 64
     x, xa, xo, g, step = _step_inputs(B, E + 1, 5, eps)

@@ -507,6 +507,67 @@ def test_stem_image_conv_forward_and_input_gradient(R, P, N, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P,N,H,W", [(48, 2, 32, 32), (64, 1, 16, 24), (96, 3, 8, 8), (48, 2, 224, 224)])
+def test_stem_dgrad_sign_is_the_sign_of_the_stem_dgrad(R, P, N, H, W):
+    """cnx_stem_conv_dgrad_sign stores sign() of exactly the fp32 value cnx_stem_conv_dgrad stores (zero rows included)."""
+    lib = R._lib.load()
+    g = torch.Generator().manual_seed(P + H)
+    w = (torch.randn(P, 3, 3, 3, generator=g) * 0.3).cuda()
+    wq = R.ops._pack_stem(w)
+    dy = torch.randn(N, H // 2, W // 2, P, generator=g).to(torch.bfloat16).cuda()
+    dy[0, 0] = 0                                                          # a band of exactly-zero gradients
+    dx = torch.empty(N, 3, H, W, device="cuda")
+    sg = torch.full((N, 3, H, W), 9, device="cuda", dtype=torch.int8)
+    assert lib.cnx_stem_conv_dgrad(dy.data_ptr(), wq.data_ptr(), dx.data_ptr(), N, H, W, P, S()) == 0
+    assert lib.cnx_stem_conv_dgrad_sign(dy.data_ptr(), wq.data_ptr(), sg.data_ptr(), N, H, W, P, S()) == 0
+    assert torch.equal(sg, torch.sign(dx).to(torch.int8))
+    assert int((sg == 0).sum()) > 0 and int((sg == 1).sum()) > 0 and int((sg == -1).sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("soft", [False, True])
+def test_attack_with_the_gradient_sign_sink_equals_the_attack_without(R, monkeypatch, soft):
+    """apgd_train on the product ConvNeXt-T-CvSt with the int8 sign sink (default) and with fp32 gradients: every output
+    identical bit for bit (Linf); L2 never opens the sink."""
+    torch.manual_seed(4)
+    model = R.get_new_model("convnext_tiny", pretrained=False, not_original=True).cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("gamma"):
+                p.fill_(0.5)
+    model.eval()
+    x = torch.rand(4, 3, 64, 64, device="cuda")
+    y = torch.softmax(torch.randn(4, 1000, device="cuda"), 1) if soft else torch.tensor([1, 2, 3, 4], device="cuda")
+    outs = {}
+    for use in (True, False):
+        monkeypatch.setattr(R.apgd, "USE_SIGN_SINK", use)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outs[use] = R.apgd_train(model, x, y, norm="Linf", eps=4 / 255, n_iter=3, mixup=object() if soft else None)
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+    # the sink really is used on this model (an int8 gradient reaches the update kernel) ...
+    xi = x.clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(xi)
+    with R.ops.input_grad_only(), R.ops.grad_sign_sink(xi) as sk:
+        (gz,) = torch.autograd.grad([out], [xi], grad_outputs=[torch.ones_like(out)])
+    assert sk.signs is not None and sk.signs.dtype == torch.int8 and float(gz.abs().max()) == 0.0
+    xj = x.clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out2 = model(xj)
+    with R.ops.input_grad_only():
+        (g2,) = torch.autograd.grad([out2], [xj], grad_outputs=[torch.ones_like(out2)])
+    assert torch.equal(sk.signs, torch.sign(g2).to(torch.int8))
+    # ... and a sink opened for a different tensor is left alone
+    with R.ops.input_grad_only(), R.ops.grad_sign_sink(x.clone()) as other:
+        xk = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out3 = model(xk)
+        (g3,) = torch.autograd.grad([out3], [xk], grad_outputs=[torch.ones_like(out3)])
+    assert other.signs is None and torch.equal(g3, g2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S,shape", [(1, (8,)), (3, (5, 8)), (64, (96, 40)), (17, (384, 96)), (512, (24, 16))])
 def test_sum_parts_bf16_is_the_fp32_sum_of_the_partials(R, S, shape):
     """cnx_sum_parts_bf16 (split-K partial products of the weight-gradient GEMMs) vs torch's fp32-accumulated sum; the wrapper

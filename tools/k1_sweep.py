@@ -43,7 +43,7 @@ N = B * E
 print("# copy baseline (torch clone: 8 B/elem)")
 med, mn = timeit(lambda: out.copy_(x))
 print(f"copy                           med {med*1e3:8.1f} us  {8*N/med/1e6:8.1f} GB/s   min {8*N/mn/1e6:8.1f}")
-for bps, un, nt in itertools.product([4, 8, 16, 32, 37, 74, 147], [1, 2, 4], [0, 1]):
+for bps, un, nt in itertools.product([37, 74, 147], [1, 2, 4], [0, 1]):
     fn = lambda: lib.apgd_linf_step_f32_ex(x.data_ptr(), xa.data_ptr(), xo.data_ptr(), gr.data_ptr(), 0, step.data_ptr(),
                                             out.data_ptr(), None, B, E, eps, 0.75, bps, un, nt, S)
     med, mn = timeit(fn)
@@ -53,6 +53,17 @@ for bps, un, nt in itertools.product([8, 16, 37], [2, 4], [0, 1]):
                                             out.data_ptr(), outb.data_ptr(), B, E, eps, 0.75, bps, un, nt, S)
     med, mn = timeit(fn)
     print(f"linf bf16g+bf16out bps={bps:4d} U={un} nt={nt}  med {med*1e3:8.1f} us  {20*N/med/1e6:8.1f} GB/s (20 B/elem: 12 rd + 2 rd + 4 wr + 2 wr)")
+sg = torch.sign(gr).to(torch.int8)
+for bps, un, nt in itertools.product([37, 74, 147], [1, 2, 4], [0, 1]):
+    fn = lambda: lib.apgd_linf_step_f32_ex(x.data_ptr(), xa.data_ptr(), xo.data_ptr(), sg.data_ptr(), 3, step.data_ptr(),
+                                            out.data_ptr(), None, B, E, eps, 0.75, bps, un, nt, S)
+    med, mn = timeit(fn)
+    print(f"linf int8-sign bps={bps:4d} U={un} nt={nt}  med {med*1e3:8.1f} us  algorithmic(20B) {20*N/med/1e6:8.1f} GB/s   moved(17B) {17*N/med/1e6:8.1f} GB/s")
+for code, gt, nm, mv in ((0, gr, "f32", 16), (3, sg, "int8", 13)):
+    fn = lambda: lib.apgd_linf_step_f32(x.data_ptr(), xa.data_ptr(), xa.data_ptr(), gt.data_ptr(), code, step.data_ptr(),
+                                         out.data_ptr(), None, B, E, eps, 1.0, S)
+    med, mn = timeit(fn)
+    print(f"linf first-iter form, {nm} grad  med {med*1e3:8.1f} us  algorithmic(16B) {16*N/med/1e6:8.1f} GB/s   moved({mv}B) {mv*N/med/1e6:8.1f} GB/s")
 xb, xba = torch.empty_like(x), torch.empty_like(x)
 med, mn = timeit(lambda: lib.apgd_init_f32(x.data_ptr(), out.data_ptr(), xb.data_ptr(), xba.data_ptr(), N, S))
 print(f"init (4 rd + 12 wr)            med {med*1e3:8.1f} us  {16*N/med/1e6:8.1f} GB/s")
