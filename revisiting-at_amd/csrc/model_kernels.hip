@@ -891,7 +891,11 @@ inline bool dw_dot2_plan(int H, int W, int C, DwDot* t) {
     t->lds = static_cast<size_t>(th_override + 6) * P2 * kDC * 4;
     if (t->lds < static_cast<size_t>(th_override) * W * kDC * 4) t->lds = static_cast<size_t>(th_override) * W * kDC * 4;
     return true;
-  } t->lds = static_cast<size_t>(th + 6) * P2 * kDC * 4;
+  }
+  t->lds = static_cast<size_t>(th + 6) * P2 * kDC * 4;
+  // the transposed output tile [th][W][32] aliases the input tile: with fp32 results it is the larger of the two once
+  // th * W > (th + 6) * P2 (e.g. a whole 20x20 map: 51 200 vs 49 920 bytes - found by the ConvNeXt-L @320 oracle test)
+  if (t->lds < static_cast<size_t>(th) * W * kDC * 4) t->lds = static_cast<size_t>(th) * W * kDC * 4;
   return t->lds <= 150 * 1024;
 }
 

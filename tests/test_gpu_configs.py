@@ -136,7 +136,22 @@ def attack_both(R, ref, prod, x, y, K, autocast, norm="Linf", eps=EPS):
 
 def replay_is_bit_exact(R, prod, x, y, K, autocast):
     """The device model's own logits / input gradients, recorded during the HIP attack and replayed through the numpy
-    oracle, must give the HIP attack's outputs bit for bit (as __graft_entry__.smoke does for a toy model)."""
+    oracle, must give the HIP attack's outputs bit for bit (as __graft_entry__.smoke does for a toy model).  Run twice:
+    with fp32 gradients through autograd (recorded by the tap), and with the int8 gradient-sign sink the product path uses
+    by default (the tap then sees the stride-0 zero; the recorded fp32 gradients of the first run must reproduce it)."""
+    saved = R.apgd.USE_SIGN_SINK
+    try:
+        R.apgd.USE_SIGN_SINK = False
+        out_f32 = _replay(R, prod, x, y, K, autocast, check=True)
+        R.apgd.USE_SIGN_SINK = True
+        out_i8 = _replay(R, prod, x, y, K, autocast, check=False)
+    finally:
+        R.apgd.USE_SIGN_SINK = saved
+    for a, b in zip(out_f32, out_i8):
+        assert torch.equal(a, b)
+
+
+def _replay(R, prod, x, y, K, autocast, check):
     rec = {"logits": [], "grads": []}
 
     class Tap(torch.autograd.Function):
@@ -162,11 +177,13 @@ def replay_is_bit_exact(R, prod, x, y, K, autocast):
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
         xb, acc, lb, xba = R.apgd_train(Rec(prod).eval(), x.cuda(), y.cuda(), norm="Linf", eps=EPS, n_iter=K)
     torch.cuda.synchronize()
-    rep = O.ReplayModel(np.stack(rec["logits"]), np.stack(rec["grads"]))
-    oxb, oacc, olb, oxba, _ = O.apgd_train_oracle(rep, x.numpy(), y.numpy(), "Linf", EPS, K)
-    assert np.array_equal(xb.cpu().numpy(), oxb) and np.array_equal(xba.cpu().numpy(), oxba)
-    assert np.array_equal(acc.cpu().numpy(), oacc)
-    np.testing.assert_allclose(lb.cpu().numpy(), olb, rtol=1e-5, atol=3e-7)
+    if check:
+        rep = O.ReplayModel(np.stack(rec["logits"]), np.stack(rec["grads"]))
+        oxb, oacc, olb, oxba, _ = O.apgd_train_oracle(rep, x.numpy(), y.numpy(), "Linf", EPS, K)
+        assert np.array_equal(xb.cpu().numpy(), oxb) and np.array_equal(xba.cpu().numpy(), oxba)
+        assert np.array_equal(acc.cpu().numpy(), oacc)
+        np.testing.assert_allclose(lb.cpu().numpy(), olb, rtol=1e-5, atol=3e-7)
+    return xb, acc, lb, xba
 
 
 # ------------------------------------------------------------------------------------------------ cfg #2 (full widths)
@@ -320,10 +337,10 @@ def test_at_train_step_matches_oracle_step(R, amp):
     g_rel = rel(flat(grads1, keys), flat(o_grads1, keys))
     upd_p = flat(traj[-1], keys) - flat(p0, keys)
     upd_o = flat(o_final, keys) - flat(p0, keys)
-    cos = float(F.cosine_similarity(upd_p, upd_o, dim=0))
+    cos = float(F.cosine_similarity(upd_p.double(), upd_o.double(), dim=0))
     ema_p = flat(emas[-1], keys) - flat(p0, keys)
     ema_o = flat(o_ema, keys) - flat(p0, keys)
-    ema_cos = float(F.cosine_similarity(ema_p, ema_o, dim=0))
+    ema_cos = float(F.cosine_similarity(ema_p.double(), ema_o.double(), dim=0))
     loss_rel = max(abs(a - b) / abs(b) for a, b in zip(losses, o_losses))
     note("at_step", amp=str(amp), losses=losses, o_losses=o_losses, grad_rel=g_rel, update_cos=cos, ema_cos=ema_cos,
          upd_norm_ratio=float(upd_p.norm() / upd_o.norm()))

@@ -29,7 +29,8 @@ def close(a, b, rtol, atol):
 
 @pytest.mark.parametrize("N,C,H,W", [(2, 96, 14, 14), (1, 192, 7, 7), (2, 384, 9, 11), (3, 8, 5, 20), (1, 768, 7, 7),
                                      (2, 200, 6, 8), (1, 96, 56, 56), (6, 64, 14, 14), (5, 32, 7, 7), (3, 64, 28, 28),
-                                     (2, 32, 30, 27), (1, 192, 80, 80), (1, 384, 40, 40), (2, 384, 4, 4)])   # cfg#4 / cfg#1 maps
+                                     (2, 32, 30, 27), (1, 192, 80, 80), (1, 384, 40, 40), (2, 384, 4, 4), (2, 64, 20, 20), (1, 32, 24, 24),
+                                     (2, 32, 10, 10)])   # cfg#4 / cfg#1 maps; 20x20: output tile > input tile
 @pytest.mark.parametrize("xdt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
 def test_dwconv7x7_fwd_bwd_data_wgrad(R, N, C, H, W, xdt, odt):
