@@ -30,6 +30,7 @@
 
 #include "apgd_hip.h"
 #include "convnext_hip.h"
+#include "mlp_internal.h"
 
 namespace {
 
@@ -177,24 +178,6 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const TW* __restrict__ W1
   o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
   reinterpret_cast<uint4*>(Wf)[q] = o;
 }
-
-struct BlkFwdArgs {
-  const uint16_t* u;       // [M, C] bf16: depthwise-conv output (ln_w != NULL) or already-normalised rows
-  const float* ln_w;       // [C] or NULL
-  const float* ln_b;       // [C]
-  float eps;
-  float* mean;             // [M] or NULL (written when LN is applied)
-  float* rstd;             // [M] or NULL
-  const uint16_t* Wf;      // packed weights
-  const float* b1;         // [4C]
-  const float* b2;         // [C]
-  const float* gamma;      // [C] or NULL
-  const void* resid;       // [M, C] TX or NULL
-  void* out;               // [M, C] TO
-  uint16_t* y2;            // [M, C] bf16 pre-gamma fc2 output, or NULL
-  long M;
-  int dbg;                 // timing experiments only (APGD_BLK_DBG): 1 = no weight DMA after the prologue, 2 = no GELU
-};
 
 #ifndef BLK_FWD96_OCC
 #define BLK_FWD96_OCC 2
@@ -931,6 +914,13 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
   static const int dbg = getenv("APGD_BLK_DBG") ? atoi(getenv("APGD_BLK_DBG")) : 0;
   a.dbg = dbg;
   hipStream_t s = as_stream(stream);
+  // C = 96: the persistent kernel with LDS-resident weights (mlp_kernels.hip); APGD_BLK_FWD_IMPL=1 selects the first-generation
+  // kernel below for A/B timing
+  static const int impl = getenv("APGD_BLK_FWD_IMPL") ? atoi(getenv("APGD_BLK_FWD_IMPL")) : 2;
+  if (impl == 2) {
+    const int r = mlp2_fwd_launch(a, C, resid_dtype, out_dtype, s);
+    if (r != -100) return r;
+  }
   switch (C) {
     case 96: return launch_blk_fwd<96>(a, resid_dtype, out_dtype, s);
     case 192: return launch_blk_fwd<192>(a, resid_dtype, out_dtype, s);

@@ -1,0 +1,376 @@
+// mlp_kernels.hip — second-generation fused ConvNeXt block tail for gfx950 (MI355X), forward:
+//     out = x + gamma * ( GELU( LN(u) W1^T + b1 ) W2^T + b2 )                 (/root/reference/models/convnext.py:40-49)
+//
+// What changed against blk_mlp_fwd_kernel (block_kernels.hip), and why (profiles/r01_kernel_microbench.md: the streaming
+// phases - 152 us - and the MFMA/GELU phase - 118 us - of the C = 96 kernel ADD UP instead of overlapping; SQ_WAIT_ANY 56-65 %):
+//
+//   * The packed weights of the stage-0 width (8 C^2 bf16 = 144 KiB at C = 96) FIT the 160 KiB LDS of a CU.  One persistent
+//     workgroup per CU loads them ONCE; after that there is no weight stream, no ring, no s_barrier: the four wavefronts of a
+//     workgroup are independent and never wait for one another again.
+//   * A wavefront owns 64 rows (two 32-row MFMA row groups): every 1 KiB weight fragment read from LDS feeds TWO MFMAs
+//     (halves the LDS operand traffic per MFMA), and the two row groups are two independent accumulation chains.
+//   * Software pipeline over tiles inside the wavefront: the next tile's rows of u and this tile's residual are requested
+//     from HBM BEFORE the hidden loop of this tile runs (they sit in registers: one wavefront per SIMD owns the whole
+//     512-register file), the result tile leaves while the next tile computes.  HBM streaming and MFMA work overlap by
+//     construction instead of by luck of the co-resident workgroups' phases.
+//   * Software pipeline over hidden slices: GELU of slice s (VALU) is independent of GEMM1 of slice s+1 (MFMA) - they are
+//     issued back to back so that the matrix pipe and the vector ALU work at the same time inside one wavefront.
+//
+// Operand conventions, weight packing (cnx_mlp_pack_weights) and numerics are those of block_kernels.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "apgd_hip.h"
+#include "convnext_hip.h"
+#include "mlp_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// GELU(z) = max(z, 0) - 0.5 |z| 2^Q(|z|), Q of degree 5: the exact-erf form to 1.2e-6 (tools/fit_gelu.py); pair -> packed bf16
+__device__ __forceinline__ uint32_t gelu2_bf16(float z0, float z1) {
+  const f32x2 az = {fabsf(z0), fabsf(z1)};
+  f32x2 q = fma2(splat2(-0.00041175442346105595f), az, splat2(0.006678475199902348f));
+  q = fma2(q, az, splat2(-0.050879760394516485f));
+  q = fma2(q, az, splat2(-0.46094072908550926f));
+  q = fma2(q, az, splat2(-1.150400682855232f));
+  q = fma2(q, az, splat2(-8.454223479528131e-05f));
+  const f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  const f32x2 pos = {fmaxf(z0, 0.0f), fmaxf(z1, 0.0f)};
+  const f32x2 g = fma2(az * e, splat2(-0.5f), pos);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(g, bf16x2));
+}
+
+template <int C, int RG>
+struct GeoR {
+  static constexpr int KS = C / 16, CB = C / 32, NHB = C / 8;
+  static constexpr int PIECES = KS + 2 * CB;                  // 1 KiB operand fragments per 32-wide hidden slice
+  static constexpr int SLICE = PIECES * 1024;
+  static constexpr int WBYTES = NHB * SLICE;                  // = 16 C^2 bytes: all of W1 and W2 in fragment order
+  static constexpr int CONST_OFF = WBYTES;                    // b1 [4C], b2 [C], gamma [C] fp32
+  static constexpr int SCR_OFF = CONST_OFF + 24 * C;
+  static constexpr int SCR_WAVE = 8 * C * 4;                  // 8 rows x C fp32: one transposition pass of the epilogue
+  static constexpr int LDS = SCR_OFF + 4 * SCR_WAVE;
+  static constexpr int ROWS = 32 * RG;                        // rows per wavefront tile
+  static constexpr int NCH = 8 * C / 4 / 64;                  // float4 chunks per lane in one 8-row pass
+  static_assert(LDS <= 160 * 1024, "weights + scratch must fit the CU's LDS");
+  static_assert((8 * C / 4) % 64 == 0, "8-row passes must tile into whole wavefront float4 sweeps");
+  static_assert((NHB * PIECES) % 4 == 0, "pieces divide over 4 wavefronts");
+};
+
+// one hidden slice s:   hf = GELU(acc_in)   |   acc_out = b1[s+1] + W1[s+1] a^T   (NEXT)   |   acc2 += hf W2[s]^T
+// The W1 fragments of slice s+1 and the W2 fragments of slice s form one stream of 1 KiB LDS reads, PF fragments ahead of
+// the MFMAs that consume them; each fragment feeds RG MFMAs (one per row group).
+template <int C, int RG, bool NEXT>
+__device__ __forceinline__ void slice_step(const unsigned char* w_lane, const float* b1s, int s, int half,
+                                           const bf16x8 (&af)[RG][C / 16], const f32x16 (&acc_in)[RG], f32x16 (&acc_out)[RG],
+                                           f32x16 (&acc2)[RG][C / 32]) {
+  using G = GeoR<C, RG>;
+  constexpr int KS = G::KS, CB = G::CB;
+  constexpr int N1 = NEXT ? KS : 0, NF = N1 + 2 * CB, PF = 4;
+  const unsigned char* w_cur = w_lane + static_cast<long>(s) * G::SLICE + KS * 1024;          // W2 fragments of slice s
+  const unsigned char* w_nxt = w_lane + static_cast<long>(s + 1) * G::SLICE;                  // W1 fragments of slice s + 1
+  auto frag = [&](int i) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(i < N1 ? w_nxt + i * 1024 : w_cur + (i - N1) * 1024);
+  };
+  bf16x8 fr[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) fr[i] = frag(i);
+  if constexpr (NEXT) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 b4 = *reinterpret_cast<const float4*>(b1s + (s + 1) * 32 + 8 * g4 + 4 * half);
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        acc_out[g][4 * g4 + 0] = b4.x; acc_out[g][4 * g4 + 1] = b4.y; acc_out[g][4 * g4 + 2] = b4.z; acc_out[g][4 * g4 + 3] = b4.w;
+      }
+    }
+  }
+  // GELU of slice s -> bf16 A-operand fragments of GEMM2 (accumulator layout of H^T == A layout of H, k permuted)
+  bf16x8 hf[RG][2];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    uint32_t pk[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) pk[r >> 1] = gelu2_bf16(acc_in[g][r], acc_in[g][r + 1]);
+    hf[g][0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+    hf[g][1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
+  }
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    if (i < N1) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) acc_out[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[g][i], acc_out[g], 0, 0, 0);
+    } else {
+      const int j = i - N1;                                   // fragment order in the slice is (t, cb): j = t * CB + cb
+#pragma unroll
+      for (int g = 0; g < RG; ++g)
+        acc2[g][j % CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[g][j / CB], fr[i % PF], acc2[g][j % CB], 0, 0, 0);
+    }
+    if (i + PF < NF) fr[i % PF] = frag(i + PF);
+  }
+}
+
+template <int C, int RG, typename TX, typename TO>
+__global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p) {
+  using G = GeoR<C, RG>;
+  constexpr int KS = G::KS, CB = G::CB, NHB = G::NHB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* b1s = reinterpret_cast<float*>(lds + G::CONST_OFF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+
+  // ---- once per workgroup: all weight fragments L2 -> LDS (async DMA, 1 KiB per instruction), constants
+  {
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf) + lane * 16;
+#pragma unroll 4
+    for (int i = 0; i < NHB * G::PIECES / 4; ++i) {
+      const int piece = i * 4 + wave;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(piece) * 1024), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
+    }
+    for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    for (int i = tid; i < C; i += 256) {
+      b1s[4 * C + i] = p.b2[i];
+      b1s[5 * C + i] = p.gamma ? p.gamma[i] : 1.0f;
+    }
+  }
+
+  const long n_tiles = (p.M + G::ROWS - 1) / G::ROWS;
+  long tile = static_cast<long>(blockIdx.x) * 4 + wave;
+  const long tstride = static_cast<long>(gridDim.x) * 4;
+
+  // raw rows of u for a tile: lane (row = l32 of row group g, half) holds channels half * C/2 + ks * 8 + (0..7)
+  uint4 raw[RG][KS];
+  auto load_u = [&](long t) {
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      long row = t * G::ROWS + g * 32 + l32;
+      if (row >= p.M) row = p.M - 1;
+      const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) raw[g][ks] = up[ks];
+    }
+  };
+  if (tile < n_tiles) load_u(tile);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                            // weights and constants are in; last barrier of the kernel
+
+  const unsigned char* w_lane = lds + lane * 16;
+  float* scr = reinterpret_cast<float*>(lds + G::SCR_OFF + wave * G::SCR_WAVE);
+  const float4* b2v = reinterpret_cast<const float4*>(b1s + 4 * C);
+  const float4* gav = reinterpret_cast<const float4*>(b1s + 5 * C);
+  constexpr int C4 = C / 4;
+  const TX* resid = static_cast<const TX*>(p.resid);
+  TO* out = static_cast<TO*>(p.out);
+  const long e_end = p.M * C;
+
+  for (; tile < n_tiles; tile += tstride) {
+    const long m0 = tile * G::ROWS;
+    // ---- LayerNorm of this tile's rows -> GEMM1 B-operand fragments
+    bf16x8 af[RG][KS];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const long row = m0 + g * 32 + l32;
+      if (p.ln_w) {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint32_t w[4] = {raw[g][ks].x, raw[g][ks].y, raw[g][ks].z, raw[g][ks].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s += bf16_lo(w[j]) + bf16_hi(w[j]);
+        }
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / C);
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint32_t w[4] = {raw[g][ks].x, raw[g][ks].y, raw[g][ks].z, raw[g][ks].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = bf16_lo(w[j]) - mean, b = bf16_hi(w[j]) - mean;
+            ss = fmaf(a, a, ss);
+            ss = fmaf(b, b, ss);
+          }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = rsqrtf(ss * (1.0f / C) + p.eps);
+        if (p.mean && half == 0 && row < p.M) { p.mean[row] = mean; p.rstd[row] = rstd; }
+        const float4* lw = reinterpret_cast<const float4*>(p.ln_w + half * (C / 2));
+        const float4* lb = reinterpret_cast<const float4*>(p.ln_b + half * (C / 2));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint32_t w[4] = {raw[g][ks].x, raw[g][ks].y, raw[g][ks].z, raw[g][ks].w};
+          const float4 w0 = lw[2 * ks], w1 = lw[2 * ks + 1], c0 = lb[2 * ks], c1 = lb[2 * ks + 1];
+          const float gw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          const float o[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          uint32_t pk[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = fmaf((bf16_lo(w[j]) - mean) * rstd, gw[2 * j], o[2 * j]);
+            const float b = fmaf((bf16_hi(w[j]) - mean) * rstd, gw[2 * j + 1], o[2 * j + 1]);
+            pk[j] = pack_bf16(a, b);
+          }
+          af[g][ks] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[g][ks] = __builtin_bit_cast(bf16x8, raw[g][ks]);
+      }
+    }
+    // ---- requests that ride under the hidden loop: the next tile's rows, this tile's residual (epilogue chunk order)
+    const long nt = tile + tstride;
+    if (nt < n_tiles) load_u(nt);
+    float4 res[RG][4][G::NCH];
+    if (resid) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < G::NCH; ++j) {
+            const long e = (m0 + g * 32 + q * 8) * C + (j * 64 + lane) * 4;
+            res[g][q][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < e_end) {
+              if constexpr (sizeof(TX) == 4) {
+                res[g][q][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resid) + e);
+              } else {
+                const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(resid) + e);
+                res[g][q][j] = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+              }
+            }
+          }
+    } else {
+#pragma unroll
+      for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < G::NCH; ++j) res[g][q][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // ---- hidden loop
+    f32x16 acc2[RG][CB];
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[g][cb][r] = 0.f;
+    f32x16 accA[RG], accB[RG];
+    {                                                         // GEMM1 of slice 0
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 b4 = *reinterpret_cast<const float4*>(b1s + 8 * g4 + 4 * half);
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          accA[g][4 * g4 + 0] = b4.x; accA[g][4 * g4 + 1] = b4.y; accA[g][4 * g4 + 2] = b4.z; accA[g][4 * g4 + 3] = b4.w;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 f = *reinterpret_cast<const bf16x8*>(w_lane + ks * 1024);
+#pragma unroll
+        for (int g = 0; g < RG; ++g) accA[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, af[g][ks], accA[g], 0, 0, 0);
+      }
+    }
+    static_assert(NHB % 2 == 0, "the slice loop is unrolled by two (accumulator ping-pong)");
+#pragma unroll 1
+    for (int s = 0; s < NHB - 2; s += 2) {
+      slice_step<C, RG, true>(w_lane, b1s, s, half, af, accA, accB, acc2);
+      slice_step<C, RG, true>(w_lane, b1s, s + 1, half, af, accB, accA, acc2);
+    }
+    slice_step<C, RG, true>(w_lane, b1s, NHB - 2, half, af, accA, accB, acc2);
+    slice_step<C, RG, false>(w_lane, b1s, NHB - 1, half, af, accB, accA, acc2);
+
+    // ---- epilogue: acc2[g][cb][r] = O[m0 + 32 g + (r&3) + 8 (r>>2) + 4 half][cb*32 + l32].  Eight rows at a time go through this
+    //      wavefront's 8 x C fp32 scratch and leave as whole rows: 16 bytes per lane for the scratch read, the residual (already
+    //      in registers) and the store.  LDS operations of one wavefront execute in order: no barrier, only compiler fences.
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) scr[(i + 4 * half) * C + cb * 32 + l32] = acc2[g][cb][4 * q + i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < G::NCH; ++j) {
+          const int idx = j * 64 + lane;
+          const long e = (m0 + g * 32 + q * 8) * C + idx * 4;
+          const int c4 = idx % C4;
+          const float4 o = reinterpret_cast<const float4*>(scr)[idx];
+          const float4 bb = b2v[c4], gg = gav[c4];
+          const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
+          if (e < e_end) {
+            if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
+            const float4 xv = res[g][q][j];
+            const float o0 = fmaf(y0, gg.x, xv.x), o1 = fmaf(y1, gg.y, xv.y);
+            const float o2 = fmaf(y2v, gg.z, xv.z), o3 = fmaf(y3, gg.w, xv.w);
+            if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + e) = make_float4(o0, o1, o2, o3);
+            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + e) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+          }
+        }
+      }
+  }
+}
+
+template <int C, int RG>
+int launch_res(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
+  using G = GeoR<C, RG>;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  const long n_tiles = (a.M + G::ROWS - 1) / G::ROWS;
+  long nb = (n_tiles + 3) / 4;
+  if (nb > n_cu) nb = n_cu;
+  const dim3 grid(static_cast<unsigned>(nb)), block(256);
+#define MLP2_LAUNCH(TX, TO)                                                                                      \
+  {                                                                                                              \
+    auto kfn = mlp2_fwd_res_kernel<C, RG, TX, TO>;                                                               \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                G::LDS);                                                                         \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, G::LDS, s, a);                                                          \
+  }
+  if (resid_dtype == APGD_F32 && out_dtype == APGD_F32) MLP2_LAUNCH(float, float)
+  else if (resid_dtype == APGD_F32) MLP2_LAUNCH(float, uint16_t)
+  else if (out_dtype == APGD_F32) MLP2_LAUNCH(uint16_t, float)
+  else MLP2_LAUNCH(uint16_t, uint16_t)
+#undef MLP2_LAUNCH
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace
+
+int mlp2_fwd_launch(const BlkFwdArgs& a, int C, int resid_dtype, int out_dtype, hipStream_t s) {
+  static const int rg = getenv("APGD_MLP2_RG") ? atoi(getenv("APGD_MLP2_RG")) : 2;      // tuning experiments only
+  if (C == 96) return rg == 1 ? launch_res<96, 1>(a, resid_dtype, out_dtype, s) : launch_res<96, 2>(a, resid_dtype, out_dtype, s);
+  return -100;
+}
