@@ -21,6 +21,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "apgd_hip.h"
 #include "convnext_hip.h"
 #include "mlp_internal.h"
@@ -57,14 +59,34 @@ __device__ __forceinline__ uint32_t gelu2_bf16(float z0, float z1) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(g, bf16x2));
 }
 
+// Prefetch loads that must stay IN FLIGHT across the hidden loop.  hipcc's own s_waitcnt bookkeeping cannot do that: vmcnt
+// retires in order and also counts stores on gfx950, so for loop-carried loads it falls back to `s_waitcnt vmcnt(0)` at the
+// first use in every iteration (draining the previous tile's stores as well), and under register pressure it waits for a load
+// right after issuing it in order to park the value in the accumulator file.  These loads are therefore hidden from the
+// compiler (cdna_hip_programming.md §5.7): inline-asm `global_load_dwordx4` straight into ACCUMULATOR registers (the 256
+// AGPRs of a one-wavefront-per-SIMD kernel are otherwise half empty), ONE hand-placed `s_waitcnt vmcnt(0)` at the end of the
+// hidden loop - by then the loads, issued ~10 us earlier, and the previous tile's stores have long retired - followed by
+// sched_barrier(0) so that no register-only consumer is hoisted above the wait (§5.4 rule 18).
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__device__ __forceinline__ void prefetch16(f32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void prefetch8(f32x2& dst, const void* p) {
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void prefetch_landed() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int C, int RG>
 struct GeoR {
   static constexpr int KS = C / 16, CB = C / 32, NHB = C / 8;
   static constexpr int PIECES = KS + 2 * CB;                  // 1 KiB operand fragments per 32-wide hidden slice
   static constexpr int SLICE = PIECES * 1024;
   static constexpr int WBYTES = NHB * SLICE;                  // = 16 C^2 bytes: all of W1 and W2 in fragment order
-  static constexpr int CONST_OFF = WBYTES;                    // b1 [4C], b2 [C], gamma [C] fp32
-  static constexpr int SCR_OFF = CONST_OFF + 24 * C;
+  static constexpr int CONST_OFF = WBYTES;                    // b1 [4C], b2 [C], gamma [C], ln_w [C], ln_b [C] fp32
+  static constexpr int SCR_OFF = CONST_OFF + 32 * C;
   static constexpr int SCR_WAVE = 8 * C * 4;                  // 8 rows x C fp32: one transposition pass of the epilogue
   static constexpr int LDS = SCR_OFF + 4 * SCR_WAVE;
   static constexpr int ROWS = 32 * RG;                        // rows per wavefront tile
@@ -78,7 +100,7 @@ struct GeoR {
 // The W1 fragments of slice s+1 and the W2 fragments of slice s form one stream of 1 KiB LDS reads, PF fragments ahead of
 // the MFMAs that consume them; each fragment feeds RG MFMAs (one per row group).
 template <int C, int RG, bool NEXT>
-__device__ __forceinline__ void slice_step(const unsigned char* w_lane, const float* b1s, int s, int half,
+__device__ __forceinline__ void slice_step(int dbg, const unsigned char* w_lane, const float* b1s, int s, int half,
                                            const bf16x8 (&af)[RG][C / 16], const f32x16 (&acc_in)[RG], f32x16 (&acc_out)[RG],
                                            f32x16 (&acc2)[RG][C / 32]) {
   using G = GeoR<C, RG>;
@@ -108,7 +130,8 @@ __device__ __forceinline__ void slice_step(const unsigned char* w_lane, const fl
   for (int g = 0; g < RG; ++g) {
     uint32_t pk[8];
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) pk[r >> 1] = gelu2_bf16(acc_in[g][r], acc_in[g][r + 1]);
+    for (int r = 0; r < 16; r += 2)
+      pk[r >> 1] = (dbg & 1) ? pack_bf16(acc_in[g][r], acc_in[g][r + 1]) : gelu2_bf16(acc_in[g][r], acc_in[g][r + 1]);   // dbg 1: timing experiment, no GELU
     hf[g][0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
     hf[g][1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
   }
@@ -150,6 +173,8 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
     for (int i = tid; i < C; i += 256) {
       b1s[4 * C + i] = p.b2[i];
       b1s[5 * C + i] = p.gamma ? p.gamma[i] : 1.0f;
+      b1s[6 * C + i] = p.ln_w ? p.ln_w[i] : 1.0f;
+      b1s[7 * C + i] = p.ln_w ? p.ln_b[i] : 0.0f;
     }
   }
 
@@ -158,20 +183,20 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
   const long tstride = static_cast<long>(gridDim.x) * 4;
 
   // raw rows of u for a tile: lane (row = l32 of row group g, half) holds channels half * C/2 + ks * 8 + (0..7)
-  uint4 raw[RG][KS];
+  f32x4 raw[RG][KS];
   auto load_u = [&](long t) {
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
       long row = t * G::ROWS + g * 32 + l32;
       if (row >= p.M) row = p.M - 1;
-      const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
+      const unsigned char* up = reinterpret_cast<const unsigned char*>(p.u + row * C + half * (C / 2));
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) raw[g][ks] = up[ks];
+      for (int ks = 0; ks < KS; ++ks) prefetch16(raw[g][ks], up + ks * 16);
     }
   };
   if (tile < n_tiles) load_u(tile);
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  prefetch_landed();                                          // the weight DMA and the first tile's rows
   __syncthreads();                                            // weights and constants are in; last barrier of the kernel
 
   const unsigned char* w_lane = lds + lane * 16;
@@ -194,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
         float s = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const uint32_t w[4] = {raw[g][ks].x, raw[g][ks].y, raw[g][ks].z, raw[g][ks].w};
+          const uint32_t w[4] = {__float_as_uint(raw[g][ks][0]), __float_as_uint(raw[g][ks][1]), __float_as_uint(raw[g][ks][2]), __float_as_uint(raw[g][ks][3])};
 #pragma unroll
           for (int j = 0; j < 4; ++j) s += bf16_lo(w[j]) + bf16_hi(w[j]);
         }
@@ -203,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
         float ss = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const uint32_t w[4] = {raw[g][ks].x, raw[g][ks].y, raw[g][ks].z, raw[g][ks].w};
+          const uint32_t w[4] = {__float_as_uint(raw[g][ks][0]), __float_as_uint(raw[g][ks][1]), __float_as_uint(raw[g][ks][2]), __float_as_uint(raw[g][ks][3])};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float a = bf16_lo(w[j]) - mean, b = bf16_hi(w[j]) - mean;
@@ -214,11 +239,11 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
         ss += __shfl_xor(ss, 32, 64);
         const float rstd = rsqrtf(ss * (1.0f / C) + p.eps);
         if (p.mean && half == 0 && row < p.M) { p.mean[row] = mean; p.rstd[row] = rstd; }
-        const float4* lw = reinterpret_cast<const float4*>(p.ln_w + half * (C / 2));
-        const float4* lb = reinterpret_cast<const float4*>(p.ln_b + half * (C / 2));
+        const float4* lw = reinterpret_cast<const float4*>(b1s + 6 * C + half * (C / 2));
+        const float4* lb = reinterpret_cast<const float4*>(b1s + 7 * C + half * (C / 2));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const uint32_t w[4] = {raw[g][ks].x, raw[g][ks].y, raw[g][ks].z, raw[g][ks].w};
+          const uint32_t w[4] = {__float_as_uint(raw[g][ks][0]), __float_as_uint(raw[g][ks][1]), __float_as_uint(raw[g][ks][2]), __float_as_uint(raw[g][ks][3])};
           const float4 w0 = lw[2 * ks], w1 = lw[2 * ks + 1], c0 = lb[2 * ks], c1 = lb[2 * ks + 1];
           const float gw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
           const float o[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
@@ -238,33 +263,23 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
     }
     // ---- requests that ride under the hidden loop: the next tile's rows, this tile's residual (epilogue chunk order)
     const long nt = tile + tstride;
-    if (nt < n_tiles) load_u(nt);
-    float4 res[RG][4][G::NCH];
-    if (resid) {
+    if (nt < n_tiles && !(p.dbg & 8)) load_u(nt);             // dbg 8: timing experiment, no HBM loads after the first tile
+    // (addresses of rows past the end are clamped: whatever is loaded there is never stored)
+    using RT = typename std::conditional<sizeof(TX) == 4, f32x4, f32x2>::type;
+    RT res[RG][4][G::NCH];
+    const bool has_res = resid != nullptr && !(p.dbg & 8);
+    if (has_res) {
 #pragma unroll
       for (int g = 0; g < RG; ++g)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int j = 0; j < G::NCH; ++j) {
-            const long e = (m0 + g * 32 + q * 8) * C + (j * 64 + lane) * 4;
-            res[g][q][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < e_end) {
-              if constexpr (sizeof(TX) == 4) {
-                res[g][q][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resid) + e);
-              } else {
-                const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(resid) + e);
-                res[g][q][j] = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
-              }
-            }
+            long e = (m0 + g * 32 + q * 8) * C + (j * 64 + lane) * 4;
+            if (e >= e_end) e = 0;
+            if constexpr (sizeof(TX) == 4) prefetch16(res[g][q][j], reinterpret_cast<const float*>(resid) + e);
+            else prefetch8(res[g][q][j], reinterpret_cast<const uint16_t*>(resid) + e);
           }
-    } else {
-#pragma unroll
-      for (int g = 0; g < RG; ++g)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int j = 0; j < G::NCH; ++j) res[g][q][j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // ---- hidden loop
@@ -293,14 +308,16 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
       }
     }
     static_assert(NHB % 2 == 0, "the slice loop is unrolled by two (accumulator ping-pong)");
+    const int n_main = (p.dbg & 4) ? 0 : NHB - 2;             // dbg 4: timing experiment, two of the twelve slices only
 #pragma unroll 1
-    for (int s = 0; s < NHB - 2; s += 2) {
-      slice_step<C, RG, true>(w_lane, b1s, s, half, af, accA, accB, acc2);
-      slice_step<C, RG, true>(w_lane, b1s, s + 1, half, af, accB, accA, acc2);
+    for (int s = 0; s < n_main; s += 2) {
+      slice_step<C, RG, true>(p.dbg, w_lane, b1s, s, half, af, accA, accB, acc2);
+      slice_step<C, RG, true>(p.dbg, w_lane, b1s, s + 1, half, af, accB, accA, acc2);
     }
-    slice_step<C, RG, true>(w_lane, b1s, NHB - 2, half, af, accA, accB, acc2);
-    slice_step<C, RG, false>(w_lane, b1s, NHB - 1, half, af, accB, accA, acc2);
+    slice_step<C, RG, true>(p.dbg, w_lane, b1s, NHB - 2, half, af, accA, accB, acc2);
+    slice_step<C, RG, false>(p.dbg, w_lane, b1s, NHB - 1, half, af, accB, accA, acc2);
 
+    prefetch_landed();                                        // next tile's rows + this tile's residual (and the previous tile's stores)
     // ---- epilogue: acc2[g][cb][r] = O[m0 + 32 g + (r&3) + 8 (r>>2) + 4 half][cb*32 + l32].  Eight rows at a time go through this
     //      wavefront's 8 x C fp32 scratch and leave as whole rows: 16 bytes per lane for the scratch read, the residual (already
     //      in registers) and the store.  LDS operations of one wavefront execute in order: no barrier, only compiler fences.
@@ -322,9 +339,17 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
           const float4 o = reinterpret_cast<const float4*>(scr)[idx];
           const float4 bb = b2v[c4], gg = gav[c4];
           const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
-          if (e < e_end) {
+          if (e < e_end && !(p.dbg & 2)) {                     // dbg 2: timing experiment, no stores
             if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
-            const float4 xv = res[g][q][j];
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_res) {
+              if constexpr (sizeof(TX) == 4) {
+                xv = make_float4(res[g][q][j][0], res[g][q][j][1], res[g][q][j][2], res[g][q][j][3]);
+              } else {
+                const uint32_t w0 = __float_as_uint(res[g][q][j][0]), w1 = __float_as_uint(res[g][q][j][1]);
+                xv = make_float4(bf16_lo(w0), bf16_hi(w0), bf16_lo(w1), bf16_hi(w1));
+              }
+            }
             const float o0 = fmaf(y0, gg.x, xv.x), o1 = fmaf(y1, gg.y, xv.y);
             const float o2 = fmaf(y2v, gg.z, xv.z), o3 = fmaf(y3, gg.w, xv.w);
             if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + e) = make_float4(o0, o1, o2, o3);
@@ -370,7 +395,11 @@ int launch_res(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t 
 }  // namespace
 
 int mlp2_fwd_launch(const BlkFwdArgs& a, int C, int resid_dtype, int out_dtype, hipStream_t s) {
-  static const int rg = getenv("APGD_MLP2_RG") ? atoi(getenv("APGD_MLP2_RG")) : 2;      // tuning experiments only
+  // rows per wavefront tile: 64 when the prefetched residual tile is bf16 (48 registers), 32 when it is fp32 (64 rows of an
+  // fp32 residual = 96 registers on top of 48 for the next rows, 160 of accumulators: the allocator spills).
+  // APGD_MLP2_RG overrides (tuning experiments only).
+  static const int rg_env = getenv("APGD_MLP2_RG") ? atoi(getenv("APGD_MLP2_RG")) : 0;
+  const int rg = rg_env ? rg_env : ((a.resid && resid_dtype == APGD_F32) ? 1 : 2);
   if (C == 96) return rg == 1 ? launch_res<96, 1>(a, resid_dtype, out_dtype, s) : launch_res<96, 2>(a, resid_dtype, out_dtype, s);
   return -100;
 }
