@@ -360,6 +360,223 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
   }
 }
 
+// =====================================================================================================================
+// Third form (the one the product uses at C = 96): the same LDS-resident weights, but TWELVE independent wavefronts per
+// workgroup (three per SIMD, <= 168 registers each), one 32-row tile at a time, plain compiler-scheduled loads.
+// Measured on MI355X (gpurun_out/r2_mlp_bench2.log): with one wavefront per SIMD (the form above) the hidden loop is bound by
+// the LATENCY of the GELU's dependent VALU chains - 2000 cycles per 12-MFMA slice against 960 in the first-generation kernel
+// with three wavefronts per SIMD - so the freed barrier time was lost again.  Here nothing ties the wavefronts of a CU
+// together (no ring, no s_barrier after the weights have landed): they drift apart, and while some are in their HBM phases
+// (rows in, residual in, result out) the others keep the matrix pipe and the VALU busy.
+template <int C, typename TX, typename TO>
+__global__ __launch_bounds__(768, 3) void mlp3_fwd_res_kernel(const BlkFwdArgs p) {
+  using G = GeoR<C, 1>;
+  constexpr int KS = G::KS, CB = G::CB, NHB = G::NHB, NW = 12;
+  constexpr int SCR3_OFF = G::CONST_OFF + 32 * C;             // 2 rows x C fp32 per wavefront
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* b1s = reinterpret_cast<float*>(lds + G::CONST_OFF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+  {
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf) + lane * 16;
+#pragma unroll 4
+    for (int i = 0; i < NHB * G::PIECES / NW; ++i) {
+      const int piece = i * NW + wave;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(piece) * 1024), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
+    }
+    for (int i = tid; i < C; i += 768) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    for (int i = tid; i < C; i += 768) {
+      b1s[4 * C + i] = p.b2[i];
+      b1s[5 * C + i] = p.gamma ? p.gamma[i] : 1.0f;
+      b1s[6 * C + i] = p.ln_w ? p.ln_w[i] : 1.0f;
+      b1s[7 * C + i] = p.ln_w ? p.ln_b[i] : 0.0f;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                            // the only barrier of the kernel
+
+  const unsigned char* w_lane = lds + lane * 16;
+  float* scr = reinterpret_cast<float*>(lds + SCR3_OFF + wave * (2 * C * 4));
+  const float4* b2v = reinterpret_cast<const float4*>(b1s + 4 * C);
+  const float4* gav = reinterpret_cast<const float4*>(b1s + 5 * C);
+  constexpr int C4 = C / 4;
+  static_assert(2 * C4 <= 64, "a 2-row pass is one float4 per lane");
+  const TX* resid = static_cast<const TX*>(p.resid);
+  TO* out = static_cast<TO*>(p.out);
+  const long n_tiles = (p.M + 31) / 32;
+
+  for (long tile = static_cast<long>(blockIdx.x) * NW + wave; tile < n_tiles; tile += static_cast<long>(gridDim.x) * NW) {
+    const long m0 = tile * 32;
+    long row = m0 + l32;
+    const bool row_ok = row < p.M;
+    if (!row_ok) row = p.M - 1;
+    bf16x8 af[KS];
+    {
+      uint4 raw[KS];
+      const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) raw[ks] = up[ks];
+      if (p.ln_w) {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s += bf16_lo(w[j]) + bf16_hi(w[j]);
+        }
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / C);
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = bf16_lo(w[j]) - mean, b = bf16_hi(w[j]) - mean;
+            ss = fmaf(a, a, ss);
+            ss = fmaf(b, b, ss);
+          }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = rsqrtf(ss * (1.0f / C) + p.eps);
+        if (p.mean && half == 0 && row_ok) { p.mean[row] = mean; p.rstd[row] = rstd; }
+        const float4* lw = reinterpret_cast<const float4*>(b1s + 6 * C + half * (C / 2));
+        const float4* lb = reinterpret_cast<const float4*>(b1s + 7 * C + half * (C / 2));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+          const float4 w0 = lw[2 * ks], w1 = lw[2 * ks + 1], c0 = lb[2 * ks], c1 = lb[2 * ks + 1];
+          const float gw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          const float o[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          uint32_t pk[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = fmaf((bf16_lo(w[j]) - mean) * rstd, gw[2 * j], o[2 * j]);
+            const float b = fmaf((bf16_hi(w[j]) - mean) * rstd, gw[2 * j + 1], o[2 * j + 1]);
+            pk[j] = pack_bf16(a, b);
+          }
+          af[ks] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
+      }
+    }
+
+    f32x16 acc2[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[cb][r] = 0.f;
+    const int n_sl = (p.dbg & 4) ? 2 : NHB;                   // dbg 4: timing experiment, two of the twelve slices only
+#pragma unroll 1
+    for (int s = 0; s < n_sl; ++s) {
+      const unsigned char* sl = w_lane + static_cast<long>(s) * G::SLICE;
+      constexpr int NF = KS + 2 * CB, PF = 4;
+      bf16x8 fr[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);
+      f32x16 acc1;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 b4 = *reinterpret_cast<const float4*>(b1s + s * 32 + 8 * g4 + 4 * half);
+        acc1[4 * g4 + 0] = b4.x; acc1[4 * g4 + 1] = b4.y; acc1[4 * g4 + 2] = b4.z; acc1[4 * g4 + 3] = b4.w;
+      }
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {                          // (one chain: the co-resident wavefronts fill the dependent-MFMA gaps)
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], acc1, 0, 0, 0);
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+      }
+      bf16x8 hf[2];
+      {
+        uint32_t pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float z0 = acc1[r], z1 = acc1[r + 1];
+          pk[r >> 1] = (p.dbg & 1) ? pack_bf16(z0, z1) : gelu2_bf16(z0, z1);          // dbg 1: timing experiment, no GELU
+        }
+        hf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        hf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
+      }
+#pragma unroll
+      for (int j = 0; j < 2 * CB; ++j) {
+        const int i = KS + j;
+        acc2[j % CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[j / CB], fr[i % PF], acc2[j % CB], 0, 0, 0);
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+      }
+    }
+
+    // ---- epilogue: two rows (r and r + 4 of an 8-row group) per pass through 2 x C floats of scratch; lanes 0 .. 2 C/4 - 1 move
+    //      16 bytes each of the residual and of the result
+    const long e_end = p.M * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) scr[half * C + cb * 32 + l32] = acc2[cb][r];
+      __builtin_amdgcn_wave_barrier();
+      const int rr = lane / C4, c4 = lane - rr * C4;           // row of the pass, float4 column
+      const long e = (m0 + (r & 3) + 8 * (r >> 2) + 4 * rr) * C + c4 * 4;
+      if (lane < 2 * C4 && e < e_end && !(p.dbg & 2)) {
+        const float4 o = reinterpret_cast<const float4*>(scr)[lane];
+        const float4 bb = b2v[c4], gg = gav[c4];
+        const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (resid) {
+          if constexpr (sizeof(TX) == 4) {
+            xv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resid) + e);
+          } else {
+            const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(resid) + e);
+            xv = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+          }
+        }
+        if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
+        const float o0 = fmaf(y0, gg.x, xv.x), o1 = fmaf(y1, gg.y, xv.y);
+        const float o2 = fmaf(y2v, gg.z, xv.z), o3 = fmaf(y3, gg.w, xv.w);
+        if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + e) = make_float4(o0, o1, o2, o3);
+        else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + e) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+      }
+    }
+  }
+}
+
+template <int C>
+int launch_res3(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
+  using G = GeoR<C, 1>;
+  constexpr int LDS3 = G::CONST_OFF + 32 * C + 12 * 2 * C * 4;
+  static_assert(LDS3 <= 160 * 1024, "weights + constants + scratch must fit the CU's LDS");
+  static_assert((G::NHB * G::PIECES) % 12 == 0, "pieces divide over 12 wavefronts");
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  const long n_tiles = (a.M + 31) / 32;
+  long nb = (n_tiles + 11) / 12;
+  if (nb > n_cu) nb = n_cu;
+  const dim3 grid(static_cast<unsigned>(nb)), block(768);
+#define MLP3_LAUNCH(TX, TO)                                                                                      \
+  {                                                                                                              \
+    auto kfn = mlp3_fwd_res_kernel<C, TX, TO>;                                                                   \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                LDS3);                                                                           \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, LDS3, s, a);                                                            \
+  }
+  if (resid_dtype == APGD_F32 && out_dtype == APGD_F32) MLP3_LAUNCH(float, float)
+  else if (resid_dtype == APGD_F32) MLP3_LAUNCH(float, uint16_t)
+  else if (out_dtype == APGD_F32) MLP3_LAUNCH(uint16_t, float)
+  else MLP3_LAUNCH(uint16_t, uint16_t)
+#undef MLP3_LAUNCH
+  return static_cast<int>(hipGetLastError());
+}
+
 template <int C, int RG>
 int launch_res(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
   using G = GeoR<C, RG>;
@@ -395,11 +612,11 @@ int launch_res(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t 
 }  // namespace
 
 int mlp2_fwd_launch(const BlkFwdArgs& a, int C, int resid_dtype, int out_dtype, hipStream_t s) {
-  // rows per wavefront tile: 64 when the prefetched residual tile is bf16 (48 registers), 32 when it is fp32 (64 rows of an
-  // fp32 residual = 96 registers on top of 48 for the next rows, 160 of accumulators: the allocator spills).
-  // APGD_MLP2_RG overrides (tuning experiments only).
-  static const int rg_env = getenv("APGD_MLP2_RG") ? atoi(getenv("APGD_MLP2_RG")) : 0;
-  const int rg = rg_env ? rg_env : ((a.resid && resid_dtype == APGD_F32) ? 1 : 2);
-  if (C == 96) return rg == 1 ? launch_res<96, 1>(a, resid_dtype, out_dtype, s) : launch_res<96, 2>(a, resid_dtype, out_dtype, s);
-  return -100;
+  // APGD_MLP2_RG (tuning experiments only): 0 = twelve independent wavefronts per CU (mlp3, the default); 1 / 2 = the
+  // one-wavefront-per-SIMD form with 32 / 64 rows per wavefront and register prefetch (mlp2)
+  static const int rg = getenv("APGD_MLP2_RG") ? atoi(getenv("APGD_MLP2_RG")) : 0;
+  if (C != 96) return -100;
+  if (rg == 1) return launch_res<96, 1>(a, resid_dtype, out_dtype, s);
+  if (rg == 2) return launch_res<96, 2>(a, resid_dtype, out_dtype, s);
+  return launch_res3<96>(a, resid_dtype, out_dtype, s);
 }
