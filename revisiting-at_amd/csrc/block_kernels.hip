@@ -32,6 +32,13 @@
 #include "convnext_hip.h"
 #include "mlp_internal.h"
 
+// Timing experiments (APGD_BLK_DBG) are compiled in only with -DMLP_ABLATE=1: tested at run time inside the hidden loop they
+// become branches that split the scheduling region (see mlp_kernels.hip).
+#ifndef MLP_ABLATE
+#define MLP_ABLATE 0
+#endif
+#define DBG(p, bit) (MLP_ABLATE && ((p).dbg & (bit)))
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
     }                                                                                                      \
   }
-  if ((p.dbg & 16) && blockIdx.x < 1024) {                // timing experiment: de-phase the co-resident workgroups of the first round
+  if (DBG(p, 16) && blockIdx.x < 1024) {                // timing experiment: de-phase the co-resident workgroups of the first round
     const int steps = ((blockIdx.x >> 8) & 3) * (p.dbg >> 8);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
   }
@@ -305,17 +312,17 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
   }
 
   // ---- hidden-slice loop
-  const int n_slices = (p.dbg & 8) ? 0 : G::NHB;          // dbg 8: prologue + epilogue only
+  const int n_slices = DBG(p, 8) ? 0 : G::NHB;          // dbg 8: prologue + epilogue only
   for (int s = 0; s < n_slices; ++s) {
     // slice s has landed once this wavefront's own pieces are in (counted wait: slice s+1 may stay in flight) and
     // every wavefront has passed the barrier; the slot of slice s+2 held slice s-1, which nobody reads any more
-    if (!(p.dbg & 4)) {
+    if (!DBG(p, 4)) {
       if (G::DEPTH > 3 && s + 2 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::FWD_ROUNDS) : "memory");
       else if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if (s + G::DEPTH - 1 < G::NHB && !(p.dbg & 1)) DMA_SLICE(s + G::DEPTH - 1)
+    if (s + G::DEPTH - 1 < G::NHB && !DBG(p, 1)) DMA_SLICE(s + G::DEPTH - 1)
     const unsigned char* sl = ring + (s % G::DEPTH) * G::FWD_SLICE + lane * 16;
 
     // One stream of NF = KS + 2 CB operand fragments per slice (1 KiB each, fragment i feeds MFMA i).  The reads run
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     bf16x8 hf[2];
     {
       uint32_t pk[8];
-      if (p.dbg & 2) {
+      if DBG(p, 2) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(acc1[r], acc1[r + 1]);
       } else {

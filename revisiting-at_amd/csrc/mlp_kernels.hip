@@ -27,6 +27,14 @@
 #include "convnext_hip.h"
 #include "mlp_internal.h"
 
+// Timing experiments (APGD_BLK_DBG) are compiled in only with -DMLP_ABLATE=1: a runtime flag test inside the hidden loop
+// turns into a branch per use and splits the scheduling region (15 branches, 23 s_nop and 12 s_waitcnt per slice were
+// measured in the ISA) - the MFMA / VALU interleave the kernel depends on is gone.
+#ifndef MLP_ABLATE
+#define MLP_ABLATE 0
+#endif
+#define DBG(p, bit) (MLP_ABLATE && ((p).dbg & (bit)))
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -131,7 +139,7 @@ __device__ __forceinline__ void slice_step(int dbg, const unsigned char* w_lane,
     uint32_t pk[8];
 #pragma unroll
     for (int r = 0; r < 16; r += 2)
-      pk[r >> 1] = (dbg & 1) ? pack_bf16(acc_in[g][r], acc_in[g][r + 1]) : gelu2_bf16(acc_in[g][r], acc_in[g][r + 1]);   // dbg 1: timing experiment, no GELU
+      pk[r >> 1] = (MLP_ABLATE && (dbg & 1)) ? pack_bf16(acc_in[g][r], acc_in[g][r + 1]) : gelu2_bf16(acc_in[g][r], acc_in[g][r + 1]);   // dbg 1: timing experiment, no GELU
     hf[g][0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
     hf[g][1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
   }
@@ -263,11 +271,11 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
     }
     // ---- requests that ride under the hidden loop: the next tile's rows, this tile's residual (epilogue chunk order)
     const long nt = tile + tstride;
-    if (nt < n_tiles && !(p.dbg & 8)) load_u(nt);             // dbg 8: timing experiment, no HBM loads after the first tile
+    if (nt < n_tiles && !DBG(p, 8)) load_u(nt);             // dbg 8: timing experiment, no HBM loads after the first tile
     // (addresses of rows past the end are clamped: whatever is loaded there is never stored)
     using RT = typename std::conditional<sizeof(TX) == 4, f32x4, f32x2>::type;
     RT res[RG][4][G::NCH];
-    const bool has_res = resid != nullptr && !(p.dbg & 8);
+    const bool has_res = resid != nullptr && !DBG(p, 8);
     if (has_res) {
 #pragma unroll
       for (int g = 0; g < RG; ++g)
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
       }
     }
     static_assert(NHB % 2 == 0, "the slice loop is unrolled by two (accumulator ping-pong)");
-    const int n_main = (p.dbg & 4) ? 0 : NHB - 2;             // dbg 4: timing experiment, two of the twelve slices only
+    const int n_main = DBG(p, 4) ? 0 : NHB - 2;             // dbg 4: timing experiment, two of the twelve slices only
 #pragma unroll 1
     for (int s = 0; s < n_main; s += 2) {
       slice_step<C, RG, true>(p.dbg, w_lane, b1s, s, half, af, accA, accB, acc2);
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
           const float4 o = reinterpret_cast<const float4*>(scr)[idx];
           const float4 bb = b2v[c4], gg = gav[c4];
           const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
-          if (e < e_end && !(p.dbg & 2)) {                     // dbg 2: timing experiment, no stores
+          if (e < e_end && !DBG(p, 2)) {                     // dbg 2: timing experiment, no stores
             if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (has_res) {
@@ -361,18 +369,50 @@ __global__ __launch_bounds__(256, 1) void mlp2_fwd_res_kernel(const BlkFwdArgs p
 }
 
 // =====================================================================================================================
-// Third form (the one the product uses at C = 96): the same LDS-resident weights, but TWELVE independent wavefronts per
-// workgroup (three per SIMD, <= 168 registers each), one 32-row tile at a time, plain compiler-scheduled loads.
+// Third form (the one the product uses at C = 96): the same LDS-resident weights, but NW = 12 (or 8) INDEPENDENT wavefronts
+// per workgroup - three (two) per SIMD - each walking its own 32 x RG-row tiles, plain compiler-scheduled loads.
 // Measured on MI355X (gpurun_out/r2_mlp_bench2.log): with one wavefront per SIMD (the form above) the hidden loop is bound by
 // the LATENCY of the GELU's dependent VALU chains - 2000 cycles per 12-MFMA slice against 960 in the first-generation kernel
 // with three wavefronts per SIMD - so the freed barrier time was lost again.  Here nothing ties the wavefronts of a CU
 // together (no ring, no s_barrier after the weights have landed): they drift apart, and while some are in their HBM phases
 // (rows in, residual in, result out) the others keep the matrix pipe and the VALU busy.
-template <int C, typename TX, typename TO>
-__global__ __launch_bounds__(768, 3) void mlp3_fwd_res_kernel(const BlkFwdArgs p) {
+//   * the residual tile and the next tile's rows are TOUCHED (one dword per 128-byte line) before the hidden loop, so that
+//     the epilogue's and the next prologue's loads find them in L2 / Infinity Cache; the hidden loop itself has no VMEM;
+//   * the epilogue requests a whole row group's residual before its first pass (it was one dependent HBM round trip per
+//     2-row pass: 94 of 324 us);
+//   * GELU(z) = 0.5 z + |z| (0.5 - 0.5 E), E = erfc(|z|/sqrt 2): 13 VALU per pair instead of 17 (no max, no canonicalising
+//     max in front of it) - with every wave64 VALU instruction costing 4 cycles here, the instruction count IS the time.
+__device__ __forceinline__ uint32_t gelu2b_bf16(float z0, float z1) {
+  const f32x2 z = {z0, z1};
+  const f32x2 az = {fabsf(z0), fabsf(z1)};
+  f32x2 q = fma2(splat2(-0.00041175442346105595f), az, splat2(0.006678475199902348f));
+  q = fma2(q, az, splat2(-0.050879760394516485f));
+  q = fma2(q, az, splat2(-0.46094072908550926f));
+  q = fma2(q, az, splat2(-1.150400682855232f));
+  q = fma2(q, az, splat2(-8.454223479528131e-05f));
+  const f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  const f32x2 w = fma2(e, splat2(-0.5f), splat2(0.5f));
+  const f32x2 g = fma2(az, w, z * splat2(0.5f));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(g, bf16x2));
+}
+
+template <int C, int NW, int RG>
+struct Geo3 {
   using G = GeoR<C, 1>;
-  constexpr int KS = G::KS, CB = G::CB, NHB = G::NHB, NW = 12;
-  constexpr int SCR3_OFF = G::CONST_OFF + 32 * C;             // 2 rows x C fp32 per wavefront
+  static constexpr int SCR_OFF = G::CONST_OFF + 32 * C;       // after b1, b2, gamma, ln_w, ln_b
+  static constexpr int SCR_WAVE = 2 * C * 4;                  // 2 rows x C fp32 per wavefront
+  static constexpr int LDS = SCR_OFF + NW * SCR_WAVE;
+  static constexpr int ROWS = 32 * RG;
+  static_assert(LDS <= 160 * 1024, "weights + constants + scratch must fit the CU's LDS");
+  static_assert((G::NHB * G::PIECES) % NW == 0, "pieces divide over the wavefronts");
+  static_assert(2 * (C / 4) <= 64, "a 2-row pass is one float4 per lane");
+};
+
+template <int C, int NW, int RG, typename TX, typename TO>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const BlkFwdArgs p) {
+  using G = GeoR<C, 1>;
+  using G3 = Geo3<C, NW, RG>;
+  constexpr int KS = G::KS, CB = G::CB, NHB = G::NHB;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* b1s = reinterpret_cast<float*>(lds + G::CONST_OFF);
 
@@ -386,8 +426,8 @@ __global__ __launch_bounds__(768, 3) void mlp3_fwd_res_kernel(const BlkFwdArgs p
       const int piece = i * NW + wave;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(piece) * 1024), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
     }
-    for (int i = tid; i < C; i += 768) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
-    for (int i = tid; i < C; i += 768) {
+    for (int i = tid; i < C; i += NW * 64) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    for (int i = tid; i < C; i += NW * 64) {
       b1s[4 * C + i] = p.b2[i];
       b1s[5 * C + i] = p.gamma ? p.gamma[i] : 1.0f;
       b1s[6 * C + i] = p.ln_w ? p.ln_w[i] : 1.0f;
@@ -398,22 +438,25 @@ __global__ __launch_bounds__(768, 3) void mlp3_fwd_res_kernel(const BlkFwdArgs p
   __syncthreads();                                            // the only barrier of the kernel
 
   const unsigned char* w_lane = lds + lane * 16;
-  float* scr = reinterpret_cast<float*>(lds + SCR3_OFF + wave * (2 * C * 4));
+  float* scr = reinterpret_cast<float*>(lds + G3::SCR_OFF + wave * G3::SCR_WAVE);
   const float4* b2v = reinterpret_cast<const float4*>(b1s + 4 * C);
   const float4* gav = reinterpret_cast<const float4*>(b1s + 5 * C);
   constexpr int C4 = C / 4;
-  static_assert(2 * C4 <= 64, "a 2-row pass is one float4 per lane");
   const TX* resid = static_cast<const TX*>(p.resid);
   TO* out = static_cast<TO*>(p.out);
-  const long n_tiles = (p.M + 31) / 32;
+  const long n_tiles = (p.M + G3::ROWS - 1) / G3::ROWS;
+  const long tstride = static_cast<long>(gridDim.x) * NW;
+  const int rr = lane / C4, c4 = lane - rr * C4;               // epilogue: row of a 2-row pass, float4 column of this lane
+  const bool ep_lane = lane < 2 * C4;
 
-  for (long tile = static_cast<long>(blockIdx.x) * NW + wave; tile < n_tiles; tile += static_cast<long>(gridDim.x) * NW) {
-    const long m0 = tile * 32;
-    long row = m0 + l32;
-    const bool row_ok = row < p.M;
-    if (!row_ok) row = p.M - 1;
-    bf16x8 af[KS];
-    {
+  for (long tile = static_cast<long>(blockIdx.x) * NW + wave; tile < n_tiles; tile += tstride) {
+    const long m0 = tile * G3::ROWS;
+    bf16x8 af[RG][KS];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      long row = m0 + g * 32 + l32;
+      const bool row_ok = row < p.M;
+      if (!row_ok) row = p.M - 1;
       uint4 raw[KS];
       const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
 #pragma unroll
@@ -457,20 +500,48 @@ __global__ __launch_bounds__(768, 3) void mlp3_fwd_res_kernel(const BlkFwdArgs p
             const float b = fmaf((bf16_hi(w[j]) - mean) * rstd, gw[2 * j + 1], o[2 * j + 1]);
             pk[j] = pack_bf16(a, b);
           }
-          af[ks] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+          af[g][ks] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
         }
       } else {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
+        for (int ks = 0; ks < KS; ++ks) af[g][ks] = __builtin_bit_cast(bf16x8, raw[ks]);
+      }
+    }
+    // ---- touch (one dword per 128-byte line) what this wavefront reads next from HBM: the residual tile of this tile and the
+    //      rows of its next tile.  The values are dropped; the lines are in L2 / Infinity Cache when the real loads come.
+    constexpr int kResLines = (G3::ROWS * C * static_cast<int>(sizeof(TX)) + 127) / 128;
+    constexpr int kULines = (G3::ROWS * C * 2 + 127) / 128;
+    constexpr int kPf = (kResLines + 63) / 64 + (kULines + 63) / 64;
+    uint32_t pf[kPf];
+    {
+      int k = 0;
+      const long lim = (p.M - m0) * C * static_cast<long>(sizeof(TX));
+      const unsigned char* rb = reinterpret_cast<const unsigned char*>(resid) + m0 * C * static_cast<long>(sizeof(TX));
+#pragma unroll
+      for (int i = 0; i < (kResLines + 63) / 64; ++i, ++k) {
+        long off = (static_cast<long>(i) * 64 + lane) * 128;
+        if (off >= lim || off >= static_cast<long>(kResLines) * 128) off = 0;
+        pf[k] = (resid && !DBG(p, 8)) ? *reinterpret_cast<const uint32_t*>(rb + off) : 0u;
+      }
+      const long nm0 = (tile + tstride) * G3::ROWS;
+      const long ulim = (p.M - nm0) * C * 2;
+      const unsigned char* ub = reinterpret_cast<const unsigned char*>(p.u) + nm0 * C * 2;
+#pragma unroll
+      for (int i = 0; i < (kULines + 63) / 64; ++i, ++k) {
+        long off = (static_cast<long>(i) * 64 + lane) * 128;
+        if (off >= static_cast<long>(kULines) * 128) off = 0;
+        pf[k] = (nm0 < p.M && off < ulim && !DBG(p, 8)) ? *reinterpret_cast<const uint32_t*>(ub + off) : 0u;
       }
     }
 
-    f32x16 acc2[CB];
+    f32x16 acc2[RG][CB];
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int g = 0; g < RG; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[cb][r] = 0.f;
-    const int n_sl = (p.dbg & 4) ? 2 : NHB;                   // dbg 4: timing experiment, two of the twelve slices only
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[g][cb][r] = 0.f;
+    const int n_sl = DBG(p, 4) ? 2 : NHB;                     // dbg 4: timing experiment, two of the twelve slices only
 #pragma unroll 1
     for (int s = 0; s < n_sl; ++s) {
       const unsigned char* sl = w_lane + static_cast<long>(s) * G::SLICE;
@@ -478,96 +549,110 @@ __global__ __launch_bounds__(768, 3) void mlp3_fwd_res_kernel(const BlkFwdArgs p
       bf16x8 fr[PF];
 #pragma unroll
       for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);
-      f32x16 acc1;
+      f32x16 acc1[RG];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const float4 b4 = *reinterpret_cast<const float4*>(b1s + s * 32 + 8 * g4 + 4 * half);
-        acc1[4 * g4 + 0] = b4.x; acc1[4 * g4 + 1] = b4.y; acc1[4 * g4 + 2] = b4.z; acc1[4 * g4 + 3] = b4.w;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          acc1[g][4 * g4 + 0] = b4.x; acc1[g][4 * g4 + 1] = b4.y; acc1[g][4 * g4 + 2] = b4.z; acc1[g][4 * g4 + 3] = b4.w;
+        }
       }
 #pragma unroll
-      for (int i = 0; i < KS; ++i) {                          // (one chain: the co-resident wavefronts fill the dependent-MFMA gaps)
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], acc1, 0, 0, 0);
+      for (int i = 0; i < KS; ++i) {                          // (one chain per row group: the co-resident wavefronts fill the gaps)
+#pragma unroll
+        for (int g = 0; g < RG; ++g) acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[g][i], acc1[g], 0, 0, 0);
         if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
       }
-      bf16x8 hf[2];
-      {
+      bf16x8 hf[RG][2];
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
         uint32_t pk[8];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float z0 = acc1[r], z1 = acc1[r + 1];
-          pk[r >> 1] = (p.dbg & 1) ? pack_bf16(z0, z1) : gelu2_bf16(z0, z1);          // dbg 1: timing experiment, no GELU
-        }
-        hf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
-        hf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
+        for (int r = 0; r < 16; r += 2)
+          pk[r >> 1] = DBG(p, 1) ? pack_bf16(acc1[g][r], acc1[g][r + 1]) : gelu2b_bf16(acc1[g][r], acc1[g][r + 1]);   // dbg 1: no GELU
+        hf[g][0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        hf[g][1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
       }
 #pragma unroll
       for (int j = 0; j < 2 * CB; ++j) {
         const int i = KS + j;
-        acc2[j % CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[j / CB], fr[i % PF], acc2[j % CB], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+          acc2[g][j % CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[g][j / CB], fr[i % PF], acc2[g][j % CB], 0, 0, 0);
         if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
       }
     }
+#pragma unroll
+    for (int i = 0; i < kPf; ++i) asm volatile("" ::"v"(pf[i]));          // the touch loads were issued (and are complete) here
 
-    // ---- epilogue: two rows (r and r + 4 of an 8-row group) per pass through 2 x C floats of scratch; lanes 0 .. 2 C/4 - 1 move
-    //      16 bytes each of the residual and of the result
-    const long e_end = p.M * C;
+    // ---- epilogue: eight 2-row passes at a time - their residual requests first, then two rows (r and r + 4 of an 8-row group)
+    //      per pass through 2 x C floats of scratch; lanes 0 .. 2 C/4 - 1 move 16 bytes each of the residual and of the result
+    const int rows_left = static_cast<int>(p.M - m0 < G3::ROWS ? p.M - m0 : G3::ROWS);
+    const long ebase = (m0 + 4 * rr) * C + c4 * 4;            // this lane's element offset in pass r = 0 of row group 0
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      __builtin_amdgcn_wave_barrier();
+    for (int gh = 0; gh < 2 * RG; ++gh) {                     // (row group, half of its 16 passes)
+      const int g = gh >> 1, r0 = (gh & 1) * 8;
+      float4 xv[8];
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) scr[half * C + cb * 32 + l32] = acc2[cb][r];
-      __builtin_amdgcn_wave_barrier();
-      const int rr = lane / C4, c4 = lane - rr * C4;           // row of the pass, float4 column
-      const long e = (m0 + (r & 3) + 8 * (r >> 2) + 4 * rr) * C + c4 * 4;
-      if (lane < 2 * C4 && e < e_end && !(p.dbg & 2)) {
-        const float4 o = reinterpret_cast<const float4*>(scr)[lane];
-        const float4 bb = b2v[c4], gg = gav[c4];
-        const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (resid) {
+      for (int k = 0; k < 8; ++k) {
+        const int r = r0 + k, ro = g * 32 + (r & 3) + 8 * (r >> 2);      // row offset of lane row 0 of this pass
+        xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (resid && ep_lane && ro + 4 * rr < rows_left && !DBG(p, 2)) {
           if constexpr (sizeof(TX) == 4) {
-            xv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resid) + e);
+            xv[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resid) + ebase + ro * C);
           } else {
-            const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(resid) + e);
-            xv = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+            const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(resid) + ebase + ro * C);
+            xv[k] = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
           }
         }
-        if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
-        const float o0 = fmaf(y0, gg.x, xv.x), o1 = fmaf(y1, gg.y, xv.y);
-        const float o2 = fmaf(y2v, gg.z, xv.z), o3 = fmaf(y3, gg.w, xv.w);
-        if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + e) = make_float4(o0, o1, o2, o3);
-        else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + e) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = r0 + k, ro = g * 32 + (r & 3) + 8 * (r >> 2);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) scr[half * C + cb * 32 + l32] = acc2[g][cb][r];
+        __builtin_amdgcn_wave_barrier();
+        if (ep_lane && ro + 4 * rr < rows_left && !DBG(p, 2)) {
+          const long e = ebase + ro * C;
+          const float4 o = reinterpret_cast<const float4*>(scr)[lane];
+          const float4 bb = b2v[c4], gg = gav[c4];
+          const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
+          if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
+          const float o0 = fmaf(y0, gg.x, xv[k].x), o1 = fmaf(y1, gg.y, xv[k].y);
+          const float o2 = fmaf(y2v, gg.z, xv[k].z), o3 = fmaf(y3, gg.w, xv[k].w);
+          if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + e) = make_float4(o0, o1, o2, o3);
+          else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + e) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+        }
       }
     }
   }
 }
 
-template <int C>
+template <int C, int NW, int RG>
 int launch_res3(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
-  using G = GeoR<C, 1>;
-  constexpr int LDS3 = G::CONST_OFF + 32 * C + 12 * 2 * C * 4;
-  static_assert(LDS3 <= 160 * 1024, "weights + constants + scratch must fit the CU's LDS");
-  static_assert((G::NHB * G::PIECES) % 12 == 0, "pieces divide over 12 wavefronts");
+  using G3 = Geo3<C, NW, RG>;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
   }
-  const long n_tiles = (a.M + 31) / 32;
-  long nb = (n_tiles + 11) / 12;
+  const long n_tiles = (a.M + G3::ROWS - 1) / G3::ROWS;
+  long nb = (n_tiles + NW - 1) / NW;
   if (nb > n_cu) nb = n_cu;
-  const dim3 grid(static_cast<unsigned>(nb)), block(768);
+  const dim3 grid(static_cast<unsigned>(nb)), block(NW * 64);
 #define MLP3_LAUNCH(TX, TO)                                                                                      \
   {                                                                                                              \
-    auto kfn = mlp3_fwd_res_kernel<C, TX, TO>;                                                                   \
+    auto kfn = mlp3_fwd_res_kernel<C, NW, RG, TX, TO>;                                                           \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                LDS3);                                                                           \
+                                G3::LDS);                                                                        \
       attr_done = true;                                                                                          \
     }                                                                                                            \
-    hipLaunchKernelGGL(kfn, grid, block, LDS3, s, a);                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, G3::LDS, s, a);                                                         \
   }
   if (resid_dtype == APGD_F32 && out_dtype == APGD_F32) MLP3_LAUNCH(float, float)
   else if (resid_dtype == APGD_F32) MLP3_LAUNCH(float, uint16_t)
@@ -612,11 +697,12 @@ int launch_res(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t 
 }  // namespace
 
 int mlp2_fwd_launch(const BlkFwdArgs& a, int C, int resid_dtype, int out_dtype, hipStream_t s) {
-  // APGD_MLP2_RG (tuning experiments only): 0 = twelve independent wavefronts per CU (mlp3, the default); 1 / 2 = the
-  // one-wavefront-per-SIMD form with 32 / 64 rows per wavefront and register prefetch (mlp2)
+  // APGD_MLP2_RG (tuning experiments only): 0 = twelve independent wavefronts per CU, 32 rows each (mlp3, the default);
+  // 8 = eight wavefronts, 64 rows each; 1 / 2 = the one-wavefront-per-SIMD form with register prefetch (mlp2)
   static const int rg = getenv("APGD_MLP2_RG") ? atoi(getenv("APGD_MLP2_RG")) : 0;
   if (C != 96) return -100;
   if (rg == 1) return launch_res<96, 1>(a, resid_dtype, out_dtype, s);
   if (rg == 2) return launch_res<96, 2>(a, resid_dtype, out_dtype, s);
-  return launch_res3<96>(a, resid_dtype, out_dtype, s);
+  if (rg == 8) return launch_res3<96, 8, 2>(a, resid_dtype, out_dtype, s);
+  return launch_res3<96, 12, 1>(a, resid_dtype, out_dtype, s);
 }
