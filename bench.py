@@ -122,26 +122,30 @@ def model_kernel_rooflines(R, dev, B, iters=10):
         best.append(min(ts))
         return sum(ts) / len(ts)
 
+    g = torch.Generator(device=dev).manual_seed(0)
+    for C, HW in ((96, 56), (192, 28)):                     # stage 0 (HBM / VALU / MFMA all within 2x of each other) and stage 1 (MFMA-bound)
+        M = B * HW * HW
+        u = torch.randn(M, C, device=dev, generator=g).to(torch.bfloat16)
+        x = torch.randn(M, C, device=dev, generator=g)
+        w1 = torch.randn(4 * C, C, device=dev, generator=g) * C ** -0.5
+        w2 = torch.randn(C, 4 * C, device=dev, generator=g) * (4 * C) ** -0.5
+        lw, lb, b1, b2, gm = (torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.zeros(4 * C, device=dev),
+                              torch.zeros(C, device=dev), torch.ones(C, device=dev))
+        wf = R.ops._pack_mlp(w1, w2)
+        o = torch.empty(M, C, device=dev)
+        t = timed(lambda: R._lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, None, None, wf.data_ptr(),
+                                                              b1.data_ptr(), b2.data_ptr(), gm.data_ptr(), x.data_ptr(), 0, o.data_ptr(), 0,
+                                                              None, M, C, stream), "cnx_block_mlp_fwd"))
+        nbytes, flops = M * C * (2 + 4 + 4), 16.0 * M * C * C
+        out.append({"kernel": "fused LN+MLP forward C=%d (cnx_block_mlp_fwd, M=%d)" % (C, M), "avg_us": round(t * 1e6, 1),
+                    "min_us": round(best[-1] * 1e6, 1),
+                    "hbm": {"achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
+                            "algorithmic_bytes_per_launch": nbytes},
+                    "mfma": {"achieved": round(flops / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4)}})
     C, HW = 96, 56
     M = B * HW * HW
-    g = torch.Generator(device=dev).manual_seed(0)
-    u = torch.randn(M, C, device=dev, generator=g).to(torch.bfloat16)
     x = torch.randn(M, C, device=dev, generator=g)
-    w1 = torch.randn(4 * C, C, device=dev, generator=g) * C ** -0.5
-    w2 = torch.randn(C, 4 * C, device=dev, generator=g) * (4 * C) ** -0.5
-    lw, lb, b1, b2, gm = (torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.zeros(4 * C, device=dev),
-                          torch.zeros(C, device=dev), torch.ones(C, device=dev))
-    wf = R.ops._pack_mlp(w1, w2)
-    o = torch.empty(M, C, device=dev)
-    t = timed(lambda: R._lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, None, None, wf.data_ptr(),
-                                                          b1.data_ptr(), b2.data_ptr(), gm.data_ptr(), x.data_ptr(), 0, o.data_ptr(), 0,
-                                                          None, M, C, stream), "cnx_block_mlp_fwd"))
-    nbytes, flops = M * C * (2 + 4 + 4), 16.0 * M * C * C
-    out.append({"kernel": "blk_mlp_fwd_kernel<96> (cnx_block_mlp_fwd, M=%d)" % M, "avg_us": round(t * 1e6, 1),
-                "min_us": round(best[-1] * 1e6, 1),
-                "hbm": {"achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
-                        "algorithmic_bytes_per_launch": nbytes},
-                "mfma": {"achieved": round(flops / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4)}})
+    b2 = torch.zeros(C, device=dev)
     w49 = torch.randn(49, C, device=dev, generator=g) * 0.1
     xo = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
     t = timed(lambda: R._lib.check(lib.cnx_dwconv7x7_nhwc(x.data_ptr(), 0, w49.data_ptr(), b2.data_ptr(), None, xo.data_ptr(), 1, B, HW,

@@ -154,7 +154,7 @@ struct Geo {
   static constexpr int DEPTH = (C <= 96) ? BLK_FWD96_DEPTH : 3;   // ring slots (DEPTH - 1 slices in flight ahead of the one being read)
   static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 24 * C;   // + b1 (4C), b2 (C), gamma (C) fp32
   static constexpr int BM = 128;                    // rows per workgroup
-  static constexpr bool AGPR_ACC = C >= 384;        // output accumulators pinned in AGPRs (inline-asm MFMA)
+  static constexpr bool AGPR_ACC = false;           // (inline-asm MFMA with AGPR-pinned accumulators: kept for experiments only)
   static_assert(FWD_PIECES % 4 == 0, "pieces must divide over 4 wavefronts");
 };
 
@@ -918,7 +918,8 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
   a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.mean = mean; a.rstd = rstd;
   a.Wf = static_cast<const uint16_t*>(Wf); a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.resid = resid; a.out = out;
   a.y2 = static_cast<uint16_t*>(y2_out); a.M = M;
-  static const int dbg = getenv("APGD_BLK_DBG") ? atoi(getenv("APGD_BLK_DBG")) : 0;
+  static const int dbg = (getenv("APGD_BLK_DBG") ? atoi(getenv("APGD_BLK_DBG")) : 0) |
+                         ((getenv("APGD_MLP3_STAGGER") ? atoi(getenv("APGD_MLP3_STAGGER")) : 0) << 8);
   a.dbg = dbg;
   hipStream_t s = as_stream(stream);
   // C = 96: the persistent kernel with LDS-resident weights (mlp_kernels.hip); APGD_BLK_FWD_IMPL=1 selects the first-generation

@@ -436,6 +436,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const Blk
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                            // the only barrier of the kernel
+  // Symmetry breaking.  The NW / 4 wavefronts that share a SIMD start together and do identical work, so without help they
+  // stay in phase for the whole kernel: all in their HBM phases at once (SIMD idle), then all in the hidden loop at once.
+  // Wavefront slot k of a SIMD (waves k*4 .. k*4+3) therefore starts `stagger` x k sleep quanta late, once; the persistent
+  // tile loop keeps the offset.  (p.dbg >> 8 = quanta of s_sleep 127 ~ 4 us each; 0 = off.)
+  {
+    const int quanta = (p.dbg >> 8) * (wave >> 2);
+    for (int i = 0; i < quanta; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   const unsigned char* w_lane = lds + lane * 16;
   float* scr = reinterpret_cast<float*>(lds + G3::SCR_OFF + wave * G3::SCR_WAVE);
