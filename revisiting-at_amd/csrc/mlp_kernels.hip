@@ -553,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const Blk
 #pragma unroll 1
     for (int s = 0; s < n_sl; ++s) {
       const unsigned char* sl = w_lane + static_cast<long>(s) * G::SLICE;
-      constexpr int NF = KS + 2 * CB, PF = 4;
+      constexpr int NF = KS + 2 * CB, PF = (NW >= 16 ? 2 : 4);
       bf16x8 fr[PF];
 #pragma unroll
       for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);
@@ -594,16 +594,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const Blk
 #pragma unroll
     for (int i = 0; i < kPf; ++i) asm volatile("" ::"v"(pf[i]));          // the touch loads were issued (and are complete) here
 
-    // ---- epilogue: eight 2-row passes at a time - their residual requests first, then two rows (r and r + 4 of an 8-row group)
+    // ---- epilogue: EB 2-row passes at a time - their residual requests first, then two rows (r and r + 4 of an 8-row group)
     //      per pass through 2 x C floats of scratch; lanes 0 .. 2 C/4 - 1 move 16 bytes each of the residual and of the result
     const int rows_left = static_cast<int>(p.M - m0 < G3::ROWS ? p.M - m0 : G3::ROWS);
     const long ebase = (m0 + 4 * rr) * C + c4 * 4;            // this lane's element offset in pass r = 0 of row group 0
+    constexpr int EB = NW >= 16 ? 4 : 8;                      // passes per batch of residual requests (registers)
 #pragma unroll
-    for (int gh = 0; gh < 2 * RG; ++gh) {                     // (row group, half of its 16 passes)
-      const int g = gh >> 1, r0 = (gh & 1) * 8;
-      float4 xv[8];
+    for (int gh = 0; gh < (16 / EB) * RG; ++gh) {             // (row group, batch of its 16 passes)
+      const int g = gh / (16 / EB), r0 = (gh % (16 / EB)) * EB;
+      float4 xv[EB];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < EB; ++k) {
         const int r = r0 + k, ro = g * 32 + (r & 3) + 8 * (r >> 2);      // row offset of lane row 0 of this pass
         xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (resid && ep_lane && ro + 4 * rr < rows_left && !DBG(p, 2)) {
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const Blk
         }
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < EB; ++k) {
         const int r = r0 + k, ro = g * 32 + (r & 3) + 8 * (r >> 2);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -712,5 +713,6 @@ int mlp2_fwd_launch(const BlkFwdArgs& a, int C, int resid_dtype, int out_dtype, 
   if (rg == 1) return launch_res<96, 1>(a, resid_dtype, out_dtype, s);
   if (rg == 2) return launch_res<96, 2>(a, resid_dtype, out_dtype, s);
   if (rg == 8) return launch_res3<96, 8, 2>(a, resid_dtype, out_dtype, s);
+  if (rg == 16) return launch_res3<96, 16, 1>(a, resid_dtype, out_dtype, s);
   return launch_res3<96, 12, 1>(a, resid_dtype, out_dtype, s);
 }
