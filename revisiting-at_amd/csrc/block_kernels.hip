@@ -91,8 +91,11 @@ __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 exp2_2(f32x2 t) { return (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)}; }
 
-// GELU of a pair (same polynomial as gelu_f), packed to bf16
+// GELU of a pair (same polynomial as gelu_f), packed to bf16:  GELU(z) = 0.5 z + |z| (0.5 - 0.5 E),  E = erfc(|z|/sqrt 2).
+// 13 VALU per pair; the max(z, 0) form cost 17 (two v_max plus the canonicalising v_max the compiler puts in front of an
+// fmaxf on MFMA results) - every wave64 VALU instruction costs 4 cycles on this part (profiles/r02_fused_mlp_study.md).
 __device__ __forceinline__ uint32_t gelu2_bf16(float z0, float z1) {
+  const f32x2 z = {z0, z1};
   const f32x2 az = {fabsf(z0), fabsf(z1)};
   f32x2 q = fma2(splat2(-0.00041175442346105595f), az, splat2(0.006678475199902348f));
   q = fma2(q, az, splat2(-0.050879760394516485f));
@@ -100,8 +103,8 @@ __device__ __forceinline__ uint32_t gelu2_bf16(float z0, float z1) {
   q = fma2(q, az, splat2(-1.150400682855232f));
   q = fma2(q, az, splat2(-8.454223479528131e-05f));
   const f32x2 e = exp2_2(q);
-  const f32x2 pos = {fmaxf(z0, 0.0f), fmaxf(z1, 0.0f)};
-  const f32x2 g = fma2(az * e, splat2(-0.5f), pos);
+  const f32x2 w = fma2(e, splat2(-0.5f), splat2(0.5f));
+  const f32x2 g = fma2(az, w, z * splat2(0.5f));
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(g, bf16x2));
 }
 
@@ -922,9 +925,9 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
                          ((getenv("APGD_MLP3_STAGGER") ? atoi(getenv("APGD_MLP3_STAGGER")) : 0) << 8);
   a.dbg = dbg;
   hipStream_t s = as_stream(stream);
-  // C = 96: the persistent kernel with LDS-resident weights (mlp_kernels.hip); APGD_BLK_FWD_IMPL=1 selects the first-generation
-  // kernel below for A/B timing
-  static const int impl = getenv("APGD_BLK_FWD_IMPL") ? atoi(getenv("APGD_BLK_FWD_IMPL")) : 2;
+  // APGD_BLK_FWD_IMPL=2 selects the barrier-free kernels with LDS-resident weights (mlp_kernels.hip, C = 96) for A/B timing;
+  // measured equal to the ring kernel below, which stays the default (see the table in mlp_kernels.hip)
+  static const int impl = getenv("APGD_BLK_FWD_IMPL") ? atoi(getenv("APGD_BLK_FWD_IMPL")) : 1;
   if (impl == 2) {
     const int r = mlp2_fwd_launch(a, C, resid_dtype, out_dtype, s);
     if (r != -100) return r;

@@ -22,5 +22,6 @@ struct BlkFwdArgs {
   int dbg;                 // timing experiments only (APGD_BLK_DBG)
 };
 
-// persistent forward, weights resident in LDS (C = 96).  Returns a launch status (0 = ok), -100 if C is not covered.
+// barrier-free persistent forward with the weights resident in LDS (C = 96).  Returns a launch status (0 = ok), -100 if C
+// is not covered.
 int mlp2_fwd_launch(const BlkFwdArgs& a, int C, int resid_dtype, int out_dtype, hipStream_t s);
