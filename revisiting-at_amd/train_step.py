@@ -99,8 +99,11 @@ def setup_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # RCCL ("nccl") on GPUs; APGD_DIST_BACKEND=gloo lets the same wiring be exercised with several ranks on ONE GPU
+        # (RCCL refuses two ranks per device), which is how the 1-GPU test box covers DDP + the hand-written backward
+        backend = os.environ.get("APGD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
+            local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world

@@ -40,7 +40,7 @@ import os, sys, json, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 import revisiting_at_amd as R
 rank, local, world = R.setup_distributed()
-assert dist.get_backend() == "nccl" and world == 2
+assert dist.get_backend() == os.environ.get("APGD_DIST_BACKEND", "nccl") and world == 2
 dev = torch.device("cuda", local)
 torch.manual_seed(0)
 A = R.architecture
@@ -59,8 +59,11 @@ tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2), dev
 def hook(_, bucket):
     st["hook_total"] += 1
     st["hook_in_attack"] += int(st["in_attack"])
-    fut = dist.all_reduce(bucket.buffer().div_(world), async_op=True).get_future()
-    return fut.then(lambda f: f.value()[0])
+    buf = bucket.buffer().div_(world)
+    dist.all_reduce(buf)                      # synchronous: gloo's CUDA work objects have no future
+    fut = torch.futures.Future()
+    fut.set_result(buf)
+    return fut
 tr.model.register_comm_hook(None, hook)
 g = torch.Generator(device=dev).manual_seed(100 + rank)
 x = torch.rand(4, 3, 64, 64, device=dev, generator=g)
@@ -78,8 +81,7 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
-def test_two_rccl_ranks_keep_identical_parameters_and_no_collective_inside_the_attack(tmp_path):
+def _run_two_ranks(tmp_path, backend):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     with socket.socket() as sk:
@@ -88,10 +90,24 @@ def test_two_rccl_ranks_keep_identical_parameters_and_no_collective_inside_the_a
     procs = []
     for r in range(2):
         env = dict(_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", APGD_DIST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, text=True))
     out = procs[0].communicate(timeout=900)[0]
     for p in procs:
         assert p.wait(timeout=300) == 0
-    res = json.loads(out.strip().splitlines()[-1])
+    return json.loads(out.strip().splitlines()[-1])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_two_rccl_ranks_keep_identical_parameters_and_no_collective_inside_the_attack(tmp_path):
+    res = _run_two_ranks(tmp_path, "nccl")
+    assert res["same"] and res["hook_in_attack"] == 0 and res["hook_total"] >= 2, res
+
+
+def test_two_ranks_on_one_gpu_with_the_product_model(tmp_path):
+    """The 1-GPU box's stand-in for the RCCL run: two rank processes share cuda:0 over gloo (RCCL refuses two ranks per
+    device).  Everything except the transport is the product path: DDP(WrappedModel(ConvNeXt)) with the fused blocks, the HIP
+    attack with its gradient-sign sink inside DDP.forward, bf16 autocast, AdamW, EMA.  Parameters stay identical across the
+    ranks, and no bucket reduction fires inside the attack."""
+    res = _run_two_ranks(tmp_path, "gloo")
     assert res["same"] and res["hook_in_attack"] == 0 and res["hook_total"] >= 2, res
