@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=6)
     p.add_argument("--cpu-threads", type=int, default=32)
     p.add_argument("--attack-only", action="store_true", help="time only apgd_train (extra info line on stderr)")
+    p.add_argument("--no-other-configs", action="store_true", help="skip the informational runs of BASELINE configs #3-#5")
     return p.parse_args()
 
 
@@ -155,6 +156,62 @@ def model_kernel_rooflines(R, dev, B, iters=10):
                 "avg_us": round(t * 1e6, 1), "min_us": round(best[-1] * 1e6, 1),
                 "hbm": {"achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
                         "algorithmic_bytes_per_launch": nbytes}})
+    return out
+
+
+def other_configs(R, dev):
+    """Single-GPU, per-GPU-batch numbers of the other BASELINE.json configurations (informational, after the timed region):
+    #3 ViT-B-CvSt APGD-2 AT @224 (per-GPU batch 256), #4 ConvNeXt-L-CvSt APGD-3 AT @320 (per-GPU batch 128),
+    #5 100-step APGD-CE evaluation attack on ConvNeXt-B-CvSt @224 (batch 100, fp32 as AA_eval.py runs it)."""
+    import torch
+    out = {}
+
+    def at_step(arch, res, batch, n_iter, steps=3, warm=2):
+        torch.manual_seed(0)
+        model = R.get_new_model(arch, pretrained=False, not_original=True, img_size=res)
+        tr = R.ATTrainStep(model, arch, R.AdvConfig(attack="apgd", norm="Linf", eps=4 / 255, n_iter=n_iter), dev, lr=1e-3,
+                           amp_dtype=torch.bfloat16, ema=True)
+        g = torch.Generator(device=dev).manual_seed(7)
+        x = torch.rand(batch, 3, res, res, device=dev, generator=g)
+        y = torch.randint(0, 1000, (batch,), device=dev, generator=g)
+        for _ in range(warm):
+            tr.step(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(x, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        del tr, model
+        torch.cuda.empty_cache()
+        return {"img_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "per_gpu_batch": batch, "res": res,
+                "n_iter": n_iter, "steps": steps}
+
+    for key, cfg in (("cfg3_vit_b_cvst_apgd2_at_224", ("vit_b", 224, 256, 2)),
+                     ("cfg4_convnext_large_cvst_apgd3_at_320", ("convnext_large", 320, 128, 3))):
+        try:
+            out[key] = at_step(*cfg)
+        except Exception as e:                               # informational: never fail the headline line over it
+            out[key] = "unavailable: %r" % (e,)
+    try:
+        torch.manual_seed(0)
+        model = R.get_new_model("convnext_base", pretrained=False, not_original=True).to(dev).to(memory_format=torch.channels_last).eval()
+        g = torch.Generator(device=dev).manual_seed(9)
+        x = torch.rand(100, 3, 224, 224, device=dev, generator=g)
+        with torch.no_grad():
+            y = model(x).argmax(1)                           # every point starts robust: the attack runs on all of them
+        R.aa_eval.apgd_attack(model, x[:8], y[:8], "Linf", 4 / 255, 2, "ce", None, True, g)        # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        R.aa_eval.apgd_attack(model, x, y, "Linf", 4 / 255, 100, "ce", None, True, g)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["cfg5_convnext_base_cvst_apgd_ce_100step_eval_224"] = {"img_s": round(100 / dt, 2), "s_per_batch": round(dt, 3),
+                                                                   "batch": 100, "n_iter": 100, "dtype": "f32"}
+        del model
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["cfg5_convnext_base_cvst_apgd_ce_100step_eval_224"] = "unavailable: %r" % (e,)
     return out
 
 
@@ -319,6 +376,11 @@ def main():
                 extra["model_kernel_rooflines"] = model_kernel_rooflines(R, dev, B)
             except Exception as e:                       # informational only: never fail the bench line over it
                 extra["model_kernel_rooflines"] = "unavailable: %r" % (e,)
+        if (rank == 0 and world == 1 and args.arch == "convnext_tiny" and R.ops.MODE != "eager" and not args.no_other_configs
+                and not args.no_cpu_baseline):
+            del trainer, model, base, x, y
+            torch.cuda.empty_cache()
+            extra["other_configs"] = other_configs(R, dev)
         extra["ops_mode"] = R.ops.MODE
         extra["device"] = torch.cuda.get_device_name(dev)
 
