@@ -88,7 +88,7 @@ int cnx_stem_conv_ln_gelu_fwd(const float* x, const void* wq, const float* bias,
 int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx,
                         int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
 /* The same input gradient reduced to its SIGN {-1, 0, +1} (int8, [N, 3, H, W]): the Linf APGD update
- * (autopgd_train_clean.py:221: step_size * torch.sign(grad)) reads nothing else of it, so the attack asks for this
+ * (autopgd_train_clean.py:221: step_size * sign(grad)) reads nothing else of it, so the attack asks for this
  * form and apgd_linf_step_f32(grad_dtype = APGD_I8) / apgd_track_rows(grad_elt = 1) move a quarter of the gradient bytes.
  * sign is taken of the same fp32 accumulator cnx_stem_conv_dgrad stores: identical decisions. */
 int cnx_stem_conv_dgrad_sign(const void* dy, const void* wq, int8_t* sign_out,
