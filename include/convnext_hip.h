@@ -139,7 +139,7 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
  *     dW1 = dHpre^T a,  db1 = rowsum(dHpre^T),  dW2 = (H^T dO)^T,  db2 = colsum(dO).
  * a_stride (elements, 0 = C, multiple of 8) is the row stride of a_out: with a ones column appended by the caller
  * (a_out [M, C+8]) the d(b1) sum rides along in the dW1 GEMM.
- * cnx_block_mlp_bwd_supported(C): widths with a kernel (96, 192). */
+ * cnx_block_mlp_bwd_supported(C): widths with a kernel (96, 128, 192, 256). */
 int cnx_block_mlp_bwd_supported(int32_t C);
 int64_t cnx_mlp_packed_bwd_elems(int32_t C);
 int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* Wb, int32_t C, void* stream);

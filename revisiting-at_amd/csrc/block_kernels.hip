@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
   TO* out = static_cast<TO*>(p.out);
   constexpr int C4 = C / 4;                                             // float4 chunks per row
   constexpr int NCH = 16 * C4 / 64;                                     // chunks per lane and pass
-  constexpr int GRP = 6;                                                // chunks in flight per lane (C/16 is a multiple of 6)
+  constexpr int GRP = (NCH % 6 == 0) ? 6 : 4;                           // chunks in flight per lane (C/16 is a multiple of 6 or of 4)
   static_assert(NCH % GRP == 0, "chunk groups");
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -887,7 +887,7 @@ int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, bool ln_bwd, hipStream_t s)
 
 extern "C" {
 
-int cnx_block_mlp_supported(int32_t C) { return (C == 96 || C == 192 || C == 384) ? 1 : 0; }
+int cnx_block_mlp_supported(int32_t C) { return (C == 96 || C == 128 || C == 192 || C == 256 || C == 384) ? 1 : 0; }
 
 int64_t cnx_mlp_packed_elems(int32_t C) { return static_cast<int64_t>(8) * C * C; }
 
@@ -934,7 +934,9 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
   }
   switch (C) {
     case 96: return launch_blk_fwd<96>(a, resid_dtype, out_dtype, s);
+    case 128: return launch_blk_fwd<128>(a, resid_dtype, out_dtype, s);
     case 192: return launch_blk_fwd<192>(a, resid_dtype, out_dtype, s);
+    case 256: return launch_blk_fwd<256>(a, resid_dtype, out_dtype, s);
     case 384: return launch_blk_fwd<384>(a, resid_dtype, out_dtype, s);
     default: return APGD_ERR_ARG;
   }
@@ -978,7 +980,9 @@ static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_
   hipStream_t s = as_stream(stream);
   switch (C) {
     case 96: return launch_blk_bwd<96>(a, g_dtype, ln_bwd, s);
+    case 128: return launch_blk_bwd<128>(a, g_dtype, ln_bwd, s);
     case 192: return launch_blk_bwd<192>(a, g_dtype, ln_bwd, s);
+    case 256: return launch_blk_bwd<256>(a, g_dtype, ln_bwd, s);
     default: return APGD_ERR_ARG;
   }
 }
@@ -998,6 +1002,6 @@ int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b,
                             true, M, C, stream);
 }
 
-int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 192) ? 1 : 0; }
+int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 128 || C == 192 || C == 256) ? 1 : 0; }
 
 }  // extern "C"

@@ -866,10 +866,11 @@ def block_fused_supported(C):
     return bool(_lib.load().cnx_block_mlp_supported(C))
 
 
-# Widths routed through the fused LN+MLP kernel.  Measured on MI355X (tools/block_bench.py, batch 256): a clear win
-# where the unfused block is HBM-bound (C = 96, 192); at C = 384 the weight stream (128 rows per workgroup) caps it
-# below the hipBLASLt composition, so that width stays on the library path for now.  APGD_BLOCK_FUSED overrides.
-_FUSED_WIDTHS = os.environ.get("APGD_BLOCK_FUSED", "96,192")
+# Widths routed through the fused LN+MLP kernels (forward, input-gradient backward, training backward).  Measured on MI355X
+# (tools/block_bench.py, batch 256): a clear win where the unfused block is HBM-bound (C = 96, 192; 128 and 256 - the first two
+# stages of ConvNeXt-B - are instantiated from the same templates); at C = 384 the weight stream (128 rows per workgroup) caps
+# it below the hipBLASLt composition, so that width stays on the library path for now.  APGD_BLOCK_FUSED overrides.
+_FUSED_WIDTHS = os.environ.get("APGD_BLOCK_FUSED", "96,128,192,256")
 _FUSED_WIDTHS = {int(v) for v in _FUSED_WIDTHS.split(",") if v.strip()}
 
 

@@ -140,7 +140,7 @@ def _grads(out, inputs, cot):
     return torch.autograd.grad(out, inputs, cot, allow_unused=True)
 
 
-@pytest.mark.parametrize("C,H", [(96, 14), (192, 7), (384, 6)])
+@pytest.mark.parametrize("C,H", [(96, 14), (192, 7), (384, 6), (128, 14), (256, 7)])
 @pytest.mark.parametrize("gamma", [True, False])
 def test_convnext_block_matches_reference_block(R, C, H, gamma):
     torch.manual_seed(C + H)
@@ -230,7 +230,7 @@ def test_apgd_train_on_product_model_under_autocast(R):
     assert (lb >= clean - 1e-2).all()        # loss_best never falls below the clean loss (up to bf16 noise)
 
 
-@pytest.mark.parametrize("C", [96, 192, 384])
+@pytest.mark.parametrize("C", [96, 128, 192, 256, 384])
 @pytest.mark.parametrize("M_", [1, 31, 128, 300, 1000])
 @pytest.mark.parametrize("gamma,ln", [(True, True), (False, True), (True, False)])
 def test_fused_block_tail_forward_vs_fp32_reference(R, C, M_, gamma, ln):
@@ -295,7 +295,7 @@ def test_fused_block_tail_argument_errors(R):
     assert lib.cnx_mlp_pack_weights(t.data_ptr(), t.data_ptr(), 2, t.data_ptr(), 96, S()) != 0   # fp16 masters: unsupported
 
 
-@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("C", [96, 128, 192, 256])
 @pytest.mark.parametrize("M_", [1, 33, 256, 328, 700])
 @pytest.mark.parametrize("gamma,emit,gdt", [(True, True, torch.float32), (False, False, torch.float32),
                                             (True, False, torch.bfloat16)])
