@@ -13,6 +13,13 @@
 #include "apgd_hip.h"
 #include "convnext_hip.h"
 
+// timing experiments (APGD_DW_DBG) are compiled in only with -DDW_ABLATE=1: a run-time flag test inside a stencil loop is a
+// branch per use (see profiles/r02_fused_mlp_study.md)
+#ifndef DW_ABLATE
+#define DW_ABLATE 0
+#endif
+#define DW_DBG(dbg, bit) (DW_ABLATE && ((dbg) & (bit)))
+
 namespace {
 
 constexpr int kWave = 64;
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
   {
     const long L = blockIdx.x, B = gridDim.x;
     const long q = B / 8, r = B % 8, xcd = L % 8, k = L / 8;
-    tsel = (dbg & 8) ? L : xcd * q + (xcd < r ? xcd : r) + k;          // dbg 8: timing experiment, plain order
+    tsel = DW_DBG(dbg, 8) ? L : xcd * q + (xcd < r ? xcd : r) + k;          // dbg 8: timing experiment, plain order
   }
   const int n_cg = C / kDC;
   const int h0 = static_cast<int>(tsel % tiles_h) * TH;
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
   // ---- staging: unit = (row, pair m, 4-channel group): two 4-channel loads (padded cols 2m, 2m+1) -> 4 packed dwords
   constexpr int kSR = 4;
   const int row_units = P2 * (kDC / 4);
-  for (int tr0 = 0; tr0 < ((dbg & 2) ? 0 : TH + 6); tr0 += kSR) {       // dbg 2: timing experiment, no staging
+  for (int tr0 = 0; tr0 < (DW_DBG(dbg, 2) ? 0 : TH + 6); tr0 += kSR) {       // dbg 2: timing experiment, no staging
     for (int i = tid; i < row_units; i += nthr) {
       const int m = i / (kDC / 4), l4 = i - m * (kDC / 4);
       const int w0 = 2 * m - 3, w1 = w0 + 1;
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
 #pragma unroll
     for (int r = 0; r < kDR + 6; ++r) {
       const int tr = sr * kDR + r;
-      if (tr >= TH + 6 || (dbg & 1)) continue;                           // dbg 1: timing experiment, no stencil arithmetic
+      if (tr >= TH + 6 || DW_DBG(dbg, 1)) continue;                           // dbg 1: timing experiment, no stencil arithmetic
       const uint32_t* trow = tile2 + (static_cast<long>(tr) * P2 + sc * (kDT / 2)) * kDC + lc;
       uint32_t d[kDT / 2 + 3];
 #pragma unroll
