@@ -11,6 +11,8 @@
 //   resident weights, 8 independent waves/CU x 64 rows (mlp3<8,2>)                                    322 / 290 us
 //   resident weights, 16 independent waves/CU x 32 rows (mlp3<16,1>)                                  313 / 270 us
 //   mlp3<12,1> + start stagger of the waves sharing a SIMD (0 / 4 / 8 / 12 us per slot)               321 / 311 / 328 / 317 us
+//   mlp3 with GELU(s) software-pipelined against GEMM1(s+1) in the same instruction stream, 8x32 / 8x64 / 12x32 rows   338 / 339 / 322 us
+//   any of the above built with -mllvm -amdgpu-sched-strategy=iterative-ilp | max-ilp (make SCHED=...)   within +-3 %
 //
 // i.e. removing the weight stream (925 MB -> 38 MB of L2 traffic per call), the per-slice barriers, the lockstep of the
 // wavefronts, halving the LDS operand reads per MFMA, or adding a wavefront per SIMD changes nothing: the kernel is bound by
@@ -128,76 +130,7 @@ struct Geo3 {
   static_assert(2 * (C / 4) <= 64, "a 2-row pass is one float4 per lane");
 };
 
-// Software-pipelined hidden slice (PIPE variants): in ONE wavefront's instruction stream the GELU of slice s (VALU) sits
-// next to the MFMAs of GEMM1 of slice s+1, which do not depend on it - the matrix pipe and the VALU of a SIMD overlap only
-// when one stream feeds both (across wavefronts their busy times were measured to add up).
-//   acc_in = Hpre^T of slice s (complete)   ->   hf = GELU(acc_in);   acc_out = b1[s+1] + W1[s+1] a^T;   acc2 += hf W2[s]^T
-template <int C, int RG, bool NEXT>
-__device__ __forceinline__ void pipe_step(const unsigned char* w_lane, const float* b1s, int s, int half,
-                                          const bf16x8 (&af)[RG][C / 16], const f32x16 (&acc_in)[RG], f32x16 (&acc_out)[RG],
-                                          f32x16 (&acc2)[RG][C / 32]) {
-  using G = GeoR<C, 1>;
-  constexpr int KS = G::KS, CB = G::CB;
-  const unsigned char* w2 = w_lane + static_cast<long>(s) * G::SLICE + KS * 1024;          // W2 fragments of slice s
-  const unsigned char* w1 = w_lane + static_cast<long>(s + 1) * G::SLICE;                  // W1 fragments of slice s + 1
-  bf16x8 hf[RG][2];
-  if constexpr (NEXT) {
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const float4 b4 = *reinterpret_cast<const float4*>(b1s + (s + 1) * 32 + 8 * g4 + 4 * half);
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        acc_out[g][4 * g4 + 0] = b4.x; acc_out[g][4 * g4 + 1] = b4.y; acc_out[g][4 * g4 + 2] = b4.z; acc_out[g][4 * g4 + 3] = b4.w;
-      }
-    }
-  }
-#pragma unroll
-  for (int h2 = 0; h2 < 2; ++h2) {                           // two halves: GELU of 8 accumulator registers, then the MFMAs that may overlap it
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      uint32_t pk[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = gelu2b_bf16(acc_in[g][8 * h2 + 2 * q], acc_in[g][8 * h2 + 2 * q + 1]);
-      hf[g][h2] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
-    }
-    if constexpr (NEXT) {
-#pragma unroll
-      for (int i = h2 * (KS / 2); i < (h2 + 1) * (KS / 2); ++i) {
-        const bf16x8 f = *reinterpret_cast<const bf16x8*>(w1 + i * 1024);
-#pragma unroll
-        for (int g = 0; g < RG; ++g) acc_out[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, af[g][i], acc_out[g], 0, 0, 0);
-      }
-    }
-    if (h2 == 1) {
-#pragma unroll
-      for (int j = 0; j < 2 * CB; ++j) {                     // fragment order in the slice is (t, cb): j = t * CB + cb
-        const bf16x8 f = *reinterpret_cast<const bf16x8*>(w2 + j * 1024);
-#pragma unroll
-        for (int g = 0; g < RG; ++g)
-          acc2[g][j % CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[g][j / CB], f, acc2[g][j % CB], 0, 0, 0);
-      }
-    }
-  }
-  // Issue order asked of the scheduler: every MFMA of GEMM1(s+1) is followed by one fragment read and its share of the GELU's
-  // ~14 VALU per pair; the first half of GEMM2 (needs hf[.][0] only) carries the rest; left alone hipcc emits the GELU as one
-  // serial block padded with s_nop and then a read-wait-MFMA chain (seen in the ISA: 86 s_nop, 24 s_waitcnt per two slices).
-  constexpr int NM1 = NEXT ? KS * RG : 0, NMA = CB * RG, VT = 112 * RG;
-  constexpr int V1 = NEXT ? (VT * 3 / 4) / NM1 : 0, V2 = (NEXT ? VT / 4 : VT) / NMA;
-#pragma unroll
-  for (int i = 0; i < NM1; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (i % RG == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, V1, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < 2 * NMA; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (i % RG == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    if (i < NMA) __builtin_amdgcn_sched_group_barrier(0x002, V2, 0);
-  }
-}
-
-template <int C, int NW, int RG, bool PIPE, typename TX, typename TO>
+template <int C, int NW, int RG, typename TX, typename TO>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const BlkFwdArgs p) {
   using G = GeoR<C, 1>;
   using G3 = Geo3<C, NW, RG>;
@@ -338,31 +271,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const Blk
       for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[g][cb][r] = 0.f;
-    if constexpr (PIPE) {
-      static_assert(NHB % 2 == 0 && KS % 2 == 0, "the pipelined slice loop is unrolled by two");
-      f32x16 accA[RG], accB[RG];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {                        // GEMM1 of slice 0
-        const float4 b4 = *reinterpret_cast<const float4*>(b1s + 8 * g4 + 4 * half);
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-          accA[g][4 * g4 + 0] = b4.x; accA[g][4 * g4 + 1] = b4.y; accA[g][4 * g4 + 2] = b4.z; accA[g][4 * g4 + 3] = b4.w;
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 f = *reinterpret_cast<const bf16x8*>(w_lane + ks * 1024);
-#pragma unroll
-        for (int g = 0; g < RG; ++g) accA[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, af[g][ks], accA[g], 0, 0, 0);
-      }
-#pragma unroll 1
-      for (int s = 0; s < NHB - 2; s += 2) {
-        pipe_step<C, RG, true>(w_lane, b1s, s, half, af, accA, accB, acc2);
-        pipe_step<C, RG, true>(w_lane, b1s, s + 1, half, af, accB, accA, acc2);
-      }
-      pipe_step<C, RG, true>(w_lane, b1s, NHB - 2, half, af, accA, accB, acc2);
-      pipe_step<C, RG, false>(w_lane, b1s, NHB - 1, half, af, accB, accA, acc2);
-    } else {
     const int n_sl = DBG(p, 4) ? 2 : NHB;                     // dbg 4: timing experiment, two of the twelve slices only
 #pragma unroll 1
     for (int s = 0; s < n_sl; ++s) {
@@ -404,7 +312,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const Blk
           acc2[g][j % CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[g][j / CB], fr[i % PF], acc2[g][j % CB], 0, 0, 0);
         if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
       }
-    }
     }
 #pragma unroll
     for (int i = 0; i < kPf; ++i) asm volatile("" ::"v"(pf[i]));          // the touch loads were issued (and are complete) here
@@ -454,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const Blk
   }
 }
 
-template <int C, int NW, int RG, bool PIPE = false>
+template <int C, int NW, int RG>
 int launch_res3(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
   using G3 = Geo3<C, NW, RG>;
   static int n_cu = 0;
@@ -469,7 +376,7 @@ int launch_res3(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t
   const dim3 grid(static_cast<unsigned>(nb)), block(NW * 64);
 #define MLP3_LAUNCH(TX, TO)                                                                                      \
   {                                                                                                              \
-    auto kfn = mlp3_fwd_res_kernel<C, NW, RG, PIPE, TX, TO>;                                                           \
+    auto kfn = mlp3_fwd_res_kernel<C, NW, RG, TX, TO>;                                                           \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
@@ -495,8 +402,5 @@ int mlp2_fwd_launch(const BlkFwdArgs& a, int C, int resid_dtype, int out_dtype, 
   if (C != 96) return -100;
   if (rg == 8) return launch_res3<96, 8, 2>(a, resid_dtype, out_dtype, s);
   if (rg == 16) return launch_res3<96, 16, 1>(a, resid_dtype, out_dtype, s);
-  if (rg == 81) return launch_res3<96, 8, 1, true>(a, resid_dtype, out_dtype, s);       // pipelined slices, 2 waves/SIMD x 32 rows
-  if (rg == 82) return launch_res3<96, 8, 2, true>(a, resid_dtype, out_dtype, s);       // pipelined slices, 2 waves/SIMD x 64 rows
-  if (rg == 121) return launch_res3<96, 12, 1, true>(a, resid_dtype, out_dtype, s);     // pipelined slices, 3 waves/SIMD
   return launch_res3<96, 12, 1>(a, resid_dtype, out_dtype, s);
 }
