@@ -308,6 +308,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.step(x, y)
+    dt_enqueue = time.perf_counter() - t0                      # host time to ENQUEUE the steps (no synchronisation inside a step)
     sync()
     dt = time.perf_counter() - t0
     events = apgd_mod.PROFILE_EVENTS
@@ -354,7 +355,7 @@ def main():
     if roof is not None and first is not None:
         roof["first_iter"] = first
 
-    extra = {}
+    extra = {"host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3)}
     if args.attack_only or True:
         # attack-only throughput (same tensors, eval mode), a few repetitions
         base = trainer.inner.base_model
