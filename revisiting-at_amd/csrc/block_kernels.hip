@@ -38,6 +38,20 @@
 #define MLP_ABLATE 0
 #endif
 #define DBG(p, bit) (MLP_ABLATE && ((p).dbg & (bit)))
+#if MLP_ABLATE
+// per-workgroup phase stamps (100 MHz wall clock) of the forward kernel, read back with cnx_dbg_blk_trace (tools/blk_trace.py)
+#define BLK_TRACE_SLOTS 12
+#define BLK_TRACE_WGS 8192
+__device__ unsigned long long g_blk_trace[BLK_TRACE_WGS * BLK_TRACE_SLOTS];
+#define TRACE(slot)                                                                                              \
+  if (threadIdx.x == 0 && blockIdx.x < BLK_TRACE_WGS) {                                                          \
+    g_blk_trace[blockIdx.x * BLK_TRACE_SLOTS + (slot)] = wall_clock64();                                         \
+    if ((slot) == 1) g_blk_trace[blockIdx.x * BLK_TRACE_SLOTS + 5] = __builtin_readcyclecounter();             \
+    if ((slot) == 2) g_blk_trace[blockIdx.x * BLK_TRACE_SLOTS + 6] = __builtin_readcyclecounter();             \
+  }
+#else
+#define TRACE(slot)
+#endif
 
 namespace {
 
@@ -108,6 +122,71 @@ __device__ __forceinline__ uint32_t gelu2_bf16(float z0, float z1) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(g, bf16x2));
 }
 
+// The same GELU in UNPACKED fp32 instructions.  On gfx950 the packed-fp32 instructions (v_pk_fma_f32, v_pk_mul_f32, ...) execute
+// on the matrix pipe's time - a SIMD does not overlap them with an MFMA, neither from the same wavefront nor from another - while
+// every other VALU instruction (v_fma_f32, v_exp_f32, v_cvt_pk_bf16_f32, integer ops) hides behind a running MFMA
+// (tools/probe/overlap_probe.cpp, profiles/r02_overlap_probe.md).  19 instructions per pair instead of 13, but they are free while
+// the matrix pipe is busy; the hidden loops mix the two forms so that both pipes finish together.  Inline asm because the
+// vectoriser re-packs scalar fp32 chains; |z| is a VOP3 source modifier here, so there is no v_and.
+__device__ __forceinline__ float fma_abs_s(float q, float z, float c) {       // q * |z| + c, c uniform
+  float d;
+  asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(d) : "v"(q), "v"(z), "s"(c));
+  return d;
+}
+__device__ __forceinline__ float gelu1(float z) {
+  float c5v = -0.00041175442346105595f;                 // the leading coefficient lives in a VGPR (one constant-bus operand per VOP3)
+  asm("" : "+v"(c5v));
+  float q = fma_abs_s(c5v, z, 0.006678475199902348f);
+  q = fma_abs_s(q, z, -0.050879760394516485f);
+  q = fma_abs_s(q, z, -0.46094072908550926f);
+  q = fma_abs_s(q, z, -1.150400682855232f);
+  q = fma_abs_s(q, z, -8.454223479528131e-05f);
+  float e, w, hz, g;
+  asm("v_exp_f32 %0, %1" : "=v"(e) : "v"(q));
+  asm("v_fma_f32 %0, %1, -0.5, 0.5" : "=v"(w) : "v"(e));
+  asm("v_mul_f32 %0, 0.5, %1" : "=v"(hz) : "v"(z));
+  asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(g) : "v"(z), "v"(w), "v"(hz));
+  return g;
+}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// The unpacked GELU of FOUR values as a list of 38 single instructions ("micro-ops"), step-major so that consecutive instructions
+// belong to different values: a dependent v_fma_f32 issues every 6 cycles, an independent one every 3.7 (overlap_probe).
+//   u = 4*step + el, step 0: hz = z/2   1-5: Horner   6: exp2   7: w = 0.5 - 0.5 E   8: g = |z| w + hz;   u = 36, 37: the two bf16 pairs
+__device__ __forceinline__ void gelu_uop(int u, float z0, float z1, float z2, float z3, float (&q)[4], float (&hz)[4], uint32_t& pk0,
+                                         uint32_t& pk1, float c5v) {
+  if (u >= 36) {
+    if (u == 36) pk0 = cvt_pk_bf16(q[0], q[1]); else pk1 = cvt_pk_bf16(q[2], q[3]);
+    return;
+  }
+  const int step = u >> 2, el = u & 3;
+  const float z = el == 0 ? z0 : el == 1 ? z1 : el == 2 ? z2 : z3;
+  float& t = q[el];
+  switch (step) {
+    case 0: asm("v_mul_f32 %0, 0.5, %1" : "=v"(hz[el]) : "v"(z)); break;
+    case 1: t = fma_abs_s(c5v, z, 0.006678475199902348f); break;
+    case 2: t = fma_abs_s(t, z, -0.050879760394516485f); break;
+    case 3: t = fma_abs_s(t, z, -0.46094072908550926f); break;
+    case 4: t = fma_abs_s(t, z, -1.150400682855232f); break;
+    case 5: t = fma_abs_s(t, z, -8.454223479528131e-05f); break;
+    case 6: asm("v_exp_f32 %0, %1" : "=v"(t) : "v"(t)); break;
+    case 7: asm("v_fma_f32 %0, %1, -0.5, 0.5" : "=v"(t) : "v"(t)); break;
+    default: asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(t) : "v"(z), "v"(t), "v"(hz[el])); break;
+  }
+}
+__device__ __forceinline__ uint32_t gelu1x2_bf16(float z0, float z1) {
+  const float g0 = gelu1(z0), g1 = gelu1(z1);
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(g0), "v"(g1));
+  return r;
+}
+#ifndef GELU_NP
+#define GELU_NP 0            // pairs (of the 8 per lane and hidden slice) the NON-pipelined loop evaluates with unpacked instructions (0..8: equal times)
+#endif
+
 // GELU'(z) with ONE exponential per value:  GELU'(-a) = 0.5 erfc(a/sqrt 2) - a phi(a) = E W(x),  E = exp(-a^2/2) = 2^(-x^2),
 // x = a sqrt(log2(e)/2), W(x) = 0.5 erfcx(a/sqrt 2) - a/sqrt(2 pi) ~ degree-6 polynomial (max |error| 1.6e-5, tools/
 // fit_gelu_grad.py; a = min(|z|, 6): GELU'(-6) = -3e-8), and  GELU'(z) = 0.5 + copysign(0.5 - E W, z).
@@ -157,6 +236,10 @@ struct Geo {
   static constexpr int DEPTH = (C <= 96) ? BLK_FWD96_DEPTH : 3;   // ring slots (DEPTH - 1 slices in flight ahead of the one being read)
   static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 24 * C;   // + b1 (4C), b2 (C), gamma (C) fp32
   static constexpr int BM = 128;                    // rows per workgroup
+  // PIPE: the hidden loop is software-pipelined inside every wavefront - GEMM1 of hidden block t runs while the (unpacked) GELU
+  // of block t-1 is evaluated - and the packed weights carry one more slice: slice t = [W1(t) | W2(t-1)], t = 0..NHB.
+  static constexpr bool PIPE = blk_fwd_pipe(C);
+  static constexpr int NSL = NHB + (PIPE ? 1 : 0);  // weight slices streamed through the ring
   static constexpr bool AGPR_ACC = false;           // (inline-asm MFMA with AGPR-pinned accumulators: kept for experiments only)
   static_assert(FWD_PIECES % 4 == 0, "pieces must divide over 4 wavefronts");
 };
@@ -166,14 +249,22 @@ struct Geo {
 template <typename TW>
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const TW* __restrict__ W1, const TW* __restrict__ W2,
                                                        uint16_t* __restrict__ Wf, int C) {
-  const int KS = C / 16, PIECES = KS + 2 * (C / 32);
-  const long total = static_cast<long>(C / 8) * PIECES * 64;
+  const int KS = C / 16, PIECES = KS + 2 * (C / 32), NHB = C / 8;
+  const bool pipe = blk_fwd_pipe(C);
+  const long total = static_cast<long>(NHB + (pipe ? 1 : 0)) * PIECES * 64;
   const long q = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (q >= total) return;
   const int lane = static_cast<int>(q & 63), l32 = lane & 31, half = lane >> 5;
   const int p = static_cast<int>((q >> 6) % PIECES);
-  const int hb = static_cast<int>((q >> 6) / PIECES);
+  int hb = static_cast<int>((q >> 6) / PIECES);
   float v[8];
+  if (pipe) {                                           // slice t = [W1(t) | W2(t-1)]; the two pieces that do not exist are zeros
+    if (p >= KS) --hb;
+    if (hb < 0 || hb >= NHB) {
+      reinterpret_cast<uint4*>(Wf)[q] = make_uint4(0u, 0u, 0u, 0u);
+      return;
+    }
+  }
   if (p < KS) {
     const TW* src = W1 + static_cast<long>(hb * 32 + l32) * C + half * (C / 2) + p * 8;
 #pragma unroll
@@ -203,6 +294,15 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
   const long m0 = static_cast<long>(blockIdx.x) * G::BM + wave * 32;
+  TRACE(0)
+#if MLP_ABLATE
+  if (threadIdx.x == 0 && blockIdx.x < BLK_TRACE_WGS) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_blk_trace[blockIdx.x * BLK_TRACE_SLOTS + 7] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+  }
+#endif
 
   // ---- weight stream: slice s -> ring slot s % DEPTH, 1 KiB pieces, piece = round*4 + wave
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf) + lane * 16;
@@ -314,8 +414,99 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     for (int i = 0; i < kResPf; ++i) pf[i] = 0u;
   }
 
+  TRACE(1)                                              // LayerNorm done, operands in registers
+  if constexpr (G::PIPE) {
+    // ---- software-pipelined hidden loop.  Iteration t (slice t = [W1(t) | W2(t-1)]):
+    //        MFMA stream:  GEMM1(t) (KS)  ->  GEMM2(t-1) first half (CB, needs pairs 0-3 of H)  ->  GEMM2(t-1) second half (CB)
+    //        VALU stream:  GELU of block t-1, 16 values per lane in UNPACKED instructions, one group after each of the first
+    //                      KS + CB MFMAs - the only VALU work that runs while the matrix pipe is busy (see gelu1 above).
+    //      sched_barrier(0) pins the interleaving; everything stays compiler-visible, so waits and hazards are the compiler's.
+    constexpr int NF = G::KS + 2 * G::CB, PF = 4, SLOTS = G::KS + G::CB, NUOP = 4 * 38;
+    float c5v = -0.00041175442346105595f;               // leading GELU coefficient in a VGPR (one constant-bus operand per VOP3)
+    asm volatile("" : "+v"(c5v));
+#if MLP_ABLATE
+    unsigned long long tr_wait = 0, tr_bar = 0, tr_work = 0, tr_t = __builtin_readcyclecounter();
+#define TR_ACC(ACC) { const unsigned long long n_ = __builtin_readcyclecounter(); ACC += n_ - tr_t; tr_t = n_; }
+#else
+#define TR_ACC(ACC)
+#endif
+#define SLICE_SYNC(T)                                                                                          \
+    TR_ACC(tr_work)                                                                                            \
+    if ((T) + 1 < G::NSL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");                 \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    TR_ACC(tr_wait)                                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    TR_ACC(tr_bar)                                                                                             \
+    if ((T) + G::DEPTH - 1 < G::NSL) DMA_SLICE((T) + G::DEPTH - 1)
+#define LOAD_BIAS(Z, T)                                                                                        \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
+      const float4 b4 = *reinterpret_cast<const float4*>(b1s + (T) * 32 + 8 * g + 4 * half);                   \
+      Z[4 * g + 0] = b4.x; Z[4 * g + 1] = b4.y; Z[4 * g + 2] = b4.z; Z[4 * g + 3] = b4.w;                      \
+    }
+    f32x16 za, zb;
+    {                                                   // t = 0: GEMM1 of block 0 only
+      SLICE_SYNC(0)
+      const unsigned char* sl = ring + lane * 16;
+      bf16x8 fr[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);
+      LOAD_BIAS(za, 0)
+#pragma unroll
+      for (int i = 0; i < G::KS; ++i) {
+        za = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], za, 0, 0, 0);
+        if (i + PF < G::KS) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+      }
+    }
+#define PIPE_ITER(T, ZIN, ZOUT)                                                                                \
+    {                                                                                                          \
+      SLICE_SYNC(T)                                                                                            \
+      const unsigned char* sl = ring + ((T) % G::DEPTH) * G::FWD_SLICE + lane * 16;                            \
+      bf16x8 fr[PF];                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);  \
+      LOAD_BIAS(ZOUT, T)                                                                                       \
+      float gq[4], ghz[4];                                                                                     \
+      uint32_t pk[8];                                                                                          \
+      bf16x8 hf0, hf1;                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int i = 0; i < SLOTS; ++i) {                                                      \
+        if (i == G::KS) hf0 = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));              \
+        if (i < G::KS) ZOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i < G::KS ? i : 0], ZOUT, 0, 0, 0); \
+        else acc2[(i - G::KS) % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf0, fr[i % PF], acc2[(i - G::KS) % G::CB], 0, 0, 0); \
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        _Pragma("unroll") for (int uo = NUOP * i / SLOTS; uo < NUOP * (i + 1) / SLOTS; ++uo) {                 \
+          const int qd = uo / 38;                                                                              \
+          gelu_uop(uo % 38, ZIN[4 * qd], ZIN[4 * qd + 1], ZIN[4 * qd + 2], ZIN[4 * qd + 3], gq, ghz, pk[2 * qd], pk[2 * qd + 1], c5v); \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+      }                                                                                                        \
+      hf1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));                                \
+      _Pragma("unroll") for (int j = G::CB; j < 2 * G::CB; ++j) {                                              \
+        const int i = G::KS + j;                                                                               \
+        acc2[j - G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf1, fr[i % PF], acc2[j - G::CB], 0, 0, 0);  \
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);                  \
+      }                                                                                                        \
+    }
+    static_assert(G::NHB % 2 == 0 && NUOP * G::KS / SLOTS >= 76, "pipelined loop: pairs 0-3 are ready when GEMM2 starts");
+    for (int t = 1; t <= G::NHB; t += 2) {
+      PIPE_ITER(t, za, zb)
+      PIPE_ITER(t + 1, zb, za)
+    }
+#if MLP_ABLATE
+    TR_ACC(tr_work)
+    if (threadIdx.x == 0 && blockIdx.x < BLK_TRACE_WGS) {
+      g_blk_trace[blockIdx.x * BLK_TRACE_SLOTS + 8] = tr_wait;
+      g_blk_trace[blockIdx.x * BLK_TRACE_SLOTS + 9] = tr_bar;
+      g_blk_trace[blockIdx.x * BLK_TRACE_SLOTS + 10] = tr_work;
+    }
+#endif
+#undef TR_ACC
+#undef PIPE_ITER
+#undef LOAD_BIAS
+#undef SLICE_SYNC
+  }
   // ---- hidden-slice loop
-  const int n_slices = DBG(p, 8) ? 0 : G::NHB;          // dbg 8: prologue + epilogue only
+  const int n_slices = (G::PIPE || DBG(p, 8)) ? 0 : G::NHB;          // dbg 8: prologue + epilogue only
   for (int s = 0; s < n_slices; ++s) {
     // slice s has landed once this wavefront's own pieces are in (counted wait: slice s+1 may stay in flight) and
     // every wavefront has passed the barrier; the slot of slice s+2 held slice s-1, which nobody reads any more
@@ -372,7 +563,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
         for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(acc1[r], acc1[r + 1]);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) pk[r >> 1] = gelu2_bf16(acc1[r], acc1[r + 1]);
+        for (int r = 0; r < 16; r += 2)
+          pk[r >> 1] = (r >> 1) < GELU_NP ? gelu1x2_bf16(acc1[r], acc1[r + 1]) : gelu2_bf16(acc1[r], acc1[r + 1]);
       }
       hf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       hf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
@@ -401,7 +593,9 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
   //      and leaves as 16 rows x C contiguous elements: 16 bytes per lane for the residual read and the result.
 #pragma unroll
   for (int i = 0; i < kResPf; ++i) asm volatile("" ::"v"(pf[i]));       // the prefetch loads are complete (and were not dropped)
+  TRACE(2)                                                              // this wavefront's hidden loop is done
   __syncthreads();                                                      // every wavefront is past its last fragment read
+  TRACE(3)
   float* scr = reinterpret_cast<float*>(ring) + wave * (16 * C);        // 16 rows x C fp32 per wavefront (<= 2/3 of the ring)
   const float4* b2v = reinterpret_cast<const float4*>(b1s + 4 * C);
   const float4* gav = reinterpret_cast<const float4*>(b1s + 5 * C);
@@ -457,6 +651,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       }
     }
   }
+  TRACE(4)                                              // stores issued (not necessarily landed)
 }
 
 template <int C>
@@ -889,12 +1084,12 @@ extern "C" {
 
 int cnx_block_mlp_supported(int32_t C) { return (C == 96 || C == 128 || C == 192 || C == 256 || C == 384) ? 1 : 0; }
 
-int64_t cnx_mlp_packed_elems(int32_t C) { return static_cast<int64_t>(8) * C * C; }
+int64_t cnx_mlp_packed_elems(int32_t C) { return static_cast<int64_t>(8) * C * C + (blk_fwd_pipe(C) ? 64 * C : 0); }
 
 int cnx_mlp_pack_weights(const void* W1, const void* W2, int w_dtype, void* Wf, int32_t C, void* stream) {
   if (C <= 0 || C % 32 != 0) return APGD_ERR_SIZE;
   if (!W1 || !W2 || !Wf) return APGD_ERR_NULL;
-  const long total = static_cast<long>(C / 8) * (C / 16 + 2 * (C / 32)) * 64;
+  const long total = static_cast<long>(C / 8 + (blk_fwd_pipe(C) ? 1 : 0)) * (C / 16 + 2 * (C / 32)) * 64;
   const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
   hipStream_t s = as_stream(stream);
   if (w_dtype == APGD_F32)
@@ -1005,3 +1200,10 @@ int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b,
 int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 128 || C == 192 || C == 256) ? 1 : 0; }
 
 }  // extern "C"
+
+#if MLP_ABLATE
+extern "C" int cnx_dbg_blk_trace(unsigned long long* host, int n_wgs) {
+  if (n_wgs > BLK_TRACE_WGS) n_wgs = BLK_TRACE_WGS;
+  return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_blk_trace), sizeof(unsigned long long) * BLK_TRACE_SLOTS * n_wgs));
+}
+#endif

@@ -4,6 +4,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// 1: the forward's hidden loop is software-pipelined and the packed weights are laid out for it - slice t = [W1(t) | W2(t-1)],
+// t = 0..C/8, the two pieces that do not exist zero-filled (block_kernels.hip, pack_fwd_kernel).  0: slice s = [W1(s) | W2(s)].
+#ifndef BLK_FWD_PIPE
+#define BLK_FWD_PIPE 1
+#endif
+// Widths that use it: measured on one box (profiles/r02_power_and_overlap.md) the pipelined loop wins from C = 128 up (4 % ... 20 %
+// at C = 384) and loses 3 - 8 % at C = 96, where the kernel sits at the package power cap and the unpacked GELU's extra instructions
+// cost more than the overlap returns.
+__host__ __device__ constexpr bool blk_fwd_pipe(int C) { return BLK_FWD_PIPE != 0 && C > 96; }
+
 struct BlkFwdArgs {
   const uint16_t* u;       // [M, C] bf16: depthwise-conv output (ln_w != NULL) or already-normalised rows
   const float* ln_w;       // [C] or NULL

@@ -145,8 +145,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp3_fwd_res_kernel(const Blk
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf) + lane * 16;
 #pragma unroll 4
     for (int i = 0; i < NHB * G::PIECES / NW; ++i) {
-      const int piece = i * NW + wave;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(piece) * 1024), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
+      const int piece = i * NW + wave;                      // LDS order: [block s][W1(s) | W2(s)]; W2(s) sits one slice later in the pipelined packing
+      const long src = piece + ((blk_fwd_pipe(C) && piece % G::PIECES >= KS) ? G::PIECES : 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + src * 1024), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
     }
     for (int i = tid; i < C; i += NW * 64) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
     for (int i = tid; i < C; i += NW * 64) {

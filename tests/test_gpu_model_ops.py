@@ -250,7 +250,7 @@ def test_fused_block_tail_forward_vs_fp32_reference(R, C, M_, gamma, ln):
     y2 = h @ w2.to(torch.bfloat16).float().t() + b2
     ref = x + (y2 * gm if gamma else y2)
     wf = R.ops._pack_mlp(w1.cuda(), w2.cuda())
-    assert wf.numel() == lib.cnx_mlp_packed_elems(C) == 8 * C * C
+    assert wf.numel() == lib.cnx_mlp_packed_elems(C) and wf.numel() in (8 * C * C, 8 * C * C + 64 * C)   # C/8 slices (+1 when pipelined)
     wf_b = R.ops._pack_mlp(w1.cuda().to(torch.bfloat16), w2.cuda().to(torch.bfloat16))
     assert torch.equal(wf, wf_b)                                      # fp32 and bf16 masters pack identically
     ud, xd = u.cuda(), x.cuda()

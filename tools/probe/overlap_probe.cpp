@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -171,8 +172,10 @@ void exact_table(float* out, unsigned* ids) {
   for (int w = 0; w < 12; ++w) printf(" %u", (h[w] >> 4) & 3);
   printf("\n\nCYCLES per group (1 MFMA 32x32x16 + NV v_pk_fma_f32) per SIMD WALL time, W waves per SIMD; for W waves all running the same\n"
          "stream the figure is for W groups.  split: every other wave of a SIMD runs only the MFMAs, the others only the VALU part.\n");
-  row<0>(out, ids); row<1>(out, ids); row<2>(out, ids); row<3>(out, ids); row<4>(out, ids); row<5>(out, ids); row<6>(out, ids);
-  row<7>(out, ids); row<8>(out, ids); row<10>(out, ids); row<12>(out, ids); row<16>(out, ids);
+  if (getenv("OVERLAP_FULL")) {
+    row<0>(out, ids); row<1>(out, ids); row<2>(out, ids); row<3>(out, ids); row<4>(out, ids); row<5>(out, ids); row<6>(out, ids);
+    row<7>(out, ids); row<8>(out, ids); row<10>(out, ids); row<12>(out, ids); row<16>(out, ids);
+  }
 }
 
 
@@ -265,6 +268,11 @@ __global__ __launch_bounds__(1024) void kinds(float* out, int iters) {
         if (OP == 5) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(r) : "v"(m));
         if (OP == 6) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r.x) : "v"(m.x));
         if (OP == 7) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(r.x) : "v"(m.x), "v"(c.x));
+        if (OP == 8) asm volatile("v_fma_f32 %0, %0, |%1|, %2" : "+v"(v[0].x) : "v"(m.x), "s"(1e-3f));            // ONE dependent chain, VOP3 modifiers + SGPR
+        if (OP == 9) asm volatile("v_fma_f32 %0, %0, |%1|, %2\n s_nop 0" : "+v"(v[0].x) : "v"(m.x), "s"(1e-3f));   // ... with the s_nop hipcc puts after inline asm
+        if (OP == 10) asm volatile("v_fma_f32 %0, %0, |%1|, %2" : "+v"(v[j & 1].x) : "v"(m.x), "s"(1e-3f));        // two interleaved chains
+        if (OP == 11) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[0].x) : "v"(m.x), "v"(c.x));                // one dependent chain, plain operands
+        if (OP == 12) asm volatile("v_fma_f32 %0, %0, |%1|, %2" : "+v"(v[j & 3].x) : "v"(m.x), "s"(1e-3f));        // four interleaved chains
       }
     }
   }
@@ -306,6 +314,8 @@ void kind_row(const char* name, float* out) {
 void kinds_table(float* out) {
   printf("\ncycles per group (1 MFMA + NV instructions of one kind) per wave; 'alone' = without the MFMA; MFMA alone = 32\n");
   kind_row<0>("v_pk_fma_f32", out); kind_row<1>("v_fma_f32", out); kind_row<2>("v_exp_f32", out); kind_row<3>("v_and_b32", out);
+  kind_row<8>("fma chain |abs| sgpr", out); kind_row<9>("fma chain + s_nop 0", out); kind_row<10>("2 fma chains", out);
+  kind_row<12>("4 fma chains", out); kind_row<11>("fma chain plain", out);
   kind_row<4>("v_cvt_pk_bf16_f32", out); kind_row<5>("v_pk_mul_f32", out); kind_row<6>("v_add_u32", out); kind_row<7>("v_pk_fma_f16", out);
 }
 
