@@ -136,54 +136,21 @@ def attack_both(R, ref, prod, x, y, K, autocast, norm="Linf", eps=EPS):
 
 def replay_is_bit_exact(R, prod, x, y, K, autocast):
     """The device model's own logits / input gradients, recorded during the HIP attack and replayed through the numpy
-    oracle, must give the HIP attack's outputs bit for bit (as __graft_entry__.smoke does for a toy model).  Run twice:
-    with fp32 gradients through autograd (recorded by the tap), and with the int8 gradient-sign sink the product path uses
-    by default (the tap then sees the stride-0 zero; the recorded fp32 gradients of the first run must reproduce it)."""
-    saved = R.apgd.USE_SIGN_SINK
-    try:
-        R.apgd.USE_SIGN_SINK = False
-        out_f32 = _replay(R, prod, x, y, K, autocast, check=True)
-        R.apgd.USE_SIGN_SINK = True
-        out_i8 = _replay(R, prod, x, y, K, autocast, check=False)
-    finally:
-        R.apgd.USE_SIGN_SINK = saved
-    for a, b in zip(out_f32, out_i8):
-        assert torch.equal(a, b)
-
-
-def _replay(R, prod, x, y, K, autocast, check):
-    rec = {"logits": [], "grads": []}
-
-    class Tap(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, t):
-            return t.view_as(t)
-
-        @staticmethod
-        def backward(ctx, g):
-            rec["grads"].append(g.detach().float().cpu().numpy())
-            return g
-
-    class Rec(torch.nn.Module):
-        def __init__(self, m):
-            super().__init__()
-            self.m = m
-
-        def forward(self, t):
-            out = self.m(Tap.apply(t) if t.requires_grad else t)
-            rec["logits"].append(out.detach().float().cpu().numpy())
-            return out
-
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-        xb, acc, lb, xba = R.apgd_train(Rec(prod).eval(), x.cuda(), y.cuda(), norm="Linf", eps=EPS, n_iter=K)
-    torch.cuda.synchronize()
-    if check:
-        rep = O.ReplayModel(np.stack(rec["logits"]), np.stack(rec["grads"]))
-        oxb, oacc, olb, oxba, _ = O.apgd_train_oracle(rep, x.numpy(), y.numpy(), "Linf", EPS, K)
-        assert np.array_equal(xb.cpu().numpy(), oxb) and np.array_equal(xba.cpu().numpy(), oxba)
-        assert np.array_equal(acc.cpu().numpy(), oacc)
-        np.testing.assert_allclose(lb.cpu().numpy(), olb, rtol=1e-5, atol=3e-7)
-    return xb, acc, lb, xba
+    oracle, must give the HIP attack's outputs bit for bit (as __graft_entry__.smoke does).  Checked in both modes: fp32
+    gradients through autograd, and the int8 gradient-sign sink the product path uses by default (the recorded 'gradient' is
+    then the sign tensor the stem kernel wrote).  The two runs are only required to AGREE on >= 99 % of the pixels: library
+    backward kernels are not run-to-run reproducible (oracle/replay_tap.py), and one flipped sign moves a pixel by a step."""
+    from oracle import replay_tap as T
+    xd, yd = x.cuda(), y.cuda()
+    out_f32, lo, gr, _ = T.record_attack(R, prod, xd, yd, "Linf", EPS, K, autocast=autocast, sink=False)
+    T.check_replay(O, out_f32, lo, gr, x, y, "Linf", EPS, K)
+    out_i8, lo, gr, used = T.record_attack(R, prod, xd, yd, "Linf", EPS, K, autocast=autocast, sink=True)
+    assert used and all(used), "the product model did not hand the attack its int8 gradient signs"
+    assert set(np.unique(gr)) <= {-1.0, 0.0, 1.0}
+    T.check_replay(O, out_i8, lo, gr, x, y, "Linf", EPS, K)
+    agree = float((out_f32[0] == out_i8[0]).float().mean())
+    note("sink_vs_fp32_gradient_runs", agree=agree)
+    assert agree >= 0.99, agree
 
 
 # ------------------------------------------------------------------------------------------------ cfg #2 (full widths)
