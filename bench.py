@@ -264,6 +264,57 @@ def spawn_ranks(args) -> int:
     return 0
 
 
+class PowerSampler:
+    """Package power and shader clock of this rank's GPU from sysfs hwmon (power1_input in uW, freq1_input in Hz), sampled by a
+    host thread during the timed steps.  The fused LN+MLP kernels run AT the package power cap (profiles/r02_power_and_overlap.md),
+    where a kernel's duration is its energy, so the step's average power is part of reading the numbers.  None if unreadable."""
+
+    def __init__(self, dev_index):
+        self.dir, self.samples, self._stop, self._th = None, [], False, None
+        try:
+            import glob
+            p = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(d).endswith(bdf):
+                    hw = glob.glob(os.path.join(d, "hwmon", "hwmon*"))
+                    if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                        self.dir = hw[0]
+        except Exception:                                       # noqa: BLE001 - telemetry is optional
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except Exception:                                       # noqa: BLE001
+            return None
+
+    def _run(self):
+        while not self._stop:
+            w, hz = self._read("power1_input"), self._read("freq1_input")
+            if w is not None:
+                self.samples.append((w * 1e-6, (hz or 0.0) * 1e-6))
+            time.sleep(0.02)
+
+    def start(self):
+        if self.dir:
+            import threading
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th:
+            self._th.join()
+        if not self.samples:
+            return None
+        ws, fs = [a for a, _ in self.samples], [b for _, b in self.samples]
+        cap = self._read("power1_cap")
+        return {"avg_W": round(sum(ws) / len(ws), 1), "max_W": round(max(ws), 1), "cap_W": round(cap * 1e-6, 1) if cap else None,
+                "avg_sclk_MHz": round(sum(fs) / len(fs), 1), "samples": len(ws)}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -305,12 +356,16 @@ def main():
         trainer.step(x, y)
     sync()
     apgd_mod.PROFILE_EVENTS = []                                # K1 launches get bracketed by HIP events
+    power = PowerSampler(dev.index or 0) if rank == 0 else None
+    if power:
+        power.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.step(x, y)
     dt_enqueue = time.perf_counter() - t0                      # host time to ENQUEUE the steps (no synchronisation inside a step)
     sync()
     dt = time.perf_counter() - t0
+    power_stats = power.stop() if power else None
     events = apgd_mod.PROFILE_EVENTS
     apgd_mod.PROFILE_EVENTS = None
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -355,7 +410,7 @@ def main():
     if roof is not None and first is not None:
         roof["first_iter"] = first
 
-    extra = {"host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3)}
+    extra = {"host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3), "package_power": power_stats}
     if args.attack_only or True:
         # attack-only throughput (same tensors, eval mode), a few repetitions
         base = trainer.inner.base_model
