@@ -119,7 +119,8 @@ int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db
  * u [M, C] bf16 = depthwise-conv output; LN (eps inside the sqrt, fp32 statistics, two-pass) is applied when
  * ln_w != NULL (mean / rstd [M] fp32 are then written if non-NULL), otherwise u is taken as already normalised.
  * Wf = cnx_mlp_pack_weights(W1 [4C, C], W2 [C, 4C]) : bf16 weights in MFMA-fragment order, cnx_mlp_packed_elems(C)
- * elements (re-pack after every optimizer step).  b1 [4C], b2 [C], gamma [C] fp32 (gamma, resid may be NULL);
+ * elements (8 C^2, or 8 C^2 + 64 C where the kernel's hidden loop is software-pipelined and wants slice t = [W1 block t |
+ * W2 block t-1]: always size the buffer with cnx_mlp_packed_elems; re-pack after every optimizer step).  b1 [4C], b2 [C], gamma [C] fp32 (gamma, resid may be NULL);
  * resid / out fp32 or bf16; y2_out (nullable) = pre-gamma fc2 output in bf16 (for d(gamma)).
  * GELU is the exact-erf form evaluated with |error| <= 1.2e-6; bf16 MFMA, fp32 accumulate. */
 int cnx_block_mlp_supported(int32_t C);
