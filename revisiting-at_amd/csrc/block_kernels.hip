@@ -315,6 +315,13 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
     }                                                                                                      \
   }
+#define DMA_PIECE(S, R)                                                                                    \
+  {                                                                                                        \
+    const unsigned char* gs = wsrc + static_cast<long>(S) * G::FWD_SLICE;                                  \
+    unsigned char* ls = ring + ((S) % G::DEPTH) * G::FWD_SLICE;                                            \
+    const int piece = (R) * 4 + wave;                                                                      \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
+  }
   if (DBG(p, 16) && blockIdx.x < 1024) {                // timing experiment: de-phase the co-resident workgroups of the first round
     const int steps = ((blockIdx.x >> 8) & 3) * (p.dbg >> 8);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
@@ -421,7 +428,17 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     //        VALU stream:  GELU of block t-1, 16 values per lane in UNPACKED instructions, one group after each of the first
     //                      KS + CB MFMAs - the only VALU work that runs while the matrix pipe is busy (see gelu1 above).
     //      sched_barrier(0) pins the interleaving; everything stays compiler-visible, so waits and hazards are the compiler's.
-    constexpr int NF = G::KS + 2 * G::CB, PF = 4, SLOTS = G::KS + G::CB, NUOP = 4 * 38;
+#ifndef BLK_PIPE_PF_WIDE
+#define BLK_PIPE_PF_WIDE 8
+#endif
+    // operand fragments in flight per wavefront: with ONE wavefront per SIMD (C >= 256) nothing else covers the LDS latency, which
+    // under the weight DMA and four reading wavefronts is ~300 cycles (3570 cycles per C = 384 slice with 4 in flight = 75 per MFMA)
+    constexpr int NF = G::KS + 2 * G::CB, PF = (C >= 256 ? BLK_PIPE_PF_WIDE : 4), SLOTS = G::KS + G::CB, NUOP = 4 * 38;
+    // the weight DMA of slice t+2 is issued one instruction at a time between the MFMAs of iteration t: a burst of FWD_ROUNDS
+    // global_load_lds at the top of the iteration stalls the in-order wavefront at issue (~1300 cycles per C = 384 slice - the
+    // texture path takes a KiB per ~16 cycles and the four wavefronts of the CU share it)
+    constexpr int DMA_EVERY = SLOTS / G::FWD_ROUNDS;
+    static_assert(DMA_EVERY >= 1 && DMA_EVERY * (G::FWD_ROUNDS - 1) < SLOTS, "one DMA instruction per DMA_EVERY MFMA slots");
     float c5v = -0.00041175442346105595f;               // leading GELU coefficient in a VGPR (one constant-bus operand per VOP3)
     asm volatile("" : "+v"(c5v));
 #if MLP_ABLATE
@@ -436,8 +453,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
     TR_ACC(tr_wait)                                                                                            \
     __builtin_amdgcn_s_barrier();                                                                              \
-    TR_ACC(tr_bar)                                                                                             \
-    if ((T) + G::DEPTH - 1 < G::NSL) DMA_SLICE((T) + G::DEPTH - 1)
+    TR_ACC(tr_bar)
 #define LOAD_BIAS(Z, T)                                                                                        \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
       const float4 b4 = *reinterpret_cast<const float4*>(b1s + (T) * 32 + 8 * g + 4 * half);                   \
@@ -446,6 +462,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     f32x16 za, zb;
     {                                                   // t = 0: GEMM1 of block 0 only
       SLICE_SYNC(0)
+      if (G::DEPTH - 1 < G::NSL) DMA_SLICE(G::DEPTH - 1)
       const unsigned char* sl = ring + lane * 16;
       bf16x8 fr[PF];
 #pragma unroll
@@ -466,14 +483,19 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       LOAD_BIAS(ZOUT, T)                                                                                       \
       float gq[4], ghz[4];                                                                                     \
       uint32_t pk[8];                                                                                          \
+      if (DBG(p, 2)) { _Pragma("unroll") for (int e = 0; e < 8; ++e) pk[e] = __builtin_bit_cast(uint32_t, ZIN[2 * e]); } \
       bf16x8 hf0, hf1;                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       _Pragma("unroll") for (int i = 0; i < SLOTS; ++i) {                                                      \
         if (i == G::KS) hf0 = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));              \
         if (i < G::KS) ZOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i < G::KS ? i : 0], ZOUT, 0, 0, 0); \
         else acc2[(i - G::KS) % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf0, fr[i % PF], acc2[(i - G::KS) % G::CB], 0, 0, 0); \
-        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);                  \
+        if (i + PF < NF && !DBG(p, 32)) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);   \
+        if (i % DMA_EVERY == 0 && i / DMA_EVERY < G::FWD_ROUNDS && !DBG(p, 1)) {                               \
+          if ((T) + G::DEPTH - 1 < G::NSL) DMA_PIECE((T) + G::DEPTH - 1, i / DMA_EVERY)                        \
+        }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (!DBG(p, 2))                                                                                        \
         _Pragma("unroll") for (int uo = NUOP * i / SLOTS; uo < NUOP * (i + 1) / SLOTS; ++uo) {                 \
           const int qd = uo / 38;                                                                              \
           gelu_uop(uo % 38, ZIN[4 * qd], ZIN[4 * qd + 1], ZIN[4 * qd + 2], ZIN[4 * qd + 3], gq, ghz, pk[2 * qd], pk[2 * qd + 1], c5v); \
@@ -484,7 +506,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       _Pragma("unroll") for (int j = G::CB; j < 2 * G::CB; ++j) {                                              \
         const int i = G::KS + j;                                                                               \
         acc2[j - G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf1, fr[i % PF], acc2[j - G::CB], 0, 0, 0);  \
-        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);                  \
+        if (i + PF < NF && !DBG(p, 32)) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);   \
       }                                                                                                        \
     }
     static_assert(G::NHB % 2 == 0 && NUOP * G::KS / SLOTS >= 76, "pipelined loop: pairs 0-3 are ready when GEMM2 starts");
@@ -504,6 +526,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
 #undef PIPE_ITER
 #undef LOAD_BIAS
 #undef SLICE_SYNC
+#undef DMA_PIECE
   }
   // ---- hidden-slice loop
   const int n_slices = (G::PIPE || DBG(p, 8)) ? 0 : G::NHB;          // dbg 8: prologue + epilogue only

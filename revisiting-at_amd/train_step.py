@@ -132,7 +132,10 @@ class ATTrainStep:
         self.inner = wrapped
         if distributed:
             ids = [self.device.index] if self.device.type == 'cuda' else None
-            wrapped = nn.parallel.DistributedDataParallel(wrapped, device_ids=ids)   # main.py:889-890
+            # main.py:889-890.  The models of this path carry constant buffers only (ImageNormalizer mean / std), so the
+            # per-forward buffer broadcast is dropped; gradients live in the all-reduce buckets (no copy in / out per step).
+            wrapped = nn.parallel.DistributedDataParallel(wrapped, device_ids=ids, broadcast_buffers=False,
+                                                          gradient_as_bucket_view=True)
         self.model = wrapped
         self.optimizer = create_optimizer(self.inner, arch, weight_decay)
         self.loss = (lambda o, t: torch.sum(-t * torch.log_softmax(o.float(), dim=-1), dim=-1).mean()) \

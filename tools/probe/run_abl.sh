@@ -1,7 +1,5 @@
-for k in 0 1 2 3 5 8; do
-  d=$((16 + k * 256))
-  for C in 96 192; do
-    hw=56; [ $C = 192 ] && hw=28
-    APGD_BLK_DBG=$d APGD_HIP_LIB=$PWD/revisiting-at_amd/libapgd_abl.so python tools/mlp_bench.py --C $C --hw $hw --what fwd --tag stagger$k 2>/dev/null
-  done
+export APGD_HIP_LIB=$PWD/revisiting-at_amd/libapgd_abl.so
+for d in 0 1 2 32 3 34 35; do
+  APGD_BLK_DBG=$d python tools/blk_trace.py --C 384 --hw 14 2>/dev/null | python3 -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('dbg $d', d['event_us'], d['phases_us']['hidden loop']['median'], d['shader_clock_GHz_in_the_hidden_loop'], d['hidden_loop_cycles_per_slice_split'])"
 done
