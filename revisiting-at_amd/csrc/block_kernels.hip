@@ -876,7 +876,8 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::MIN_ROUNDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + 2 < G::NHB) DMA_SLICE(s + 2)
+    // (the DMA of slice s + 2 is issued one instruction at a time between the MFMAs below: a burst here stalls the in-order
+    //  wavefront at issue while the texture path drains - measured on the forward, profiles/r02_power_and_overlap.md)
     const unsigned char* sl = ring + (s % G::DEPTH) * G::SLICE + lane * 16;
 
     f32x16 acc1, acc2;
@@ -904,8 +905,15 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
       if (i & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i >> 1], acc2, 0, 0, 0);
       else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i >> 1], acc1, 0, 0, 0);
       if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      constexpr int DMA_EVERY = (2 * G::KS) / G::ROUNDS;
+      static_assert(DMA_EVERY >= 1 && DMA_EVERY * (G::ROUNDS - 1) < 2 * G::KS, "one DMA instruction per DMA_EVERY MFMAs");
+      if (i % DMA_EVERY == 0 && i / DMA_EVERY < G::ROUNDS && s + 2 < G::NHB) {
+        const int piece = (i / DMA_EVERY) * G::WAVES + wave;
+        if (piece < G::PIECES)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(s + 2) * G::SLICE + piece * 1024),
+                                           (lds_ptr_t)(ring + ((s + 2) % G::DEPTH) * G::SLICE + piece * 1024), 16, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     bf16x8 dhf[2];
     {

@@ -1,8 +1,8 @@
 for rep in 1 2; do
 for lib in hip c1; do
   export APGD_HIP_LIB=$PWD/revisiting-at_amd/libapgd_$lib.so
-  for cfg in "128 56 f32" "192 28 f32" "256 28 f32" "384 14 f32"; do set -- $cfg
-    python tools/mlp_bench.py --C $1 --hw $2 --resid $3 --what fwd --iters 40 --tag $lib 2>/dev/null
+  for cfg in "96 56" "128 56" "192 28" "256 28"; do set -- $cfg
+    python tools/mlp_bench.py --C $1 --hw $2 --what bwd_in --iters 30 --tag $lib 2>/dev/null
   done
 done
 done
