@@ -38,6 +38,11 @@
 #define MLP_ABLATE 0
 #endif
 #define DBG(p, bit) (MLP_ABLATE && ((p).dbg & (bit)))
+// compile-time ablations of the pipelined loop (-DPIPE_ABL=mask: 1 no weight DMA, 2 no GELU, 4 no MFMAs, 8 no LDS fragment reads)
+#ifndef PIPE_ABL
+#define PIPE_ABL 0
+#endif
+#define PABL(bit) ((PIPE_ABL & (bit)) != 0)
 #if MLP_ABLATE
 // per-workgroup phase stamps (100 MHz wall clock) of the forward kernel, read back with cnx_dbg_blk_trace (tools/blk_trace.py)
 #define BLK_TRACE_SLOTS 12
@@ -483,19 +488,20 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       LOAD_BIAS(ZOUT, T)                                                                                       \
       float gq[4], ghz[4];                                                                                     \
       uint32_t pk[8];                                                                                          \
-      if (DBG(p, 2)) { _Pragma("unroll") for (int e = 0; e < 8; ++e) pk[e] = __builtin_bit_cast(uint32_t, ZIN[2 * e]); } \
+      if (PABL(2)) { _Pragma("unroll") for (int e = 0; e < 8; ++e) pk[e] = __builtin_bit_cast(uint32_t, ZIN[2 * e]); } \
       bf16x8 hf0, hf1;                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       _Pragma("unroll") for (int i = 0; i < SLOTS; ++i) {                                                      \
         if (i == G::KS) hf0 = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));              \
-        if (i < G::KS) ZOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i < G::KS ? i : 0], ZOUT, 0, 0, 0); \
+        if (PABL(4)) { asm volatile("" ::"v"(fr[i % PF])); }                                                  \
+        else if (i < G::KS) ZOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i < G::KS ? i : 0], ZOUT, 0, 0, 0); \
         else acc2[(i - G::KS) % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf0, fr[i % PF], acc2[(i - G::KS) % G::CB], 0, 0, 0); \
-        if (i + PF < NF && !DBG(p, 32)) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);   \
-        if (i % DMA_EVERY == 0 && i / DMA_EVERY < G::FWD_ROUNDS && !DBG(p, 1)) {                               \
+        if (i + PF < NF && !PABL(8)) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);   \
+        if (i % DMA_EVERY == 0 && i / DMA_EVERY < G::FWD_ROUNDS && !PABL(1)) {                               \
           if ((T) + G::DEPTH - 1 < G::NSL) DMA_PIECE((T) + G::DEPTH - 1, i / DMA_EVERY)                        \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if (!DBG(p, 2))                                                                                        \
+        if (!PABL(2))                                                                                        \
         _Pragma("unroll") for (int uo = NUOP * i / SLOTS; uo < NUOP * (i + 1) / SLOTS; ++uo) {                 \
           const int qd = uo / 38;                                                                              \
           gelu_uop(uo % 38, ZIN[4 * qd], ZIN[4 * qd + 1], ZIN[4 * qd + 2], ZIN[4 * qd + 3], gq, ghz, pk[2 * qd], pk[2 * qd + 1], c5v); \
@@ -505,8 +511,9 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       hf1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));                                \
       _Pragma("unroll") for (int j = G::CB; j < 2 * G::CB; ++j) {                                              \
         const int i = G::KS + j;                                                                               \
-        acc2[j - G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf1, fr[i % PF], acc2[j - G::CB], 0, 0, 0);  \
-        if (i + PF < NF && !DBG(p, 32)) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);   \
+        if (PABL(4)) { asm volatile("" ::"v"(fr[i % PF]), "v"(hf1)); }                                        \
+        else acc2[j - G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf1, fr[i % PF], acc2[j - G::CB], 0, 0, 0);  \
+        if (i + PF < NF && !PABL(8)) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);   \
       }                                                                                                        \
     }
     static_assert(G::NHB % 2 == 0 && NUOP * G::KS / SLOTS >= 76, "pipelined loop: pairs 0-3 are ready when GEMM2 starts");

@@ -1,5 +1,6 @@
-export APGD_HIP_LIB=$PWD/revisiting-at_amd/libapgd_abl.so
-for d in 0 1 2 32 3 34 35; do
-  APGD_BLK_DBG=$d python tools/blk_trace.py --C 384 --hw 14 2>/dev/null | python3 -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('dbg $d', d['event_us'], d['phases_us']['hidden loop']['median'], d['shader_clock_GHz_in_the_hidden_loop'], d['hidden_loop_cycles_per_slice_split'])"
+for m in 14 30 16; do
+  for cfg in "384 14" "192 28"; do set -- $cfg
+  APGD_HIP_LIB=$PWD/revisiting-at_amd/libapgd_pa$m.so python tools/blk_trace.py --C $1 --hw $2 2>/dev/null | python3 -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('PIPE_ABL $m C', d['C'], 'event', d['event_us'], 'loop_us', d['phases_us']['hidden loop']['median'], 'GHz', d['shader_clock_GHz_in_the_hidden_loop'], d['hidden_loop_cycles_per_slice_split'])"
+  done
 done
