@@ -130,28 +130,13 @@ __device__ __forceinline__ uint32_t gelu2_bf16(float z0, float z1) {
 // The same GELU in UNPACKED fp32 instructions.  On gfx950 the packed-fp32 instructions (v_pk_fma_f32, v_pk_mul_f32, ...) execute
 // on the matrix pipe's time - a SIMD does not overlap them with an MFMA, neither from the same wavefront nor from another - while
 // every other VALU instruction (v_fma_f32, v_exp_f32, v_cvt_pk_bf16_f32, integer ops) hides behind a running MFMA
-// (tools/probe/overlap_probe.cpp, profiles/r02_overlap_probe.md).  19 instructions per pair instead of 13, but they are free while
-// the matrix pipe is busy; the hidden loops mix the two forms so that both pipes finish together.  Inline asm because the
-// vectoriser re-packs scalar fp32 chains; |z| is a VOP3 source modifier here, so there is no v_and.
+// (tools/probe/overlap_probe.cpp, profiles/r02_power_and_overlap.md).  19 instructions per pair instead of 13, but they run while
+// the matrix pipe is busy: the pipelined hidden loop (C >= 128) places them between the MFMAs.  Inline asm because the vectoriser
+// re-packs scalar fp32 chains; |z| is a VOP3 source modifier here, so there is no v_and.
 __device__ __forceinline__ float fma_abs_s(float q, float z, float c) {       // q * |z| + c, c uniform
   float d;
   asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(d) : "v"(q), "v"(z), "s"(c));
   return d;
-}
-__device__ __forceinline__ float gelu1(float z) {
-  float c5v = -0.00041175442346105595f;                 // the leading coefficient lives in a VGPR (one constant-bus operand per VOP3)
-  asm("" : "+v"(c5v));
-  float q = fma_abs_s(c5v, z, 0.006678475199902348f);
-  q = fma_abs_s(q, z, -0.050879760394516485f);
-  q = fma_abs_s(q, z, -0.46094072908550926f);
-  q = fma_abs_s(q, z, -1.150400682855232f);
-  q = fma_abs_s(q, z, -8.454223479528131e-05f);
-  float e, w, hz, g;
-  asm("v_exp_f32 %0, %1" : "=v"(e) : "v"(q));
-  asm("v_fma_f32 %0, %1, -0.5, 0.5" : "=v"(w) : "v"(e));
-  asm("v_mul_f32 %0, 0.5, %1" : "=v"(hz) : "v"(z));
-  asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(g) : "v"(z), "v"(w), "v"(hz));
-  return g;
 }
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
   uint32_t r;
@@ -182,15 +167,6 @@ __device__ __forceinline__ void gelu_uop(int u, float z0, float z1, float z2, fl
     default: asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(t) : "v"(z), "v"(t), "v"(hz[el])); break;
   }
 }
-__device__ __forceinline__ uint32_t gelu1x2_bf16(float z0, float z1) {
-  const float g0 = gelu1(z0), g1 = gelu1(z1);
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(g0), "v"(g1));
-  return r;
-}
-#ifndef GELU_NP
-#define GELU_NP 0            // pairs (of the 8 per lane and hidden slice) the NON-pipelined loop evaluates with unpacked instructions (0..8: equal times)
-#endif
 
 // GELU'(z) with ONE exponential per value:  GELU'(-a) = 0.5 erfc(a/sqrt 2) - a phi(a) = E W(x),  E = exp(-a^2/2) = 2^(-x^2),
 // x = a sqrt(log2(e)/2), W(x) = 0.5 erfcx(a/sqrt 2) - a/sqrt(2 pi) ~ degree-6 polynomial (max |error| 1.6e-5, tools/
@@ -215,17 +191,6 @@ __device__ __forceinline__ f32x2 gelu_from_grad2(float z0, float z1, f32x2 gp, f
   return z * Phi;
 }
 
-// MFMA with the accumulator pinned in the AGPR half of the register file.  At C = 384 a wavefront's state (96 operand
-// registers + 192 accumulator registers) exceeds the 256 architectural VGPRs; left to itself the register allocator
-// parks OPERANDS in AGPRs and copies them back before every MFMA (273 v_accvgpr_read per slice measured).  Pinning the
-// big accumulator tile - which only MFMAs touch inside the loop - in AGPRs leaves everything else in VGPRs.
-// (hipcc pads nothing inside asm: `s_nop 1` covers a VALU-written operand; the accumulators are read back only after
-// MFMA_DRAIN.)
-#define MFMA_AGPR(ACC, A, B) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
-#define MFMA_VGPR(ACC, A, B) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
-#define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 template <int C>
 struct Geo {
@@ -245,7 +210,6 @@ struct Geo {
   // of block t-1 is evaluated - and the packed weights carry one more slice: slice t = [W1(t) | W2(t-1)], t = 0..NHB.
   static constexpr bool PIPE = blk_fwd_pipe(C);
   static constexpr int NSL = NHB + (PIPE ? 1 : 0);  // weight slices streamed through the ring
-  static constexpr bool AGPR_ACC = false;           // (inline-asm MFMA with AGPR-pinned accumulators: kept for experiments only)
   static_assert(FWD_PIECES % 4 == 0, "pieces must divide over 4 wavefronts");
 };
 
@@ -570,18 +534,12 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     for (int r = 0; r < 16; ++r) acc1b[r] = 0.f;
 #pragma unroll
     for (int i = 0; i < G::KS; ++i) {
-      if constexpr (G::AGPR_ACC) {
-        if (i & 1) { MFMA_VGPR(acc1b, fr[i % PF], af[i]); } else { MFMA_VGPR(acc1, fr[i % PF], af[i]); }
-        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
-      } else {
-        if (i & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], acc1b, 0, 0, 0);
-        else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], acc1, 0, 0, 0);
-        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
-      }
+      if (i & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], acc1b, 0, 0, 0);
+      else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], acc1, 0, 0, 0);
+      if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
     }
-    if constexpr (G::AGPR_ACC) MFMA_DRAIN();                    // asm MFMA results are about to be read by VALU code
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
     // GELU -> bf16 A-operand fragments of GEMM2
@@ -593,8 +551,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
         for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16(acc1[r], acc1[r + 1]);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2)
-          pk[r >> 1] = (r >> 1) < GELU_NP ? gelu1x2_bf16(acc1[r], acc1[r + 1]) : gelu2_bf16(acc1[r], acc1[r + 1]);
+        for (int r = 0; r < 16; r += 2) pk[r >> 1] = gelu2_bf16(acc1[r], acc1[r + 1]);
       }
       hf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       hf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
@@ -603,18 +560,12 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
 #pragma unroll
     for (int j = 0; j < 2 * G::CB; ++j) {                      // fragment order in the slice is (t, cb): j = t*CB + cb
       const int i = G::KS + j;
-      if constexpr (G::AGPR_ACC) {
-        MFMA_AGPR(acc2[j % G::CB], hf[j / G::CB], fr[i % PF]);
-        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
-      } else {
-        acc2[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[j / G::CB], fr[i % PF], acc2[j % G::CB], 0, 0, 0);
-        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
+      acc2[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[j / G::CB], fr[i % PF], acc2[j % G::CB], 0, 0, 0);
+      if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
   }
-  if constexpr (G::AGPR_ACC) MFMA_DRAIN();
 #undef DMA_SLICE
 
   // ---- epilogue: acc2[cb][r] = O[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32].  Straight from the accumulators every
@@ -780,10 +731,6 @@ struct GeoB {
 #define BLK_BWD96_WAVES 4
 #endif
   static constexpr int WAVES = (C <= 96) ? BLK_BWD96_WAVES : 4;
-#ifndef BLK_BWD192_AGPR
-#define BLK_BWD192_AGPR 0
-#endif
-  static constexpr bool AGPR_ACC = (C >= 192) && BLK_BWD192_AGPR;   // da accumulators pinned in AGPRs (inline-asm MFMA)
   static constexpr int PIECES = 2 * KS + 2 * CB;
   static constexpr int SLICE = PIECES * 1024;
   static constexpr int ROUNDS = (PIECES + WAVES - 1) / WAVES;      // DMA instructions per wavefront per slice (upper bound)
@@ -982,20 +929,14 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
 #pragma unroll
     for (int j = 0; j < 2 * G::CB; ++j) {
       const int i = 2 * G::KS + j;
-      if constexpr (G::AGPR_ACC) {
-        // experiment (BLK_BWD192_AGPR=1): da accumulators pinned in AGPRs.  The allocator then parks the a / dO operand
-        // fragments in AGPRs instead (96 v_accvgpr moves per slice instead of 128): measured 418 vs 408 us, left off
-        MFMA_AGPR(acc3[j % G::CB], dhf[j / G::CB], fr[i % PF]);
-        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
-      } else {
-        acc3[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf[j / G::CB], fr[i % PF], acc3[j % G::CB], 0, 0, 0);
-        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
+      // (pinning the da accumulators in AGPRs with inline-asm MFMAs was measured and dropped: the allocator then parks the a / dO
+      //  operand fragments in AGPRs instead - 418 vs 408 us at C = 192)
+      acc3[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf[j / G::CB], fr[i % PF], acc3[j % G::CB], 0, 0, 0);
+      if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
   }
-  if constexpr (G::AGPR_ACC) MFMA_DRAIN();
 #undef DMA_SLICE
 
   // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]; as in the forward the tile leaves through
