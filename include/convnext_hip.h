@@ -157,6 +157,23 @@ int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
                             int64_t M, int32_t C, void* stream);
 
+/* The same pair for widths whose input-gradient kernel cannot hold the operands of the Hpre recomputation (C = 384: one
+ * wavefront per SIMD is full with dO, the du accumulators and the LayerNorm backward): the forward ALSO writes
+ * Hpre = LN(u) W1^T + b1 (what models/convnext.py:42 hands to GELU) as bf16 into a caller-allocated workspace of
+ * cnx_block_mlp_hpre_elems(M, C) elements, in the accumulator order of the kernels (opaque to the caller), and
+ * cnx_block_mlp_bwd_input_hpre reads it back instead of recomputing: two GEMMs per hidden slice instead of three.
+ * Only worth its 2 x 8 C bytes per row of extra HBM traffic where the block is not HBM-bound.  Same arguments otherwise
+ * (no y2_out: input-gradient passes only; mean / rstd are required).  cnx_block_mlp_hpre_supported(C): 384. */
+int cnx_block_mlp_hpre_supported(int32_t C);
+int64_t cnx_block_mlp_hpre_elems(int64_t M, int32_t C);
+int cnx_block_mlp_fwd_hpre(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
+                           const void* Wf, const float* b1, const float* b2, const float* gamma,
+                           const void* resid, int resid_dtype, void* out, int out_dtype, void* hpre_ws,
+                           int64_t M, int32_t C, void* stream);
+int cnx_block_mlp_bwd_input_hpre(const void* u, const float* ln_w, const float* mean, const float* rstd,
+                                 const void* g, int g_dtype, const float* gamma, const void* Wb, const void* hpre_ws,
+                                 void* du, int64_t M, int32_t C, void* stream);
+
 /* Fused multi-head softmax attention of the ViT family (timm 0.8 `Attention.forward`, reached through the models of
  * /root/reference/utils_architecture.py:272-301):
  *     q, k, v = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4);   out = softmax(q k^T * scale) v

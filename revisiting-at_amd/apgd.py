@@ -138,7 +138,7 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
     """
     if need_grad:
         x_in.requires_grad_(True)
-        with torch.enable_grad():
+        with torch.enable_grad(), ops.attack_forward():          # the backward below asks for the input gradient only
             logits = model(x_in)
         dl = _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, True, kind, *(() if y_target is None else (y_target,)))
         if dl.shape != logits.shape or dl.dtype != logits.dtype:

@@ -446,6 +446,14 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
 #define PIPE_ITER(T, ZIN, ZOUT)                                                                                \
     {                                                                                                          \
       SLICE_SYNC(T)                                                                                            \
+      if (p.hpre) {   /* Hpre of block T-1 for the input-gradient kernel: 16 bf16 per lane, accumulator order */ \
+        uint4* dst = reinterpret_cast<uint4*>(p.hpre) +                                                        \
+                     ((static_cast<long>(blockIdx.x) * 4 + wave) * G::NHB + ((T) - 1)) * 128 + lane * 2;       \
+        dst[0] = make_uint4(cvt_pk_bf16(ZIN[0], ZIN[1]), cvt_pk_bf16(ZIN[2], ZIN[3]), cvt_pk_bf16(ZIN[4], ZIN[5]),   \
+                            cvt_pk_bf16(ZIN[6], ZIN[7]));                                                      \
+        dst[1] = make_uint4(cvt_pk_bf16(ZIN[8], ZIN[9]), cvt_pk_bf16(ZIN[10], ZIN[11]), cvt_pk_bf16(ZIN[12], ZIN[13]), \
+                            cvt_pk_bf16(ZIN[14], ZIN[15]));                                                    \
+      }                                                                                                        \
       const unsigned char* sl = ring + ((T) % G::DEPTH) * G::FWD_SLICE + lane * 16;                            \
       bf16x8 fr[PF];                                                                                           \
       _Pragma("unroll") for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);  \
@@ -720,6 +728,7 @@ struct BlkBwdArgs {
   uint16_t* do_out;        // emit: [M, C] bf16 g * gamma
   uint16_t* ht_out;        // emit: [4C, M] bf16 GELU(Hpre)^T
   uint16_t* dhpt_out;      // emit: [4C, M] bf16 dHpre^T
+  const uint16_t* hpre;    // HPRE kernels: the forward's Hpre workspace (cnx_block_mlp_fwd_hpre), else unused
   long M;
   long a_stride;           // row stride of a_out in elements (>= C; lets the caller append a ones column for d(b1))
 };
@@ -742,12 +751,19 @@ struct GeoB {
   static_assert(WAVES * 16 * C * 4 <= DEPTH * SLICE, "the epilogue tile reuses the weight ring");
 };
 
-template <int C, typename TG, bool EMIT, bool LNB>
+// HPRE: Hpre comes from the workspace the pipelined forward wrote (cnx_block_mlp_fwd_hpre) instead of being recomputed - no
+// LN(u) operand fragments (C/4 registers less per lane: what makes C = 384 fit one wavefront per SIMD), a third fewer MFMAs,
+// and only the W2^T and GEMM3 pieces of a packed slice go through LDS (KS + 2 CB KiB: three ring slots fit at C = 384).
+template <int C, typename TG, bool EMIT, bool LNB, bool HPRE = false>
 __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_mlp_bwd_kernel(const BlkBwdArgs p) {
   using G = GeoB<C>;
+  static_assert(!(HPRE && EMIT), "the emit mode recomputes LN(u) anyway");
+  constexpr int LP0 = HPRE ? G::KS : 0;                          // first packed piece of a slice that goes through LDS
+  constexpr int LPIECES = G::PIECES - LP0, LSLICE = LPIECES * 1024;
+  constexpr int LROUNDS = (LPIECES + G::WAVES - 1) / G::WAVES, LMIN_ROUNDS = LPIECES / G::WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* ring = lds;
-  float* b1s = reinterpret_cast<float*>(lds + G::DEPTH * G::SLICE);
+  float* b1s = reinterpret_cast<float*>(lds + G::DEPTH * LSLICE);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -757,24 +773,25 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wb) + lane * 16;
 #define DMA_SLICE(S)                                                                                       \
   {                                                                                                        \
-    const unsigned char* gs = wsrc + static_cast<long>(S) * G::SLICE;                                      \
-    unsigned char* ls = ring + ((S) % G::DEPTH) * G::SLICE;                                                \
-    _Pragma("unroll") for (int i = 0; i < G::ROUNDS; ++i) {                                                \
+    const unsigned char* gs = wsrc + static_cast<long>(S) * G::SLICE + LP0 * 1024;                         \
+    unsigned char* ls = ring + ((S) % G::DEPTH) * LSLICE;                                                  \
+    _Pragma("unroll") for (int i = 0; i < LROUNDS; ++i) {                                                  \
       const int piece = i * G::WAVES + wave;                                                               \
-      if (piece < G::PIECES)                                                                               \
+      if (piece < LPIECES)                                                                                 \
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
     }                                                                                                      \
   }
   DMA_SLICE(0)
   DMA_SLICE(1)
-  for (int i = tid; i < C; i += G::WAVES * 64) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  if constexpr (!HPRE)
+    for (int i = tid; i < C; i += G::WAVES * 64) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
 
   long row = m0 + l32;
   const bool row_ok = row < p.M;
   if (!row_ok) row = p.M - 1;
   // ---- a = LN(u) with the saved statistics, and dO = g * gamma: B-operand fragments (lane = row, k = channel)
-  bf16x8 af[G::KS], gf[G::KS];
-  {
+  bf16x8 af[HPRE ? 1 : G::KS], gf[G::KS];
+  if constexpr (!HPRE) {
     const float mean = p.mean[row], rstd = p.rstd[row];
     const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
     const float4* lw = reinterpret_cast<const float4*>(p.ln_w + half * (C / 2));
@@ -797,6 +814,8 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
       af[ks] = __builtin_bit_cast(bf16x8, packed);
       if (EMIT && row_ok) reinterpret_cast<uint4*>(p.a_out + row * p.a_stride + half * (C / 2))[ks] = packed;
     }
+  }
+  {
     const float4* gmp = p.gamma ? reinterpret_cast<const float4*>(p.gamma + half * (C / 2)) : nullptr;
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
@@ -827,14 +846,21 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     for (int r = 0; r < 16; ++r) acc3[cb][r] = 0.f;
 
   for (int s = 0; s < G::NHB; ++s) {
-    if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::MIN_ROUNDS) : "memory");
+    uint4 hraw[2];
+    if constexpr (HPRE) {                                 // this wavefront's Hpre tile of slice s (issued before the wait below)
+      const uint4* hp = reinterpret_cast<const uint4*>(p.hpre) +
+                        ((static_cast<long>(blockIdx.x) * G::WAVES + wave) * G::NHB + s) * 128 + lane * 2;
+      hraw[0] = hp[0]; hraw[1] = hp[1];
+    }
+    if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LMIN_ROUNDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // (the DMA of slice s + 2 is issued one instruction at a time between the MFMAs below: a burst here stalls the in-order
     //  wavefront at issue while the texture path drains - measured on the forward, profiles/r02_power_and_overlap.md)
-    const unsigned char* sl = ring + (s % G::DEPTH) * G::SLICE + lane * 16;
+    const unsigned char* sl = ring + (s % G::DEPTH) * LSLICE + lane * 16;
 
     f32x16 acc1, acc2;
+    if constexpr (!HPRE)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const float4 b4 = *reinterpret_cast<const float4*>(b1s + s * 32 + 8 * g4 + 4 * half);
@@ -845,29 +871,48 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     // one stream of NF = 2 KS + 2 CB operand fragments per slice, read PF fragments ahead of the MFMA that consumes them
     // (as in the forward): fragment i < 2 KS alternates W1 / W2^T k-steps (two independent accumulation chains), then the
     // W1 B-fragments of GEMM3 in (t, cb) order so that consecutive MFMAs update different accumulators
-    constexpr int NF = 2 * G::KS + 2 * G::CB, PF = 4;
-    auto piece_of = [](int i) constexpr {
-      if (i < 2 * G::KS) return (i & 1) ? G::KS + (i >> 1) : (i >> 1);
-      const int j = i - 2 * G::KS;                        // j = t * CB + cb  ->  packed piece (cb, t)
-      return 2 * G::KS + (j % G::CB) * 2 + (j / G::CB);
+    // HPRE: the stream is the KS W2^T fragments (compact LDS pieces 0 .. KS-1, two accumulation chains) and then GEMM3's.
+    constexpr int NG = HPRE ? G::KS : 2 * G::KS;              // MFMAs before the activation
+    constexpr int NF = NG + 2 * G::CB, PF = 4;
+    auto piece_of = [](int i) constexpr {                     // fragment i of the stream -> piece of the LDS slice
+      if (i < NG) return HPRE ? i : ((i & 1) ? G::KS + (i >> 1) : (i >> 1));
+      const int j = i - NG;                                   // j = t * CB + cb  ->  packed piece (cb, t)
+      return (2 * G::KS - LP0) + (j % G::CB) * 2 + (j / G::CB);
     };
     bf16x8 fr[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i) * 1024);
+    f32x16 acc2b;                                             // HPRE: second chain of the dH accumulation
+    if constexpr (HPRE) {
 #pragma unroll
-    for (int i = 0; i < 2 * G::KS; ++i) {
-      if (i & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i >> 1], acc2, 0, 0, 0);
-      else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i >> 1], acc1, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) acc2b[r] = 0.f;
+      const uint32_t hw[8] = {hraw[0].x, hraw[0].y, hraw[0].z, hraw[0].w, hraw[1].x, hraw[1].y, hraw[1].z, hraw[1].w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { acc1[2 * k] = bf16_lo(hw[k]); acc1[2 * k + 1] = bf16_hi(hw[k]); }
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      if constexpr (HPRE) {
+        if (i & 1) acc2b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i], acc2b, 0, 0, 0);
+        else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i], acc2, 0, 0, 0);
+      } else {
+        if (i & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i >> 1], acc2, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i >> 1], acc1, 0, 0, 0);
+      }
       if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
-      constexpr int DMA_EVERY = (2 * G::KS) / G::ROUNDS;
-      static_assert(DMA_EVERY >= 1 && DMA_EVERY * (G::ROUNDS - 1) < 2 * G::KS, "one DMA instruction per DMA_EVERY MFMAs");
-      if (i % DMA_EVERY == 0 && i / DMA_EVERY < G::ROUNDS && s + 2 < G::NHB) {
+      constexpr int DMA_EVERY = NG / LROUNDS;
+      static_assert(DMA_EVERY >= 1 && DMA_EVERY * (LROUNDS - 1) < NG, "one DMA instruction per DMA_EVERY MFMAs");
+      if (i % DMA_EVERY == 0 && i / DMA_EVERY < LROUNDS && s + 2 < G::NHB) {
         const int piece = (i / DMA_EVERY) * G::WAVES + wave;
-        if (piece < G::PIECES)
-          __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(s + 2) * G::SLICE + piece * 1024),
-                                           (lds_ptr_t)(ring + ((s + 2) % G::DEPTH) * G::SLICE + piece * 1024), 16, 0, 0);
+        if (piece < LPIECES)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(s + 2) * G::SLICE + (LP0 + piece) * 1024),
+                                           (lds_ptr_t)(ring + ((s + 2) % G::DEPTH) * LSLICE + piece * 1024), 16, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (HPRE) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] += acc2b[r];
     }
     bf16x8 dhf[2];
     {
@@ -928,7 +973,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     }
 #pragma unroll
     for (int j = 0; j < 2 * G::CB; ++j) {
-      const int i = 2 * G::KS + j;
+      const int i = NG + j;
       // (pinning the da accumulators in AGPRs with inline-asm MFMAs was measured and dropped: the allocator then parks the a / dO
       //  operand fragments in AGPRs instead - 418 vs 408 us at C = 192)
       acc3[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf[j / G::CB], fr[i % PF], acc3[j % G::CB], 0, 0, 0);
@@ -948,7 +993,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     //      16 rows per pass, 4 lanes per row (lane = row*4 + q; q takes the 8-channel chunks q, q+4, ...): the row sums
     //      are two quad exchanges, a row's four lanes store 64 contiguous bytes per chunk step.
     constexpr int CP = C + 4;                                             // padded row: the 4 lanes x 16 rows spread over the banks
-    static_assert(G::WAVES * 16 * CP * 4 <= G::DEPTH * G::SLICE, "the epilogue tile reuses the weight ring");
+    static_assert(G::WAVES * 16 * CP * 4 <= G::DEPTH * LSLICE, "the epilogue tile reuses the weight ring");
     float* scr = reinterpret_cast<float*>(ring) + wave * (16 * CP);
     constexpr int NJ = C / 32;                                            // 8-channel chunks per lane
     const int rl = lane >> 2, q = lane & 3;
@@ -1057,6 +1102,26 @@ int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, bool ln_bwd, hipStream_t s)
   return launch_status();
 }
 
+template <int C>
+int launch_blk_bwd_hpre(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
+  using G = GeoB<C>;
+  constexpr int LDS_BYTES = G::DEPTH * (G::KS + 2 * G::CB) * 1024 + 16 * C;
+  const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(G::WAVES * 64);
+#define BLK_LAUNCH(TG)                                                                                           \
+  {                                                                                                              \
+    auto kfn = blk_mlp_bwd_kernel<C, TG, false, true, true>;                                                     \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, LDS_BYTES, s, a);                                                       \
+  }
+  if (g_dtype == APGD_F32) BLK_LAUNCH(float) else BLK_LAUNCH(uint16_t)
+#undef BLK_LAUNCH
+  return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1081,9 +1146,10 @@ int cnx_mlp_pack_weights(const void* W1, const void* W2, int w_dtype, void* Wf, 
   return launch_status();
 }
 
-int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
-                      const void* Wf, const float* b1, const float* b2, const float* gamma, const void* resid,
-                      int resid_dtype, void* out, int out_dtype, void* y2_out, int64_t M, int32_t C, void* stream) {
+static int block_mlp_fwd_impl(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
+                              const void* Wf, const float* b1, const float* b2, const float* gamma, const void* resid,
+                              int resid_dtype, void* out, int out_dtype, void* y2_out, void* hpre_ws, int64_t M, int32_t C,
+                              void* stream) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!u || !Wf || !b1 || !b2 || !out) return APGD_ERR_NULL;
@@ -1095,6 +1161,8 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
   a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.mean = mean; a.rstd = rstd;
   a.Wf = static_cast<const uint16_t*>(Wf); a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.resid = resid; a.out = out;
   a.y2 = static_cast<uint16_t*>(y2_out); a.M = M;
+  a.hpre = static_cast<uint16_t*>(hpre_ws);
+  if (hpre_ws && !blk_fwd_pipe(C)) return APGD_ERR_ARG;          // only the pipelined loop writes the workspace
   static const int dbg = (getenv("APGD_BLK_DBG") ? atoi(getenv("APGD_BLK_DBG")) : 0) |
                          ((getenv("APGD_MLP3_STAGGER") ? atoi(getenv("APGD_MLP3_STAGGER")) : 0) << 8);
   a.dbg = dbg;
@@ -1102,7 +1170,7 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
   // APGD_BLK_FWD_IMPL=2 selects the barrier-free kernels with LDS-resident weights (mlp_kernels.hip, C = 96) for A/B timing;
   // measured equal to the ring kernel below, which stays the default (see the table in mlp_kernels.hip)
   static const int impl = getenv("APGD_BLK_FWD_IMPL") ? atoi(getenv("APGD_BLK_FWD_IMPL")) : 1;
-  if (impl == 2) {
+  if (impl == 2 && !hpre_ws) {
     const int r = mlp2_fwd_launch(a, C, resid_dtype, out_dtype, s);
     if (r != -100) return r;
   }
@@ -1112,6 +1180,43 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
     case 192: return launch_blk_fwd<192>(a, resid_dtype, out_dtype, s);
     case 256: return launch_blk_fwd<256>(a, resid_dtype, out_dtype, s);
     case 384: return launch_blk_fwd<384>(a, resid_dtype, out_dtype, s);
+    default: return APGD_ERR_ARG;
+  }
+}
+
+int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
+                      const void* Wf, const float* b1, const float* b2, const float* gamma, const void* resid,
+                      int resid_dtype, void* out, int out_dtype, void* y2_out, int64_t M, int32_t C, void* stream) {
+  return block_mlp_fwd_impl(u, ln_w, ln_b, eps, mean, rstd, Wf, b1, b2, gamma, resid, resid_dtype, out, out_dtype, y2_out, nullptr,
+                            M, C, stream);
+}
+
+int cnx_block_mlp_hpre_supported(int32_t C) { return C == 384 ? 1 : 0; }
+
+int64_t cnx_block_mlp_hpre_elems(int64_t M, int32_t C) { return M <= 0 ? 0 : ((M + 127) / 128) * 128 * 4 * static_cast<int64_t>(C); }
+
+int cnx_block_mlp_fwd_hpre(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
+                           const void* Wf, const float* b1, const float* b2, const float* gamma, const void* resid,
+                           int resid_dtype, void* out, int out_dtype, void* hpre_ws, int64_t M, int32_t C, void* stream) {
+  if (!hpre_ws) return APGD_ERR_NULL;
+  if (!cnx_block_mlp_hpre_supported(C)) return APGD_ERR_ARG;
+  return block_mlp_fwd_impl(u, ln_w, ln_b, eps, mean, rstd, Wf, b1, b2, gamma, resid, resid_dtype, out, out_dtype, nullptr, hpre_ws,
+                            M, C, stream);
+}
+
+int cnx_block_mlp_bwd_input_hpre(const void* u, const float* ln_w, const float* mean, const float* rstd, const void* g,
+                                 int g_dtype, const float* gamma, const void* Wb, const void* hpre_ws, void* du, int64_t M,
+                                 int32_t C, void* stream) {
+  if (M < 0 || C <= 0) return APGD_ERR_SIZE;
+  if (M == 0) return APGD_OK;
+  if (!u || !ln_w || !mean || !rstd || !g || !Wb || !hpre_ws || !du) return APGD_ERR_NULL;
+  if (g_dtype != APGD_F32 && g_dtype != APGD_BF16) return APGD_ERR_DTYPE;
+  BlkBwdArgs a;
+  a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = nullptr; a.mean = mean; a.rstd = rstd; a.g = g; a.gamma = gamma;
+  a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = nullptr; a.da = static_cast<uint16_t*>(du);
+  a.a_out = a.do_out = a.ht_out = a.dhpt_out = nullptr; a.hpre = static_cast<const uint16_t*>(hpre_ws); a.M = M; a.a_stride = C;
+  switch (C) {
+    case 384: return launch_blk_bwd_hpre<384>(a, g_dtype, as_stream(stream));
     default: return APGD_ERR_ARG;
   }
 }
@@ -1148,7 +1253,7 @@ static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_
   a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = ln_b; a.mean = mean; a.rstd = rstd; a.g = g; a.gamma = gamma;
   a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = b1; a.da = static_cast<uint16_t*>(da);
   a.a_out = static_cast<uint16_t*>(a_out); a.do_out = static_cast<uint16_t*>(do_out);
-  a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.M = M;
+  a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.hpre = nullptr; a.M = M;
   if (a_stride != 0 && (a_stride < C || a_stride % 8 != 0)) return APGD_ERR_ARG;
   a.a_stride = a_stride ? a_stride : C;
   hipStream_t s = as_stream(stream);

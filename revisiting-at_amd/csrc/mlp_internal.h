@@ -28,6 +28,7 @@ struct BlkFwdArgs {
   const void* resid;       // [M, C] TX or NULL
   void* out;               // [M, C] TO
   uint16_t* y2;            // [M, C] bf16 pre-gamma fc2 output, or NULL
+  uint16_t* hpre;          // pipelined kernels only: workspace for Hpre = LN(u) W1^T + b1 in accumulator order (see cnx_block_mlp_fwd_hpre), or NULL
   long M;
   int dbg;                 // timing experiments only (APGD_BLK_DBG)
 };

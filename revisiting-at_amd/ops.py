@@ -47,6 +47,25 @@ class input_grad_only:
         return False
 
 
+# Set by apgd_train around a model FORWARD whose backward will ask for the input gradient only (the attack's own calls):
+# lets an operator pick a forward variant that saves what only an input-gradient backward can use (the C = 384 block's Hpre
+# workspace) - at forward time a Python autograd.Function cannot know which gradients the engine will request.
+_ATTACK_FWD = False
+
+
+class attack_forward:
+    def __enter__(self):
+        global _ATTACK_FWD
+        self._prev = _ATTACK_FWD
+        _ATTACK_FWD = True
+        return self
+
+    def __exit__(self, *exc):
+        global _ATTACK_FWD
+        _ATTACK_FWD = self._prev
+        return False
+
+
 # Gradient-sign sink of the Linf attack.  ``step_size * sign(grad)`` (autopgd_train_clean.py:221) is the only use the Linf
 # update makes of the input gradient, so when the layer that produces it is our own first stem convolution AND its input
 # is the attack iterate itself, the attack hands it an int8 buffer: the kernel stores sign(dx) (a quarter of the bytes)
@@ -699,7 +718,8 @@ class _BlockFused(torch.autograd.Function):
     kernel as its ``add`` operand, and parameter gradients are skipped entirely inside the attack."""
 
     @staticmethod
-    def forward(ctx, x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
+    def forward(ctx, x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma, grad_mode=True):
+        # grad_mode: torch.is_grad_enabled() of the CALLER (inside forward() it is always off)
         lib = _lib.load()
         N, H, W, C = x.shape
         M = N * H * W
@@ -712,10 +732,32 @@ class _BlockFused(torch.autograd.Function):
                                           _code(u), N, H, W, C, 0, _stream()), "cnx_dwconv7x7_nhwc")
         out = torch.empty(x.shape, device=x.device,
                           dtype=torch.float32 if (gamma is not None or x.dtype == torch.float32) else x.dtype)
-        need_grad = any(ctx.needs_input_grad)        # all False when the caller runs under no_grad
+        need_grad = grad_mode and any(ctx.needs_input_grad)   # (needs_input_grad ignores torch.no_grad: parameters still 'require' it)
         need_p = need_grad and any(ctx.needs_input_grad[1:])
         fused = _use_fused_block(C) and bool(lib.cnx_block_mlp_bwd_supported(C))
+        # C = 384 (no recomputing backward at that width): the fused forward serves the passes that need no backward at all,
+        # and - with its Hpre workspace - the attack's passes, whose backward asks for the input gradient only
+        via_hpre = (not fused) and _use_hpre_block(C) and ((not need_grad) or _ATTACK_FWD)
         mean = rstd = y2 = a = hpre = h = None
+        if via_hpre:
+            wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
+            if need_grad:
+                mean = torch.empty(M, device=x.device, dtype=torch.float32)
+                rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+                hpre = torch.empty(lib.cnx_block_mlp_hpre_elems(M, C), device=x.device, dtype=torch.bfloat16)
+                _lib.check(lib.cnx_block_mlp_fwd_hpre(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, mean.data_ptr(),
+                                                      rstd.data_ptr(), wf.data_ptr(), b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf),
+                                                      x.data_ptr(), _code(x), out.data_ptr(), _code(out), hpre.data_ptr(), M, C,
+                                                      _stream()), "cnx_block_mlp_fwd_hpre")
+                wa = _cached((w1, w2), "mlp_packed_bwd", _pack_mlp_bwd)
+                ctx.fused = "hpre"
+                ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, None, b1f, gf, None, None, hpre, None)
+                ctx.has_dw_bias, ctx.eps = dw_b is not None, eps
+            else:
+                _lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, None, None, wf.data_ptr(),
+                                                 b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), _code(x),
+                                                 out.data_ptr(), _code(out), None, M, C, _stream()), "cnx_block_mlp_fwd")
+            return out
         if need_grad or not fused:
             mean = torch.empty(M, device=x.device, dtype=torch.float32)
             rstd = torch.empty(M, device=x.device, dtype=torch.float32)
@@ -763,7 +805,17 @@ class _BlockFused(torch.autograd.Function):
         dw1 = db1 = dw2 = db2 = dgamma = None
         da = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)            # gradient w.r.t. LN(u)
         d_u = None
-        if ctx.fused and not want_p:
+        if ctx.fused == "hpre":
+            # ---- attack backward at C = 384: Hpre from the forward's workspace, dH / GELU' / da / LayerNorm backward in ONE kernel
+            if want_p:
+                raise _lib.ApgdHipError("a block forward run under ops.attack_forward() can only be differentiated w.r.t. its input")
+            if g2.dtype not in (torch.float32, torch.bfloat16):
+                g2 = g2.float()
+            d_u = da.view(u.shape)
+            _lib.check(lib.cnx_block_mlp_bwd_input_hpre(u.data_ptr(), lw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g2.data_ptr(),
+                                                        _code(g2), _lib.ptr(gf), w1b.data_ptr(), hpre.data_ptr(), d_u.data_ptr(),
+                                                        M, C, _stream()), "cnx_block_mlp_bwd_input_hpre")
+        elif ctx.fused and not want_p:
             # ---- attack backward: ONE kernel down to the depthwise-conv output (LayerNorm backward in its epilogue)
             if g2.dtype not in (torch.float32, torch.bfloat16):
                 g2 = g2.float()
@@ -859,7 +911,7 @@ class _BlockFused(torch.autograd.Function):
             dww = g49.t().reshape(C, 1, 7, 7)
             if not ctx.has_dw_bias:
                 dwb = None
-        return dx, dww, dwb, dlw, dlb, None, dw1, db1, dw2, db2, dgamma
+        return dx, dww, dwb, dlw, dlb, None, dw1, db1, dw2, db2, dgamma, None
 
 
 def block_fused_supported(C):
@@ -872,6 +924,19 @@ def block_fused_supported(C):
 # it below the hipBLASLt composition, so that width stays on the library path for now.  APGD_BLOCK_FUSED overrides.
 _FUSED_WIDTHS = os.environ.get("APGD_BLOCK_FUSED", "96,128,192,256")
 _FUSED_WIDTHS = {int(v) for v in _FUSED_WIDTHS.split(",") if v.strip()}
+
+
+# Widths whose attack passes (forward without backward; forward + input-gradient backward) use the fused kernels with the
+# Hpre workspace while the training pass stays on the library GEMMs (cnx_block_mlp_fwd_hpre).  APGD_BLOCK_HPRE overrides ("" = none).
+_HPRE_WIDTHS = os.environ.get("APGD_BLOCK_HPRE", "384")
+_HPRE_WIDTHS = {int(v) for v in _HPRE_WIDTHS.split(",") if v.strip().isdigit()}
+
+
+def _use_hpre_block(C):
+    if MODE == "eager" or C not in _HPRE_WIDTHS:
+        return False
+    lib = _lib.load()
+    return bool(lib.cnx_block_mlp_hpre_supported(C)) and bool(lib.cnx_block_mlp_supported(C))
 
 
 def _use_fused_block(C):
@@ -892,7 +957,8 @@ def convnext_block(x, dw_w, dw_b, ln_w, ln_b, eps, w1, b1, w2, b2, gamma):
         if xr.dtype not in (torch.float32, torch.bfloat16):
             xr = xr.float()
         if _act_dtype(xr) == torch.bfloat16 and x.shape[1] % 4 == 0:
-            return _BlockFused.apply(xr, dw_w, dw_b, ln_w, ln_b, float(eps), w1, b1, w2, b2, gamma).permute(0, 3, 1, 2)
+            return _BlockFused.apply(xr, dw_w, dw_b, ln_w, ln_b, float(eps), w1, b1, w2, b2, gamma,
+                                     torch.is_grad_enabled()).permute(0, 3, 1, 2)
         y = dwconv_ln(xr, dw_w, dw_b, ln_w, ln_b, eps)
     y = F.linear(F.gelu(F.linear(y, w1, b1)), w2, b2)
     if gamma is not None:

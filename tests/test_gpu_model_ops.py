@@ -180,6 +180,54 @@ def test_convnext_block_matches_reference_block(R, C, H, gamma):
     assert float((gb.float().cpu() - gref[0]).norm() / gref[0].norm()) < 1.5e-2
 
 
+@pytest.mark.parametrize("gamma", [True, False])
+@pytest.mark.parametrize("N,H", [(2, 14), (3, 9), (1, 5)])
+def test_block_c384_attack_passes_use_the_hpre_kernels_and_match_the_reference_block(R, gamma, N, H):
+    """C = 384 (9 of ConvNeXt-T's 18 blocks): the attack's passes run cnx_block_mlp_fwd[_hpre] / cnx_block_mlp_bwd_input_hpre
+    (forward writes Hpre, the input-gradient kernel reads it back), the training pass stays on the library GEMMs.  All three
+    against the fp32 reference block; a parameter gradient asked of an attack-forward graph is refused."""
+    C = 384
+    assert R._lib.load().cnx_block_mlp_hpre_supported(C) == 1 and R.ops._use_hpre_block(C)
+    torch.manual_seed(7 * N + H)
+    ref = M.CNBlock(C, ls_init=0.5 if gamma else 0).eval()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.2)
+    x = torch.randn(N, C, H, H)
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    cot = torch.randn_like(yr)
+    (gref,) = torch.autograd.grad(yr, xr, cot)
+    blk = R.architecture.ConvNeXtBlock(C, ls_init_value=0.5 if gamma else 0).cuda().eval()
+    blk.load_state_dict(ref.state_dict())
+
+    def relerr(a, b):
+        return float((a.detach().float().cpu() - b.detach()).norm() / b.detach().norm())
+
+    res_ref = (yr - x).detach()
+    # attack pass: forward under attack_forward, backward under input_grad_only
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16), R.ops.attack_forward():
+        ya = blk(xd)
+    with R.ops.input_grad_only():
+        (ga,) = torch.autograd.grad(ya, xd, cot.cuda(), retain_graph=True)
+    assert relerr(ya.float().cpu() - x, res_ref) < 1e-2 and relerr(ga, gref) < 1.5e-2
+    with pytest.raises(R._lib.ApgdHipError):
+        torch.autograd.grad(ya, [xd] + list(blk.parameters()), cot.cuda())
+    # forward without a backward (the attack's last iteration)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        yn = blk(x.cuda().contiguous(memory_format=torch.channels_last))
+    assert torch.equal(yn, ya.detach())
+    # training pass (library GEMMs): same numbers up to bf16 noise, all gradients available
+    xt = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yt = blk(xt)
+    gt = torch.autograd.grad(yt, [xt] + list(blk.parameters()), cot.cuda())
+    assert relerr(yt.float().cpu() - x, res_ref) < 1e-2 and relerr(gt[0], gref) < 1.5e-2
+    assert relerr(ga, gt[0].float().cpu()) < 1.5e-2
+
+
 def test_full_model_matches_reference_model_fp32(R):
     torch.manual_seed(0)
     ref = M.ConvNeXtTimm(depths=(1, 1, 2, 1), dims=(32, 64, 96, 128), num_classes=10)

@@ -117,4 +117,38 @@ if "bwd_in" in args.what.split(","):
     med, mn = timeit(runb)
     res["bwd_in"] = {"med_us": round(med, 1), "min_us": round(mn, 1), "TFLOPs": round(1.5 * flops / med / 1e6, 1),
                      "mfma_frac": round(1.5 * flops / med / 1e6 / 2500, 4), "rel_err": err}
+if "hpre" in args.what.split(","):
+    wf = R.ops._pack_mlp(w1, w2)
+    wb = R.ops._pack_mlp_bwd(w1, w2)
+    out = torch.empty(M, C, device=dev)
+    mean = torch.empty(M, device=dev)
+    rstd = torch.empty(M, device=dev)
+    hp = torch.empty(lib.cnx_block_mlp_hpre_elems(M, C), device=dev, dtype=torch.bfloat16)
+    gout = torch.randn(M, C, device=dev, generator=g)
+    du = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+
+    def runf():
+        R._lib.check(lib.cnx_block_mlp_fwd_hpre(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, mean.data_ptr(), rstd.data_ptr(), wf.data_ptr(),
+                                                b1.data_ptr(), b2.data_ptr(), gm.data_ptr(), x.data_ptr(), code(x.dtype), out.data_ptr(), 0,
+                                                hp.data_ptr(), M, C, S), "fwd_hpre")
+
+    def runb():
+        R._lib.check(lib.cnx_block_mlp_bwd_input_hpre(u.data_ptr(), lw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gout.data_ptr(), 0,
+                                                      gm.data_ptr(), wb.data_ptr(), hp.data_ptr(), du.data_ptr(), M, C, S), "bwd_hpre")
+    runf()
+    runb()
+    torch.cuda.synchronize()
+    rows = torch.randint(0, M, (min(args.check_rows, 2048),), device=dev, generator=g)
+    ur = u[rows].float().requires_grad_()
+    a = F.layer_norm(ur, (C,), lw, lb, 1e-6)
+    h = F.gelu(a @ w1.to(torch.bfloat16).float().t() + b1)
+    y = (h @ w2.to(torch.bfloat16).float().t() + b2) * gm
+    (gu,) = torch.autograd.grad(y, ur, gout[rows])
+    err = float((du[rows].float() - gu).norm() / gu.norm())
+    want = ref_fwd(rows)
+    ferr = float((out[rows] - want).abs().max() / want.abs().max())
+    medf, mnf = timeit(runf)
+    medb, mnb = timeit(runb)
+    res["hpre"] = {"fwd_med_us": round(medf, 1), "fwd_min_us": round(mnf, 1), "bwd_med_us": round(medb, 1), "bwd_min_us": round(mnb, 1),
+                   "fwd_max_rel_err": ferr, "bwd_rel_err": err}
 print(json.dumps(res))

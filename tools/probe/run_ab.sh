@@ -1,10 +1,5 @@
 for rep in 1 2; do
-for lib in hip c1; do
-  export APGD_HIP_LIB=$PWD/revisiting-at_amd/libapgd_$lib.so
-  for cfg in "96 56" "128 56" "192 28" "256 28"; do set -- $cfg
-    python tools/mlp_bench.py --C $1 --hw $2 --what bwd_in --iters 30 --tag $lib 2>/dev/null
-  done
+for h in 384 none; do
+  APGD_BLOCK_HPRE=$h python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench hpre=$h', d['value'], d['ms_per_step'], d['extra']['attack_only_img_s'], d['extra']['package_power'])"
 done
 done
-unset APGD_HIP_LIB
-python -m pytest tests/test_gpu_model_ops.py -q -x -k "fused or block" 2>&1 | tail -2
