@@ -192,6 +192,36 @@ __device__ __forceinline__ f32x2 gelu_from_grad2(float z0, float z1, f32x2 gp, f
 }
 
 
+// dHpre = dH * GELU'(Hpre) for FOUR values as 62 single UNPACKED instructions, step-major (as gelu_uop; same arithmetic and rounding
+// points as gelu_grad2 above, so the results are bit-identical to the packed form):
+//   u = 4*step + el, step 0: a = min(|z|, 6)  1: x = a k  2: t = -(x x)  3: E = exp2 t  4-9: W(x) Horner  10: E W  11: 0.5 - .
+//   12: copysign(., z)  13: 0.5 + .  14: dH * .;   u = 60, 61: the two bf16 pairs
+__device__ __forceinline__ void gelu_grad_uop(int u, const float (&z)[4], const float (&dh)[4], float (&x)[4], float (&e)[4], float (&w)[4],
+                                              uint32_t& pk0, uint32_t& pk1, float c6v) {
+  if (u >= 60) {
+    if (u == 60) pk0 = cvt_pk_bf16(w[0], w[1]); else pk1 = cvt_pk_bf16(w[2], w[3]);
+    return;
+  }
+  const int step = u >> 2, el = u & 3;
+  switch (step) {
+    case 0: asm("v_min_f32 %0, |%1|, %2" : "=v"(x[el]) : "v"(z[el]), "s"(6.0f)); break;
+    case 1: asm("v_mul_f32 %0, %1, %2" : "=v"(x[el]) : "v"(x[el]), "s"(0.8493218002880191f)); break;
+    case 2: asm("v_mul_f32 %0, -%1, %1" : "=v"(e[el]) : "v"(x[el])); break;
+    case 3: asm("v_exp_f32 %0, %1" : "=v"(e[el]) : "v"(e[el])); break;
+    case 4: asm("v_fma_f32 %0, %1, %2, %3" : "=v"(w[el]) : "v"(c6v), "v"(x[el]), "s"(-1.8196647143e-02f)); break;
+    case 5: asm("v_fma_f32 %0, %1, %2, %3" : "=v"(w[el]) : "v"(w[el]), "v"(x[el]), "s"(7.6242087502e-02f)); break;
+    case 6: asm("v_fma_f32 %0, %1, %2, %3" : "=v"(w[el]) : "v"(w[el]), "v"(x[el]), "s"(-1.9087504279e-01f)); break;
+    case 7: asm("v_fma_f32 %0, %1, %2, %3" : "=v"(w[el]) : "v"(w[el]), "v"(x[el]), "s"(3.3884271219e-01f)); break;
+    case 8: asm("v_fma_f32 %0, %1, %2, %3" : "=v"(w[el]) : "v"(w[el]), "v"(x[el]), "s"(-9.3857446811e-01f)); break;
+    case 9: asm("v_fma_f32 %0, %1, %2, %3" : "=v"(w[el]) : "v"(w[el]), "v"(x[el]), "s"(4.9998430368e-01f)); break;
+    case 10: asm("v_mul_f32 %0, %1, %2" : "=v"(w[el]) : "v"(e[el]), "v"(w[el])); break;
+    case 11: asm("v_sub_f32 %0, 0.5, %1" : "=v"(w[el]) : "v"(w[el])); break;
+    case 12: asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(w[el]) : "s"(0x7fffffff), "v"(w[el]), "v"(z[el])); break;
+    case 13: asm("v_add_f32 %0, 0.5, %1" : "=v"(w[el]) : "v"(w[el])); break;
+    default: asm("v_mul_f32 %0, %1, %2" : "=v"(w[el]) : "v"(dh[el]), "v"(w[el])); break;
+  }
+}
+
 template <int C>
 struct Geo {
   static constexpr int KS = C / 16;                 // k-steps of a GEMM whose contraction runs over channels
@@ -781,10 +811,11 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
     }                                                                                                      \
   }
-  DMA_SLICE(0)
-  DMA_SLICE(1)
-  if constexpr (!HPRE)
+  if constexpr (!HPRE) {                                  // (the pipelined HPRE loop below arranges its ring differently)
+    DMA_SLICE(0)
+    DMA_SLICE(1)
     for (int i = tid; i < C; i += G::WAVES * 64) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  }
 
   long row = m0 + l32;
   const bool row_ok = row < p.M;
@@ -845,13 +876,111 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc3[cb][r] = 0.f;
 
-  for (int s = 0; s < G::NHB; ++s) {
-    uint4 hraw[2];
-    if constexpr (HPRE) {                                 // this wavefront's Hpre tile of slice s (issued before the wait below)
-      const uint4* hp = reinterpret_cast<const uint4*>(p.hpre) +
-                        ((static_cast<long>(blockIdx.x) * G::WAVES + wave) * G::NHB + s) * 128 + lane * 2;
-      hraw[0] = hp[0]; hraw[1] = hp[1];
+  if constexpr (HPRE) {
+    // ---- software-pipelined hidden loop (one wavefront per SIMD: nothing else hides the activation math).  LDS slice L = t + 1,
+    //      t = -1 .. NHB-1, holds [W2^T fragments of block t+1 | GEMM3 fragments of block t]; iteration L:
+    //        MFMA stream:  dH(t+1) = dO W2^T (KS)  ->  GEMM3(t) first half (CB, needs pairs 0-3 of dHpre(t))  ->  second half (CB)
+    //        VALU stream:  dHpre(t) = dH(t) * GELU'(Hpre(t)), 16 values per lane in UNPACKED instructions behind the first KS + CB MFMAs
+    //      Hpre(t+1) is loaded (2 x 16 bytes per lane) at the top of iteration L and converted at the top of L + 1.
+    static_assert(LPIECES % G::WAVES == 0 && G::NHB % 2 == 0, "uniform DMA count per slice; two-iteration unroll");
+    constexpr int NF = G::KS + 2 * G::CB, PF = 4, SLOTS = G::KS + G::CB, NUOP = 4 * 62, DMA_EVERY = SLOTS / LROUNDS;
+    static_assert(DMA_EVERY >= 1 && NUOP * G::KS / SLOTS >= 124, "pairs 0-3 are ready when GEMM3 starts");
+    float c6v = 1.8761737253e-03f;                        // leading coefficient of W(x) in a VGPR (one constant-bus operand per VOP3)
+    asm volatile("" : "+v"(c6v));
+    const long tile = static_cast<long>(blockIdx.x) * G::WAVES + wave;
+#define H_DMA_PIECE(L, Q)                                                                                      \
+    {                                                                                                          \
+      const int q_ = (Q) * G::WAVES + wave;                /* compact piece: < KS W2^T of block L, else GEMM3 of block L-1 */ \
+      const int blk_ = q_ < G::KS ? ((L) < G::NHB ? (L) : G::NHB - 1) : ((L) > 0 ? (L) - 1 : 0);              \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(blk_) * G::SLICE + (LP0 + q_) * 1024), \
+                                       (lds_ptr_t)(ring + ((L) % G::DEPTH) * LSLICE + q_ * 1024), 16, 0, 0);   \
     }
+#define H_LOAD_HPRE(DST, T)                                                                                    \
+    {                                                                                                          \
+      const uint4* hp_ = reinterpret_cast<const uint4*>(p.hpre) + (tile * G::NHB + ((T) < G::NHB ? (T) : G::NHB - 1)) * 128 + lane * 2; \
+      DST[0] = hp_[0]; DST[1] = hp_[1];                                                                        \
+    }
+#pragma unroll
+    for (int q = 0; q < LROUNDS; ++q) H_DMA_PIECE(0, q)
+#pragma unroll
+    for (int q = 0; q < LROUNDS; ++q) H_DMA_PIECE(1, q)
+    uint4 hra[2], hrb[2];
+    f32x16 dha, dhb;
+    {                                                     // L = 0: dH of block 0 only
+      H_LOAD_HPRE(hra, 0)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LROUNDS + 2) : "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int q = 0; q < LROUNDS; ++q) H_DMA_PIECE(2, q)
+      const unsigned char* sl = ring + lane * 16;
+      bf16x8 fr[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dha[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < G::KS; ++i) {
+        dha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i], dha, 0, 0, 0);
+        if (i + PF < G::KS) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
+      }
+    }
+#define H_ITER(L, HCUR, HNEXT, DHIN, DHOUT)                                                                    \
+    {                                                                                                          \
+      H_LOAD_HPRE(HNEXT, L)                               /* Hpre of block t+1 = L, used by the next iteration */ \
+      if ((L) + 1 <= G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LROUNDS + 2) : "memory");                \
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                    \
+      __builtin_amdgcn_s_barrier();                                                                            \
+      const unsigned char* sl = ring + ((L) % G::DEPTH) * LSLICE + lane * 16;                                  \
+      bf16x8 fr[PF];                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024);  \
+      float zq[16];                                                                                            \
+      {                                                                                                        \
+        const uint32_t hw_[8] = {HCUR[0].x, HCUR[0].y, HCUR[0].z, HCUR[0].w, HCUR[1].x, HCUR[1].y, HCUR[1].z, HCUR[1].w}; \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) { zq[2 * k] = bf16_lo(hw_[k]); zq[2 * k + 1] = bf16_hi(hw_[k]); } \
+      }                                                                                                        \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) DHOUT[r] = 0.f;                                           \
+      float gx[4], ge[4], gw[4];                                                                               \
+      uint32_t pk[8];                                                                                          \
+      bf16x8 dhf0, dhf1;                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int i = 0; i < SLOTS; ++i) {                                                      \
+        if (i == G::KS) dhf0 = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));             \
+        if (i < G::KS) DHOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i < G::KS ? i : 0], DHOUT, 0, 0, 0); \
+        else acc3[(i - G::KS) % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf0, fr[i % PF], acc3[(i - G::KS) % G::CB], 0, 0, 0); \
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + gemm3_piece(i + PF) * 1024);       \
+        if (i % DMA_EVERY == 0 && i / DMA_EVERY < LROUNDS && (L) + 2 <= G::NHB) H_DMA_PIECE((L) + 2, i / DMA_EVERY) \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        _Pragma("unroll") for (int uo = NUOP * i / SLOTS; uo < NUOP * (i + 1) / SLOTS; ++uo) {                 \
+          const int qd = uo / 62;                                                                              \
+          const float z4[4] = {zq[4 * qd], zq[4 * qd + 1], zq[4 * qd + 2], zq[4 * qd + 3]};                    \
+          const float d4[4] = {DHIN[4 * qd], DHIN[4 * qd + 1], DHIN[4 * qd + 2], DHIN[4 * qd + 3]};            \
+          gelu_grad_uop(uo % 62, z4, d4, gx, ge, gw, pk[2 * qd], pk[2 * qd + 1], c6v);                         \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+      }                                                                                                        \
+      dhf1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));                               \
+      _Pragma("unroll") for (int j = G::CB; j < 2 * G::CB; ++j) {                                              \
+        const int i = G::KS + j;                                                                               \
+        acc3[j - G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf1, fr[i % PF], acc3[j - G::CB], 0, 0, 0); \
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + gemm3_piece(i + PF) * 1024);       \
+      }                                                                                                        \
+    }
+    // fragment i of an iteration's stream -> piece of the compact LDS slice: the KS W2^T pieces in order, then GEMM3's in
+    // (t, cb) order (consecutive MFMAs update different accumulators) out of the packed (cb, t) order
+    auto gemm3_piece = [](int i) constexpr {
+      if (i < G::KS) return i;
+      const int j = i - G::KS;
+      return G::KS + (j % G::CB) * 2 + (j / G::CB);
+    };
+    for (int L = 1; L <= G::NHB; L += 2) {
+      H_ITER(L, hra, hrb, dha, dhb)
+      H_ITER(L + 1, hrb, hra, dhb, dha)
+    }
+#undef H_ITER
+#undef H_LOAD_HPRE
+#undef H_DMA_PIECE
+  }
+  for (int s = 0; s < (HPRE ? 0 : G::NHB); ++s) {        // the recomputing loop (every mode but HPRE)
     if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LMIN_ROUNDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -860,7 +989,6 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     const unsigned char* sl = ring + (s % G::DEPTH) * LSLICE + lane * 16;
 
     f32x16 acc1, acc2;
-    if constexpr (!HPRE)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const float4 b4 = *reinterpret_cast<const float4*>(b1s + s * 32 + 8 * g4 + 4 * half);
@@ -871,48 +999,30 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
     // one stream of NF = 2 KS + 2 CB operand fragments per slice, read PF fragments ahead of the MFMA that consumes them
     // (as in the forward): fragment i < 2 KS alternates W1 / W2^T k-steps (two independent accumulation chains), then the
     // W1 B-fragments of GEMM3 in (t, cb) order so that consecutive MFMAs update different accumulators
-    // HPRE: the stream is the KS W2^T fragments (compact LDS pieces 0 .. KS-1, two accumulation chains) and then GEMM3's.
-    constexpr int NG = HPRE ? G::KS : 2 * G::KS;              // MFMAs before the activation
+    constexpr int NG = 2 * G::KS;                             // MFMAs before the activation
     constexpr int NF = NG + 2 * G::CB, PF = 4;
-    auto piece_of = [](int i) constexpr {                     // fragment i of the stream -> piece of the LDS slice
-      if (i < NG) return HPRE ? i : ((i & 1) ? G::KS + (i >> 1) : (i >> 1));
+    auto piece_of = [](int i) constexpr {
+      if (i < NG) return (i & 1) ? G::KS + (i >> 1) : (i >> 1);
       const int j = i - NG;                                   // j = t * CB + cb  ->  packed piece (cb, t)
-      return (2 * G::KS - LP0) + (j % G::CB) * 2 + (j / G::CB);
+      return 2 * G::KS + (j % G::CB) * 2 + (j / G::CB);
     };
     bf16x8 fr[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i) * 1024);
-    f32x16 acc2b;                                             // HPRE: second chain of the dH accumulation
-    if constexpr (HPRE) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2b[r] = 0.f;
-      const uint32_t hw[8] = {hraw[0].x, hraw[0].y, hraw[0].z, hraw[0].w, hraw[1].x, hraw[1].y, hraw[1].z, hraw[1].w};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { acc1[2 * k] = bf16_lo(hw[k]); acc1[2 * k + 1] = bf16_hi(hw[k]); }
-    }
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-      if constexpr (HPRE) {
-        if (i & 1) acc2b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i], acc2b, 0, 0, 0);
-        else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i], acc2, 0, 0, 0);
-      } else {
-        if (i & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i >> 1], acc2, 0, 0, 0);
-        else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i >> 1], acc1, 0, 0, 0);
-      }
+      if (i & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i >> 1], acc2, 0, 0, 0);
+      else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i >> 1], acc1, 0, 0, 0);
       if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + piece_of(i + PF) * 1024);
       constexpr int DMA_EVERY = NG / LROUNDS;
-      static_assert(DMA_EVERY >= 1 && DMA_EVERY * (LROUNDS - 1) < NG, "one DMA instruction per DMA_EVERY MFMAs");
+      static_assert(HPRE || (DMA_EVERY >= 1 && DMA_EVERY * (LROUNDS - 1) < NG), "one DMA instruction per DMA_EVERY MFMAs");
       if (i % DMA_EVERY == 0 && i / DMA_EVERY < LROUNDS && s + 2 < G::NHB) {
         const int piece = (i / DMA_EVERY) * G::WAVES + wave;
         if (piece < LPIECES)
-          __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(s + 2) * G::SLICE + (LP0 + piece) * 1024),
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(s + 2) * G::SLICE + piece * 1024),
                                            (lds_ptr_t)(ring + ((s + 2) % G::DEPTH) * LSLICE + piece * 1024), 16, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (HPRE) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[r] += acc2b[r];
     }
     bf16x8 dhf[2];
     {
