@@ -124,7 +124,7 @@ def model_kernel_rooflines(R, dev, B, iters=10):
         return sum(ts) / len(ts)
 
     g = torch.Generator(device=dev).manual_seed(0)
-    for C, HW in ((96, 56), (192, 28)):                     # stage 0 (HBM / VALU / MFMA all within 2x of each other) and stage 1 (MFMA-bound)
+    for C, HW in ((96, 56), (192, 28), (384, 14)):          # stages 0, 1 and 2 of ConvNeXt-T (2 / 2 / 9 of its blocks' attack passes)
         M = B * HW * HW
         u = torch.randn(M, C, device=dev, generator=g).to(torch.bfloat16)
         x = torch.randn(M, C, device=dev, generator=g)
@@ -143,6 +143,27 @@ def model_kernel_rooflines(R, dev, B, iters=10):
                     "hbm": {"achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
                             "algorithmic_bytes_per_launch": nbytes},
                     "mfma": {"achieved": round(flops / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4)}})
+        if lib.cnx_block_mlp_hpre_supported(C):             # the attack's forward / input-gradient pair at this width
+            wb = R.ops._pack_mlp_bwd(w1, w2)
+            mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+            hp = torch.empty(lib.cnx_block_mlp_hpre_elems(M, C), device=dev, dtype=torch.bfloat16)
+            gout = torch.randn(M, C, device=dev, generator=g)
+            du = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+            tf = timed(lambda: R._lib.check(lib.cnx_block_mlp_fwd_hpre(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, mean.data_ptr(),
+                                                                        rstd.data_ptr(), wf.data_ptr(), b1.data_ptr(), b2.data_ptr(),
+                                                                        gm.data_ptr(), x.data_ptr(), 0, o.data_ptr(), 0, hp.data_ptr(), M, C,
+                                                                        stream), "cnx_block_mlp_fwd_hpre"))
+            bf = best[-1]
+            tb = timed(lambda: R._lib.check(lib.cnx_block_mlp_bwd_input_hpre(u.data_ptr(), lw.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                                              gout.data_ptr(), 0, gm.data_ptr(), wb.data_ptr(), hp.data_ptr(),
+                                                                              du.data_ptr(), M, C, stream), "cnx_block_mlp_bwd_input_hpre"))
+            for name, tt, bb, fl, nb in (("forward + Hpre workspace (cnx_block_mlp_fwd_hpre", tf, bf, flops, nbytes + 8 * M * C),
+                                         ("input gradient from the workspace (cnx_block_mlp_bwd_input_hpre", tb, best[-1], flops,
+                                          M * C * (4 + 2 + 2 + 8))):
+                out.append({"kernel": "fused LN+MLP %s, C=%d, M=%d)" % (name, C, M), "avg_us": round(tt * 1e6, 1), "min_us": round(bb * 1e6, 1),
+                            "hbm": {"achieved": round(nb / tt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nb / tt / 8e12, 4),
+                                    "algorithmic_bytes_per_launch": nb},
+                            "mfma": {"achieved": round(fl / tt / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / tt / 2.5e15, 4)}})
     C, HW = 96, 56
     M = B * HW * HW
     x = torch.randn(M, C, device=dev, generator=g)
