@@ -187,7 +187,8 @@ int cnx_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int32_t
 
 /* Backward of the same op: dqkv [B, N, 3*H*d] bf16 from qkv, out, dout ([B, N, H*d] bf16) and the saved lse.  Two
  * kernels stream 32x32 blocks of P = exp(S*scale - lse) through the MFMA accumulators (no N x N tensor in memory):
- * dQ (+ D_q = rowsum(dO*O), written to dvec [B, H, N] fp32 scratch), then dK and dV.  N <= 224, d == 64. */
+ * dQ (+ D_q = rowsum(dO*O), written to dvec [B, H, N] fp32 scratch), then dK and dV.  N <= 416, d == 64
+ * (N <= 224: every operand image in LDS; above, the dK / dV kernel takes its row operands from memory). */
 int cnx_attention_bwd_supported(int32_t N, int32_t head_dim);
 int cnx_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dvec,
                       int64_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream);

@@ -301,17 +301,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
   }
 }
 
-template <int NKB>
+// ROWS_LDS = false (N > 224): four operand images of 13 blocks would be 208 KiB, so only the two TRANSPOSED images live in LDS
+// and the row operands of S = Q K^T and dP = dO V^T - 16 contiguous bytes per lane - come straight from memory (the (b, h)
+// slice is L2-resident: each wavefront re-reads it once per key block), one query block ahead of the MFMAs that use them.
+template <int NKB, bool ROWS_LDS>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ dvec,
                                                               uint16_t* __restrict__ dqkv, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int IMG = NKB * kKS * 1024;
+  constexpr int NROW = ROWS_LDS ? 2 : 0;                              // row images in LDS
   unsigned char* qr_ = lds;                                           // Q row image
   unsigned char* dor = lds + IMG;                                     // dO row image
-  uint16_t* qt = reinterpret_cast<uint16_t*>(lds + 2 * IMG);          // Q transposed
-  uint16_t* dot_ = reinterpret_cast<uint16_t*>(lds + 3 * IMG);        // dO transposed
-  float* lse_s = reinterpret_cast<float*>(lds + 4 * IMG);             // [NKB*32] lse * log2(e)
+  uint16_t* qt = reinterpret_cast<uint16_t*>(lds + NROW * IMG);       // Q transposed
+  uint16_t* dot_ = reinterpret_cast<uint16_t*>(lds + (NROW + 1) * IMG);   // dO transposed
+  float* lse_s = reinterpret_cast<float*>(lds + (NROW + 2) * IMG);    // [NKB*32] lse * log2(e)
   float* dv_s = lse_s + NKB * 32;                                     // [NKB*32] D_q
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -320,8 +324,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
   const uint16_t* kb_ = qb + os;
   const uint16_t* vb = qb + 2 * os;
   const uint16_t* dob = dout + static_cast<long>(b) * N * os + h * kD;
-  stage_rows<NKB>(qr_, qb, ts, N, tid);
-  stage_rows<NKB>(dor, dob, os, N, tid);
+  if constexpr (ROWS_LDS) {
+    stage_rows<NKB>(qr_, qb, ts, N, tid);
+    stage_rows<NKB>(dor, dob, os, N, tid);
+  }
   stage_transposed<NKB>(qt, qb, ts, N, tid);
   stage_transposed<NKB>(dot_, dob, os, N, tid);
   for (int i = tid; i < NKB * 32; i += 256) {
@@ -350,15 +356,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
     for (int db = 0; db < kDB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    // ROWS_LDS = false: this lane's rows of Q and dO for query block qblk (queries past N are clamped: their lse is +inf,
+    // so P and dS vanish whatever the operands)
+    bf16x8 qn[kKS], dn[kKS];
+    auto load_rows = [&](int qblk) {
+      int q = qblk * 32 + l32;
+      if (q >= N) q = N - 1;
+#pragma unroll
+      for (int ks = 0; ks < kKS; ++ks) {
+        qn[ks] = *reinterpret_cast<const bf16x8*>(qb + q * ts + ks * 16 + half * 8);
+        dn[ks] = *reinterpret_cast<const bf16x8*>(dob + static_cast<long>(q) * os + ks * 16 + half * 8);
+      }
+    };
+    if constexpr (!ROWS_LDS) load_rows(0);
 #pragma unroll 1
-    for (int qblk = 0; qblk < NKB; ++qblk) {
+    for (int qblk = 0; qblk < (ROWS_LDS ? NKB : nkb); ++qblk) {
       f32x16 sc, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+      bf16x8 qc[kKS], dc[kKS];
+      if constexpr (!ROWS_LDS) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) { qc[ks] = qn[ks]; dc[ks] = dn[ks]; }
+        if (qblk + 1 < nkb) load_rows(qblk + 1);                       // in flight behind this block's 24 MFMAs
+      }
 #pragma unroll
       for (int ks = 0; ks < kKS; ++ks) {
-        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qrf + (qblk * kKS + ks) * 1024);
-        const bf16x8 da = *reinterpret_cast<const bf16x8*>(dorf + (qblk * kKS + ks) * 1024);
+        const bf16x8 qa = ROWS_LDS ? *reinterpret_cast<const bf16x8*>(qrf + (qblk * kKS + ks) * 1024) : qc[ks];
+        const bf16x8 da = ROWS_LDS ? *reinterpret_cast<const bf16x8*>(dorf + (qblk * kKS + ks) * 1024) : dc[ks];
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sc, 0, 0, 0);      // D[i = q][j = k]: lane = key
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
       }
@@ -418,6 +443,25 @@ int launch_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, i
   return launch_status();
 }
 
+template <int NKB, bool ROWS_LDS>
+int launch_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, uint16_t* dqkv, float* dvec,
+                    int64_t B, int32_t N, int32_t H, float scale, hipStream_t s) {
+  const size_t lds_q = static_cast<size_t>(NKB) * (2 * kKS + 2 * kDB) * 1024;
+  const size_t lds_kv = static_cast<size_t>(NKB) * (ROWS_LDS ? 4 : 2) * kKS * 1024 + 2 * NKB * 32 * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds_q));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<NKB, ROWS_LDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_kv));
+    attr_done = true;
+  }
+  const dim3 grid(static_cast<unsigned>(B * H)), block(256);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<NKB>, grid, block, lds_q, s, qkv, out, dout, lse, dqkv, dvec, N, H, scale);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKB, ROWS_LDS>), grid, block, lds_kv, s, qkv, dout, lse, dvec, dqkv, N, H, scale);
+  return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -438,7 +482,8 @@ int cnx_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int32_t
   return launch_attn_fwd<13>(q, o, lse, B, N, H, scale, s);
 }
 
-int cnx_attention_bwd_supported(int32_t N, int32_t head_dim) { return (head_dim == kD && N >= 1 && N <= 224) ? 1 : 0; }
+int cnx_attention_bwd_supported(int32_t N, int32_t head_dim) { return (head_dim == kD && N >= 1 && N <= 416) ? 1 : 0; }
+
 
 int cnx_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dvec,
                       int64_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream) {
@@ -448,24 +493,12 @@ int cnx_attention_bwd(const void* qkv, const void* out, const void* dout, const 
   if (!cnx_attention_bwd_supported(N, head_dim)) return APGD_ERR_ARG;
   if (B * H > 0x7fffffff) return APGD_ERR_SIZE;
   hipStream_t s = as_stream(stream);
-  constexpr int NKB = 7;
-  const size_t lds_q = static_cast<size_t>(NKB) * (2 * kKS + 2 * kDB) * 1024;
-  const size_t lds_kv = static_cast<size_t>(NKB) * 4 * kKS * 1024 + 2 * NKB * 32 * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds_q));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds_kv));
-    attr_done = true;
-  }
-  const dim3 grid(static_cast<unsigned>(B * H)), block(256);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<NKB>, grid, block, lds_q, s, static_cast<const uint16_t*>(qkv),
-                     static_cast<const uint16_t*>(out), static_cast<const uint16_t*>(dout), lse, static_cast<uint16_t*>(dqkv), dvec, N,
-                     H, scale);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<NKB>, grid, block, lds_kv, s, static_cast<const uint16_t*>(qkv),
-                     static_cast<const uint16_t*>(dout), lse, dvec, static_cast<uint16_t*>(dqkv), N, H, scale);
-  return launch_status();
+  const auto* q = static_cast<const uint16_t*>(qkv);
+  const auto* o = static_cast<const uint16_t*>(out);
+  const auto* d = static_cast<const uint16_t*>(dout);
+  auto* g = static_cast<uint16_t*>(dqkv);
+  if (N <= 224) return launch_attn_bwd<7, true>(q, o, d, lse, g, dvec, B, N, H, scale, s);
+  return launch_attn_bwd<13, false>(q, o, d, lse, g, dvec, B, N, H, scale, s);
 }
 
 }  // extern "C"

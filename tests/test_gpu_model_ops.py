@@ -419,7 +419,7 @@ def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt)
     assert lib.cnx_block_mlp_bwd_supported(384) == 0
 
 
-@pytest.mark.parametrize("N", [1, 5, 32, 33, 197, 224, 401])
+@pytest.mark.parametrize("N", [1, 5, 32, 33, 197, 224, 225, 257, 401, 416])
 @pytest.mark.parametrize("B,H", [(2, 3), (1, 12)])
 def test_fused_attention_forward_and_backward_vs_fp32_reference(R, N, B, H):
     """cnx_attention_fwd (K/V in LDS, scores in MFMA accumulators) vs fp32 torch attention on the same bf16 qkv; the
@@ -435,6 +435,8 @@ def test_fused_attention_forward_and_backward_vs_fp32_reference(R, N, B, H):
     sc = (q @ k.transpose(-2, -1)) * scale
     ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(B, N, C)
     assert lib.cnx_attention_supported(N, d) == 1 and lib.cnx_attention_supported(N, 32) == 0
+    assert lib.cnx_attention_bwd_supported(N, d) == 1 and lib.cnx_attention_bwd_supported(417, d) == 0   # (N <= 224: all operand
+    # images in LDS; 225 .. 416 = 320 x 320 inputs: the row operands of the dK / dV kernel come from L2)
     qd = qkv.cuda().requires_grad_()
     out = R.ops.attention(qd, H, scale)
     assert out.dtype == torch.bfloat16 and out.shape == (B, N, C)
