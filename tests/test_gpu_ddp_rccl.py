@@ -35,6 +35,26 @@ def test_bench_spawns_two_rccl_ranks():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["scaling"] == "weak"
 
 
+def test_bench_under_torch_distributed_run_with_two_ranks_sharing_the_gpu():
+    """The driver's launch line for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) on the
+    1-GPU box: two ranks over gloo on cuda:0 (APGD_DIST_BACKEND is the only difference from the RCCL run).  One JSON line from
+    rank 0 with the whole-job rate."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(_env(), APGD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--no-cpu-baseline", "--no-other-configs"], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]          # whole-job images per second
+
+
 _WORKER = r"""
 import os, sys, json, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
