@@ -228,6 +228,55 @@ def test_block_c384_attack_passes_use_the_hpre_kernels_and_match_the_reference_b
     assert relerr(ga, gt[0].float().cpu()) < 1.5e-2
 
 
+@pytest.mark.parametrize("M_", [1, 31, 32, 129, 1000])
+@pytest.mark.parametrize("gdt", [torch.float32, torch.bfloat16])
+def test_hpre_kernel_pair_vs_fp32_reference_through_the_c_abi(R, M_, gdt):
+    """cnx_block_mlp_fwd_hpre / cnx_block_mlp_bwd_input_hpre (C = 384) called directly: ragged row counts (the workspace is
+    sized in 128-row workgroups), fp32 and bf16 incoming gradients, output equal to the plain fused forward bit for bit, input
+    gradient vs fp32 autograd of the same bf16-quantised operands; argument errors."""
+    lib = R._lib.load()
+    C = 384
+    g = torch.Generator().manual_seed(M_)
+    u = (torch.randn(M_, C, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    w1 = torch.randn(4 * C, C, generator=g) * C ** -0.5
+    w2 = torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    b1, b2 = torch.randn(4 * C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    gm = torch.randn(C, generator=g)
+    x = torch.randn(M_, C, generator=g)
+    gout = torch.randn(M_, C, generator=g)
+    ur = u.float().requires_grad_()
+    a = F.layer_norm(ur, (C,), lw, lb, 1e-6)
+    y = x + gm * (F.gelu(a @ w1.to(torch.bfloat16).float().t() + b1) @ w2.to(torch.bfloat16).float().t() + b2)
+    (gref,) = torch.autograd.grad(y, ur, gout.to(gdt).float())
+    wf, wb = R.ops._pack_mlp(w1.cuda(), w2.cuda()), R.ops._pack_mlp_bwd(w1.cuda(), w2.cuda())
+    ud, xd, lwd, lbd, b1d, b2d, gmd = (t.cuda() for t in (u, x, lw, lb, b1, b2, gm))
+    n_ws = lib.cnx_block_mlp_hpre_elems(M_, C)
+    assert n_ws == ((M_ + 127) // 128) * 128 * 4 * C and lib.cnx_block_mlp_hpre_elems(0, C) == 0
+    ws = torch.full((n_ws,), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out, out0 = torch.empty(M_, C, device="cuda"), torch.empty(M_, C, device="cuda")
+    mean, rstd = torch.empty(M_, device="cuda"), torch.empty(M_, device="cuda")
+    P = R._lib.ptr
+    fwd = lambda o, w, m: lib.cnx_block_mlp_fwd_hpre(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), 1e-6, mean.data_ptr(), rstd.data_ptr(),
+                                                     wf.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), gmd.data_ptr(), xd.data_ptr(), 0,
+                                                     o.data_ptr(), 0, w, m, C, S())
+    assert fwd(out, ws.data_ptr(), M_) == 0
+    assert lib.cnx_block_mlp_fwd(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), 1e-6, None, None, wf.data_ptr(), b1d.data_ptr(),
+                                 b2d.data_ptr(), gmd.data_ptr(), xd.data_ptr(), 0, out0.data_ptr(), 0, None, M_, C, S()) == 0
+    assert torch.equal(out, out0)
+    assert float((out.cpu() - y.detach()).norm() / y.detach().norm()) < 1e-2
+    gd = gout.to(gdt).cuda()
+    du = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+    bwd = lambda w, m, c: lib.cnx_block_mlp_bwd_input_hpre(ud.data_ptr(), lwd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
+                                                           R._lib.dtype_code(gdt), gmd.data_ptr(), wb.data_ptr(), w, du.data_ptr(), m, c, S())
+    assert bwd(ws.data_ptr(), M_, C) == 0
+    assert float((du.float().cpu() - gref).norm() / gref.norm()) < 1.5e-2
+    # argument handling: empty batch is a no-op, missing workspace / unsupported width are refused
+    assert fwd(out, ws.data_ptr(), 0) == 0 and bwd(ws.data_ptr(), 0, C) == 0
+    assert fwd(out, None, M_) < 0 and bwd(None, M_, C) < 0 and bwd(ws.data_ptr(), M_, 192) < 0
+    assert lib.cnx_block_mlp_hpre_supported(384) == 1 and lib.cnx_block_mlp_hpre_supported(192) == 0
+
+
 def test_full_model_matches_reference_model_fp32(R):
     torch.manual_seed(0)
     ref = M.ConvNeXtTimm(depths=(1, 1, 2, 1), dims=(32, 64, 96, 128), num_classes=10)
