@@ -692,6 +692,20 @@ def _wgrad_t(xt, y):
     return _sum_parts(part)
 
 
+# d(b1) of the fused blocks as an extra column of the dW1 GEMM (APGD_DB1_IN_GEMM=0: a separate reduction over [4C, M])
+_DB1_IN_GEMM = os.environ.get("APGD_DB1_IN_GEMM", "1") != "0"
+_ONES_COL = {}
+
+
+def _ones_col(device):
+    t = _ONES_COL.get(device)
+    if t is None:
+        t = torch.zeros(8, device=device, dtype=torch.bfloat16)
+        t[0] = 1
+        _ONES_COL[device] = t
+    return t
+
+
 def _pack_mlp_bwd(w1, w2):
     """fc1 / fc2 weights -> the three operand-fragment sets of the fused backward (``cnx_mlp_pack_weights_bwd``)."""
     lib = _lib.load()
@@ -826,8 +840,12 @@ class _BlockFused(torch.autograd.Function):
         elif ctx.fused:
             # ---- one kernel: LN recompute, dO = g*gamma, Hpre / dH / dHpre per hidden slice on-chip, da
             a = dos = ht = dhpt = None
+            a_cols = C + 8 if _DB1_IN_GEMM else C
             if want_p:
-                a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+                # with 8 extra columns (1, 0, ..., 0) behind LN(u), the d(b1) sum is column C of the dW1 GEMM's result
+                a = torch.empty(M, a_cols, device=x.device, dtype=torch.bfloat16)
+                if a_cols != C:
+                    a[:, C:] = _ones_col(x.device)
                 dos = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
                 ht = torch.empty(4 * C, M, device=x.device, dtype=torch.bfloat16)
                 dhpt = torch.empty(4 * C, M, device=x.device, dtype=torch.bfloat16)
@@ -835,11 +853,14 @@ class _BlockFused(torch.autograd.Function):
                 g2 = g2.float()
             _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                              g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
-                                             da.data_ptr(), _lib.ptr(a), 0, _lib.ptr(dos), _lib.ptr(ht), _lib.ptr(dhpt), M, C,
-                                             _stream()), "cnx_block_mlp_bwd")
+                                             da.data_ptr(), _lib.ptr(a), (a_cols if want_p else 0), _lib.ptr(dos), _lib.ptr(ht),
+                                             _lib.ptr(dhpt), M, C, _stream()), "cnx_block_mlp_bwd")
             if want_p:
-                dw1 = _wgrad_t(dhpt, a)                                          # [4C, C]
-                db1 = dhpt.sum(1, dtype=torch.float32)
+                dw1 = _wgrad_t(dhpt, a)                                          # [4C, C (+8)]
+                if a_cols != C:
+                    dw1, db1 = dw1[:, :C], dw1[:, C].contiguous()
+                else:
+                    db1 = dhpt.sum(1, dtype=torch.float32)
                 dw2 = _wgrad_t(ht, dos).t()                                      # [C, 4C]
                 # d(gamma) = sum_m g*y2 and d(b2) = sum_m dO in ONE pass over g and y2 (sums-only mode of the tail kernel;
                 # as separate torch reductions they were a cast, a product and two sums: ~390 us per block at 56x56)
