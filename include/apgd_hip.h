@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define APGD_HIP_VERSION 10200 /* major*10000 + minor*100 + patch */
+#define APGD_HIP_VERSION 10300 /* major*10000 + minor*100 + patch */
 
 #define APGD_OK 0
 #define APGD_ERR_NULL (-1)    /* required pointer is NULL */
@@ -143,6 +143,18 @@ int apgd_track_rows(const uint8_t* flags, float* x_adv, void* grad, float* x_bes
  * min/max of adv;  out[b*3 + {0,1,2}] = {linf, min, max}.  Used by tests and --check runs. */
 int apgd_check_imgs_f32(const float* adv, const float* x, float* out, int64_t B, int64_t E,
                         void* stream);
+
+/* adv.attack = fgsm - the other value of the trainer's attack selector (main.py:836-842 -> fgsm_train.py:72-100): random start,
+ * one signed gradient step, projection; two element-wise passes around the single forward / backward.
+ *   apgd_fgsm_start_f32 : x_adv = x + ((2 t - 1) * eps) * noise_level, clamped to [0, 1] when clamp != 0 (:81-84); t = the uniform
+ *                         draw of the reference (:81), produced by the caller with its own generator
+ *   apgd_fgsm_step_f32  : out = x_adv + alpha_eps * sign(grad);  project != 0:  out = clamp01(x + clamp(out - x, -eps, eps)) (:95-98).
+ *                         alpha_eps = (float)(alpha * eps) formed in double by the caller; grad fp32, bf16 or int8 signs
+ * n = number of elements; every operation is rounded to fp32 on its own (no contraction), results bit-identical to the reference's. */
+int apgd_fgsm_start_f32(const float* x, const float* t, float* x_adv, int64_t n, float eps, float noise_level, int32_t clamp,
+                        void* stream);
+int apgd_fgsm_step_f32(const float* x, const float* x_adv, const void* grad, int32_t grad_dtype, float* out, int64_t n,
+                       float alpha_eps, float eps, int32_t project, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@ Drop-in for the ``adv.attack=apgd`` path of nmndeep/revisiting-at
 from . import _lib
 from . import ops, architecture
 from .apgd import apgd_train, checkpoint_schedule, criterion_names
+from .fgsm import fgsm_train
 from . import aa_eval
 from .aa_eval import apgd_attack, run_standard_evaluation, robust_accuracy
 from .wrapped_model import WrappedModel
@@ -17,6 +18,6 @@ from . import mixup, checkpoint
 from .mixup import Mixup, SoftTargetCrossEntropy
 
 __version__ = "0.1.0"
-__all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "WrappedModel", "AdvConfig",
+__all__ = ["apgd_train", "fgsm_train", "checkpoint_schedule", "criterion_names", "WrappedModel", "AdvConfig",
            "build_perturb", "wrap_model_for_at", "get_new_model", "normalize_model", "ATTrainStep", "create_optimizer",
            "setup_distributed", "_lib"]

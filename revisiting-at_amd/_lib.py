@@ -34,6 +34,8 @@ PROTOTYPES = {
     "apgd_state_update": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p]),
     "apgd_track_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _p]),
     "apgd_check_imgs_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p]),
+    "apgd_fgsm_start_f32": (C.c_int, [_p, _p, _p, _i64, _f, _f, _i32, _p]),
+    "apgd_fgsm_step_f32": (C.c_int, [_p, _p, _p, _i32, _p, _i64, _f, _f, _i32, _p]),
     # include/convnext_hip.h
     "cnx_dwconv7x7_nhwc": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, C.c_int, _i64, _i32, _i32, _i32, _i32, _p]),
     "cnx_dwconv7x7_wgrad_ws_floats": (C.c_int64, [_i32]),

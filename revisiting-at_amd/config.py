@@ -12,6 +12,7 @@ from dataclasses import dataclass, fields
 from typing import Optional, Sequence
 
 from .apgd import apgd_train
+from .fgsm import fgsm_train
 from .wrapped_model import WrappedModel
 
 
@@ -56,7 +57,8 @@ class AdvConfig:
 
 
 def build_perturb(cfg: AdvConfig, mixup=None):
-    """``functools.partial(apgd_train, norm, eps, n_iter, verbose, mixup)`` (``main.py:834-835``).
+    """``functools.partial(apgd_train, norm, eps, n_iter, verbose, mixup)`` (``main.py:834-835``) or
+    ``functools.partial(fgsm_train, eps, use_rs=True, alpha, noise_level, skip_projection)`` (``main.py:836-842``).
 
     Returns None for ``adv.attack == 'none'`` (the model is then not wrapped, ``main.py:831``).
     """
@@ -65,8 +67,9 @@ def build_perturb(cfg: AdvConfig, mixup=None):
     if cfg.attack == 'apgd':
         return functools.partial(apgd_train, norm=cfg.norm, eps=cfg.eps, n_iter=cfg.n_iter,
                                  verbose=cfg.verbose == 1, mixup=mixup)
-    if cfg.attack == 'fgsm':
-        raise NotImplementedError("adv.attack=fgsm (main.py:836-842) is outside the APGD hot path")
+    if cfg.attack == 'fgsm':                                  # main.py:836-842
+        return functools.partial(fgsm_train, eps=cfg.eps, use_rs=True, alpha=cfg.alpha, noise_level=cfg.noise_level,
+                                 skip_projection=cfg.skip_projection == 1)
     raise ValueError(f"unknown adv.attack {cfg.attack!r}")
 
 

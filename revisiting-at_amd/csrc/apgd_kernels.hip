@@ -900,3 +900,81 @@ int apgd_check_imgs_f32(const float* adv, const float* x, float* out, int64_t B,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- adv.attack = fgsm (fgsm_train.py:72-100, main.py:836-842)
+// The other value of the trainer's attack selector: random start, ONE signed gradient step, projection.  Two element-wise
+// passes around the single forward / backward; the gradient may arrive as fp32, bf16 or the stem kernel's int8 signs.
+namespace {
+__device__ __forceinline__ float sign3(float g) { return static_cast<float>(g > 0.0f) - static_cast<float>(g < 0.0f); }
+
+// x_adv = x + ((2 t - 1) * eps) * noise   (:81-82; every operation rounded on its own, as the reference's tensor expression)
+__global__ __launch_bounds__(kBlock) void fgsm_start_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                            float* __restrict__ out, int64_t n, float eps, float noise, int clamp) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < n; e += stride) {
+    float v = 2.0f * t[e];
+    v = v - 1.0f;
+    v = v * eps;
+    v = v * noise;
+    v = x[e] + v;
+    out[e] = clamp ? clamp01(v) : v;
+  }
+}
+
+// out = x_adv + (alpha eps) sign(g);  unless skip_projection: out = clamp01(x + clamp(out - x, -eps, eps))   (:95-98)
+template <typename GT>
+__global__ __launch_bounds__(kBlock) void fgsm_step_kernel(const float* __restrict__ x, const float* __restrict__ xa,
+                                                           const GT* __restrict__ g, float* __restrict__ out, int64_t n,
+                                                           float alpha_eps, float eps, int project) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < n; e += stride) {
+    float v = alpha_eps * sign3(Elt<GT>::load(g, e));
+    v = xa[e] + v;
+    if (project) {
+      const float xc = x[e];
+      float d = v - xc;
+      d = fminf(fmaxf(d, -eps), eps);
+      v = clamp01(xc + d);
+    }
+    out[e] = v;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int apgd_fgsm_start_f32(const float* x, const float* t, float* x_adv, int64_t n, float eps, float noise_level, int32_t clamp,
+                        void* stream) {
+  if (n < 0) return APGD_ERR_SIZE;
+  if (n == 0) return APGD_OK;
+  if (!x || !t || !x_adv) return APGD_ERR_NULL;
+  hipLaunchKernelGGL(fgsm_start_kernel, dim3(blocks_for(n, kBlock, 16384)), dim3(kBlock), 0, as_stream(stream), x, t, x_adv, n, eps,
+                     noise_level, clamp);
+  return launch_status();
+}
+
+int apgd_fgsm_step_f32(const float* x, const float* x_adv, const void* grad, int32_t grad_dtype, float* out, int64_t n,
+                       float alpha_eps, float eps, int32_t project, void* stream) {
+  if (n < 0) return APGD_ERR_SIZE;
+  if (n == 0) return APGD_OK;
+  if (!x || !x_adv || !grad || !out) return APGD_ERR_NULL;
+  const dim3 grid(blocks_for(n, kBlock, 16384)), block(kBlock);
+  hipStream_t s = as_stream(stream);
+  switch (grad_dtype) {
+    case APGD_F32:
+      hipLaunchKernelGGL(fgsm_step_kernel<float>, grid, block, 0, s, x, x_adv, static_cast<const float*>(grad), out, n, alpha_eps, eps, project);
+      break;
+    case APGD_BF16:
+      hipLaunchKernelGGL(fgsm_step_kernel<uint16_t>, grid, block, 0, s, x, x_adv, static_cast<const uint16_t*>(grad), out, n, alpha_eps, eps,
+                         project);
+      break;
+    case APGD_I8:
+      hipLaunchKernelGGL(fgsm_step_kernel<int8_t>, grid, block, 0, s, x, x_adv, static_cast<const int8_t*>(grad), out, n, alpha_eps, eps,
+                         project);
+      break;
+    default: return APGD_ERR_DTYPE;
+  }
+  return launch_status();
+}
+
+}  // extern "C"

@@ -39,8 +39,9 @@ def test_build_perturb_wiring():
     p = R.build_perturb(R.AdvConfig(attack="apgd", n_iter=5, eps=0.1, norm="L2", verbose=1), mixup=mix)
     assert isinstance(p, functools.partial) and p.func is R.apgd_train  # main.py:834-835
     assert p.keywords == dict(norm="L2", eps=0.1, n_iter=5, verbose=True, mixup=mix)
-    with pytest.raises(NotImplementedError):
-        R.build_perturb(R.AdvConfig(attack="fgsm"))
+    f = R.build_perturb(R.AdvConfig(attack="fgsm", eps=0.02, alpha=1.25, noise_level=2.0, skip_projection=1))
+    assert isinstance(f, functools.partial) and f.func is R.fgsm_train  # main.py:836-842
+    assert f.keywords == dict(eps=0.02, use_rs=True, alpha=1.25, noise_level=2.0, skip_projection=True)
     with pytest.raises(ValueError):
         R.build_perturb(R.AdvConfig(attack="pgd"))
     m = nn.Linear(3, 2)
@@ -99,3 +100,14 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_fgsm_train_has_no_cpu_fallback_and_keeps_the_reference_errors():
+    m = nn.Linear(3, 2).eval()
+    x, y = torch.rand(2, 3), torch.tensor([0, 1])
+    with pytest.raises(R._lib.ApgdHipError):
+        R.fgsm_train(m, x, y, 0.1)                                        # CPU tensor: no fallback in the product
+    with pytest.raises(KeyError):
+        R.fgsm_train(m, x, y, 0.1, loss="dlr")                            # criterion_dict of fgsm_train.py has 'ce' only
+    with pytest.raises(AssertionError):
+        R.fgsm_train(m.train(), x, y, 0.1)                                # fgsm_train.py:74
