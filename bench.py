@@ -221,7 +221,10 @@ def other_configs(R, dev):
         x = torch.rand(32, 3, 224, 224, device=dev, generator=g)
         with torch.no_grad():
             y = model(x).argmax(1)                           # every point starts robust: the attack runs on all of them
-        R.aa_eval.apgd_attack(model, x[:8], y[:8], "Linf", 4 / 255, 2, "ce", None, True, g)        # warm-up
+        # warm-up at the SAME batch size: MIOpen's find mode times every solver (its naive kernels included, 4 - 10 ms each)
+        # the first time it meets a convolution shape - ~10 s for this model's twelve fp32 problems, which a warm-up at
+        # another batch size leaves inside the timed run (round 2's first cfg5 figure, 2.4 img/s, was mostly that)
+        R.aa_eval.apgd_attack(model, x, y, "Linf", 4 / 255, 2, "ce", None, True, g)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         R.aa_eval.apgd_attack(model, x, y, "Linf", 4 / 255, 100, "ce", None, True, g)
