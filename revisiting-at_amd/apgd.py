@@ -168,7 +168,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
     Returns ``(x_best, acc, loss_best, x_best_adv)`` (``:371``): fresh, detached tensors with
     ``x``'s shape and memory format; ``acc`` is bool ``[B]``, ``loss_best`` fp32 ``[B]``.
     ``y`` is int64 ``[B]``, or fp32 ``[B, n_cls]`` probabilities iff ``mixup is not None``
-    (``:194-197``).  Supported: ``norm in {'Linf', 'L2'}``, ``loss in {'ce', 'dlr'}``.
+    (``:194-197``).  Supported: ``norm in {'Linf', 'L2', 'L1'}`` (L1: ``loss='ce'``, see ``apgd_l1.py``), ``loss in {'ce', 'dlr'}``.
     """
     assert not model.training                                           # :125
     if use_rs:
@@ -183,8 +183,14 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
     kind = LOSS_KIND[loss]
     if kind == 1 and mixup is not None:
         raise NotImplementedError("loss='dlr' needs hard labels (dlr_loss indexes x[arange, y], :103)")
+    if norm == 'L1':                                                   # :160-167, 239-250, 351-362 ("next" row: apgd_l1.py)
+        if kind != 0:
+            raise NotImplementedError("norm='L1' is built for loss='ce'")
+        from . import apgd_l1
+        return apgd_l1.apgd_l1(model, x, y, eps, n_iter, mixup is not None, is_train, verbose, _model_fwd_bwd, ApgdWorkspace,
+                               _stream_ptr)
     if norm not in ('Linf', 'L2'):
-        raise NotImplementedError(f"norm={norm!r}: the HIP path covers Linf and L2 (SURVEY.md §8 a2, a8)")
+        raise NotImplementedError(f"norm={norm!r}: the HIP path covers Linf, L2 and L1 (L0 is broken in the reference itself, :257)")
     return _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=mixup is not None, verbose=verbose)
 
 

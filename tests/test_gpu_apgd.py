@@ -560,7 +560,7 @@ def test_error_behaviour(R):
     with pytest.raises(R._lib.ApgdHipError):
         R.apgd_train(m, x.cpu(), y.cpu(), norm="Linf", eps=0.1, n_iter=1)    # no CPU fallback
     with pytest.raises(NotImplementedError):
-        R.apgd_train(m, x, y, norm="L1", eps=0.1, n_iter=1)                  # L1/L0 are outside the HIP path
+        R.apgd_train(m, x, y, norm="L0", eps=0.1, n_iter=1)                  # L0 calls an undefined L0_projection in the reference (:257)
 
 
 # ------------------------------------------------------------------------------ evaluation attacks (AA_eval.py path)
