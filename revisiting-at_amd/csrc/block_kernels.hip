@@ -427,12 +427,9 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     //        VALU stream:  GELU of block t-1, 16 values per lane in UNPACKED instructions, one group after each of the first
     //                      KS + CB MFMAs - the only VALU work that runs while the matrix pipe is busy (see gelu1 above).
     //      sched_barrier(0) pins the interleaving; everything stays compiler-visible, so waits and hazards are the compiler's.
-#ifndef BLK_PIPE_PF_WIDE
-#define BLK_PIPE_PF_WIDE 8
-#endif
-    // operand fragments in flight per wavefront: with ONE wavefront per SIMD (C >= 256) nothing else covers the LDS latency, which
-    // under the weight DMA and four reading wavefronts is ~300 cycles (3570 cycles per C = 384 slice with 4 in flight = 75 per MFMA)
-    constexpr int NF = G::KS + 2 * G::CB, PF = (C >= 256 ? BLK_PIPE_PF_WIDE : 4), SLOTS = G::KS + G::CB, NUOP = 4 * 38;
+    // (PF = operand fragments in flight per wavefront; 8 instead of 4 measured the same at one wavefront per SIMD: the LDS latency
+    //  is covered, what stalled the C >= 256 loops was the weight DMA - see DMA_EVERY below)
+    constexpr int NF = G::KS + 2 * G::CB, PF = 4, SLOTS = G::KS + G::CB, NUOP = 4 * 38;
     // the weight DMA of slice t+2 is issued one instruction at a time between the MFMAs of iteration t: a burst of FWD_ROUNDS
     // global_load_lds at the top of the iteration stalls the in-order wavefront at issue (~1300 cycles per C = 384 slice - the
     // texture path takes a KiB per ~16 cycles and the four wavefronts of the CU share it)
