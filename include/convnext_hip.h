@@ -174,6 +174,20 @@ int cnx_block_mlp_bwd_input_hpre(const void* u, const float* ln_w, const float* 
                                  const void* g, int g_dtype, const float* gamma, const void* Wb, const void* hpre_ws,
                                  void* du, int64_t M, int32_t C, void* stream);
 
+/* Second ConvStem convolution (utils_architecture.py:207-209 `ConvBlock1`: 48 -> 96; `ConvBlock3`: 64 -> 96): 3x3, stride 2, padding 1
+ * on channels-last bf16 activations, forward and input gradient as implicit GEMMs on MFMA (filter resident in LDS, activations as
+ * 16-byte loads straight from the NHWC tensor).  x [N, H, W, CI] bf16 -> out [N, H/2, W/2, CO] bf16 (+ bias [CO] fp32, nullable);
+ * dgrad: dy [N, H/2, W/2, CO] bf16 -> dx [N, H, W, CI] bf16.  packed = cnx_conv3x3s2_pack(w [CO, CI, 3, 3] fp32 or bf16):
+ * cnx_conv3x3s2_packed_elems(CI, CO) bf16 elements.  Results are reproducible from run to run (the library's backward-data
+ * kernel for this layer is not).  cnx_conv3x3s2_supported: CO == 96, CI in {48, 64}, H % 8 == 0, W % 16 == 0. */
+int cnx_conv3x3s2_supported(int32_t CI, int32_t CO, int32_t H, int32_t W);
+int64_t cnx_conv3x3s2_packed_elems(int32_t CI, int32_t CO);
+int cnx_conv3x3s2_pack(const void* w, int w_dtype, void* packed, int32_t CI, int32_t CO, void* stream);
+int cnx_conv3x3s2_fwd(const void* x, const void* packed, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
+                      int32_t CI, int32_t CO, void* stream);
+int cnx_conv3x3s2_dgrad(const void* dy, const void* packed, void* dx, int64_t N, int32_t H, int32_t W, int32_t CI, int32_t CO,
+                        void* stream);
+
 /* Fused multi-head softmax attention of the ViT family (timm 0.8 `Attention.forward`, reached through the models of
  * /root/reference/utils_architecture.py:272-301):
  *     q, k, v = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4);   out = softmax(q k^T * scale) v

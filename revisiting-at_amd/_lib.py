@@ -51,6 +51,11 @@ PROTOTYPES = {
     "cnx_mlp_pack_weights_bwd": (C.c_int, [_p, _p, C.c_int, _p, _i32, _p]),
     "cnx_block_mlp_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p]),
     "cnx_block_mlp_bwd_input": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _i64, _i32, _p]),
+    "cnx_conv3x3s2_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "cnx_conv3x3s2_packed_elems": (C.c_int64, [_i32, _i32]),
+    "cnx_conv3x3s2_pack": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _p]),
+    "cnx_conv3x3s2_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "cnx_conv3x3s2_dgrad": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cnx_block_mlp_hpre_supported": (C.c_int, [_i32]),
     "cnx_block_mlp_hpre_elems": (C.c_int64, [_i64, _i32]),
     "cnx_block_mlp_fwd_hpre": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _i64, _i32, _p]),

@@ -105,6 +105,16 @@ class _ImageConv(nn.Conv2d):
         return super().forward(x)
 
 
+class _StemConv2(nn.Conv2d):
+    """A later ConvStem convolution (3x3, stride 2: ``ConvBlock1`` 48 -> 96, ``ConvBlock3`` 64 -> 96): plain ``nn.Conv2d`` for the
+    state dict, routed through the hand-written implicit-GEMM kernel when its input is a channels-last bf16 activation."""
+
+    def forward(self, x):
+        if ops.conv3x3s2_supported(x, self):
+            return ops.conv3x3s2(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class _StemSequential(nn.Sequential):
     """``nn.Sequential`` (same indices / state-dict keys) that runs the first convolution and its LayerNorm + GELU as one
     kernel when the input is the fp32 image batch under bf16 autocast."""
@@ -128,7 +138,7 @@ class _StemSequential(nn.Sequential):
 def _stem(chans, strides, final_1x1=None):
     layers = []
     for cin, cout, s in zip(chans[:-1], chans[1:], strides):
-        conv = _ImageConv if (cin == 3 and s == 2) else nn.Conv2d
+        conv = _ImageConv if (cin == 3 and s == 2) else (_StemConv2 if s == 2 else nn.Conv2d)
         layers += [conv(cin, cout, kernel_size=3, stride=s, padding=1), _CfLnGelu(cout), nn.Identity()]
     if final_1x1 is not None:
         layers.append(nn.Conv2d(chans[-1], final_1x1, kernel_size=1, stride=1, padding=0))

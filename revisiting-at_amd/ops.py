@@ -493,6 +493,86 @@ def stem_conv(x, weight, bias):
     return _StemConv.apply(x, weight, bias)
 
 
+# ------------------------------------------------------------------------------ second ConvStem convolution
+def _pack_conv2(w):
+    lib = _lib.load()
+    CO, CI = w.shape[0], w.shape[1]
+    w = w.contiguous()
+    if w.dtype not in (torch.float32, torch.bfloat16):
+        w = w.float()
+    pk = torch.empty(lib.cnx_conv3x3s2_packed_elems(CI, CO), device=w.device, dtype=torch.bfloat16)
+    _lib.check(lib.cnx_conv3x3s2_pack(w.data_ptr(), _code(w), pk.data_ptr(), CI, CO, _stream()), "cnx_conv3x3s2_pack")
+    return pk
+
+
+# 1: forward through cnx_conv3x3s2_fwd; 2: input gradient through cnx_conv3x3s2_dgrad as well (APGD_CONV2 overrides; 0 = library)
+_CONV2_MODE = int(os.environ.get("APGD_CONV2", "1"))
+
+
+def conv3x3s2_supported(x, conv):
+    """3x3 / stride 2 / padding 1 convolution of a channels-last bf16 activation with a kernel for its widths and map size."""
+    if MODE == "eager" or not _CONV2_MODE or not x.is_cuda or x.dim() != 4 or x.dtype != torch.bfloat16:
+        return False
+    if conv.kernel_size != (3, 3) or conv.stride != (2, 2) or conv.padding != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1:
+        return False
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    return bool(_lib.load().cnx_conv3x3s2_supported(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3]))
+
+
+class _Conv3x3s2(torch.autograd.Function):
+    """``Conv2d(CI, CO, 3, stride 2, padding 1)`` on a channels-last bf16 activation (NCHW-shaped views of NHWC rows in and out).
+    Forward = ``cnx_conv3x3s2_fwd`` (implicit GEMM on MFMA, filter resident in LDS); the input gradient is the library's
+    backward-data kernel or, with ``APGD_CONV2=2``, ``cnx_conv3x3s2_dgrad``; filter / bias gradients stay in the library."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        N, CI, H, W = x.shape
+        CO = weight.shape[0]
+        pk = _cached((weight,), "conv2_packed", _pack_conv2)
+        bf = _f32(bias) if bias is not None else None
+        xr = x.permute(0, 2, 3, 1)
+        out = torch.empty(N, H // 2, W // 2, CO, device=x.device, dtype=torch.bfloat16)
+        _lib.check(lib.cnx_conv3x3s2_fwd(xr.data_ptr(), pk.data_ptr(), _lib.ptr(bf), out.data_ptr(), N, H, W, CI, CO, _stream()),
+                   "cnx_conv3x3s2_fwd")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, weight, pk)
+            ctx.has_bias = bias is not None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, weight, pk = ctx.saved_tensors
+        N, CI, H, W = x.shape
+        CO = weight.shape[0]
+        if g.dtype != torch.bfloat16 or not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        want_w = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY
+        dx = dw = db = None
+        if ctx.needs_input_grad[0] and _CONV2_MODE >= 2:
+            dxr = torch.empty(N, H, W, CI, device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.cnx_conv3x3s2_dgrad(g.permute(0, 2, 3, 1).data_ptr(), pk.data_ptr(), dxr.data_ptr(), N, H, W, CI, CO,
+                                               _stream()), "cnx_conv3x3s2_dgrad")
+            dx = dxr.permute(0, 3, 1, 2)
+        need_lib_dx = ctx.needs_input_grad[0] and dx is None
+        if need_lib_dx or want_w:
+            wl = _cached((weight,), "bf16_cl", lambda w: w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+            r = torch.ops.aten.convolution_backward(g, x, wl, [CO] if ctx.has_bias else None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                    [bool(need_lib_dx), bool(want_w), bool(want_w and ctx.has_bias)])
+            if need_lib_dx:
+                dx = r[0]
+            if want_w:
+                dw = r[1].to(weight.dtype)
+                db = r[2].to(weight.dtype) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def conv3x3s2(x, weight, bias):
+    return _Conv3x3s2.apply(x, weight, bias)
+
+
 # ------------------------------------------------------------------------------ depthwise 7x7 + LayerNorm
 class _DwConvLN(torch.autograd.Function):
     """[N,H,W,C] rows in -> LN(dwconv7x7(x)) rows out (``models/convnext.py:39-41``)."""
