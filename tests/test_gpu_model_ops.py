@@ -277,6 +277,52 @@ def test_hpre_kernel_pair_vs_fp32_reference_through_the_c_abi(R, M_, gdt):
     assert lib.cnx_block_mlp_hpre_supported(384) == 1 and lib.cnx_block_mlp_hpre_supported(192) == 0
 
 
+@pytest.mark.parametrize("CI,N,H,W", [(48, 2, 32, 32), (48, 3, 8, 16), (48, 1, 112, 112), (64, 2, 32, 48), (64, 1, 16, 16)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_second_stem_convolution_vs_library(R, CI, N, H, W, bias):
+    """cnx_conv3x3s2_fwd / _dgrad (3x3, stride 2, padding 1; ConvBlock1's 48 -> 96, ConvBlock3's 64 -> 96) vs F.conv2d in fp32 on the
+    same bf16-quantised operands; borders, odd tile counts, the autograd wrapper (library filter / bias gradients), reproducibility."""
+    lib = R._lib.load()
+    CO = 96
+    assert lib.cnx_conv3x3s2_supported(CI, CO, H, W) == 1 and lib.cnx_conv3x3s2_supported(CI, CO, H + 4, W) == 0
+    assert lib.cnx_conv3x3s2_supported(32, CO, H, W) == 0
+    g = torch.Generator().manual_seed(CI + H + W)
+    x = torch.randn(N, CI, H, W, generator=g).to(torch.bfloat16)
+    w = torch.randn(CO, CI, 3, 3, generator=g) * (9 * CI) ** -0.5
+    b = torch.randn(CO, generator=g) * 0.2 if bias else None
+    cot = torch.randn(N, CO, H // 2, W // 2, generator=g).to(torch.bfloat16)
+    xr = x.float().requires_grad_()
+    wr = w.to(torch.bfloat16).float().requires_grad_()
+    ref = F.conv2d(xr, wr, b, stride=2, padding=1)
+    gx, gw = torch.autograd.grad(ref, [xr, wr], cot.float())
+    conv = torch.nn.Conv2d(CI, CO, 3, stride=2, padding=1, bias=bias).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        if bias:
+            conv.bias.copy_(b)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    assert R.ops.conv3x3s2_supported(xd, conv) and not R.ops.conv3x3s2_supported(xd.float(), conv)
+    out = R.ops.conv3x3s2(xd, conv.weight, conv.bias)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    rel = lambda a, b_: float((a.float().cpu() - b_).norm() / b_.norm())
+    assert rel(out.detach(), ref.detach()) < 4e-3
+    grads = torch.autograd.grad(out, [xd, conv.weight] + ([conv.bias] if bias else []), cot.cuda())
+    assert rel(grads[0], gx) < 6e-3 and rel(grads[1], gw) < 1e-2
+    if bias:
+        assert rel(grads[2], cot.float().sum((0, 2, 3))) < 1e-2
+    # the input-gradient kernel through the C ABI, twice: same bits
+    pk = R.ops._pack_conv2(conv.weight.detach())
+    dys = cot.cuda().permute(0, 2, 3, 1).contiguous()
+    dx1 = torch.empty(N, H, W, CI, device="cuda", dtype=torch.bfloat16)
+    dx2 = torch.full_like(dx1, float("nan"))
+    for d in (dx1, dx2):
+        assert lib.cnx_conv3x3s2_dgrad(dys.data_ptr(), pk.data_ptr(), d.data_ptr(), N, H, W, CI, CO, S()) == 0
+    assert torch.equal(dx1, dx2) and rel(dx1.permute(0, 3, 1, 2), gx) < 6e-3
+    assert lib.cnx_conv3x3s2_fwd(xd.data_ptr(), pk.data_ptr(), None, out.data_ptr(), 0, H, W, CI, CO, S()) == 0
+    assert lib.cnx_conv3x3s2_fwd(xd.data_ptr(), None, None, out.data_ptr(), N, H, W, CI, CO, S()) < 0
+    assert lib.cnx_conv3x3s2_dgrad(dys.data_ptr(), pk.data_ptr(), dx1.data_ptr(), N, H + 2, W, CI, CO, S()) < 0
+
+
 def test_full_model_matches_reference_model_fp32(R):
     torch.manual_seed(0)
     ref = M.ConvNeXtTimm(depths=(1, 1, 2, 1), dims=(32, 64, 96, 128), num_classes=10)
