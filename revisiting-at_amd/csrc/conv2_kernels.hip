@@ -10,10 +10,8 @@
 //             zero outside the image), B fragments = the whole filter, resident in LDS in fragment order (9 * CI/16 * CO/32 KiB).
 //             In the accumulator a lane owns one output channel, so bias add and the NHWC store are 64 contiguous bytes per
 //             half-wave and position.
-//   dgrad     a wavefront = a 4 x 8 block of input positions of ONE parity class (iy & 1, ix & 1): with stride 2 a position is
-//             reached by 1, 2, 2 or 4 taps depending on its parity; D[pos][ci] = sum_k dY[pos'][k] Wt[k][ci], k = (tap, co).
-//             A fragments from the NHWC output gradient, B fragments (transposed filter, per tap) resident in LDS.
-// One workgroup of 16 wavefronts per CU shares the filter; wavefronts take tiles in a grid-stride loop.
+//   dgrad     a wavefront = a 4 x 8 block of 2 x 2 input patches against their 2 x 2 output neighbours (see conv2_dgrad_kernel).
+// One workgroup of 6 - 12 wavefronts per CU shares the filter; wavefronts take tiles in a grid-stride loop.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,32 +33,21 @@ __device__ __forceinline__ uint16_t to_bf16(float v) {
   return static_cast<uint16_t>(__builtin_bit_cast(uint32_t, __builtin_convertvector(p, bf16x2)) & 0xffffu);
 }
 
-constexpr int kWaves = 16;
 
 // ------------------------------------------------------------------ filter pre-arrangement
 // forward  piece (ks, nb), ks = tap * CI/16 + cg: lane (n = l32, half), e -> W[nb*32 + n][cg*16 + half*8 + e][tap/3][tap%3]
-// dgrad    piece (tap, ks, nb), ks over CO/16, nb over ceil(CI/32): lane (n, half), e -> W[ks*16 + half*8 + e][nb*32 + n][tap] (0 if
-//          nb*32 + n >= CI)
+// (the input gradient's pieces: see conv2_pack_dgrad_kernel below; packed buffer = [forward pieces | 64 zeros | dgrad pieces | 64 zeros])
 template <typename TW>
-__global__ __launch_bounds__(256) void conv2_pack_kernel(const TW* __restrict__ w, uint16_t* __restrict__ wf, uint16_t* __restrict__ wd,
-                                                         int CI, int CO) {
-  const int KSF = 9 * (CI / 16), NBF = CO / 32, KSD = CO / 16, NBD = (CI + 31) / 32;
-  const long nf = static_cast<long>(KSF) * NBF * 512, nd = 9L * KSD * NBD * 512;
+__global__ __launch_bounds__(256) void conv2_pack_kernel(const TW* __restrict__ w, uint16_t* __restrict__ wf, int CI, int CO) {
+  const int KSF = 9 * (CI / 16), NBF = CO / 32;
+  const long nf = static_cast<long>(KSF) * NBF * 512;
   const long q = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
-  if (q < nf) {
-    const int e = q & 7, lane = (q >> 3) & 63, piece = static_cast<int>(q >> 9);
-    const int nb = piece % NBF, ks = piece / NBF, tap = ks / (CI / 16), cg = ks % (CI / 16);
-    const int co = nb * 32 + (lane & 31), ci = cg * 16 + (lane >> 5) * 8 + e;
-    wf[q] = to_bf16(static_cast<float>(w[(static_cast<long>(co) * CI + ci) * 9 + tap]));
-  } else if (q >= nf + nd && q < nf + nd + 64) {
-    wd[q - nf] = 0;                                       // the zero page (read through the same pointer arithmetic as wd)
-  } else if (q < nf + nd) {
-    const long p = q - nf;
-    const int e = p & 7, lane = (p >> 3) & 63, piece = static_cast<int>(p >> 9);
-    const int nb = piece % NBD, ks = (piece / NBD) % KSD, tap = piece / (NBD * KSD);
-    const int ci = nb * 32 + (lane & 31), co = ks * 16 + (lane >> 5) * 8 + e;
-    wd[p] = ci < CI ? to_bf16(static_cast<float>(w[(static_cast<long>(co) * CI + ci) * 9 + tap])) : static_cast<uint16_t>(0);
-  }
+  if (q >= nf + 64) return;
+  if (q >= nf) { wf[q] = 0; return; }                                  // the zero page behind the pieces (taps outside the image)
+  const int e = q & 7, lane = (q >> 3) & 63, piece = static_cast<int>(q >> 9);
+  const int nb = piece % NBF, ks = piece / NBF, tap = ks / (CI / 16), cg = ks % (CI / 16);
+  const int co = nb * 32 + (lane & 31), ci = cg * 16 + (lane >> 5) * 8 + e;
+  wf[q] = to_bf16(static_cast<float>(w[(static_cast<long>(co) * CI + ci) * 9 + tap]));
 }
 
 // ------------------------------------------------------------------ forward
@@ -86,7 +73,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void conv2_fwd_kernel(const uint16_
   for (int i = tid; i < CO; i += kFwdWaves * 64) bias_s[i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const unsigned char* wl = lds + lane * 16;
-  const uint16_t* zero_page = wf + KS * NB * 512 + 9 * (CO / 16) * ((CI + 31) / 32) * 512;     // 64 zero elements behind the packed filter
+  const uint16_t* zero_page = wf + KS * NB * 512;            // 64 zero elements behind the forward pieces
   const int OH = H / 2, OW = W / 2, TX = OW / 8, TY = OH / 4;
   const long n_tiles = static_cast<long>(N) * TY * TX;
   const long t_first = static_cast<long>(blockIdx.x) * kFwdWaves + wave, t_stride = static_cast<long>(gridDim.x) * kFwdWaves;
@@ -164,73 +151,153 @@ __global__ __launch_bounds__(kFwdWaves * 64) void conv2_fwd_kernel(const uint16_
 }
 
 // ------------------------------------------------------------------ input gradient
-template <int CI, int CO>
-__global__ __launch_bounds__(kWaves * 64) void conv2_dgrad_kernel(const uint16_t* __restrict__ dy_, const uint16_t* __restrict__ wd,
-                                                                  uint16_t* __restrict__ dx_, int N, int H, int W) {
-  constexpr int KSD = CO / 16, NB = (CI + 31) / 32;
+// A wavefront = a 4 x 8 block of 2 x 2 input PATCHES (128 input positions).  With stride 2 the four positions of patch (gy, gx) -
+// classes (py, px) - see exactly the 2 x 2 output positions q = (a, b): (gy + a, gx + b), each through at most one tap:
+//     a = 0, py = 0 -> ky = 1;   a = 0, py = 1 -> ky = 2;   a = 1, py = 1 -> ky = 0;   (a = 1, py = 0: none)       same in x
+// so  D[(class, ci)][patch] = sum over (q, co) of  Wp[(class, ci)][(q, co)] dY[(q, co)][patch]  with 9 of the 16 (q, class) blocks
+// non-zero.  K = 4 CO in 4 steps of CO/16 fragments (one neighbour q per step, its dY row read as 16-byte loads, one step ahead of
+// the MFMAs), N = 4 CI in 32-wide blocks of which only those touching a connected class are computed (15 of 24 at CI = 48).
+// The result leaves through a wavefront-private LDS tile, one row parity at a time: the two positions of a patch in a row are
+// adjacent in memory, so a row of 8 patches is one contiguous run.
+__host__ __device__ constexpr bool dg_connected(int q, int cls) {
+  const int a = q >> 1, b = q & 1, py = cls >> 1, px = cls & 1;
+  return (a == 0 || py == 1) && (b == 0 || px == 1);
+}
+__host__ __device__ constexpr bool dg_block_used(int q, int nb, int CI) {      // does N-block nb touch a class connected to q?
+  for (int cls = 0; cls < 4; ++cls)
+    if (dg_connected(q, cls) && nb * 32 < (cls + 1) * CI && (nb + 1) * 32 > cls * CI) return true;
+  return false;
+}
+__host__ __device__ constexpr int dg_blocks_before(int q, int nb, int CI) {    // used (q', nb') pairs before (q, nb), q-major
+  int n = 0;
+  for (int qq = 0; qq <= q; ++qq)
+    for (int b = 0; b < 4 * CI / 32; ++b) {
+      if (qq == q && b >= nb) break;
+      if (dg_block_used(qq, b, CI)) ++n;
+    }
+  return n;
+}
+__host__ __device__ constexpr int dg_tap(int q, int cls) {                      // ky * 3 + kx of the tap connecting them
+  const int a = q >> 1, b = q & 1, py = cls >> 1, px = cls & 1;
+  const int ky = a ? 0 : (py ? 2 : 1), kx = b ? 0 : (px ? 2 : 1);
+  return ky * 3 + kx;
+}
+
+// dgrad filter pieces: for q, for used nb (in that order), for ks: piece index = (dg_blocks_before(q, nb) * KSD + ks);
+// lane (n = l32, half), e -> Wp[nb*32 + n][(q, ks*16 + half*8 + e)]
+template <typename TW>
+__global__ __launch_bounds__(256) void conv2_pack_dgrad_kernel(const TW* __restrict__ w, uint16_t* __restrict__ wd, int CI, int CO) {
+  const int KSD = CO / 16, NBLK = 4 * CI / 32;
+  const int n_used = dg_blocks_before(3, NBLK, CI);
+  const long total = static_cast<long>(n_used) * KSD * 512;
+  const long p = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= total + 64) return;
+  if (p >= total) { wd[p] = 0; return; }                               // the zero page behind the pieces
+  const int e = p & 7, lane = (p >> 3) & 63, piece = static_cast<int>(p >> 9);
+  const int ks = piece % KSD, ub = piece / KSD;
+  int q = 0, nb = 0;
+  for (int qq = 0; qq < 4; ++qq)
+    for (int b = 0; b < NBLK; ++b)
+      if (dg_block_used(qq, b, CI) && dg_blocks_before(qq, b, CI) == ub) { q = qq; nb = b; }
+  const int n = nb * 32 + (lane & 31), cls = n / CI, ci = n - cls * CI;
+  const int co = ks * 16 + (lane >> 5) * 8 + e;
+  float v = 0.f;
+  if (dg_connected(q, cls)) v = static_cast<float>(w[(static_cast<long>(co) * CI + ci) * 9 + dg_tap(q, cls)]);
+  wd[p] = to_bf16(v);
+}
+
+template <int CI> struct DgWaves {
+  static constexpr int WKB = dg_blocks_before(3, 4 * CI / 32, CI) * 6;          // KiB of filter pieces (CO = 96: 6 k-steps)
+  static constexpr int SKB = 32 * 2 * CI * 2 / 1024;                            // KiB of one wavefront's half-tile
+  static constexpr int value = (158 - WKB) / SKB > 12 ? 12 : (158 - WKB) / SKB;
+};
+
+template <int CI, int CO, int NW = DgWaves<CI>::value>
+__global__ __launch_bounds__(NW * 64) void conv2_dgrad_kernel(const uint16_t* __restrict__ dy_, const uint16_t* __restrict__ wd,
+                                                              uint16_t* __restrict__ dx_, int N, int H, int W) {
+  constexpr int KSD = CO / 16, NBLK = 4 * CI / 32, NUSED = dg_blocks_before(3, NBLK, CI);
+  constexpr int WBYTES = NUSED * KSD * 1024, HALF_BYTES = 32 * 2 * CI * 2;
+  static_assert((2 * CI) % 32 == 0 && CI % 4 == 0, "a row parity is a whole number of N-blocks; 4 consecutive n share a class");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 9 * KSD * NB * 64; i += kWaves * 64) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(wd)[i];
+  unsigned char* scr = lds + WBYTES + wave * HALF_BYTES;
+  for (int i = tid; i < NUSED * KSD * 64; i += NW * 64) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(wd)[i];
   __syncthreads();
   const unsigned char* wl = lds + lane * 16;
-  const uint16_t* zero_page = wd + 9 * KSD * NB * 512;
-  const int OH = H / 2, OW = W / 2;                   // dy is [N, OH, OW, CO]; a parity class of dx is an OH x OW grid
-  const int TX = OW / 8, TY = OH / 4;
-  const long per_class = static_cast<long>(N) * TY * TX, n_tiles = 4 * per_class;
-  for (long t = static_cast<long>(blockIdx.x) * kWaves + wave; t < n_tiles; t += static_cast<long>(gridDim.x) * kWaves) {
-    // classes in the order (odd, odd), (odd, even), (even, odd), (even, even): 4, 2, 2, 1 taps - heavy tiles first
-    const int cls = static_cast<int>(t / per_class);
-    const long tile = t - cls * per_class;
-    const int py = cls < 2 ? 1 : 0, px = (cls & 1) ? 0 : 1;
-    const int tx = static_cast<int>(tile % TX), ty = static_cast<int>((tile / TX) % TY), b = static_cast<int>(tile / (static_cast<long>(TX) * TY));
-    const int gy = ty * 4 + (l32 >> 3), gx = tx * 8 + (l32 & 7);          // position inside the class grid
-    const int iy = 2 * gy + py, ix = 2 * gx + px;
-    const uint16_t* db = dy_ + static_cast<long>(b) * OH * OW * CO + half * 8;
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    // taps (ky, kx) with iy + 1 - ky even: iy even -> ky = 1; iy odd -> ky in {0, 2};  oy = (iy + 1 - ky) / 2
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      if (a == 1 && py == 0) break;
-      const int ky = py ? 2 * a : 1;
-      const int oy = (iy + 1 - ky) >> 1;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (c == 1 && px == 0) break;
-        const int kx = px ? 2 * c : 1;
-        const int ox = (ix + 1 - kx) >> 1;
-        const bool ok = oy >= 0 && oy < OH && ox >= 0 && ox < OW;
-        const uint16_t* p = ok ? db + (static_cast<long>(oy) * OW + ox) * CO : zero_page;
-        const int kstep = ok ? 16 : 0;
-        const int tap = ky * 3 + kx;
-        bf16x8 af[KSD];
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(p + ks * kstep);
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(wl + ((tap * KSD + ks) * NB + nb) * 1024);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfrag, acc[nb], 0, 0, 0);
-          }
-      }
+  const uint16_t* zero_page = wd + NUSED * KSD * 512;
+  const int OH = H / 2, OW = W / 2, TX = OW / 8, TY = OH / 4;
+  const long n_tiles = static_cast<long>(N) * TY * TX;
+  const long t_first = static_cast<long>(blockIdx.x) * NW + wave, t_stride = static_cast<long>(gridDim.x) * NW;
+  const long my_tiles = t_first < n_tiles ? (n_tiles - t_first + t_stride - 1) / t_stride : 0;
+  const long n_steps = 4 * my_tiles;
+#define DG_LOAD(DST, ST)                                                                                       \
+  {                                                                                                            \
+    const long tile_ = t_first + ((ST) >> 2) * t_stride;                                                       \
+    const int q_ = static_cast<int>((ST) & 3);                                                                 \
+    const int tx_ = static_cast<int>(tile_ % TX), ty_ = static_cast<int>((tile_ / TX) % TY);                   \
+    const int b_ = static_cast<int>(tile_ / (static_cast<long>(TX) * TY));                                     \
+    const int oy_ = ty_ * 4 + (l32 >> 3) + (q_ >> 1), ox_ = tx_ * 8 + (l32 & 7) + (q_ & 1);                    \
+    const bool ok_ = oy_ < OH && ox_ < OW;                                                                     \
+    const uint16_t* p_ = ok_ ? dy_ + ((static_cast<long>(b_) * OH + oy_) * OW + ox_) * CO + half * 8 : zero_page; \
+    const int kstep_ = ok_ ? 16 : 0;                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < KSD; ++ks) DST[ks] = *reinterpret_cast<const bf16x8*>(p_ + ks * kstep_); \
+  }
+  f32x16 acc[NBLK];
+#define DG_MFMAS(CUR, Q)                                                                                       \
+  _Pragma("unroll") for (int nb = 0; nb < NBLK; ++nb)                                                          \
+    if (dg_block_used(Q, nb, CI)) {                                                                            \
+      _Pragma("unroll") for (int ks = 0; ks < KSD; ++ks) {                                                     \
+        const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(wl + (dg_blocks_before(Q, nb, CI) * KSD + ks) * 1024); \
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, CUR[ks], acc[nb], 0, 0, 0);                     \
+      }                                                                                                        \
     }
-    uint16_t* ob = dx_ + static_cast<long>(b) * H * W * CI;
+#define DG_STEP(CUR, NXT, ST, Q)                                                                               \
+  {                                                                                                            \
+    if ((ST) + 1 < n_steps) DG_LOAD(NXT, (ST) + 1)                                                             \
+    if ((Q) == 0) {                                                                                            \
+      _Pragma("unroll") for (int nb = 0; nb < NBLK; ++nb)                                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;                                       \
+    }                                                                                                          \
+    DG_MFMAS(CUR, Q)                                                                                           \
+  }
+  bf16x8 fa[KSD], fb[KSD];
+  if (n_steps > 0) DG_LOAD(fa, 0)
+  for (long st = 0; st < n_steps; st += 4) {
+    DG_STEP(fa, fb, st, 0)
+    DG_STEP(fb, fa, st + 1, 1)
+    DG_STEP(fa, fb, st + 2, 2)
+    DG_STEP(fb, fa, st + 3, 3)
+    // acc[nb][r]: n = nb*32 + (r & 3) + 8 (r >> 2) + 4 half = class * CI + ci, patch l32
+    const long tile_c = t_first + (st >> 2) * t_stride;
+    const int tx_c = static_cast<int>(tile_c % TX), ty_c = static_cast<int>((tile_c / TX) % TY);
+    const int b_c = static_cast<int>(tile_c / (static_cast<long>(TX) * TY));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const long pos = static_cast<long>(2 * (ty * 4 + (i >> 3)) + py) * W + 2 * (tx * 8 + (i & 7)) + px;
+    for (int py = 0; py < 2; ++py) {
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int ci = nb * 32 + l32;
-        if (ci < CI) ob[pos * CI + ci] = to_bf16(acc[nb][r]);
+      for (int nb = py * (2 * CI / 32); nb < (py + 1) * (2 * CI / 32); ++nb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int n0 = nb * 32 + 8 * g4 + 4 * half - py * 2 * CI;             // (px, ci) index inside this row parity
+          const uint32_t lo = static_cast<uint32_t>(to_bf16(acc[nb][4 * g4 + 0])) | (static_cast<uint32_t>(to_bf16(acc[nb][4 * g4 + 1])) << 16);
+          const uint32_t hi = static_cast<uint32_t>(to_bf16(acc[nb][4 * g4 + 2])) | (static_cast<uint32_t>(to_bf16(acc[nb][4 * g4 + 3])) << 16);
+          *reinterpret_cast<uint2*>(scr + (l32 * 2 * CI + n0) * 2) = make_uint2(lo, hi);
+        }
+      __builtin_amdgcn_wave_barrier();
+      constexpr int ROWB = 8 * 2 * CI * 2;                                      // 8 patches x 2 positions x CI channels: contiguous in dx
+      unsigned char* ob = reinterpret_cast<unsigned char*>(dx_) +
+                          ((static_cast<long>(b_c) * H + 2 * (ty_c * 4) + py) * W + 2 * (tx_c * 8)) * CI * 2;
+#pragma unroll
+      for (int qq = 0; qq < HALF_BYTES / 1024; ++qq) {
+        const int off = (qq * 64 + lane) * 16, ry = off / ROWB, cb = off - ry * ROWB;
+        *reinterpret_cast<uint4*>(ob + static_cast<long>(2 * ry) * W * CI * 2 + cb) = *reinterpret_cast<const uint4*>(scr + off);
       }
     }
   }
+#undef DG_STEP
+#undef DG_MFMAS
+#undef DG_LOAD
 }
 
 template <int CI, int CO>
@@ -252,16 +319,18 @@ int launch_fwd(const uint16_t* x, const uint16_t* wf, const float* bias, uint16_
 
 template <int CI, int CO>
 int launch_dgrad(const uint16_t* dy, const uint16_t* wd, uint16_t* dx, int N, int H, int W, hipStream_t s) {
-  constexpr int LDS = 9 * (CO / 16) * ((CI + 31) / 32) * 1024;
+  constexpr int NW = DgWaves<CI>::value;
+  constexpr int LDS = dg_blocks_before(3, 4 * CI / 32, CI) * (CO / 16) * 1024 + NW * 32 * 2 * CI * 2;
+  static_assert(LDS <= 160 * 1024 && NW >= 4, "filter pieces + per-wavefront half tiles must fit the LDS");
   auto kfn = conv2_dgrad_kernel<CI, CO>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  const long n_tiles = 4L * N * (H / 8) * (W / 16);
-  const int grid = static_cast<int>(n_tiles < 256L * kWaves ? (n_tiles + kWaves - 1) / kWaves : 256);
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves * 64), LDS, s, dy, wd, dx, N, H, W);
+  const long n_tiles = static_cast<long>(N) * (H / 8) * (W / 16);
+  const int grid = static_cast<int>(n_tiles < 256L * NW ? (n_tiles + NW - 1) / NW : 256);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), LDS, s, dy, wd, dx, N, H, W);
   return launch_status();
 }
 
@@ -274,21 +343,25 @@ int cnx_conv3x3s2_supported(int32_t CI, int32_t CO, int32_t H, int32_t W) {
   return (geo && CO == 96 && (CI == 48 || CI == 64)) ? 1 : 0;
 }
 
-int64_t cnx_conv3x3s2_packed_elems(int32_t CI, int32_t CO) {
-  return 9L * (CI / 16) * (CO / 32) * 512 + 9L * (CO / 16) * ((CI + 31) / 32) * 512 + 64;   // + a zero page for taps outside the image
-}
+static long conv2_fwd_elems(int CI, int CO) { return 9L * (CI / 16) * (CO / 32) * 512 + 64; }
+static long conv2_dgrad_elems(int CI, int CO) { return static_cast<long>(dg_blocks_before(3, 4 * CI / 32, CI)) * (CO / 16) * 512 + 64; }
+
+int64_t cnx_conv3x3s2_packed_elems(int32_t CI, int32_t CO) { return conv2_fwd_elems(CI, CO) + conv2_dgrad_elems(CI, CO); }
 
 int cnx_conv3x3s2_pack(const void* w, int w_dtype, void* packed, int32_t CI, int32_t CO, void* stream) {
   if (!w || !packed) return APGD_ERR_NULL;
   if (CI <= 0 || CO <= 0 || CI % 16 != 0 || CO % 32 != 0) return APGD_ERR_SIZE;
-  const long nf = 9L * (CI / 16) * (CO / 32) * 512, total = cnx_conv3x3s2_packed_elems(CI, CO);
+  const long nf = conv2_fwd_elems(CI, CO), nd = conv2_dgrad_elems(CI, CO);
   uint16_t* wf = static_cast<uint16_t*>(packed);
-  const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
-  if (w_dtype == APGD_F32)
-    hipLaunchKernelGGL(conv2_pack_kernel<float>, grid, block, 0, as_stream(stream), static_cast<const float*>(w), wf, wf + nf, CI, CO);
-  else if (w_dtype == APGD_BF16)
-    hipLaunchKernelGGL(conv2_pack_kernel<__bf16>, grid, block, 0, as_stream(stream), static_cast<const __bf16*>(w), wf, wf + nf, CI, CO);
-  else return APGD_ERR_DTYPE;
+  const dim3 gf(static_cast<unsigned>((nf + 255) / 256)), gd(static_cast<unsigned>((nd + 255) / 256)), block(256);
+  hipStream_t s = as_stream(stream);
+  if (w_dtype == APGD_F32) {
+    hipLaunchKernelGGL(conv2_pack_kernel<float>, gf, block, 0, s, static_cast<const float*>(w), wf, CI, CO);
+    hipLaunchKernelGGL(conv2_pack_dgrad_kernel<float>, gd, block, 0, s, static_cast<const float*>(w), wf + nf, CI, CO);
+  } else if (w_dtype == APGD_BF16) {
+    hipLaunchKernelGGL(conv2_pack_kernel<__bf16>, gf, block, 0, s, static_cast<const __bf16*>(w), wf, CI, CO);
+    hipLaunchKernelGGL(conv2_pack_dgrad_kernel<__bf16>, gd, block, 0, s, static_cast<const __bf16*>(w), wf + nf, CI, CO);
+  } else return APGD_ERR_DTYPE;
   return launch_status();
 }
 
@@ -311,7 +384,7 @@ int cnx_conv3x3s2_dgrad(const void* dy, const void* packed, void* dx, int64_t N,
   if (N == 0) return APGD_OK;
   if (!dy || !packed || !dx) return APGD_ERR_NULL;
   if (!cnx_conv3x3s2_supported(CI, CO, H, W) || N > 0x7fffffff) return APGD_ERR_ARG;
-  const auto* wd = static_cast<const uint16_t*>(packed) + 9L * (CI / 16) * (CO / 32) * 512;
+  const auto* wd = static_cast<const uint16_t*>(packed) + conv2_fwd_elems(CI, CO);
   const auto* g = static_cast<const uint16_t*>(dy);
   auto* o = static_cast<uint16_t*>(dx);
   if (CI == 48) return launch_dgrad<48, 96>(g, wd, o, static_cast<int>(N), H, W, as_stream(stream));

@@ -505,8 +505,8 @@ def _pack_conv2(w):
     return pk
 
 
-# 1: forward through cnx_conv3x3s2_fwd; 2: input gradient through cnx_conv3x3s2_dgrad as well (APGD_CONV2 overrides; 0 = library)
-_CONV2_MODE = int(os.environ.get("APGD_CONV2", "1"))
+# 2 (default): forward and input gradient through cnx_conv3x3s2_fwd / _dgrad; 1: forward only; 0: library (APGD_CONV2 overrides)
+_CONV2_MODE = int(os.environ.get("APGD_CONV2", "2"))
 
 
 def conv3x3s2_supported(x, conv):
@@ -523,7 +523,8 @@ def conv3x3s2_supported(x, conv):
 class _Conv3x3s2(torch.autograd.Function):
     """``Conv2d(CI, CO, 3, stride 2, padding 1)`` on a channels-last bf16 activation (NCHW-shaped views of NHWC rows in and out).
     Forward = ``cnx_conv3x3s2_fwd`` (implicit GEMM on MFMA, filter resident in LDS); the input gradient is the library's
-    backward-data kernel or, with ``APGD_CONV2=2``, ``cnx_conv3x3s2_dgrad``; filter / bias gradients stay in the library."""
+    the input gradient ``cnx_conv3x3s2_dgrad`` (2 x 2 input patches against their 2 x 2 output neighbours); filter / bias gradients stay in
+    the library."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
