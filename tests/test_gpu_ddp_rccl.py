@@ -35,6 +35,32 @@ def test_bench_spawns_two_rccl_ranks():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["scaling"] == "weak"
 
 
+def test_bench_line_carries_the_contract_fields():
+    """`python bench.py` on one GPU (small run): ONE JSON line with the driver's fields, the roofline object of the dominant
+    kernel (both forms), a CPU baseline measured by the oracle, package power; `vs_baseline` null (no published number)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-steps", "1", "--cpu-batch", "4",
+                        "--no-other-configs"], env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("adversarial images/sec") and d["unit"] == "img/s" and d["n_gpus"] == 1 and d["steps"] == 2
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "bf16"
+    assert d["data"].startswith("synthetic") and "workload" in d["config"] and d["config"]["global_batch"] == 256
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "first_iter"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0.3 < rf["frac"] < 1.0 and 0.3 < rf["first_iter"]["frac"] < 1.05
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "img/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert d["extra"]["ops_mode"] == "hip"
+
+
 def test_bench_under_torch_distributed_run_with_two_ranks_sharing_the_gpu():
     """The driver's launch line for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) on the
     1-GPU box: two ranks over gloo on cuda:0 (APGD_DIST_BACKEND is the only difference from the RCCL run).  One JSON line from
