@@ -760,6 +760,9 @@ struct BlkBwdArgs {
   long a_stride;           // row stride of a_out in elements (>= C; lets the caller append a ones column for d(b1))
 };
 
+#ifndef BLK_BWD_PIPE
+#define BLK_BWD_PIPE 1
+#endif
 template <int C>
 struct GeoB {
   static constexpr int KS = C / 16, CB = C / 32, NHB = C / 8;
@@ -785,6 +788,10 @@ template <int C, typename TG, bool EMIT, bool LNB, bool HPRE = false>
 __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_mlp_bwd_kernel(const BlkBwdArgs p) {
   using G = GeoB<C>;
   static_assert(!(HPRE && EMIT), "the emit mode recomputes LN(u) anyway");
+  // PIPE_R: the recomputing input-gradient kernel at one wavefront per SIMD (C >= 128) runs the software-pipelined loop too
+  // (GEMM1 / dH of block t+1 interleaved with the unpacked GELU' of block t); C = 96 (two wavefronts per SIMD, power cap) and the
+  // emit mode keep the straight loop.
+  constexpr bool PIPE_R = !HPRE && !EMIT && LNB && (C == 128 || C == 192) && BLK_BWD_PIPE;   // (C = 256: the second accumulator set spills)
   constexpr int LP0 = HPRE ? G::KS : 0;                          // first packed piece of a slice that goes through LDS
   constexpr int LPIECES = G::PIECES - LP0, LSLICE = LPIECES * 1024;
   constexpr int LROUNDS = (LPIECES + G::WAVES - 1) / G::WAVES, LMIN_ROUNDS = LPIECES / G::WAVES;
@@ -808,9 +815,11 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
     }                                                                                                      \
   }
-  if constexpr (!HPRE) {                                  // (the pipelined HPRE loop below arranges its ring differently)
-    DMA_SLICE(0)
-    DMA_SLICE(1)
+  if constexpr (!HPRE) {                                  // (the pipelined loops below arrange their ring differently)
+    if constexpr (!PIPE_R) {
+      DMA_SLICE(0)
+      DMA_SLICE(1)
+    }
     for (int i = tid; i < C; i += G::WAVES * 64) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
   }
 
@@ -977,7 +986,103 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_ml
 #undef H_LOAD_HPRE
 #undef H_DMA_PIECE
   }
-  for (int s = 0; s < (HPRE ? 0 : G::NHB); ++s) {        // the recomputing loop (every mode but HPRE)
+  if constexpr (PIPE_R) {
+    // ---- software-pipelined recomputing loop.  LDS slice L = t + 1 holds [W1(t+1) | W2^T(t+1) | GEMM3 pieces of block t]; iteration L:
+    //        MFMA stream:  Hpre(t+1) = a W1^T + b1 and dH(t+1) = dO W2^T, alternating (2 KS)  ->  GEMM3(t) (CB + CB)
+    //        VALU stream:  dHpre(t) = dH(t) * GELU'(Hpre(t)) in unpacked instructions behind the first 2 KS + CB MFMAs
+    static_assert(G::PIECES % G::WAVES == 0 && G::NHB % 2 == 0, "uniform DMA count per slice; two-iteration unroll");
+    constexpr int NG = 2 * G::KS, NF = NG + 2 * G::CB, PF = 4, SLOTS = NG + G::CB, NUOP = 4 * 62, RND = G::PIECES / G::WAVES;
+    constexpr int DMA_EVERY = SLOTS / RND;
+    static_assert(DMA_EVERY >= 1 && NUOP * NG / SLOTS >= 124, "pairs 0-3 are ready when GEMM3 starts");
+    float c6v = 1.8761737253e-03f;
+    asm volatile("" : "+v"(c6v));
+#define R_DMA_PIECE(L, Q)                                                                                      \
+    {                                                                                                          \
+      const int q_ = (Q) * G::WAVES + wave;                /* piece < 2 KS: W1 / W2^T of block L, else GEMM3 of block L-1 */ \
+      const int blk_ = q_ < NG ? ((L) < G::NHB ? (L) : G::NHB - 1) : ((L) > 0 ? (L) - 1 : 0);                  \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(blk_) * G::SLICE + q_ * 1024),     \
+                                       (lds_ptr_t)(ring + ((L) % G::DEPTH) * G::SLICE + q_ * 1024), 16, 0, 0); \
+    }
+#define R_BIAS(Z, T)                                                                                           \
+    _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                                         \
+      const float4 b4 = *reinterpret_cast<const float4*>(b1s + ((T) < G::NHB ? (T) : G::NHB - 1) * 32 + 8 * g4 + 4 * half); \
+      Z[4 * g4 + 0] = b4.x; Z[4 * g4 + 1] = b4.y; Z[4 * g4 + 2] = b4.z; Z[4 * g4 + 3] = b4.w;                  \
+    }
+    auto r_piece = [](int i) constexpr {                  // fragment i of an iteration's stream -> piece of the slice
+      if (i < NG) return (i & 1) ? G::KS + (i >> 1) : (i >> 1);
+      const int j = i - NG;                               // j = t * CB + cb  ->  packed piece (cb, t)
+      return NG + (j % G::CB) * 2 + (j / G::CB);
+    };
+#pragma unroll
+    for (int q = 0; q < RND; ++q) R_DMA_PIECE(0, q)
+#pragma unroll
+    for (int q = 0; q < RND; ++q) R_DMA_PIECE(1, q)
+    f32x16 za, zb, dha, dhb;
+    {                                                     // L = 0: Hpre and dH of block 0 only
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RND) : "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int q = 0; q < RND; ++q) R_DMA_PIECE(2, q)
+      const unsigned char* sl = ring + lane * 16;
+      bf16x8 fr[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + r_piece(i) * 1024);
+      R_BIAS(za, 0)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dha[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        if (i & 1) dha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i >> 1], dha, 0, 0, 0);
+        else za = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i >> 1], za, 0, 0, 0);
+        if (i + PF < NG) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + r_piece(i + PF) * 1024);
+      }
+    }
+#define R_ITER(L, ZIN, DHIN, ZOUT, DHOUT)                                                                      \
+    {                                                                                                          \
+      if ((L) + 1 <= G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RND) : "memory");                        \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+      __builtin_amdgcn_s_barrier();                                                                            \
+      const unsigned char* sl = ring + ((L) % G::DEPTH) * G::SLICE + lane * 16;                                \
+      bf16x8 fr[PF];                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + r_piece(i) * 1024); \
+      R_BIAS(ZOUT, L)                                                                                          \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) DHOUT[r] = 0.f;                                           \
+      float gx[4], ge[4], gw[4];                                                                               \
+      uint32_t pk[8];                                                                                          \
+      bf16x8 dhf0, dhf1;                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int i = 0; i < SLOTS; ++i) {                                                      \
+        if (i == NG) dhf0 = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));                \
+        if (i < NG && (i & 1)) DHOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[(i < NG ? i : 0) >> 1], DHOUT, 0, 0, 0); \
+        else if (i < NG) ZOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[(i < NG ? i : 0) >> 1], ZOUT, 0, 0, 0); \
+        else acc3[(i - NG) % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf0, fr[i % PF], acc3[(i - NG) % G::CB], 0, 0, 0); \
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + r_piece(i + PF) * 1024);           \
+        if (i % DMA_EVERY == 0 && i / DMA_EVERY < RND && (L) + 2 <= G::NHB) R_DMA_PIECE((L) + 2, i / DMA_EVERY) \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        _Pragma("unroll") for (int uo = NUOP * i / SLOTS; uo < NUOP * (i + 1) / SLOTS; ++uo) {                 \
+          const int qd = uo / 62;                                                                              \
+          const float z4[4] = {ZIN[4 * qd], ZIN[4 * qd + 1], ZIN[4 * qd + 2], ZIN[4 * qd + 3]};                \
+          const float d4[4] = {DHIN[4 * qd], DHIN[4 * qd + 1], DHIN[4 * qd + 2], DHIN[4 * qd + 3]};            \
+          gelu_grad_uop(uo % 62, z4, d4, gx, ge, gw, pk[2 * qd], pk[2 * qd + 1], c6v);                         \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+      }                                                                                                        \
+      dhf1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));                               \
+      _Pragma("unroll") for (int j = G::CB; j < 2 * G::CB; ++j) {                                              \
+        const int i = NG + j;                                                                                  \
+        acc3[j - G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf1, fr[i % PF], acc3[j - G::CB], 0, 0, 0); \
+        if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + r_piece(i + PF) * 1024);           \
+      }                                                                                                        \
+    }
+    for (int L = 1; L <= G::NHB; L += 2) {
+      R_ITER(L, za, dha, zb, dhb)
+      R_ITER(L + 1, zb, dhb, za, dha)
+    }
+#undef R_ITER
+#undef R_BIAS
+#undef R_DMA_PIECE
+  }
+  for (int s = 0; s < ((HPRE || PIPE_R) ? 0 : G::NHB); ++s) {        // the straight recomputing loop (C = 96, emit mode)
     if (s + 1 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LMIN_ROUNDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
