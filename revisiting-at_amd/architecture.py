@@ -112,6 +112,11 @@ class _StemConv2(nn.Conv2d):
     def forward(self, x):
         if ops.conv3x3s2_supported(x, self):
             return ops.conv3x3s2(x, self.weight, self.bias)
+        if x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.out_channels % 16:
+            # Library guard: MIOpen's fp32 NHWC backward-data implicit-GEMM solver reads past the end of its operands at
+            # some narrow widths (8 -> 12 and 16 -> 24 on 8x8 maps fault when the tensor ends a mapped segment:
+            # profiles/r02_miopen_nhwc_bwd_fault.md, tools/probe/conv_fault_fuzz.py); its NCHW solvers do not.
+            x = x.contiguous()
         return super().forward(x)
 
 

@@ -236,6 +236,20 @@ def test_product_modules_on_the_hip_path_match_reference_fixtures(R, name):
     assert rel(g, torch.from_numpy(gx)) <= 1e-3
 
 
+@pytest.mark.parametrize("name", ["stem_block3", "stem_block1"])
+def test_narrow_fp32_stems_survive_an_allocator_layout_fuzz(name):
+    """The fp32 ConvStem fixtures run while random small allocations move their tensors around the caching allocator's segments
+    (``tools/probe/fault_fuzz.py``, own process: a GPU memory fault aborts it).  Guards the library work-around in
+    ``architecture._StemConv2`` - MIOpen's fp32 NHWC backward-data solver read past its operands at widths 8 -> 12 and took one
+    full-suite run in three down with it (profiles/r02_miopen_nhwc_bwd_fault.md)."""
+    import subprocess
+    import sys
+    last = os.path.join(ROOT, "gpurun_out", f"fuzz_last_test_{name}.txt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "fault_fuzz.py"), "--name", name, "--iters", "250",
+                        "--no-sync", "--last", last], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "clean 250" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
+
+
 # ------------------------------------------------------------------------------------------------ a11: whole AT step
 def _oracle_at_steps(ref, x, y, n_steps, lr, decay=0.9999):
     """CPU fp32 restatement of main.py:961-997 with the reference's optimizer groups (main.py:395-459: names containing
