@@ -157,13 +157,15 @@ int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b,
                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
                             int64_t M, int32_t C, void* stream);
 
-/* The same pair for widths whose input-gradient kernel cannot hold the operands of the Hpre recomputation (C = 384: one
- * wavefront per SIMD is full with dO, the du accumulators and the LayerNorm backward): the forward ALSO writes
+/* The same pair with Hpre handed over through HBM instead of recomputed: the forward ALSO writes
  * Hpre = LN(u) W1^T + b1 (what models/convnext.py:42 hands to GELU) as bf16 into a caller-allocated workspace of
  * cnx_block_mlp_hpre_elems(M, C) elements, in the accumulator order of the kernels (opaque to the caller), and
- * cnx_block_mlp_bwd_input_hpre reads it back instead of recomputing: two GEMMs per hidden slice instead of three.
- * Only worth its 2 x 8 C bytes per row of extra HBM traffic where the block is not HBM-bound.  Same arguments otherwise
- * (no y2_out: input-gradient passes only; mean / rstd are required).  cnx_block_mlp_hpre_supported(C): 384. */
+ * cnx_block_mlp_bwd_input_hpre reads it back: two GEMMs per hidden slice instead of three and no LN(u) operand fragments
+ * in registers (C = 384, whose recomputing kernel does not fit one wavefront per SIMD, exists only in this form; C = 192
+ * runs two wavefronts per SIMD in this form, one in the recomputing one).  Worth its 2 x 8 C bytes per row of extra HBM
+ * traffic where the block is not HBM-bound: measured 15 - 19 % less time for the pair at C = 128, 192, 256.  Same
+ * arguments otherwise (no y2_out: input-gradient passes only; mean / rstd are required).
+ * cnx_block_mlp_hpre_supported(C): 128, 192, 256, 384. */
 int cnx_block_mlp_hpre_supported(int32_t C);
 int64_t cnx_block_mlp_hpre_elems(int64_t M, int32_t C);
 int cnx_block_mlp_fwd_hpre(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,

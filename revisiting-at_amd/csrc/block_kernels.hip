@@ -785,7 +785,7 @@ struct GeoB {
 // LN(u) operand fragments (C/4 registers less per lane: what makes C = 384 fit one wavefront per SIMD), a third fewer MFMAs,
 // and only the W2^T and GEMM3 pieces of a packed slice go through LDS (KS + 2 CB KiB: three ring slots fit at C = 384).
 template <int C, typename TG, bool EMIT, bool LNB, bool HPRE = false>
-__global__ __launch_bounds__(GeoB<C>::WAVES * 64, (C <= 96 ? 2 : 1)) void blk_mlp_bwd_kernel(const BlkBwdArgs p) {
+__global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192)) ? 2 : 1)) void blk_mlp_bwd_kernel(const BlkBwdArgs p) {
   using G = GeoB<C>;
   static_assert(!(HPRE && EMIT), "the emit mode recomputes LN(u) anyway");
   // PIPE_R: the recomputing input-gradient kernel at one wavefront per SIMD (C >= 128) runs the software-pipelined loop too
@@ -1403,7 +1403,7 @@ int cnx_block_mlp_fwd(const void* u, const float* ln_w, const float* ln_b, float
                             M, C, stream);
 }
 
-int cnx_block_mlp_hpre_supported(int32_t C) { return C == 384 ? 1 : 0; }
+int cnx_block_mlp_hpre_supported(int32_t C) { return (C == 128 || C == 192 || C == 256 || C == 384) ? 1 : 0; }
 
 int64_t cnx_block_mlp_hpre_elems(int64_t M, int32_t C) { return M <= 0 ? 0 : ((M + 127) / 128) * 128 * 4 * static_cast<int64_t>(C); }
 
@@ -1428,6 +1428,9 @@ int cnx_block_mlp_bwd_input_hpre(const void* u, const float* ln_w, const float* 
   a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = nullptr; a.da = static_cast<uint16_t*>(du);
   a.a_out = a.do_out = a.ht_out = a.dhpt_out = nullptr; a.hpre = static_cast<const uint16_t*>(hpre_ws); a.M = M; a.a_stride = C;
   switch (C) {
+    case 128: return launch_blk_bwd_hpre<128>(a, g_dtype, as_stream(stream));
+    case 192: return launch_blk_bwd_hpre<192>(a, g_dtype, as_stream(stream));
+    case 256: return launch_blk_bwd_hpre<256>(a, g_dtype, as_stream(stream));
     case 384: return launch_blk_bwd_hpre<384>(a, g_dtype, as_stream(stream));
     default: return APGD_ERR_ARG;
   }

@@ -830,9 +830,11 @@ class _BlockFused(torch.autograd.Function):
         need_grad = grad_mode and any(ctx.needs_input_grad)   # (needs_input_grad ignores torch.no_grad: parameters still 'require' it)
         need_p = need_grad and any(ctx.needs_input_grad[1:])
         fused = _use_fused_block(C) and bool(lib.cnx_block_mlp_bwd_supported(C))
-        # C = 384 (no recomputing backward at that width): the fused forward serves the passes that need no backward at all,
-        # and - with its Hpre workspace - the attack's passes, whose backward asks for the input gradient only
-        via_hpre = (not fused) and _use_hpre_block(C) and ((not need_grad) or _ATTACK_FWD)
+        # The attack's passes (backward = input gradient only) run on the forward / input-gradient pair that hands Hpre over
+        # through HBM instead of recomputing it (C = 128 ... 384: 15 - 19 % less time for the pair than fused forward +
+        # recomputing backward; at C = 384 there is no recomputing backward and the plain fused forward also serves the passes
+        # that need no backward at all)
+        via_hpre = _use_hpre_block(C) and ((need_grad and _ATTACK_FWD) or ((not need_grad) and not fused))
         mean = rstd = y2 = a = hpre = h = None
         if via_hpre:
             wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
@@ -901,7 +903,7 @@ class _BlockFused(torch.autograd.Function):
         da = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)            # gradient w.r.t. LN(u)
         d_u = None
         if ctx.fused == "hpre":
-            # ---- attack backward at C = 384: Hpre from the forward's workspace, dH / GELU' / da / LayerNorm backward in ONE kernel
+            # ---- attack backward (C = 128 ... 384): Hpre from the forward's workspace, dH / GELU' / da / LayerNorm backward in ONE kernel
             if want_p:
                 raise _lib.ApgdHipError("a block forward run under ops.attack_forward() can only be differentiated w.r.t. its input")
             if g2.dtype not in (torch.float32, torch.bfloat16):
@@ -1030,7 +1032,7 @@ _FUSED_WIDTHS = {int(v) for v in _FUSED_WIDTHS.split(",") if v.strip()}
 
 # Widths whose attack passes (forward without backward; forward + input-gradient backward) use the fused kernels with the
 # Hpre workspace while the training pass stays on the library GEMMs (cnx_block_mlp_fwd_hpre).  APGD_BLOCK_HPRE overrides ("" = none).
-_HPRE_WIDTHS = os.environ.get("APGD_BLOCK_HPRE", "384")
+_HPRE_WIDTHS = os.environ.get("APGD_BLOCK_HPRE", "128,192,256,384")
 _HPRE_WIDTHS = {int(v) for v in _HPRE_WIDTHS.split(",") if v.strip().isdigit()}
 
 

@@ -180,13 +180,14 @@ def test_convnext_block_matches_reference_block(R, C, H, gamma):
     assert float((gb.float().cpu() - gref[0]).norm() / gref[0].norm()) < 1.5e-2
 
 
+@pytest.mark.parametrize("C", [384, 192, 128])
 @pytest.mark.parametrize("gamma", [True, False])
 @pytest.mark.parametrize("N,H", [(2, 14), (3, 9), (1, 5)])
-def test_block_c384_attack_passes_use_the_hpre_kernels_and_match_the_reference_block(R, gamma, N, H):
-    """C = 384 (9 of ConvNeXt-T's 18 blocks): the attack's passes run cnx_block_mlp_fwd[_hpre] / cnx_block_mlp_bwd_input_hpre
-    (forward writes Hpre, the input-gradient kernel reads it back), the training pass stays on the library GEMMs.  All three
-    against the fp32 reference block; a parameter gradient asked of an attack-forward graph is refused."""
-    C = 384
+def test_block_c384_attack_passes_use_the_hpre_kernels_and_match_the_reference_block(R, gamma, N, H, C):
+    """C = 384 (9 of ConvNeXt-T's 18 blocks), 192, 128: the attack's passes run cnx_block_mlp_fwd[_hpre] /
+    cnx_block_mlp_bwd_input_hpre (forward writes Hpre, the input-gradient kernel reads it back), the training pass stays on the
+    library GEMMs (384) or the recomputing fused pair (192, 128).  All three against the fp32 reference block; a parameter
+    gradient asked of an attack-forward graph is refused."""
     assert R._lib.load().cnx_block_mlp_hpre_supported(C) == 1 and R.ops._use_hpre_block(C)
     torch.manual_seed(7 * N + H)
     ref = M.CNBlock(C, ls_init=0.5 if gamma else 0).eval()
@@ -228,14 +229,14 @@ def test_block_c384_attack_passes_use_the_hpre_kernels_and_match_the_reference_b
     assert relerr(ga, gt[0].float().cpu()) < 1.5e-2
 
 
+@pytest.mark.parametrize("C", [128, 192, 256, 384])
 @pytest.mark.parametrize("M_", [1, 31, 32, 129, 1000])
 @pytest.mark.parametrize("gdt", [torch.float32, torch.bfloat16])
-def test_hpre_kernel_pair_vs_fp32_reference_through_the_c_abi(R, M_, gdt):
-    """cnx_block_mlp_fwd_hpre / cnx_block_mlp_bwd_input_hpre (C = 384) called directly: ragged row counts (the workspace is
+def test_hpre_kernel_pair_vs_fp32_reference_through_the_c_abi(R, M_, gdt, C):
+    """cnx_block_mlp_fwd_hpre / cnx_block_mlp_bwd_input_hpre (C = 128 ... 384) called directly: ragged row counts (the workspace is
     sized in 128-row workgroups), fp32 and bf16 incoming gradients, output equal to the plain fused forward bit for bit, input
     gradient vs fp32 autograd of the same bf16-quantised operands; argument errors."""
     lib = R._lib.load()
-    C = 384
     g = torch.Generator().manual_seed(M_)
     u = (torch.randn(M_, C, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
     w1 = torch.randn(4 * C, C, generator=g) * C ** -0.5
@@ -273,8 +274,8 @@ def test_hpre_kernel_pair_vs_fp32_reference_through_the_c_abi(R, M_, gdt):
     assert float((du.float().cpu() - gref).norm() / gref.norm()) < 1.5e-2
     # argument handling: empty batch is a no-op, missing workspace / unsupported width are refused
     assert fwd(out, ws.data_ptr(), 0) == 0 and bwd(ws.data_ptr(), 0, C) == 0
-    assert fwd(out, None, M_) < 0 and bwd(None, M_, C) < 0 and bwd(ws.data_ptr(), M_, 192) < 0
-    assert lib.cnx_block_mlp_hpre_supported(384) == 1 and lib.cnx_block_mlp_hpre_supported(192) == 0
+    assert fwd(out, None, M_) < 0 and bwd(None, M_, C) < 0 and bwd(ws.data_ptr(), M_, 96) < 0
+    assert lib.cnx_block_mlp_hpre_supported(C) == 1 and lib.cnx_block_mlp_hpre_supported(96) == 0
 
 
 @pytest.mark.parametrize("CI,N,H,W", [(48, 2, 32, 32), (48, 3, 8, 16), (48, 1, 112, 112), (64, 2, 32, 48), (64, 1, 16, 16)])
