@@ -55,6 +55,13 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
                       const float* weight, const float* bias, const float* mean, const float* rstd,
                       void* dx, int dx_dtype, float* dweight, float* dbias, float* ws,
                       int64_t M, int32_t C, int32_t gelu, void* stream);
+/* The same with the gradient that reached x along a skip connection summed in:  dx = add + d(loss)/dx  (add: fp32 [M, C],
+ * dx fp32).  In the transformer blocks of the ViT models (timm Block.forward: x + ls(attn(norm(x)))) x feeds both the
+ * LayerNorm and the residual sum, and autograd would add the two gradients in a separate pass over the residual stream. */
+int cnx_layernorm_bwd_add(const void* dy, int dy_dtype, const void* x, int x_dtype,
+                          const float* weight, const float* bias, const float* mean, const float* rstd,
+                          const float* add, void* dx, int dx_dtype, float* dweight, float* dbias, float* ws,
+                          int64_t M, int32_t C, int32_t gelu, void* stream);
 
 /* The downsample layers of the stages (models/convnext.py:76-83: LayerNorm over C, then Conv2d(C, C', kernel 2, stride 2)) as
  * LayerNorm + GEMM: cnx_layernorm_fwd_patch2 writes LN(x) of an [N, H, W, C] tensor in 2x2-patch form
@@ -113,6 +120,8 @@ int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const floa
                            float* dgamma, float* db2, float* ws, int64_t M, int32_t C, void* stream);
 int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db1, float* ws,
                         int64_t M, int32_t N, void* stream);
+/* y = GELU(x) (exact-erf form, nn.GELU() of models/convnext.py:43 and of the timm Mlp) on n bf16 elements, n % 8 == 0. */
+int cnx_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 
 /* Fused block tail (models/convnext.py:40-49): LayerNorm -> fc1 -> GELU -> fc2 -> gamma -> +residual, ONE kernel:
  *     out[m, :] = resid[m, :] + gamma * (GELU(LN(u[m, :]) W1^T + b1) W2^T + b2)

@@ -73,11 +73,14 @@ PROTOTYPES = {
     "cnx_scale_residual": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int, _i64, _i32, _p]),
     "cnx_scale_residual_bwd": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "cnx_gelu_bwd_colsum": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "cnx_gelu_fwd": (C.c_int, [_p, _p, _i64, _p]),
     "cnx_attention_bwd_supported": (C.c_int, [_i32, _i32]),
     "cnx_attention_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _f, _p]),
     "cnx_attention_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _f, _p]),
     "cnx_layernorm_bwd": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32,
                                     _i32, _p]),
+    "cnx_layernorm_bwd_add": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32,
+                                        _i32, _p]),
     "cnx_layernorm_fwd_patch2": (C.c_int, [_p, C.c_int, _p, _p, C.c_float, _p, C.c_int, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_layernorm_bwd_patch2": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32,
                                            _p]),

@@ -371,8 +371,13 @@ class VitBlock(nn.Module):
     def forward(self, x):
         g1 = self.ls1.gamma if isinstance(self.ls1, _LayerScale) else None
         g2 = self.ls2.gamma if isinstance(self.ls2, _LayerScale) else None
-        x = ops.scale_residual(x, self.attn(self.norm1(x)), g1)            # x + ls1(attn(norm1(x)))
-        return ops.scale_residual(x, self.mlp(self.norm2(x)), g2)          # x + ls2(mlp(norm2(x)))
+        # x + ls1(attn(norm1(x))), x + ls2(mlp(norm2(x))): the LayerNorm hands x back for the skip connection so that its
+        # backward kernel sums both gradients of x (ops.layer_norm_skip)
+        h, xs = ops.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = ops.scale_residual(xs, self.attn(h), g1)
+        h, xs = ops.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        m = self.mlp
+        return ops.mlp_residual(xs, h, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, g2)
 
 
 class PatchEmbed(nn.Module):

@@ -1510,7 +1510,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, TO* __restrict__ dx,
-                                                            float* __restrict__ ws, long M, int C, int gelu) {
+                                                            float* __restrict__ ws, long M, int C, int gelu,
+                                                            const float* __restrict__ add) {
   constexpr int RPB = 256 / GROUP;
   __shared__ float red[2][RPB][GROUP * 4];            // per row-group partial parameter gradients (one chunk)
   const int gl = threadIdx.x % GROUP, gr = threadIdx.x / GROUP;
@@ -1554,6 +1555,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict
         float4 o;
         o.x = rs * (g[k].x - c1 - xh[k].x * c2); o.y = rs * (g[k].y - c1 - xh[k].y * c2);
         o.z = rs * (g[k].z - c1 - xh[k].z * c2); o.w = rs * (g[k].w - c1 - xh[k].w * c2);
+        if (add) { const float4 a4 = load4(add + row * C + c); o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w; }
         store4(dx + row * C + c, o);
       }
     }
@@ -1672,7 +1674,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, TO* __restrict__ dx,
                                                                  float* __restrict__ ws, long M, int C, int gelu, int pH,
-                                                                 int pW) {
+                                                                 int pW, const float* __restrict__ add) {
   constexpr int RPB = 256 / G;
   __shared__ float red[2][RPB][G * 8];                // per row-group partial parameter gradients (one chunk)
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
@@ -1712,6 +1714,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
       F8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o.v[e] = rs * (g[k].v[e] - c1 - xh[k].v[e] * c2);
+      if (add) {                                      // + the gradient that reached x along the skip connection (fp32, same shape)
+        const F8 a8 = load8(add + row * C + (gl + k * G) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] += a8.v[e];
+      }
       store8(dx + row * C + (gl + k * G) * 8, o);
     }
   }
@@ -1731,6 +1738,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
       for (int r = 0; r < RPB; ++r) t += red[which][r][cc];
       pw[which * C + k * G * 8 + cc] = t;
     }
+  }
+}
+
+// y = GELU(x) on bf16, exact-erf form (the activation between the two library GEMMs of the MLPs that have no fused block
+// kernel: ConvNeXt C = 384 (training pass) / 768, ViT): 16 bytes per lane, two chunks in flight.  ATen's kernel ran the
+// [50 432, 3072] tensor of ViT-B at 4.8 TB/s.
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long n8) {
+  const long stride = static_cast<long>(gridDim.x) * 256;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8; i += 2 * stride) {
+    const long j = i + stride;
+    const F8 a = load8(x + i * 8);
+    F8 b = a;
+    if (j < n8) b = load8(x + j * 8);
+    F8 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { oa.v[e] = gelu_f(a.v[e]); ob.v[e] = gelu_f(b.v[e]); }
+    store8(y + i * 8, oa);
+    if (j < n8) store8(y + j * 8, ob);
   }
 }
 
@@ -1781,14 +1806,15 @@ int launch_ln_fwd(const TX* x, const float* w, const float* b, float eps, TY* y,
 
 template <typename TD, typename TX, typename TO>
 int launch_ln_bwd(const TD* dy, const TX* x, const float* w, const float* b, const float* mean, const float* rstd, TO* dx,
-                  float* ws, long M, int C, int gelu, int* nblocks, hipStream_t s, int pH = 0, int pW = 0) {
+                  float* ws, long M, int C, int gelu, int* nblocks, hipStream_t s, int pH = 0, int pW = 0,
+                  const float* add = nullptr) {
 #define LN_BWD(G, NV)                                                                                          \
   {                                                                                                            \
     const long rpb = 256 / G;                                                                                  \
     long nb = (M + rpb - 1) / rpb; if (nb > kLnBwdBlocks) nb = kLnBwdBlocks;                                   \
     *nblocks = static_cast<int>(nb);                                                                           \
     hipLaunchKernelGGL((layernorm_bwd_kernel<TD, TX, TO, G, NV>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dy, \
-                       x, w, b, mean, rstd, dx, ws, M, C, gelu);                                               \
+                       x, w, b, mean, rstd, dx, ws, M, C, gelu, add);                                          \
     return launch_status();                                                                                    \
   }
   static const int wide_on = getenv("APGD_LN_WIDE") ? atoi(getenv("APGD_LN_WIDE")) : 1;
@@ -1799,7 +1825,7 @@ int launch_ln_bwd(const TD* dy, const TX* x, const float* w, const float* b, con
     long nb = (M + rpb - 1) / rpb; if (nb > kLnBwdBlocks) nb = kLnBwdBlocks;                                   \
     *nblocks = static_cast<int>(nb);                                                                           \
     hipLaunchKernelGGL((layernorm_bwd_wide_kernel<TD, TX, TO, G>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dy, \
-                       x, w, b, mean, rstd, dx, ws, M, C, gelu, pH, pW);                                       \
+                       x, w, b, mean, rstd, dx, ws, M, C, gelu, pH, pW, add);                                  \
     return launch_status();                                                                                    \
   }
     if (g == 2) LN_BWD_W(2)
@@ -2115,10 +2141,12 @@ int64_t cnx_layernorm_bwd_ws_floats(int32_t C) { return static_cast<int64_t>(kLn
 
 static int layernorm_bwd_impl(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight, const float* bias,
                               const float* mean, const float* rstd, void* dx, int dx_dtype, float* dweight, float* dbias,
-                              float* ws, int64_t M, int32_t C, int32_t gelu, int pH, int pW, void* stream) {
+                              float* ws, int64_t M, int32_t C, int32_t gelu, int pH, int pW, void* stream,
+                              const float* add = nullptr) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!dy || !x || !weight || !mean || !rstd || !dx) return APGD_ERR_NULL;
+  if (add && dx_dtype != APGD_F32) return APGD_ERR_DTYPE;          // the skip gradient is summed in fp32 into an fp32 result
   if (gelu && !bias) return APGD_ERR_NULL;
   if (dweight && (!dbias || !ws)) return APGD_ERR_NULL;
   if (C % 4 != 0) return APGD_ERR_ARG;
@@ -2128,7 +2156,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_dtype, const void* x, int x
   int nb = 0, rc = APGD_ERR_DTYPE;
 #define LNB(TD, TX, TO)                                                                                          \
   rc = launch_ln_bwd(static_cast<const TD*>(dy), static_cast<const TX*>(x), weight, bias, mean, rstd,            \
-                     static_cast<TO*>(dx), wsp, M, C, gelu, &nb, s, pH, pW)
+                     static_cast<TO*>(dx), wsp, M, C, gelu, &nb, s, pH, pW, add)
   const int key = dy_dtype * 4 + x_dtype * 2 + dx_dtype;
   switch (key) {
     case 0: LNB(float, float, float); break;
@@ -2156,6 +2184,13 @@ int cnx_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
                       float* ws, int64_t M, int32_t C, int32_t gelu, void* stream) {
   return layernorm_bwd_impl(dy, dy_dtype, x, x_dtype, weight, bias, mean, rstd, dx, dx_dtype, dweight, dbias, ws, M, C, gelu, 0, 0,
                             stream);
+}
+
+int cnx_layernorm_bwd_add(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight, const float* bias,
+                          const float* mean, const float* rstd, const float* add, void* dx, int dx_dtype, float* dweight,
+                          float* dbias, float* ws, int64_t M, int32_t C, int32_t gelu, void* stream) {
+  return layernorm_bwd_impl(dy, dy_dtype, x, x_dtype, weight, bias, mean, rstd, dx, dx_dtype, dweight, dbias, ws, M, C, gelu, 0, 0,
+                            stream, add);
 }
 
 int cnx_layernorm_bwd_patch2(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight, const float* mean,
@@ -2221,6 +2256,17 @@ int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const floa
   if (sums)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, dgamma, db2, C, 2 * C,
                        static_cast<int>(M < parts ? M : parts));
+  return launch_status();
+}
+
+int cnx_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
+  if (n < 0 || n % 8 != 0) return APGD_ERR_SIZE;
+  if (n == 0) return APGD_OK;
+  if (!x || !y) return APGD_ERR_NULL;
+  const long n8 = n / 8;
+  long nb = (n8 + 511) / 512; if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, as_stream(stream),
+                     static_cast<const uint16_t*>(x), static_cast<uint16_t*>(y), n8);
   return launch_status();
 }
 

@@ -200,6 +200,65 @@ def _ln_rows(x_rows, weight, bias, eps, gelu):
     return _LayerNormRows.apply(x_rows, weight, bias, float(eps), bool(gelu), _act_dtype(x_rows))
 
 
+class _LayerNormRowsSkip(torch.autograd.Function):
+    """``(LN(x), x)`` for an fp32 residual stream ``x`` that feeds both a LayerNorm branch and the skip connection around it
+    (timm ``Block.forward``: ``x + ls(attn(norm1(x)))``).  Autograd hands BOTH output gradients to one backward call, so the
+    sum ``d(skip) + LN'(d(branch))`` is formed inside the LayerNorm backward kernel (``cnx_layernorm_bwd_add``) instead of by a
+    separate pass over the residual stream (two 155 MB fp32 reads and one write per block and backward pass at ViT-B / 224)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        lib = _lib.load()
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        w, b = _f32(weight), _f32(bias)
+        _lib.check(lib.cnx_layernorm_fwd(x.data_ptr(), _code(x), w.data_ptr(), b.data_ptr(), eps, y.data_ptr(), _code(y),
+                                         mean.data_ptr(), rstd.data_ptr(), M, C, 0, _stream()), "cnx_layernorm_fwd")
+        ctx.save_for_backward(x, w, b, mean, rstd)
+        ctx.C, ctx.M = C, M
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        lib = _lib.load()
+        x, w, b, mean, rstd = ctx.saved_tensors
+        C, M = ctx.C, ctx.M
+        want_p = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY
+        if dy is None:                                   # the LayerNorm output was not used
+            return dskip, None, None, None, None
+        dy = dy.contiguous()
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            if dskip.dtype != torch.float32:
+                dskip = dskip.float()
+        dx = torch.empty_like(x)
+        dw = db = ws = None
+        if want_p:
+            dw = torch.empty(C, device=x.device, dtype=torch.float32)
+            db = torch.empty(C, device=x.device, dtype=torch.float32)
+            ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device=x.device, dtype=torch.float32)
+        _lib.check(lib.cnx_layernorm_bwd_add(dy.data_ptr(), _code(dy), x.data_ptr(), _code(x), w.data_ptr(), b.data_ptr(),
+                                             mean.data_ptr(), rstd.data_ptr(), _lib.ptr(dskip), dx.data_ptr(), _code(dx),
+                                             _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), M, C, 0, _stream()),
+                   "cnx_layernorm_bwd_add")
+        return dx, dw, db, None, None
+
+
+_LN_SKIP = os.environ.get("APGD_LN_SKIP", "1") != "0"
+
+
+def layer_norm_skip(x, weight, bias, eps):
+    """``(LN(x), x')`` where ``x'`` is ``x`` for the skip connection around the LayerNorm branch: use ``x'`` in the residual sum
+    and the backward adds the two gradients of ``x`` inside the LayerNorm backward kernel.  Falls back to the plain pair."""
+    if (MODE == "eager" or not _LN_SKIP or not x.is_cuda or x.dtype != torch.float32 or x.shape[-1] % 4 != 0 or not _hip_dtype_ok(x)
+            or not x.is_contiguous() or not (torch.is_grad_enabled() and x.requires_grad)):
+        return layer_norm_last(x, weight, bias, eps), x
+    return _LayerNormRowsSkip.apply(x, weight, bias, float(eps), _act_dtype(x))
+
+
 class _ScaleResidual(torch.autograd.Function):
     """``x + gamma * y`` over rows (``x`` fp32 or bf16 residual stream, ``y`` bf16 branch output, ``gamma`` [C] or None) ->
     fp32: the residual connections of the ViT blocks (timm ``Block.forward``: ``x + ls(attn(norm(x)))``).  One kernel each way
@@ -787,6 +846,98 @@ def _ones_col(device):
     return t
 
 
+def _gelu_bf16(x):
+    """GELU of a bf16 device tensor through ``cnx_gelu_fwd`` (no autograd: for use inside the autograd functions)."""
+    if MODE == "eager" or not x.is_cuda or x.dtype != torch.bfloat16 or not x.is_contiguous() or x.numel() % 8 != 0:
+        return F.gelu(x)
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().cnx_gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "cnx_gelu_fwd")
+    return y
+
+
+class _MlpResidual(torch.autograd.Function):
+    """``xs + gamma * fc2(GELU(fc1(h)))`` for the second half of a transformer block (timm ``Block.forward``:
+    ``x + ls2(mlp(norm2(x)))``, ``Mlp`` = Linear, GELU, Linear): the two linears are library GEMMs with the bias in their
+    epilogue, everything between and after them is one pass each - ``cnx_gelu_fwd``, ``cnx_scale_residual``; backward
+    ``cnx_scale_residual_bwd`` (dO = g * gamma with d(gamma) and d(b2) column sums), ``cnx_gelu_bwd_colsum`` (GELU' with d(b1)),
+    split-K weight gradients - instead of autograd's chain of casts, ATen GELU kernels and per-bias reductions."""
+
+    @staticmethod
+    def forward(ctx, xs, h, w1, b1, w2, b2, gamma):
+        lib = _lib.load()
+        C = h.shape[-1]
+        M = h.numel() // C
+        h2 = h.reshape(M, C)
+        w1b = _cached((w1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+        w2b = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+        b1b = _cached((b1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+        b2b = _cached((b2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
+        gf = _f32(gamma) if gamma is not None else None
+        hpre = torch.addmm(b1b, h2, w1b.t())                                     # [M, 4C]
+        hg = _gelu_bf16(hpre)
+        y2 = torch.addmm(b2b, hg, w2b.t())                                       # [M, C] bf16, pre-gamma
+        out = torch.empty(xs.shape, device=xs.device, dtype=torch.float32)
+        _lib.check(lib.cnx_scale_residual(xs.data_ptr(), _code(xs), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out), M, C,
+                                          _stream()), "cnx_scale_residual")
+        ctx.save_for_backward(h2, hpre, hg, y2 if gf is not None else None, w1b, w2b, gf)
+        ctx.M, ctx.C, ctx.xs_dtype, ctx.h_shape = M, C, xs.dtype, h.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        h2, hpre, hg, y2, w1b, w2b, gf = ctx.saved_tensors
+        M, C = ctx.M, ctx.C
+        nig = ctx.needs_input_grad
+        want_p = any(nig[2:]) and not _INPUT_GRAD_ONLY
+        g = g.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        dxs = None
+        if nig[0]:
+            dxs = g if g.dtype == ctx.xs_dtype else g.to(ctx.xs_dtype)
+        dhin = dw1 = db1 = dw2 = db2 = dgamma = None
+        if nig[1] or want_p:
+            dos = torch.empty(M, C, device=g.device, dtype=torch.bfloat16)
+            ws = None
+            if want_p:
+                dgamma = torch.empty(C, device=g.device, dtype=torch.float32)
+                db2 = torch.empty(C, device=g.device, dtype=torch.float32)
+                db1 = torch.empty(4 * C, device=g.device, dtype=torch.float32)
+                ws = torch.empty(lib.cnx_colsum_ws_floats(4 * C), device=g.device, dtype=torch.float32)
+            _lib.check(lib.cnx_scale_residual_bwd(g.data_ptr(), _code(g), _lib.ptr(y2) if want_p else None, _lib.ptr(gf), dos.data_ptr(),
+                                                  _lib.ptr(dgamma), _lib.ptr(db2), _lib.ptr(ws), M, C, _stream()),
+                       "cnx_scale_residual_bwd")
+            dh = dos @ w2b                                                       # [M, 4C]
+            dhpre = torch.empty_like(dh)
+            _lib.check(lib.cnx_gelu_bwd_colsum(dh.data_ptr(), hpre.data_ptr(), dhpre.data_ptr(), _lib.ptr(db1), _lib.ptr(ws), M,
+                                               4 * C, _stream()), "cnx_gelu_bwd_colsum")
+            del dh
+            if nig[1]:
+                dhin = (dhpre @ w1b).view(ctx.h_shape)
+            if want_p:
+                dw2 = _wgrad(dos, hg)
+                dw1 = _wgrad(dhpre, h2)
+                if gf is None:
+                    dgamma = None
+        return dxs, dhin, dw1, db1, dw2, db2, dgamma
+
+
+_MLP_RESIDUAL = os.environ.get("APGD_MLP_RESIDUAL", "1") != "0"
+
+
+def mlp_residual(xs, h, w1, b1, w2, b2, gamma=None):
+    """``xs + gamma * fc2(GELU(fc1(h)))`` (fp32 result): ``_MlpResidual`` for a bf16 activation ``h`` under bf16 autocast, the
+    plain composition otherwise."""
+    C = h.shape[-1]
+    if (MODE == "eager" or not _MLP_RESIDUAL or not h.is_cuda or h.dtype != torch.bfloat16 or not h.is_contiguous() or not xs.is_contiguous()
+            or xs.dtype not in (torch.float32, torch.bfloat16) or xs.shape != h.shape or C % 8 != 0 or b1 is None or b2 is None
+            or tuple(w1.shape) != (4 * C, C) or tuple(w2.shape) != (C, 4 * C)
+            or not (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
+        return scale_residual(xs, F.linear(F.gelu(F.linear(h, w1, b1)), w2, b2), gamma)
+    return _MlpResidual.apply(xs, h, w1, b1, w2, b2, gamma)
+
+
 def _pack_mlp_bwd(w1, w2):
     """fc1 / fc2 weights -> the three operand-fragment sets of the fused backward (``cnx_mlp_pack_weights_bwd``)."""
     lib = _lib.load()
@@ -879,7 +1030,7 @@ class _BlockFused(torch.autograd.Function):
             b1b = _cached((b1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
             b2b = _cached((b2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
             hpre = torch.addmm(b1b, a, wa.t())                                   # [M, 4C]
-            h = F.gelu(hpre)
+            h = _gelu_bf16(hpre)
             y2 = torch.addmm(b2b, h, wb_.t())                                    # [M, C] bf16, pre-gamma
             _lib.check(lib.cnx_scale_residual(x.data_ptr(), _code(x), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out),
                                               M, C, _stream()), "cnx_scale_residual")

@@ -180,6 +180,100 @@ def test_convnext_block_matches_reference_block(R, C, H, gamma):
     assert float((gb.float().cpu() - gref[0]).norm() / gref[0].norm()) < 1.5e-2
 
 
+@pytest.mark.parametrize("gamma", [True, False])
+@pytest.mark.parametrize("shape", [(3, 197, 768), (2, 50, 384), (4, 16, 96)])
+def test_mlp_residual_vs_fp32_reference(R, shape, gamma):
+    """``ops.mlp_residual`` (second half of a ViT block: xs + ls2(fc2(GELU(fc1(h))))) on library GEMMs + cnx_gelu_fwd /
+    cnx_scale_residual[_bwd] / cnx_gelu_bwd_colsum vs fp32 autograd of the same bf16-quantised operands: output, both input
+    gradients, all parameter gradients; attack mode (input gradients only); cnx_gelu_fwd vs torch GELU."""
+    torch.manual_seed(sum(shape) + int(gamma))
+    C = shape[-1]
+    xs = torch.randn(*shape, device="cuda")
+    h = torch.randn(*shape, device="cuda").to(torch.bfloat16)
+    w1 = (torch.randn(4 * C, C, device="cuda") * C ** -0.5).requires_grad_()
+    w2 = (torch.randn(C, 4 * C, device="cuda") * (4 * C) ** -0.5).requires_grad_()
+    b1, b2 = (0.2 * torch.randn(4 * C, device="cuda")).requires_grad_(), (0.2 * torch.randn(C, device="cuda")).requires_grad_()
+    gm = (0.5 + 0.2 * torch.randn(C, device="cuda")).requires_grad_() if gamma else None
+    g = torch.randn(*shape, device="cuda")
+    q = lambda t: t.detach().to(torch.bfloat16).float()
+    # fp32 reference on the bf16-quantised operands
+    xr, hr = xs.clone().requires_grad_(), h.float().requires_grad_()
+    pr = [q(w1).requires_grad_(), q(b1).requires_grad_(), q(w2).requires_grad_(), q(b2).requires_grad_()]
+    y = F.linear(F.gelu(F.linear(hr, pr[0], pr[1])), pr[2], pr[3])
+    gr = gm.detach().clone().requires_grad_() if gamma else None
+    ref = xr + (y * gr if gamma else y)
+    gref = torch.autograd.grad(ref, [xr, hr] + pr + ([gr] if gamma else []), g)
+    xd, hd = xs.clone().requires_grad_(), h.clone().requires_grad_()
+    params = [w1, b1, w2, b2] + ([gm] if gamma else [])
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = R.ops.mlp_residual(xd, hd, w1, b1, w2, b2, gm)
+    assert out.dtype == torch.float32 and isinstance(out.grad_fn, R.ops._MlpResidual._backward_cls)
+    got = torch.autograd.grad(out, [xd, hd] + params, g, retain_graph=True)
+    rel_ = lambda a_, b_: float((a_.float() - b_).norm() / (b_.norm() + 1e-30))
+    assert rel_(out - xs, (ref - xr).detach()) < 1e-2
+    assert torch.equal(got[0], g)
+    bars = [2e-2] * 6
+    for a_, b_, bar in zip(got[1:], gref[1:], bars):
+        assert rel_(a_, b_) < bar, (rel_(a_, b_), a_.shape)
+    with R.ops.input_grad_only():
+        ga = torch.autograd.grad(out, [xd, hd], g)
+    assert torch.equal(ga[1], got[1])
+    # the stand-alone GELU kernel
+    t = torch.randn(4096 * 8, device="cuda").mul_(3).to(torch.bfloat16)
+    yk = R.ops._gelu_bf16(t)
+    assert float((yk.float() - F.gelu(t.float())).abs().max()) < 2e-2 and float((yk.float() - F.gelu(t).float()).abs().mean()) < 1e-4
+    lib = R._lib.load()
+    assert lib.cnx_gelu_fwd(t.data_ptr(), yk.data_ptr(), 0, S()) == 0 and lib.cnx_gelu_fwd(t.data_ptr(), yk.data_ptr(), 12, S()) < 0
+    assert lib.cnx_gelu_fwd(None, yk.data_ptr(), 16, S()) < 0
+
+
+@pytest.mark.parametrize("shape", [(3, 197, 768), (2, 50, 384), (5, 7, 96), (1, 3, 40)])
+def test_layer_norm_skip_sums_both_gradients_of_x_in_the_backward_kernel(R, shape):
+    """``ops.layer_norm_skip`` (ViT blocks: x feeds norm(x) and the skip connection): outputs equal the plain LayerNorm op and x,
+    and d(loss)/dx = skip gradient + LayerNorm backward comes out of ONE kernel (``cnx_layernorm_bwd_add``), bit-identical to the
+    two-step sum, parameter gradients unchanged; a missing branch / skip gradient and the no-grad path are handled."""
+    torch.manual_seed(sum(shape))
+    C = shape[-1]
+    x = torch.randn(*shape, device="cuda")
+    w, b = (1 + 0.2 * torch.randn(C, device="cuda")).requires_grad_(), (0.2 * torch.randn(C, device="cuda")).requires_grad_()
+    gy = torch.randn(*shape, device="cuda").to(torch.bfloat16)
+    gs = torch.randn(*shape, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        xa = x.clone().requires_grad_()
+        y0 = R.ops.layer_norm_last(xa, w, b, 1e-6)
+        g0 = torch.autograd.grad([y0, xa * 1.0], [xa, w, b], [gy, gs])
+        xb = x.clone().requires_grad_()
+        y1, xs = R.ops.layer_norm_skip(xb, w, b, 1e-6)
+        assert y1.dtype == torch.bfloat16 and torch.equal(y1, y0) and torch.equal(xs, xb)
+        g1 = torch.autograd.grad([y1, xs * 1.0], [xb, w, b], [gy, gs])
+        for a_, b_ in zip(g0, g1):
+            assert torch.equal(a_, b_)
+        # only one of the two outputs used
+        y2, xs2 = R.ops.layer_norm_skip(xb, w, b, 1e-6)
+        (g2,) = torch.autograd.grad(xs2 * 1.0, xb, gs)
+        assert torch.equal(g2, gs)
+        y3, xs3 = R.ops.layer_norm_skip(xb, w, b, 1e-6)
+        (g3,) = torch.autograd.grad(y3, xb, gy)
+        (g3r,) = torch.autograd.grad(R.ops.layer_norm_last(xa, w, b, 1e-6), xa, gy)
+        assert torch.equal(g3, g3r)
+        with torch.no_grad():
+            y4, xs4 = R.ops.layer_norm_skip(x, w, b, 1e-6)
+        assert xs4 is x and torch.equal(y4, y0)
+    # fp32 reference
+    xr = x.clone().requires_grad_()
+    yr = F.layer_norm(xr, (C,), w.detach(), b.detach(), 1e-6)
+    (gr,) = torch.autograd.grad([yr, xr * 1.0], xr, [gy.float(), gs])
+    assert float((g1[0] - gr).norm() / gr.norm()) < 1e-5
+    # the C ABI refuses a skip gradient for a bf16 result
+    lib = R._lib.load()
+    M_ = x.numel() // C
+    if C % 4 == 0:
+        t = torch.empty(M_, device="cuda")
+        rc = lib.cnx_layernorm_bwd_add(gy.data_ptr(), 1, x.data_ptr(), 0, w.data_ptr(), b.data_ptr(), t.data_ptr(), t.data_ptr(), gs.data_ptr(),
+                                       torch.empty_like(gy).data_ptr(), 1, None, None, None, M_, C, 0, S())
+        assert rc < 0
+
+
 @pytest.mark.parametrize("C", [384, 192, 128])
 @pytest.mark.parametrize("gamma", [True, False])
 @pytest.mark.parametrize("N,H", [(2, 14), (3, 9), (1, 5)])
