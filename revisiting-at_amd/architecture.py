@@ -337,9 +337,9 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x)
+        qkv = ops.linear_lib(x, self.qkv.weight, self.qkv.bias)
         o = ops.attention(qkv, self.num_heads, self.scale)      # [B, N, C]
-        return self.proj(o)
+        return ops.linear_lib(o, self.proj.weight, self.proj.bias)
 
 
 class _LayerScale(nn.Module):

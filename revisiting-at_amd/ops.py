@@ -923,6 +923,55 @@ class _MlpResidual(torch.autograd.Function):
         return dxs, dhin, dw1, db1, dw2, db2, dgamma
 
 
+class _LinearLib(torch.autograd.Function):
+    """``x W^T + b`` on bf16 rows (the qkv / proj linears of the ViT attention, timm ``Attention.forward``): the library GEMM with
+    the bias in its epilogue; backward = input-gradient GEMM, the weight gradient as a split-K batched GEMM (``_wgrad``: K =
+    50 432 rows as one GEMM is a handful of output tiles) and the bias gradient as a deterministic column sum
+    (``cnx_scale_residual_bwd`` with neither gamma nor y) instead of autograd's single long-K GEMM and an ATen reduction."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        wb = _cached((w,), "bf16", lambda t: t.to(torch.bfloat16).contiguous())
+        bb = _cached((b,), "bf16", lambda t: t.to(torch.bfloat16).contiguous())
+        y = torch.addmm(bb, x2, wb.t())
+        ctx.save_for_backward(x2, wb)
+        ctx.x_shape = x.shape
+        return y.view(x.shape[:-1] + (w.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, wb = ctx.saved_tensors
+        N = wb.shape[0]
+        dy2 = dy.reshape(-1, N)
+        if dy2.dtype != torch.bfloat16 or not dy2.is_contiguous():
+            dy2 = dy2.to(torch.bfloat16).contiguous()
+        M = dy2.shape[0]
+        dx = (dy2 @ wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY:
+            dw = _wgrad(dy2, x2)
+            db = torch.empty(N, device=dy2.device, dtype=torch.float32)
+            zeros = torch.empty(N, device=dy2.device, dtype=torch.float32)
+            ws = torch.empty(lib.cnx_colsum_ws_floats(N), device=dy2.device, dtype=torch.float32)
+            _lib.check(lib.cnx_scale_residual_bwd(dy2.data_ptr(), _code(dy2), None, None, None, zeros.data_ptr(), db.data_ptr(),
+                                                  ws.data_ptr(), M, N, _stream()), "cnx_scale_residual_bwd(colsum)")
+        return dx, dw, db
+
+
+_LINEAR_LIB = os.environ.get("APGD_LINEAR_LIB", "1") != "0"
+
+
+def linear_lib(x, w, b):
+    """``F.linear(x, w, b)`` for a bf16 activation under bf16 autocast through ``_LinearLib``; the plain call otherwise."""
+    if (MODE == "eager" or not _LINEAR_LIB or not x.is_cuda or x.dtype != torch.bfloat16 or b is None or not x.is_contiguous()
+            or w.shape[0] % 4 != 0 or not (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
+        return F.linear(x, w, b)
+    return _LinearLib.apply(x, w, b)
+
+
 _MLP_RESIDUAL = os.environ.get("APGD_MLP_RESIDUAL", "1") != "0"
 
 

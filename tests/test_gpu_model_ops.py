@@ -180,6 +180,35 @@ def test_convnext_block_matches_reference_block(R, C, H, gamma):
     assert float((gb.float().cpu() - gref[0]).norm() / gref[0].norm()) < 1.5e-2
 
 
+@pytest.mark.parametrize("shape,N", [((3, 197, 768), 2304), ((256, 197, 384), 384), ((2, 5, 64), 36)])
+def test_linear_lib_vs_autograd_linear(R, shape, N):
+    """``ops.linear_lib`` (qkv / proj of the ViT attention): same output as ``F.linear`` under autocast, input / weight / bias
+    gradients vs fp32 autograd on the bf16-quantised operands (the weight gradient is a split-K batched GEMM, the bias
+    gradient a deterministic column sum); attack mode skips the parameter gradients."""
+    torch.manual_seed(N)
+    K = shape[-1]
+    x = torch.randn(*shape, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).requires_grad_()
+    b = (0.2 * torch.randn(N, device="cuda")).requires_grad_()
+    g = torch.randn(*shape[:-1], N, device="cuda").to(torch.bfloat16)
+    xd = x.clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = R.ops.linear_lib(xd, w, b)
+        y0 = F.linear(x, w, b)
+    assert isinstance(y.grad_fn, R.ops._LinearLib._backward_cls) and y.dtype == torch.bfloat16
+    assert float((y.float() - y0.float()).abs().max()) <= 0.05 * float(y0.float().abs().max())
+    gx, gw, gb = torch.autograd.grad(y, [xd, w, b], g, retain_graph=True)
+    xr = x.float().requires_grad_()
+    wr, br = w.detach().to(torch.bfloat16).float().requires_grad_(), b.detach().clone().requires_grad_()
+    rx, rw, rb = torch.autograd.grad(F.linear(xr, wr, br), [xr, wr, br], g.float())
+    rel_ = lambda a_, b_: float((a_.float() - b_).norm() / (b_.norm() + 1e-30))
+    assert gw.dtype == torch.float32 and gb.dtype == torch.float32
+    assert rel_(gx, rx) < 1e-2 and rel_(gw, rw) < 1e-2 and rel_(gb, rb) < 1e-3, (rel_(gx, rx), rel_(gw, rw), rel_(gb, rb))
+    with R.ops.input_grad_only():
+        (ga,) = torch.autograd.grad(y, xd, g)
+    assert torch.equal(ga, gx)
+
+
 @pytest.mark.parametrize("gamma", [True, False])
 @pytest.mark.parametrize("shape", [(3, 197, 768), (2, 50, 384), (4, 16, 96)])
 def test_mlp_residual_vs_fp32_reference(R, shape, gamma):
