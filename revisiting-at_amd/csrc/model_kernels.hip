@@ -667,7 +667,11 @@ __global__ __launch_bounds__(256) void dwconv7x7_roll_kernel(const TI* __restric
 struct DwRoll { int threads, units, rs, n_seg; size_t lds; };
 inline bool dw_roll_plan(int H, int W, int C, int in_bytes, int out_bytes, DwRoll* t) {
   static const int off = getenv("APGD_DW_ROLL") ? atoi(getenv("APGD_DW_ROLL")) : 1;          // 0: tile kernel everywhere
-  if (!off || C % kDC != 0 || H * W < 784) return false;
+  // smallest map (pixels).  28x28 and up always; 20x20 ... 27x27 (ConvNeXt-L @320 stage 2, 768 channels, batch 128; too many
+  // strips for the multi-image kernel) measured 123 -> 107 us forward and 235 -> 125 us input gradient + add against the
+  // whole-image tile kernel; at 10x10 the tile / multi-image kernels stay ahead for fp32 inputs.
+  static const int roll_min = getenv("APGD_DW_ROLL_MIN") ? atoi(getenv("APGD_DW_ROLL_MIN")) : 400;
+  if (!off || C % kDC != 0 || H * W < roll_min) return false;
   const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
   if (n_sc > 8) return false;
   t->threads = ((n_sc * kDC + 63) / 64) * 64;      // (extra staging-only wavefronts were tried at 28x28: fewer workgroups fit, slower)

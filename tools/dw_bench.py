@@ -20,7 +20,10 @@ def timeit(fn, iters=10, warm=3):
 
 
 code = {torch.float32: 0, torch.bfloat16: 1}
-for C, HW in ((96, 56), (192, 28), (384, 14), (768, 7)):
+SHAPES = ((96, 56), (192, 28), (384, 14), (768, 7))
+if len(sys.argv) > 2:                                   # e.g. "768x20,1536x10,192x80,384x40" (ConvNeXt-L @320)
+    SHAPES = tuple(tuple(int(v) for v in t.split("x")) for t in sys.argv[2].split(","))
+for C, HW in SHAPES:
     n = B * HW * HW * C
     w = torch.randn(49, C, device="cuda")
     b = torch.randn(C, device="cuda")
