@@ -462,8 +462,9 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
 // fused "+ add" operand), written to the ring after it - and the filter registers are set up once per band.
 //   LDS: ring [10][P2][32] dwords + output tile [4][W][32] TO (transposed epilogue: 16 bytes per lane).
 // ------------------------------------------------------------------------------------------------
+constexpr int kRollMaxThreads = 320;                  // 10 column strips of 8 x 32 channels: maps up to 80 pixels wide (ConvNeXt-L @320)
 template <typename TI, typename TO, int U, bool FA = false>
-__global__ __launch_bounds__(256) void dwconv7x7_roll_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
+__global__ __launch_bounds__(kRollMaxThreads) void dwconv7x7_roll_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
                                                              const float* __restrict__ bias, const float* __restrict__ add,
                                                              TO* __restrict__ out, int H, int W, int C, int flip, int RS,
                                                              int n_seg) {
@@ -673,7 +674,12 @@ inline bool dw_roll_plan(int H, int W, int C, int in_bytes, int out_bytes, DwRol
   static const int roll_min = getenv("APGD_DW_ROLL_MIN") ? atoi(getenv("APGD_DW_ROLL_MIN")) : 400;
   if (!off || C % kDC != 0 || H * W < roll_min) return false;
   const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
-  if (n_sc > 8) return false;
+  static const int max_sc = getenv("APGD_DW_ROLL_SC") ? atoi(getenv("APGD_DW_ROLL_SC")) : kRollMaxThreads / kDC;
+  if (n_sc > max_sc || n_sc * kDC > kRollMaxThreads) return false;
+  // 65 ... 80 pixels wide (ConvNeXt-L @320 stage 0, 80x80x192, batch 128): five wavefronts and up to 96 KB of LDS leave one
+  // workgroup per CU - still ahead of the tile kernels for bf16 inputs (697 -> 441 us all-bf16, 897 -> 792 us input gradient
+  // + add), behind them for fp32 inputs (503 -> 559 us)
+  if (n_sc > 8 && in_bytes != 2) return false;
   t->threads = ((n_sc * kDC + 63) / 64) * 64;      // (extra staging-only wavefronts were tried at 28x28: fewer workgroups fit, slower)
   t->units = (P2 * (kDC / 4) + t->threads - 1) / t->threads;
   if (t->units > 2) return false;
