@@ -10,6 +10,7 @@ steps = int(sys.argv[5]) if len(sys.argv) > 5 else 4
 dev = torch.device("cuda")
 torch.manual_seed(0)
 torch.backends.cudnn.benchmark = True                       # as bench.py (main.py:25)
+R.ops.load_gemm_table()                                     # as bench.py's trainer (APGD_GEMM_TABLE=0 disables)
 model = R.get_new_model(arch, pretrained=False, not_original=True, img_size=res)
 tr = R.ATTrainStep(model, arch, R.AdvConfig(attack="apgd", norm="Linf", eps=4 / 255, n_iter=n_iter), dev, lr=1e-3, amp_dtype=torch.bfloat16, ema=True)
 g = torch.Generator(device=dev).manual_seed(7)
