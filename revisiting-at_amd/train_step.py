@@ -95,6 +95,9 @@ class DeviceEma:
 def setup_distributed():
     """One process per GPU, RCCL via the "nccl" backend (``main.py:351-356``); reads the torchrun env."""
     import torch.distributed as dist
+    # dmabuf IPC (the only mode the host driver of this pool supports): must be in the environment before the HIP runtime
+    # starts in this process, or RCCL's buffer exchange fails with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
