@@ -134,7 +134,7 @@ def attack_both(R, ref, prod, x, y, K, autocast, norm="Linf", eps=EPS):
                 loss_rel=float(np.abs(lb.cpu().numpy() - olb).max() / (np.abs(olb).max() + 1e-30)))
 
 
-def replay_is_bit_exact(R, prod, x, y, K, autocast):
+def replay_is_bit_exact(R, prod, x, y, K, autocast, agree_bar=0.99):
     """The device model's own logits / input gradients, recorded during the HIP attack and replayed through the numpy
     oracle, must give the HIP attack's outputs bit for bit (as __graft_entry__.smoke does).  Checked in both modes: fp32
     gradients through autograd, and the int8 gradient-sign sink the product path uses by default (the recorded 'gradient' is
@@ -150,7 +150,7 @@ def replay_is_bit_exact(R, prod, x, y, K, autocast):
     T.check_replay(O, out_i8, lo, gr, x, y, "Linf", EPS, K)
     agree = float((out_f32[0] == out_i8[0]).float().mean())
     note("sink_vs_fp32_gradient_runs", agree=agree)
-    assert agree >= 0.99, agree
+    assert agree >= agree_bar, agree
 
 
 # ------------------------------------------------------------------------------------------------ cfg #2 (full widths)
@@ -206,8 +206,17 @@ def test_cfg3_vit_cvst_vs_oracle_vittimm(R, monkeypatch, arch):
 
 
 def test_convnext_base_cvst_convblock3_vs_oracle(R, monkeypatch):
-    """ConvNeXt-B-CvSt (ConvBlock3 stem, widths 128/256/512/1024: BASELINE config #5's model)."""
-    check_model_parity(R, monkeypatch, "convnext_base_model", "convnext_base", 224, 2, fp32_bars=(2e-4, 2e-3))
+    """ConvNeXt-B-CvSt (ConvBlock3 stem, widths 128/256/512/1024: BASELINE config #5's model); the bf16 attack runs the
+    C = 128 / 256 stages on the Hpre forward / input-gradient pair."""
+    ref, prod, x, y = check_model_parity(R, monkeypatch, "convnext_base_model", "convnext_base", 224, 2, fp32_bars=(2e-4, 2e-3))
+    monkeypatch.setattr(R.ops, "MODE", "hip")
+    assert R.ops._use_hpre_block(128) and R.ops._use_hpre_block(256)
+    a16 = attack_both(R, ref, prod, x, y, 2, autocast=True)
+    note("convnext_base_attack", bf16=a16)
+    assert a16["same"] >= 0.90 and a16["loss_rel"] <= 5e-2, a16
+    # (the ConvBlock3 stem's stride-1 convolution runs MIOpen's backward-data kernel, which is not reproducible run to run:
+    # each run must replay bit for bit, two runs of two images may differ in a few per cent of the pixels)
+    replay_is_bit_exact(R, prod, x, y, 2, autocast=True, agree_bar=0.90)
 
 
 # ------------------------------------------------------------------------------------------------ reference fixtures on the HIP path
