@@ -205,15 +205,17 @@ __device__ __forceinline__ void stage_transposed(uint16_t* img, const uint16_t* 
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-template <int NKB>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+// VG (N <= 224): the V row operands of dP = dO V^T come straight from memory (16 contiguous bytes per lane, the (b, h) slice is
+// L2-resident), one key block ahead of the MFMAs that use them: 56 instead of 84 KB of LDS, two workgroups per CU.
+template <int NKB, bool VG>
+__global__ __launch_bounds__(256, (VG ? 2 : 1)) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
                                                              const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              uint16_t* __restrict__ dqkv, float* __restrict__ dvec, int N, int H,
                                                              float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* kr = lds;                                            // K row image
-  unsigned char* vr = lds + NKB * kKS * 1024;                         // V row image
-  uint16_t* kt = reinterpret_cast<uint16_t*>(lds + 2 * NKB * kKS * 1024);   // K transposed image
+  unsigned char* vr = lds + NKB * kKS * 1024;                         // V row image (not with VG)
+  uint16_t* kt = reinterpret_cast<uint16_t*>(lds + (VG ? 1 : 2) * NKB * kKS * 1024);   // K transposed image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const long ts = 3L * H * kD, os = static_cast<long>(H) * kD;
@@ -223,10 +225,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
   const uint16_t* ob = o + static_cast<long>(b) * N * os + h * kD;
   const uint16_t* dob = dout + static_cast<long>(b) * N * os + h * kD;
   stage_rows<NKB>(kr, kb_, ts, N, tid);
-  stage_rows<NKB>(vr, vb, ts, N, tid);
+  if constexpr (!VG) stage_rows<NKB>(vr, vb, ts, N, tid);
   stage_transposed<NKB>(kt, kb_, ts, N, tid);
   __syncthreads();
   const float c2 = scale * 1.4426950408889634f;
+  // VG: lane (l32, half) of key block kblk reads V[min(kblk*32 + l32, N-1)][ks*16 + half*8 .. +8] (rows past N only meet p = 0)
+  auto v_global = [&](int kblk, bf16x8* dst) {
+    const int kr_ = min(kblk * 32 + l32, N - 1);
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(vb + kr_ * ts + ks * 16 + half * 8);
+  };
   const unsigned char* krf = kr + lane * 16;
   const unsigned char* vrf = vr + lane * 16;
   const uint16_t* ktf = kt + lane * 8;
@@ -256,15 +264,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     for (int db = 0; db < kDB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+    bf16x8 vnext[kKS];
+    if constexpr (VG) v_global(0, vnext);
 #pragma unroll 1
     for (int kblk = 0; kblk < NKB; ++kblk) {
       f32x16 st, dpt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+      bf16x8 vcur[kKS];
+      if constexpr (VG) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) vcur[ks] = vnext[ks];
+        v_global(min(kblk + 1, NKB - 1), vnext);
+      }
 #pragma unroll
       for (int ks = 0; ks < kKS; ++ks) {
         const bf16x8 ka = *reinterpret_cast<const bf16x8*>(krf + (kblk * kKS + ks) * 1024);
-        const bf16x8 va = *reinterpret_cast<const bf16x8*>(vrf + (kblk * kKS + ks) * 1024);
+        bf16x8 va;
+        if constexpr (VG) va = vcur[ks];
+        else va = *reinterpret_cast<const bf16x8*>(vrf + (kblk * kKS + ks) * 1024);
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpt, 0, 0, 0);
       }
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 // and the row operands of S = Q K^T and dP = dO V^T - 16 contiguous bytes per lane - come straight from memory (the (b, h)
 // slice is L2-resident: each wavefront re-reads it once per key block), one query block ahead of the MFMAs that use them.
 template <int NKB, bool ROWS_LDS>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, ((NKB <= 7 && !ROWS_LDS) ? 2 : 1)) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ dvec,
                                                               uint16_t* __restrict__ dqkv, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -446,18 +464,29 @@ int launch_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, i
 template <int NKB, bool ROWS_LDS>
 int launch_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, uint16_t* dqkv, float* dvec,
                     int64_t B, int32_t N, int32_t H, float scale, hipStream_t s) {
-  const size_t lds_q = static_cast<size_t>(NKB) * (2 * kKS + 2 * kDB) * 1024;
+  static const bool vg_on = !(getenv("APGD_ATTN_VG") && atoi(getenv("APGD_ATTN_VG")) == 0);
+  constexpr bool VG = NKB <= 7;
+  const bool vg = VG && vg_on;
+  const size_t lds_q = static_cast<size_t>(NKB) * ((vg ? 1 : 2) * kKS + 2 * kDB) * 1024;
   const size_t lds_kv = static_cast<size_t>(NKB) * (ROWS_LDS ? 4 : 2) * kKS * 1024 + 2 * NKB * 32 * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds_q));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKB, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(static_cast<size_t>(NKB) * (2 * kKS + 2 * kDB) * 1024));
+    if constexpr (VG)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKB, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(static_cast<size_t>(NKB) * (kKS + 2 * kDB) * 1024));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<NKB, ROWS_LDS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_kv));
     attr_done = true;
   }
   const dim3 grid(static_cast<unsigned>(B * H)), block(256);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<NKB>, grid, block, lds_q, s, qkv, out, dout, lse, dqkv, dvec, N, H, scale);
+  if constexpr (VG) {
+    if (vg) hipLaunchKernelGGL((attn_bwd_dq_kernel<NKB, true>), grid, block, lds_q, s, qkv, out, dout, lse, dqkv, dvec, N, H, scale);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<NKB, false>), grid, block, lds_q, s, qkv, out, dout, lse, dqkv, dvec, N, H, scale);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NKB, false>), grid, block, lds_q, s, qkv, out, dout, lse, dqkv, dvec, N, H, scale);
+  }
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKB, ROWS_LDS>), grid, block, lds_kv, s, qkv, dout, lse, dvec, dqkv, N, H, scale);
   return launch_status();
 }
@@ -497,7 +526,11 @@ int cnx_attention_bwd(const void* qkv, const void* out, const void* dout, const 
   const auto* o = static_cast<const uint16_t*>(out);
   const auto* d = static_cast<const uint16_t*>(dout);
   auto* g = static_cast<uint16_t*>(dqkv);
-  if (N <= 224) return launch_attn_bwd<7, true>(q, o, d, lse, g, dvec, B, N, H, scale, s);
+  // N <= 224: row operands from memory too (56 KB of LDS and 246 registers: two workgroups per CU; with the row images in LDS -
+  // 112 KB, 303 registers - it is one); APGD_ATTN_DKV_ROWS=1 selects the LDS-row form
+  static const bool rows_lds = getenv("APGD_ATTN_DKV_ROWS") && atoi(getenv("APGD_ATTN_DKV_ROWS")) == 1;
+  if (N <= 224) return rows_lds ? launch_attn_bwd<7, true>(q, o, d, lse, g, dvec, B, N, H, scale, s)
+                                : launch_attn_bwd<7, false>(q, o, d, lse, g, dvec, B, N, H, scale, s);
   return launch_attn_bwd<13, false>(q, o, d, lse, g, dvec, B, N, H, scale, s);
 }
 
