@@ -111,3 +111,27 @@ def test_fgsm_train_has_no_cpu_fallback_and_keeps_the_reference_errors():
         R.fgsm_train(m, x, y, 0.1, loss="dlr")                            # criterion_dict of fgsm_train.py has 'ce' only
     with pytest.raises(AssertionError):
         R.fgsm_train(m.train(), x, y, 0.1)                                # fgsm_train.py:74
+
+
+def test_vit_block_operators_fall_back_to_the_plain_composition_off_the_device():
+    """``ops.layer_norm_skip`` / ``ops.mlp_residual`` / ``ops.linear_lib`` (the ViT block's fused forms) dispatch to the plain
+    PyTorch composition for CPU tensors - the model surface stays importable and testable without a GPU; the ATTACK has no CPU
+    path (``test_apgd_train_has_no_cpu_fallback``)."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    C = 16
+    x = torch.randn(2, 5, C, requires_grad=True)
+    w, b = torch.randn(C), torch.randn(C)
+    y, xs = R.ops.layer_norm_skip(x, w, b, 1e-6)
+    assert xs is x and torch.equal(y, F.layer_norm(x, (C,), w, b, 1e-6))
+    w1, b1, w2, b2 = torch.randn(4 * C, C), torch.randn(4 * C), torch.randn(C, 4 * C), torch.randn(C)
+    g = torch.randn(C)
+    h = torch.randn(2, 5, C)
+    ref = x + g * F.linear(F.gelu(F.linear(h, w1, b1)), w2, b2)
+    assert torch.allclose(R.ops.mlp_residual(x, h, w1, b1, w2, b2, g), ref, atol=1e-6)
+    assert torch.allclose(R.ops.mlp_residual(x, h, w1, b1, w2, b2, None), x + F.linear(F.gelu(F.linear(h, w1, b1)), w2, b2), atol=1e-6)
+    assert torch.equal(R.ops.linear_lib(h, w1, b1), F.linear(h, w1, b1))
+    blk = R.architecture.VitBlock(C, 2, init_values=0.1).eval()
+    out = blk(x)
+    (gx,) = torch.autograd.grad(out.sum(), x)
+    assert out.shape == x.shape and torch.isfinite(gx).all()
