@@ -22,6 +22,8 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -239,13 +241,14 @@ def other_configs(R, dev):
     return out
 
 
-def spawn_ranks(args) -> int:
+def spawn_ranks(args, child_argv=None, ndev=None) -> int:
     """``python bench.py --gpus N`` without a torchrun environment: start N fresh rank processes (one per GPU, RCCL over
     xGMI; the reference's ``mp.spawn`` of ``main.py:1128-1152``), relay rank 0's JSON line, and fail if the job that ran is
     not an N-rank job.  The parent never touches the GPU (``torch.cuda.device_count()`` does not initialise HIP on this
-    image) and never re-execs itself: the ranks are plain child processes."""
+    image) and never re-execs itself: the ranks are plain child processes.  ``child_argv`` / ``ndev`` let the CPU tests drive
+    the same launcher with a gloo worker (tests/test_bench_launcher.py)."""
     n = args.gpus
-    ndev = torch.cuda.device_count()
+    ndev = torch.cuda.device_count() if ndev is None else ndev
     if ndev < n:
         print(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible", file=sys.stderr)
         return 2
@@ -253,21 +256,45 @@ def spawn_ranks(args) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     threads = os.environ.get("OMP_NUM_THREADS") or str(max(1, min(8, (os.cpu_count() or n) // n)))
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=threads,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = []
-    for p in procs:
-        try:
-            codes.append(p.wait(timeout=600))
-        except subprocess.TimeoutExpired:
-            p.kill()                                         # the exact child we started, by handle
-            codes.append(-9)
+        # ranks > 0: stderr into a temporary file, shown if the job fails (a rank that dies at start-up used to be invisible)
+        errs.append(None if r == 0 else tempfile.TemporaryFile())
+        procs.append(subprocess.Popen(child_argv or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r]))
+    # rank 0's pipe is drained by a thread while ALL children are polled under one deadline: when any rank exits non-zero (bad
+    # device, RCCL failure, import error) the others - parked in init_process_group or a collective - are ended by handle and
+    # the job fails at once instead of hanging on rank 0's pipe
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("APGD_BENCH_TIMEOUT_S", "1800"))
+    codes = [None] * n
+    failed = False
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes) or time.monotonic() > deadline:
+            failed = True
+            break
+        time.sleep(0.05)
+    if failed:
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                p.kill()                                     # the exact children we started, by handle
+                p.wait()
+                codes[i] = -9
+    reader.join(timeout=10)
+    out0 = (chunks[0] if chunks else b"").decode()
+    if any(codes):
+        for r, f in enumerate(errs):
+            if f is not None and codes[r] not in (0, -9):
+                f.seek(0)
+                sys.stderr.write(f"---- rank {r} stderr (tail) ----\n" + f.read().decode(errors="replace")[-4000:] + "\n")
     if any(codes):
         sys.stdout.write(out0)
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)

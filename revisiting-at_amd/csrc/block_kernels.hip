@@ -1375,17 +1375,13 @@ static int block_mlp_fwd_impl(const void* u, const float* ln_w, const float* ln_
   a.y2 = static_cast<uint16_t*>(y2_out); a.M = M;
   a.hpre = static_cast<uint16_t*>(hpre_ws);
   if (hpre_ws && !blk_fwd_pipe(C)) return APGD_ERR_ARG;          // only the pipelined loop writes the workspace
-  static const int dbg = (getenv("APGD_BLK_DBG") ? atoi(getenv("APGD_BLK_DBG")) : 0) |
-                         ((getenv("APGD_MLP3_STAGGER") ? atoi(getenv("APGD_MLP3_STAGGER")) : 0) << 8);
+#if MLP_ABLATE
+  static const int dbg = getenv("APGD_BLK_DBG") ? atoi(getenv("APGD_BLK_DBG")) : 0;   // timing experiments: ablation builds only
   a.dbg = dbg;
+#else
+  a.dbg = 0;
+#endif
   hipStream_t s = as_stream(stream);
-  // APGD_BLK_FWD_IMPL=2 selects the barrier-free kernels with LDS-resident weights (mlp_kernels.hip, C = 96) for A/B timing;
-  // measured equal to the ring kernel below, which stays the default (see the table in mlp_kernels.hip)
-  static const int impl = getenv("APGD_BLK_FWD_IMPL") ? atoi(getenv("APGD_BLK_FWD_IMPL")) : 1;
-  if (impl == 2 && !hpre_ws) {
-    const int r = mlp2_fwd_launch(a, C, resid_dtype, out_dtype, s);
-    if (r != -100) return r;
-  }
   switch (C) {
     case 96: return launch_blk_fwd<96>(a, resid_dtype, out_dtype, s);
     case 128: return launch_blk_fwd<128>(a, resid_dtype, out_dtype, s);

@@ -55,8 +55,17 @@ __global__ __launch_bounds__(256) void conv2_pack_kernel(const TW* __restrict__ 
 // MFMAs that use them (two register sets), so the HBM / L2 latency of a step hides behind the previous step's 9 * CI/16 * CO/32
 // MFMAs.  D[co][pos] (filter fragment first): a lane owns one position and, per accumulator register group, 4 consecutive channels
 // - 8-byte writes into a wavefront-private LDS tile, which leaves as 16 bytes per lane of contiguous NHWC rows.
-// (wavefronts per workgroup: 12 where filter + output tiles fit the 160 KiB of LDS - CI = 48: 81 + 72 KiB -, else 8)
-template <int CI> struct FwdWaves { static constexpr int value = (9 * (CI / 16) * 3 + 12 * 6 + 1 <= 160) ? 12 : 8; };
+// (wavefronts per workgroup: C2_MAX_WAVES, see above)
+// one LDS fragment read per MFMA in the schedule: left alone the scheduler hoists a dozen filter-fragment reads ahead of the MFMAs
+// and the 12-wavefront builds (168 registers) spill loop invariants, whose reloads then queue behind the prefetched loads
+#define C2_PACE { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+// Wavefronts per workgroup.  Round 2 ran 12 (forward) / 11 (input gradient) at CI = 48 - three per SIMD, 168 registers - and both
+// kernels spilled 4-10 registers whose reloads queue behind the prefetched operand loads; with 8 (two per SIMD, no scratch) the
+// same box measured 133-151 vs 140-149 us forward and 152-173 vs 150-167 us input gradient, i.e. no difference.  8 it is.
+#ifndef C2_MAX_WAVES
+#define C2_MAX_WAVES 8
+#endif
+template <int CI> struct FwdWaves { static constexpr int value = (9 * (CI / 16) * 3 + 12 * 6 + 1 <= 160 && C2_MAX_WAVES >= 12) ? 12 : 8; };
 
 template <int CI, int CO, int kFwdWaves = FwdWaves<CI>::value>
 __global__ __launch_bounds__(kFwdWaves * 64) void conv2_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wf,
@@ -75,18 +84,20 @@ __global__ __launch_bounds__(kFwdWaves * 64) void conv2_fwd_kernel(const uint16_
   const unsigned char* wl = lds + lane * 16;
   const uint16_t* zero_page = wf + KS * NB * 512;            // 64 zero elements behind the forward pieces
   const int OH = H / 2, OW = W / 2, TX = OW / 8, TY = OH / 4;
-  const long n_tiles = static_cast<long>(N) * TY * TX;
-  const long t_first = static_cast<long>(blockIdx.x) * kFwdWaves + wave, t_stride = static_cast<long>(gridDim.x) * kFwdWaves;
-  const long my_tiles = t_first < n_tiles ? (n_tiles - t_first + t_stride - 1) / t_stride : 0;
-  const long n_steps = 3 * my_tiles;
+  // tile / step counters are 32-bit (the C ABI refuses more than 2^29 tiles): 64-bit wave-uniform divisions and counters cost the
+  // 12-wavefront build (168 registers) five spilled registers, reloaded between the prefetched loads of every step
+  const int n_tiles = N * TY * TX;
+  const int t_first = static_cast<int>(blockIdx.x) * kFwdWaves + wave, t_stride = static_cast<int>(gridDim.x) * kFwdWaves;
+  const int my_tiles = t_first < n_tiles ? (n_tiles - t_first + t_stride - 1) / t_stride : 0;
+  const int n_steps = 3 * my_tiles;
 
   // operand fragments of row step `st` -> DST
 #define C2_LOAD(DST, ST)                                                                                       \
   {                                                                                                            \
-    const long tile_ = t_first + ((ST) / 3) * t_stride;                                                        \
-    const int dy_ = static_cast<int>((ST) % 3);                                                                \
-    const int tx_ = static_cast<int>(tile_ % TX), ty_ = static_cast<int>((tile_ / TX) % TY);                   \
-    const int b_ = static_cast<int>(tile_ / (static_cast<long>(TX) * TY));                                     \
+    const int tile_ = t_first + ((ST) / 3) * t_stride;                                                         \
+    const int dy_ = (ST) % 3;                                                                                  \
+    const int tx_ = tile_ % TX, ty_ = (tile_ / TX) % TY;                                                       \
+    const int b_ = tile_ / (TX * TY);                                                                          \
     const int iy_ = 2 * (ty_ * 4 + (l32 >> 3)) + dy_ - 1, ix0_ = 2 * (tx_ * 8 + (l32 & 7)) - 1;                \
     const uint16_t* xb_ = x + static_cast<long>(b_) * H * W * CI + half * 8;                                   \
     _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                                         \
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void conv2_fwd_kernel(const uint16_
 #define C2_STEP(CUR, NXT, ST)                                                                                  \
   {                                                                                                            \
     if ((ST) + 1 < n_steps) C2_LOAD(NXT, (ST) + 1)                                                             \
-    const int dy_c = static_cast<int>((ST) % 3);                                                               \
+    const int dy_c = (ST) % 3;                                                                                 \
     if (dy_c == 0) {                                                                                           \
       _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                        \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;                                       \
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void conv2_fwd_kernel(const uint16_
       _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                      \
         const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(wl + ((dy_c * RF + jf) * NB + nb) * 1024);         \
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, CUR[jf], acc[nb], 0, 0, 0);                     \
+        C2_PACE                                                                                                \
       }                                                                                                        \
     if (dy_c == 2) {                                                                                           \
       /* acc[nb][r]: channel nb*32 + (r & 3) + 8 (r >> 2) + 4 half of position l32 */                          \
@@ -128,9 +140,9 @@ __global__ __launch_bounds__(kFwdWaves * 64) void conv2_fwd_kernel(const uint16_
           *reinterpret_cast<uint2*>(scr + (l32 * CO + c0) * 2) = make_uint2(lo, hi);                           \
         }                                                                                                      \
       __builtin_amdgcn_wave_barrier();                                                                         \
-      const long tile_c = t_first + ((ST) / 3) * t_stride;                                                     \
-      const int tx_c = static_cast<int>(tile_c % TX), ty_c = static_cast<int>((tile_c / TX) % TY);             \
-      const int b_c = static_cast<int>(tile_c / (static_cast<long>(TX) * TY));                                 \
+      const int tile_c = t_first + ((ST) / 3) * t_stride;                                                      \
+      const int tx_c = tile_c % TX, ty_c = (tile_c / TX) % TY;                                                 \
+      const int b_c = tile_c / (TX * TY);                                                                      \
       unsigned char* ob_ = reinterpret_cast<unsigned char*>(out) +                                             \
                            ((static_cast<long>(b_c) * OH + ty_c * 4) * OW + tx_c * 8) * CO * 2;                \
       constexpr int ROWB = 8 * CO * 2;                      /* bytes of 8 positions: contiguous in the NHWC output */ \
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void conv2_fwd_kernel(const uint16_
   }
   bf16x8 fa[RF], fb[RF];
   if (n_steps > 0) C2_LOAD(fa, 0)
-  for (long st = 0; st < n_steps; st += 2) {
+  for (int st = 0; st < n_steps; st += 2) {
     C2_STEP(fa, fb, st)
     if (st + 1 < n_steps) C2_STEP(fb, fa, st + 1)
   }
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256) void conv2_pack_dgrad_kernel(const TW* __restr
 template <int CI> struct DgWaves {
   static constexpr int WKB = dg_blocks_before(3, 4 * CI / 32, CI) * 6;          // KiB of filter pieces (CO = 96: 6 k-steps)
   static constexpr int SKB = 32 * 2 * CI * 2 / 1024;                            // KiB of one wavefront's half-tile
-  static constexpr int value = (158 - WKB) / SKB > 12 ? 12 : (158 - WKB) / SKB;
+  static constexpr int value = (158 - WKB) / SKB > C2_MAX_WAVES ? C2_MAX_WAVES : (158 - WKB) / SKB;
 };
 
 template <int CI, int CO, int NW = DgWaves<CI>::value>
@@ -227,16 +239,16 @@ __global__ __launch_bounds__(NW * 64) void conv2_dgrad_kernel(const uint16_t* __
   const unsigned char* wl = lds + lane * 16;
   const uint16_t* zero_page = wd + NUSED * KSD * 512;
   const int OH = H / 2, OW = W / 2, TX = OW / 8, TY = OH / 4;
-  const long n_tiles = static_cast<long>(N) * TY * TX;
-  const long t_first = static_cast<long>(blockIdx.x) * NW + wave, t_stride = static_cast<long>(gridDim.x) * NW;
-  const long my_tiles = t_first < n_tiles ? (n_tiles - t_first + t_stride - 1) / t_stride : 0;
-  const long n_steps = 4 * my_tiles;
+  const int n_tiles = N * TY * TX;                      // 32-bit counters: see conv2_fwd_kernel
+  const int t_first = static_cast<int>(blockIdx.x) * NW + wave, t_stride = static_cast<int>(gridDim.x) * NW;
+  const int my_tiles = t_first < n_tiles ? (n_tiles - t_first + t_stride - 1) / t_stride : 0;
+  const int n_steps = 4 * my_tiles;
 #define DG_LOAD(DST, ST)                                                                                       \
   {                                                                                                            \
-    const long tile_ = t_first + ((ST) >> 2) * t_stride;                                                       \
-    const int q_ = static_cast<int>((ST) & 3);                                                                 \
-    const int tx_ = static_cast<int>(tile_ % TX), ty_ = static_cast<int>((tile_ / TX) % TY);                   \
-    const int b_ = static_cast<int>(tile_ / (static_cast<long>(TX) * TY));                                     \
+    const int tile_ = t_first + ((ST) >> 2) * t_stride;                                                        \
+    const int q_ = (ST) & 3;                                                                                   \
+    const int tx_ = tile_ % TX, ty_ = (tile_ / TX) % TY;                                                       \
+    const int b_ = tile_ / (TX * TY);                                                                          \
     const int oy_ = ty_ * 4 + (l32 >> 3) + (q_ >> 1), ox_ = tx_ * 8 + (l32 & 7) + (q_ & 1);                    \
     const bool ok_ = oy_ < OH && ox_ < OW;                                                                     \
     const uint16_t* p_ = ok_ ? dy_ + ((static_cast<long>(b_) * OH + oy_) * OW + ox_) * CO + half * 8 : zero_page; \
@@ -250,6 +262,7 @@ __global__ __launch_bounds__(NW * 64) void conv2_dgrad_kernel(const uint16_t* __
       _Pragma("unroll") for (int ks = 0; ks < KSD; ++ks) {                                                     \
         const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(wl + (dg_blocks_before(Q, nb, CI) * KSD + ks) * 1024); \
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, CUR[ks], acc[nb], 0, 0, 0);                     \
+        C2_PACE                                                                                                \
       }                                                                                                        \
     }
 #define DG_STEP(CUR, NXT, ST, Q)                                                                               \
@@ -263,15 +276,15 @@ __global__ __launch_bounds__(NW * 64) void conv2_dgrad_kernel(const uint16_t* __
   }
   bf16x8 fa[KSD], fb[KSD];
   if (n_steps > 0) DG_LOAD(fa, 0)
-  for (long st = 0; st < n_steps; st += 4) {
+  for (int st = 0; st < n_steps; st += 4) {
     DG_STEP(fa, fb, st, 0)
     DG_STEP(fb, fa, st + 1, 1)
     DG_STEP(fa, fb, st + 2, 2)
     DG_STEP(fb, fa, st + 3, 3)
     // acc[nb][r]: n = nb*32 + (r & 3) + 8 (r >> 2) + 4 half = class * CI + ci, patch l32
-    const long tile_c = t_first + (st >> 2) * t_stride;
-    const int tx_c = static_cast<int>(tile_c % TX), ty_c = static_cast<int>((tile_c / TX) % TY);
-    const int b_c = static_cast<int>(tile_c / (static_cast<long>(TX) * TY));
+    const int tile_c = t_first + (st >> 2) * t_stride;
+    const int tx_c = tile_c % TX, ty_c = (tile_c / TX) % TY;
+    const int b_c = tile_c / (TX * TY);
 #pragma unroll
     for (int py = 0; py < 2; ++py) {
       __builtin_amdgcn_wave_barrier();

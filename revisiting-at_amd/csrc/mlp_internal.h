@@ -1,5 +1,5 @@
-// mlp_internal.h — shared between block_kernels.hip (C ABI, first-generation kernels) and mlp_kernels.hip
-// (persistent second-generation kernels).  Not part of the C ABI.
+// mlp_internal.h — argument block and layout switches of the fused LN + MLP kernels (block_kernels.hip).  Not part of the C ABI.
+// (tools/probe/mlp_kernels.hip - the round-2 study of LDS-resident-weight variants, not built into the library - includes it too.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,6 +33,3 @@ struct BlkFwdArgs {
   int dbg;                 // timing experiments only (APGD_BLK_DBG)
 };
 
-// barrier-free persistent forward with the weights resident in LDS (C = 96).  Returns a launch status (0 = ok), -100 if C
-// is not covered.
-int mlp2_fwd_launch(const BlkFwdArgs& a, int C, int resid_dtype, int out_dtype, hipStream_t s);

@@ -462,9 +462,13 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
 // fused "+ add" operand), written to the ring after it - and the filter registers are set up once per band.
 //   LDS: ring [10][P2][32] dwords + output tile [4][W][32] TO (transposed epilogue: 16 bytes per lane).
 // ------------------------------------------------------------------------------------------------
-constexpr int kRollMaxThreads = 320;                  // 10 column strips of 8 x 32 channels: maps up to 80 pixels wide (ConvNeXt-L @320)
-template <typename TI, typename TO, int U, bool FA = false>
-__global__ __launch_bounds__(kRollMaxThreads) void dwconv7x7_roll_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
+constexpr int kRollMaxThreads = 384;                  // 10 column strips of 8 x 32 channels (maps up to 80 pixels wide, ConvNeXt-L @320) + staging-only lanes
+// MAXT: the launch bound is part of the instantiation - 256 threads (maps up to 64 pixels wide: every ConvNeXt-T / -B / ViT
+// shape) - and only the 9 / 10-strip launches of the 65 ... 80-pixel maps are built with the wider bound, always with ONE staging
+// unit per thread (a sixth, staging-only wavefront instead of two units on five): round 2 had one 320-thread bound for all
+// and its U = 2 kernels - the 28x28 maps of the headline configuration among them - carried 21-22 spilled VGPRs.
+template <typename TI, typename TO, int U, bool FA = false, int MAXT = 256>
+__global__ __launch_bounds__(MAXT) void dwconv7x7_roll_kernel(const TI* __restrict__ x, const float* __restrict__ w49c,
                                                              const float* __restrict__ bias, const float* __restrict__ add,
                                                              TO* __restrict__ out, int H, int W, int C, int flip, int RS,
                                                              int n_seg) {
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(kRollMaxThreads) void dwconv7x7_roll_kernel(const T
     }
     const int n_chunks = (h_end - h0) * W * CH;
     const long obase = ((n * H + h0) * static_cast<long>(W)) * C + cbase;
+    static_assert(MAXT <= 256 || U == 1, "wide launches stage one unit per thread");
     float4 a4[AC];
     if constexpr (sizeof(TS) == 4) {
       if (add) {
@@ -681,8 +686,9 @@ inline bool dw_roll_plan(int H, int W, int C, int in_bytes, int out_bytes, DwRol
   // + add), behind them for fp32 inputs (503 -> 559 us)
   if (n_sc > 8 && in_bytes != 2) return false;
   t->threads = ((n_sc * kDC + 63) / 64) * 64;      // (extra staging-only wavefronts were tried at 28x28: fewer workgroups fit, slower)
+  if (n_sc > 8) t->threads = std::min(kRollMaxThreads, ((P2 * (kDC / 4) + 63) / 64) * 64);   // wide maps: one staging unit per thread
   t->units = (P2 * (kDC / 4) + t->threads - 1) / t->threads;
-  if (t->units > 2) return false;
+  if (t->units > 2 || (t->threads > 256 && t->units != 1)) return false;
   const int chunks = kDR * W * (kDC * out_bytes / 16);
   if ((chunks + t->threads - 1) / t->threads > 8) return false;                                // AC in the kernel
   static const int rs_env = getenv("APGD_DW_RS") ? atoi(getenv("APGD_DW_RS")) : 0;            // tuning experiments only
@@ -1883,9 +1889,9 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     DwMulti mp;
     if (dw_roll_plan(H, W, C, 2, 4, &rp)) {
       const dim3 grid(static_cast<unsigned>(static_cast<long>(N) * (C / kDC) * rp.n_seg)), block(rp.threads);
-#define DWRA_LAUNCH(UU)                                                                                               \
+#define DWRA_LAUNCH(UU, MT)                                                                                           \
   {                                                                                                                   \
-    auto kfn = dwconv7x7_roll_kernel<uint16_t, uint16_t, UU, true>;                                                   \
+    auto kfn = dwconv7x7_roll_kernel<uint16_t, uint16_t, UU, true, MT>;                                               \
     static bool attr_done = false;                                                                                    \
     if (!attr_done) {                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1894,7 +1900,8 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     hipLaunchKernelGGL(kfn, grid, block, rp.lds, s, static_cast<const uint16_t*>(x), w49c, bias, add,                 \
                        static_cast<uint16_t*>(out), H, W, C, flip, rp.rs, rp.n_seg);                                   \
   }
-      if (rp.units == 1) DWRA_LAUNCH(1) else DWRA_LAUNCH(2)
+      if (rp.threads > 256) DWRA_LAUNCH(1, kRollMaxThreads)
+      else if (rp.units == 1) DWRA_LAUNCH(1, 256) else DWRA_LAUNCH(2, 256)
 #undef DWRA_LAUNCH
       return launch_status();
     }
@@ -1920,9 +1927,9 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     DwRoll rp;
     if (dw_roll_plan(H, W, C, x_dtype == APGD_F32 ? 4 : 2, out_dtype == APGD_F32 ? 4 : 2, &rp)) {
       const dim3 grid(static_cast<unsigned>(static_cast<long>(N) * (C / kDC) * rp.n_seg)), block(rp.threads);
-#define DWR_LAUNCH(TI, TO, UU)                                                                                        \
+#define DWR_LAUNCH(TI, TO, UU, MT)                                                                                    \
   {                                                                                                                   \
-    auto kfn = dwconv7x7_roll_kernel<TI, TO, UU>;                                                                     \
+    auto kfn = dwconv7x7_roll_kernel<TI, TO, UU, false, MT>;                                                          \
     static bool attr_done = false;                                                                                    \
     if (!attr_done) {                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1931,7 +1938,11 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     hipLaunchKernelGGL(kfn, grid, block, rp.lds, s, static_cast<const TI*>(x), w49c, bias, add, static_cast<TO*>(out), H, W, \
                        C, flip, rp.rs, rp.n_seg);                                                                      \
   }
-#define DWR_DISPATCH(TI, TO) { if (rp.units == 1) DWR_LAUNCH(TI, TO, 1) else DWR_LAUNCH(TI, TO, 2) }
+#define DWR_DISPATCH(TI, TO)                                                                                          \
+  {                                                                                                                   \
+    if (rp.threads > 256) { if constexpr (sizeof(TI) == 2) DWR_LAUNCH(TI, TO, 1, kRollMaxThreads) } /* plan: bf16 inputs only */ \
+    else if (rp.units == 1) DWR_LAUNCH(TI, TO, 1, 256) else DWR_LAUNCH(TI, TO, 2, 256)                                \
+  }
       if (x_dtype == APGD_F32) DWR_DISPATCH(float, uint16_t)
       else if (out_dtype == APGD_F32) DWR_DISPATCH(uint16_t, float)
       else DWR_DISPATCH(uint16_t, uint16_t)

@@ -34,7 +34,7 @@
 
 #include "apgd_hip.h"
 #include "convnext_hip.h"
-#include "mlp_internal.h"
+#include "../../revisiting-at_amd/csrc/mlp_internal.h"
 
 // Timing experiments (APGD_BLK_DBG) are compiled in only with -DMLP_ABLATE=1: a runtime flag test inside the hidden loop
 // turns into a branch per use and splits the scheduling region (15 branches, 23 s_nop and 12 s_waitcnt per slice were
