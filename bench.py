@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--cpu-threads", type=int, default=32)
     p.add_argument("--attack-only", action="store_true", help="time only apgd_train (extra info line on stderr)")
     p.add_argument("--no-other-configs", action="store_true", help="skip the informational runs of BASELINE configs #3-#5")
+    p.add_argument("--graph", type=int, default=1, help="1: the attack is replayed from hipGraphs (adv.graph, graphed.py); 0: eager")
     return p.parse_args()
 
 
@@ -182,17 +183,17 @@ def model_kernel_rooflines(R, dev, B, iters=10):
     return out
 
 
-def other_configs(R, dev):
+def other_configs(R, dev, graph=1):
     """Single-GPU, per-GPU-batch numbers of the other BASELINE.json configurations (informational, after the timed region):
     #3 ViT-B-CvSt APGD-2 AT @224 (per-GPU batch 256), #4 ConvNeXt-L-CvSt APGD-3 AT @320 (per-GPU batch 128),
     #5 100-step APGD-CE evaluation attack on ConvNeXt-B-CvSt @224 (batch 32, fp32 as AA_eval.py runs it)."""
     import torch
     out = {}
 
-    def at_step(arch, res, batch, n_iter, steps=3, warm=2):
+    def at_step(arch, res, batch, n_iter, steps=3, warm=4):
         torch.manual_seed(0)
         model = R.get_new_model(arch, pretrained=False, not_original=True, img_size=res)
-        tr = R.ATTrainStep(model, arch, R.AdvConfig(attack="apgd", norm="Linf", eps=4 / 255, n_iter=n_iter), dev, lr=1e-3,
+        tr = R.ATTrainStep(model, arch, R.AdvConfig(attack="apgd", norm="Linf", eps=4 / 255, n_iter=n_iter, graph=graph), dev, lr=1e-3,
                            amp_dtype=torch.bfloat16, ema=True)
         g = torch.Generator(device=dev).manual_seed(7)
         x = torch.rand(batch, 3, res, res, device=dev, generator=g)
@@ -386,7 +387,7 @@ def main():
     torch.backends.cudnn.benchmark = True                      # main.py:25
 
     model = R.get_new_model(args.arch, pretrained=False, not_original=True)
-    adv = R.AdvConfig(attack="apgd", norm="Linf", eps=args.eps, n_iter=args.n_iter)
+    adv = R.AdvConfig(attack="apgd", norm="Linf", eps=args.eps, n_iter=args.n_iter, graph=args.graph)
     trainer = R.ATTrainStep(model, args.arch, adv, dev, lr=1e-3, distributed=world > 1, channels_last=True,
                             amp_dtype=torch.bfloat16, ema=True, mixup=object() if args.soft_labels else None,
                             soft_targets=args.soft_labels, gemm_table=True)
@@ -403,7 +404,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the attack's hipGraphs are captured on its third call (graphed.WARMUP_CALLS eager calls first): never inside the timed region
+    n_warm = max(args.warmup, R.graphed.WARMUP_CALLS + 1) if args.graph else args.warmup
+    for _ in range(n_warm):
         trainer.step(x, y)
     sync()
     apgd_mod.PROFILE_EVENTS = []                                # K1 launches get bracketed by HIP events
@@ -461,7 +464,8 @@ def main():
     if roof is not None and first is not None:
         roof["first_iter"] = first
 
-    extra = {"host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3), "package_power": power_stats}
+    extra = {"host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3), "package_power": power_stats,
+             "attack_graph": dict(R.graphed.STATS, enabled=bool(args.graph))}
     if args.attack_only or True:
         # attack-only throughput (same tensors, eval mode), a few repetitions
         base = trainer.inner.base_model
@@ -487,7 +491,7 @@ def main():
                 and not args.no_cpu_baseline):
             del trainer, model, base, x, y
             torch.cuda.empty_cache()
-            extra["other_configs"] = other_configs(R, dev)
+            extra["other_configs"] = other_configs(R, dev, args.graph)
         extra["ops_mode"] = R.ops.MODE
         extra["device"] = torch.cuda.get_device_name(dev)
 
@@ -501,7 +505,7 @@ def main():
             "metric": "adversarial images/sec, ConvNeXt-T-CvSt APGD-2 AT @224" if args.arch == "convnext_tiny"
                       and args.n_iter == 2 and args.res == 224 else
                       f"adversarial images/sec, {args.arch}-CvSt APGD-{args.n_iter} AT @{args.res}",
-            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.arch}-CvSt APGD-{args.n_iter} adversarial-training step, eps={args.eps:.6f} Linf, "

@@ -8,7 +8,7 @@ from . import _lib
 from . import ops, architecture
 from .apgd import apgd_train, checkpoint_schedule, criterion_names
 from .fgsm import fgsm_train
-from . import aa_eval
+from . import aa_eval, graphed
 from .aa_eval import apgd_attack, run_standard_evaluation, robust_accuracy
 from .wrapped_model import WrappedModel
 from .config import AdvConfig, build_perturb, wrap_model_for_at

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -35,6 +36,9 @@ PROFILE_EVENTS = None
 # Linf only reads sign(grad) (:221): let our own stem kernel hand the attack int8 signs instead of the fp32 gradient
 # (ops.grad_sign_sink).  Same decisions bit for bit; 17 instead of 20 bytes per element in the update kernel.
 USE_SIGN_SINK = True
+
+# default of apgd_train(graph=None): hipGraph replay of the attack (graphed.py)
+GRAPH_DEFAULT = os.environ.get("APGD_GRAPH", "0") not in ("0", "")
 
 # losses the reference's criterion_dict names (autopgd_train_clean.py:113-114)
 criterion_names = ("ce", "softloss", "dlr", "dlr-targeted")
@@ -162,13 +166,18 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
 
 
 def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
-               verbose=False, mixup=None, is_train=True):
+               verbose=False, mixup=None, is_train=True, graph=None):
     """Drop-in for the reference's ``apgd_train`` (``autopgd_train_clean.py:123-124``).
 
     Returns ``(x_best, acc, loss_best, x_best_adv)`` (``:371``): fresh, detached tensors with
     ``x``'s shape and memory format; ``acc`` is bool ``[B]``, ``loss_best`` fp32 ``[B]``.
     ``y`` is int64 ``[B]``, or fp32 ``[B, n_cls]`` probabilities iff ``mixup is not None``
     (``:194-197``).  Supported: ``norm in {'Linf', 'L2', 'L1'}`` (L1: ``loss='ce'``, see ``apgd_l1.py``), ``loss in {'ce', 'dlr'}``.
+
+    ``graph`` (an addition of this path; default: the ``APGD_GRAPH`` environment variable, off): replay the attack - static
+    shapes, no host synchronisation - from hipGraphs captured on the third call with a given (model, shapes, arguments), so
+    that the host enqueues a handful of launches per attack instead of several hundred (``graphed.py``).  Same kernels, same
+    results; the model's parameters are read at replay time.
     """
     assert not model.training                                           # :125
     if use_rs:
@@ -191,14 +200,20 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
                                _stream_ptr)
     if norm not in ('Linf', 'L2'):
         raise NotImplementedError(f"norm={norm!r}: the HIP path covers Linf, L2 and L1 (L0 is broken in the reference itself, :257)")
+    if graph is None:
+        graph = GRAPH_DEFAULT
+    if graph and not verbose:
+        from . import graphed
+        return graphed.run(model, x, y, norm, eps, n_iter, kind, mixup is not None)
     return _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=mixup is not None, verbose=verbose)
 
 
-def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, y_target=None, x_init=None):
+def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, y_target=None, x_init=None, rec=None):
     """The device loop shared by ``apgd_train`` and the evaluation attacks (``aa_eval.apgd_attack``).
 
     ``x_init`` (optional) replaces the clean image as the start point (AutoAttack's random start); the ball stays
-    centred on ``x``.  ``kind`` 2 = targeted DLR with ``y_target``.
+    centred on ``x``.  ``kind`` 2 = targeted DLR with ``y_target``.  ``rec`` (``graphed._Recorder``) is set while the loop is
+    being captured into hipGraph segments: the update-kernel launches are handed to it as closures and stay outside the graphs.
     """
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise _lib.ApgdHipError("apgd_train needs a device (MI355X) tensor; there is no CPU fallback")
@@ -253,17 +268,22 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
         a = 0.75 if i > 0 else 1.0                                           # :218
         out = free.pop()
         if norm == 'Linf':
-            g_code = _lib.dtype_code(grad.dtype)
-            if PROFILE_EVENTS is not None:
-                ev0 = torch.cuda.Event(enable_timing=True)
-                ev0.record()
-            _lib.check(lib.apgd_linf_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
-                                              step_size.data_ptr(), out.data_ptr(), None, B, E, eps, a, stream),
-                       "apgd_linf_step_f32")                                 # :214-226
-            if PROFILE_EVENTS is not None:
-                ev1 = torch.cuda.Event(enable_timing=True)
-                ev1.record()
-                PROFILE_EVENTS.append(("apgd_linf_step_f32", i, ev0, ev1, grad.element_size()))
+            def k1(i=i, a=a, cur=cur, old=old, grad=grad, out=out):
+                # (the stream is looked up when the closure RUNS: under graph replay that is not the capture stream)
+                if PROFILE_EVENTS is not None:
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                _lib.check(lib.apgd_linf_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(),
+                                                  _lib.dtype_code(grad.dtype), step_size.data_ptr(), out.data_ptr(), None, B, E,
+                                                  eps, a, _stream_ptr()), "apgd_linf_step_f32")   # :214-226
+                if PROFILE_EVENTS is not None:
+                    ev1 = torch.cuda.Event(enable_timing=True)
+                    ev1.record()
+                    PROFILE_EVENTS.append(("apgd_linf_step_f32", i, ev0, ev1, grad.element_size()))
+            if rec is not None:
+                rec.eager(k1)
+            else:
+                k1()
         else:
             _lib.check(lib.apgd_l2_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(),
                                             step_size.data_ptr(), out.data_ptr(), l2_ws.data_ptr(), B, E, eps, a,

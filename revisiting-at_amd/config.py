@@ -27,6 +27,7 @@ class AdvConfig:
     noise_level: float = 1.
     skip_projection: int = 0
     alpha: float = 1.
+    graph: int = 0                # (addition of this path) 1: replay the attack from hipGraphs - apgd_train(graph=True), graphed.py
 
     @classmethod
     def from_argv(cls, argv: Sequence[str]) -> "AdvConfig":
@@ -66,7 +67,7 @@ def build_perturb(cfg: AdvConfig, mixup=None):
         return None
     if cfg.attack == 'apgd':
         return functools.partial(apgd_train, norm=cfg.norm, eps=cfg.eps, n_iter=cfg.n_iter,
-                                 verbose=cfg.verbose == 1, mixup=mixup)
+                                 verbose=cfg.verbose == 1, mixup=mixup, **({"graph": True} if cfg.graph else {}))
     if cfg.attack == 'fgsm':                                  # main.py:836-842
         return functools.partial(fgsm_train, eps=cfg.eps, use_rs=True, alpha=cfg.alpha, noise_level=cfg.noise_level,
                                  skip_projection=cfg.skip_projection == 1)

@@ -71,6 +71,27 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int launch_status() { return static_cast<int>(hipGetLastError()); }
 
+// Weight DMA: one global_load_lds_dwordx4 (64 lanes x 16 bytes -> 1 KiB of LDS at `ldst`, a wave-uniform address; lane l lands at
+// ldst + 16 l).  Inline asm on purpose (BLK_GLDS_ASM=0 selects the builtin for A/B): the builtin is a FLAT-encoded instruction
+// with a global AND an LDS memory operand, for which the compiler's wait-count pass sets its "pending flat" state - every
+// lgkmcnt / vmcnt wait it inserts while one is in flight becomes a wait for ZERO.  In the hidden loops that turned the counted
+// wait in front of every third MFMA (fragment read four MFMAs ago) into lgkmcnt(0) - a wait for the fragment read issued one
+// MFMA ago, ~80 cycles each, a dozen per C = 384 slice.  Completion of these loads is counted by hand (asm vmcnt waits before
+// the slice barriers); compiler-inserted vmcnt waits do not know them and can only over-wait (in-order return).
+#ifndef BLK_GLDS_ASM
+#define BLK_GLDS_ASM 1
+#endif
+__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* ldst) {
+#if BLK_GLDS_ASM
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)ldst)));
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#else
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)gsrc, (lds_ptr_t)ldst, 16, 0, 0);
+#endif
+}
+
 // fp32 pair -> packed bf16 pair, round to nearest even (one v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   const f32x2 v = {lo, hi};
@@ -282,7 +303,11 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const TW* __restrict__ W1
 #ifndef BLK_FWD96_OCC
 #define BLK_FWD96_OCC 2
 #endif
-template <int C, typename TX, typename TO>
+// WS: the pipelined loop also writes the Hpre workspace (cnx_block_mlp_fwd_hpre).  A template flag, not a test of p.hpre: ANY
+// branch inside the hidden loop makes the compiler's wait-count pass merge its scoreboards at the join and wait lgkmcnt(0) - for
+// the fragment read issued one MFMA ago - instead of the counted wait (a dozen ~80-cycle stalls per C = 384 slice in round 2's
+// loop, which tested p.hpre and the "is there a slice left to prefetch" conditions at run time).
+template <int C, typename TX, typename TO, bool WS = false>
 __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(const BlkFwdArgs p) {
   using G = Geo<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     unsigned char* ls = ring + ((S) % G::DEPTH) * G::FWD_SLICE;                                            \
     _Pragma("unroll") for (int i = 0; i < G::FWD_ROUNDS; ++i) {                                            \
       const int piece = i * 4 + wave;                                                                      \
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
+      glds16(gs + piece * 1024, ls + piece * 1024); \
     }                                                                                                      \
   }
 #define DMA_PIECE(S, R)                                                                                    \
@@ -319,7 +344,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     const unsigned char* gs = wsrc + static_cast<long>(S) * G::FWD_SLICE;                                  \
     unsigned char* ls = ring + ((S) % G::DEPTH) * G::FWD_SLICE;                                            \
     const int piece = (R) * 4 + wave;                                                                      \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
+    glds16(gs + piece * 1024, ls + piece * 1024); \
   }
   if (DBG(p, 16) && blockIdx.x < 1024) {                // timing experiment: de-phase the co-resident workgroups of the first round
     const int steps = ((blockIdx.x >> 8) & 3) * (p.dbg >> 8);
@@ -443,9 +468,11 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
 #else
 #define TR_ACC(ACC)
 #endif
-#define SLICE_SYNC(T)                                                                                          \
+    // ST ("steady"): a compile-time promise that slices T + 1 and T + DEPTH - 1 exist, so the iteration is straight-line code;
+    // the last two iterations are instantiated with a constant T instead and their conditions fold away as well.
+#define SLICE_SYNC(T, ST)                                                                                      \
     TR_ACC(tr_work)                                                                                            \
-    if ((T) + 1 < G::NSL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");                 \
+    if (ST || (T) + 1 < G::NSL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::FWD_ROUNDS) : "memory");           \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
     TR_ACC(tr_wait)                                                                                            \
     __builtin_amdgcn_s_barrier();                                                                              \
@@ -455,9 +482,12 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       const float4 b4 = *reinterpret_cast<const float4*>(b1s + (T) * 32 + 8 * g + 4 * half);                   \
       Z[4 * g + 0] = b4.x; Z[4 * g + 1] = b4.y; Z[4 * g + 2] = b4.z; Z[4 * g + 3] = b4.w;                      \
     }
+    // (Measured and dropped in round 3: GEMM1's k-steps alternating between two accumulators, summed behind GEMM2 - the theory
+    //  being that a dependent MFMA behind interleaved VALU work waits for its predecessor's write-back.  201 -> 212 us at
+    //  C = 384, 232 -> 243 at C = 256: the stalls were the wait-count pass's lgkmcnt(0), see glds16.)
     f32x16 za, zb;
     {                                                   // t = 0: GEMM1 of block 0 only
-      SLICE_SYNC(0)
+      SLICE_SYNC(0, false)
       if (G::DEPTH - 1 < G::NSL) DMA_SLICE(G::DEPTH - 1)
       const unsigned char* sl = ring + lane * 16;
       bf16x8 fr[PF];
@@ -470,10 +500,10 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
         if (i + PF < G::KS) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
       }
     }
-#define PIPE_ITER(T, ZIN, ZOUT)                                                                                \
+#define PIPE_ITER(T, ZIN, ZOUT, ST)                                                                            \
     {                                                                                                          \
-      SLICE_SYNC(T)                                                                                            \
-      if (p.hpre) {   /* Hpre of block T-1 for the input-gradient kernel: 16 bf16 per lane, accumulator order */ \
+      SLICE_SYNC(T, ST)                                                                                        \
+      if constexpr (WS) {   /* Hpre of block T-1 for the input-gradient kernel: 16 bf16 per lane, accumulator order */ \
         uint4* dst = reinterpret_cast<uint4*>(p.hpre) +                                                        \
                      ((static_cast<long>(blockIdx.x) * 4 + wave) * G::NHB + ((T) - 1)) * 128 + lane * 2;       \
         dst[0] = make_uint4(cvt_pk_bf16(ZIN[0], ZIN[1]), cvt_pk_bf16(ZIN[2], ZIN[3]), cvt_pk_bf16(ZIN[4], ZIN[5]),   \
@@ -497,7 +527,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
         else acc2[(i - G::KS) % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf0, fr[i % PF], acc2[(i - G::KS) % G::CB], 0, 0, 0); \
         if (i + PF < NF && !PABL(8)) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);   \
         if (i % DMA_EVERY == 0 && i / DMA_EVERY < G::FWD_ROUNDS && !PABL(1)) {                               \
-          if ((T) + G::DEPTH - 1 < G::NSL) DMA_PIECE((T) + G::DEPTH - 1, i / DMA_EVERY)                        \
+          if (ST || (T) + G::DEPTH - 1 < G::NSL) DMA_PIECE((T) + G::DEPTH - 1, i / DMA_EVERY)                  \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if (!PABL(2))                                                                                        \
@@ -516,10 +546,13 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       }                                                                                                        \
     }
     static_assert(G::NHB % 2 == 0 && NUOP * G::KS / SLOTS >= 76, "pipelined loop: pairs 0-3 are ready when GEMM2 starts");
-    for (int t = 1; t <= G::NHB; t += 2) {
-      PIPE_ITER(t, za, zb)
-      PIPE_ITER(t + 1, zb, za)
+    static_assert(G::NHB >= 4 && G::NSL == G::NHB + 1 && G::DEPTH == 3, "steady iterations 1 .. NHB-2, then the constant-T tail");
+    for (int t = 1; t + 1 <= G::NHB - 2; t += 2) {
+      PIPE_ITER(t, za, zb, true)
+      PIPE_ITER(t + 1, zb, za, true)
     }
+    PIPE_ITER(G::NHB - 1, za, zb, false)
+    PIPE_ITER(G::NHB, zb, za, false)
 #if MLP_ABLATE
     TR_ACC(tr_work)
     if (threadIdx.x == 0 && blockIdx.x < BLK_TRACE_WGS) {
@@ -674,9 +707,10 @@ template <int C>
 int launch_blk_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
   using G = Geo<C>;
   const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(256);
-#define BLK_LAUNCH(TX, TO)                                                                                       \
+#define BLK_LAUNCH(TX, TO) { if (a.hpre) { if constexpr (G::PIPE) BLK_LAUNCH_WS(TX, TO, true) } else BLK_LAUNCH_WS(TX, TO, false) }
+#define BLK_LAUNCH_WS(TX, TO, WSV)                                                                               \
   {                                                                                                              \
-    auto kfn = blk_mlp_fwd_kernel<C, TX, TO>;                                                                    \
+    auto kfn = blk_mlp_fwd_kernel<C, TX, TO, WSV>;                                                               \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
@@ -690,6 +724,7 @@ int launch_blk_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStrea
   else if (out_dtype == APGD_F32) BLK_LAUNCH(uint16_t, float)
   else BLK_LAUNCH(uint16_t, uint16_t)
 #undef BLK_LAUNCH
+#undef BLK_LAUNCH_WS
   return launch_status();
 }
 
@@ -812,7 +847,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
     _Pragma("unroll") for (int i = 0; i < LROUNDS; ++i) {                                                  \
       const int piece = i * G::WAVES + wave;                                                               \
       if (piece < LPIECES)                                                                                 \
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + piece * 1024), (lds_ptr_t)(ls + piece * 1024), 16, 0, 0); \
+        glds16(gs + piece * 1024, ls + piece * 1024); \
     }                                                                                                      \
   }
   if constexpr (!HPRE) {                                  // (the pipelined loops below arrange their ring differently)
@@ -898,8 +933,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
     {                                                                                                          \
       const int q_ = (Q) * G::WAVES + wave;                /* compact piece: < KS W2^T of block L, else GEMM3 of block L-1 */ \
       const int blk_ = q_ < G::KS ? ((L) < G::NHB ? (L) : G::NHB - 1) : ((L) > 0 ? (L) - 1 : 0);              \
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(blk_) * G::SLICE + (LP0 + q_) * 1024), \
-                                       (lds_ptr_t)(ring + ((L) % G::DEPTH) * LSLICE + q_ * 1024), 16, 0, 0);   \
+      glds16(wsrc + static_cast<long>(blk_) * G::SLICE + (LP0 + q_) * 1024, ring + ((L) % G::DEPTH) * LSLICE + q_ * 1024);   \
     }
 #define H_LOAD_HPRE(DST, T)                                                                                    \
     {                                                                                                          \
@@ -930,10 +964,12 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
         if (i + PF < G::KS) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);
       }
     }
-#define H_ITER(L, HCUR, HNEXT, DHIN, DHOUT)                                                                    \
+    // ST ("steady"): compile-time promise that slices L + 1 and L + 2 exist - straight-line code, no branch inside the loop body
+    // (see blk_mlp_fwd_kernel); the last two iterations are instantiated with a constant L
+#define H_ITER(L, HCUR, HNEXT, DHIN, DHOUT, ST)                                                                \
     {                                                                                                          \
       H_LOAD_HPRE(HNEXT, L)                               /* Hpre of block t+1 = L, used by the next iteration */ \
-      if ((L) + 1 <= G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LROUNDS + 2) : "memory");                \
+      if (ST || (L) + 1 <= G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LROUNDS + 2) : "memory");          \
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                    \
       __builtin_amdgcn_s_barrier();                                                                            \
       const unsigned char* sl = ring + ((L) % G::DEPTH) * LSLICE + lane * 16;                                  \
@@ -954,7 +990,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
         if (i < G::KS) DHOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i < G::KS ? i : 0], DHOUT, 0, 0, 0); \
         else acc3[(i - G::KS) % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf0, fr[i % PF], acc3[(i - G::KS) % G::CB], 0, 0, 0); \
         if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + gemm3_piece(i + PF) * 1024);       \
-        if (i % DMA_EVERY == 0 && i / DMA_EVERY < LROUNDS && (L) + 2 <= G::NHB) H_DMA_PIECE((L) + 2, i / DMA_EVERY) \
+        if (i % DMA_EVERY == 0 && i / DMA_EVERY < LROUNDS && (ST || (L) + 2 <= G::NHB)) H_DMA_PIECE((L) + 2, i / DMA_EVERY) \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int uo = NUOP * i / SLOTS; uo < NUOP * (i + 1) / SLOTS; ++uo) {                 \
           const int qd = uo / 62;                                                                              \
@@ -978,10 +1014,13 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
       const int j = i - G::KS;
       return G::KS + (j % G::CB) * 2 + (j / G::CB);
     };
-    for (int L = 1; L <= G::NHB; L += 2) {
-      H_ITER(L, hra, hrb, dha, dhb)
-      H_ITER(L + 1, hrb, hra, dhb, dha)
+    static_assert(G::NHB >= 4, "steady iterations 1 .. NHB-2, then the constant-L tail");
+    for (int L = 1; L + 1 <= G::NHB - 2; L += 2) {
+      H_ITER(L, hra, hrb, dha, dhb, true)
+      H_ITER(L + 1, hrb, hra, dhb, dha, true)
     }
+    H_ITER(G::NHB - 1, hra, hrb, dha, dhb, false)
+    H_ITER(G::NHB, hrb, hra, dhb, dha, false)
 #undef H_ITER
 #undef H_LOAD_HPRE
 #undef H_DMA_PIECE
@@ -1000,8 +1039,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
     {                                                                                                          \
       const int q_ = (Q) * G::WAVES + wave;                /* piece < 2 KS: W1 / W2^T of block L, else GEMM3 of block L-1 */ \
       const int blk_ = q_ < NG ? ((L) < G::NHB ? (L) : G::NHB - 1) : ((L) > 0 ? (L) - 1 : 0);                  \
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(blk_) * G::SLICE + q_ * 1024),     \
-                                       (lds_ptr_t)(ring + ((L) % G::DEPTH) * G::SLICE + q_ * 1024), 16, 0, 0); \
+      glds16(wsrc + static_cast<long>(blk_) * G::SLICE + q_ * 1024, ring + ((L) % G::DEPTH) * G::SLICE + q_ * 1024); \
     }
 #define R_BIAS(Z, T)                                                                                           \
     _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                                         \
@@ -1037,9 +1075,9 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
         if (i + PF < NG) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + r_piece(i + PF) * 1024);
       }
     }
-#define R_ITER(L, ZIN, DHIN, ZOUT, DHOUT)                                                                      \
+#define R_ITER(L, ZIN, DHIN, ZOUT, DHOUT, ST)                                                                  \
     {                                                                                                          \
-      if ((L) + 1 <= G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RND) : "memory");                        \
+      if (ST || (L) + 1 <= G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RND) : "memory");                  \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
       __builtin_amdgcn_s_barrier();                                                                            \
       const unsigned char* sl = ring + ((L) % G::DEPTH) * G::SLICE + lane * 16;                                \
@@ -1057,7 +1095,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
         else if (i < NG) ZOUT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[(i < NG ? i : 0) >> 1], ZOUT, 0, 0, 0); \
         else acc3[(i - NG) % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf0, fr[i % PF], acc3[(i - NG) % G::CB], 0, 0, 0); \
         if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + r_piece(i + PF) * 1024);           \
-        if (i % DMA_EVERY == 0 && i / DMA_EVERY < RND && (L) + 2 <= G::NHB) R_DMA_PIECE((L) + 2, i / DMA_EVERY) \
+        if (i % DMA_EVERY == 0 && i / DMA_EVERY < RND && (ST || (L) + 2 <= G::NHB)) R_DMA_PIECE((L) + 2, i / DMA_EVERY) \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int uo = NUOP * i / SLOTS; uo < NUOP * (i + 1) / SLOTS; ++uo) {                 \
           const int qd = uo / 62;                                                                              \
@@ -1074,10 +1112,12 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
         if (i + PF < NF) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + r_piece(i + PF) * 1024);           \
       }                                                                                                        \
     }
-    for (int L = 1; L <= G::NHB; L += 2) {
-      R_ITER(L, za, dha, zb, dhb)
-      R_ITER(L + 1, zb, dhb, za, dha)
+    for (int L = 1; L + 1 <= G::NHB - 2; L += 2) {
+      R_ITER(L, za, dha, zb, dhb, true)
+      R_ITER(L + 1, zb, dhb, za, dha, true)
     }
+    R_ITER(G::NHB - 1, za, dha, zb, dhb, false)
+    R_ITER(G::NHB, zb, dhb, za, dha, false)
 #undef R_ITER
 #undef R_BIAS
 #undef R_DMA_PIECE
@@ -1121,8 +1161,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
       if (i % DMA_EVERY == 0 && i / DMA_EVERY < LROUNDS && s + 2 < G::NHB) {
         const int piece = (i / DMA_EVERY) * G::WAVES + wave;
         if (piece < LPIECES)
-          __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + static_cast<long>(s + 2) * G::SLICE + piece * 1024),
-                                           (lds_ptr_t)(ring + ((s + 2) % G::DEPTH) * LSLICE + piece * 1024), 16, 0, 0);
+          glds16(wsrc + static_cast<long>(s + 2) * G::SLICE + piece * 1024, ring + ((s + 2) % G::DEPTH) * LSLICE + piece * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1199,6 +1238,11 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
   // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32]; as in the forward the tile leaves through
   //      the dead weight ring, 16 rows per pass, so that a lane stores 16 bytes (8 bf16) of a contiguous run instead of 2
   __syncthreads();
+  // the lane's coordinates are recomputed here from an opaque lane id: kept live across the hidden loop they cost the C = 384
+  // kernel (all 512 registers in use) a spilled register
+  int lane_e = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+  asm volatile("" : "+v"(lane_e));
+  const int l32e = lane_e & 31, halfe = lane_e >> 5;
   if constexpr (LNB) {
     // ---- ... and the LayerNorm backward rides along (input-gradient-only calls): with t = ln_w * da and
     //      xh = (u - mean) * rstd,   du = rstd * (t - mean_c(t) - xh * mean_c(t * xh)).
@@ -1208,7 +1252,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
     static_assert(G::WAVES * 16 * CP * 4 <= G::DEPTH * LSLICE, "the epilogue tile reuses the weight ring");
     float* scr = reinterpret_cast<float*>(ring) + wave * (16 * CP);
     constexpr int NJ = C / 32;                                            // 8-channel chunks per lane
-    const int rl = lane >> 2, q = lane & 3;
+    const int rl = lane_e >> 2, q = lane_e & 3;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       __builtin_amdgcn_wave_barrier();
@@ -1216,7 +1260,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
       for (int cb = 0; cb < G::CB; ++cb)
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-          scr[((r & 3) + 8 * (r >> 2) + 4 * half) * CP + cb * 32 + l32] = acc3[cb][8 * pass + r];
+          scr[((r & 3) + 8 * (r >> 2) + 4 * halfe) * CP + cb * 32 + l32e] = acc3[cb][8 * pass + r];
       __builtin_amdgcn_wave_barrier();
       const long m = m0 + 16 * pass + rl;
       const long mc = m < p.M ? m : p.M - 1;
@@ -1275,11 +1319,11 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
       for (int cb = 0; cb < G::CB; ++cb)
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-          scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc3[cb][8 * pass + r];
+          scr[((r & 3) + 8 * (r >> 2) + 4 * halfe) * C + cb * 32 + l32e] = acc3[cb][8 * pass + r];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
-        const int idx = j * 64 + lane;
+        const int idx = j * 64 + lane_e;
         const long e = e0 + idx * 8;
         const float4 lo = reinterpret_cast<const float4*>(scr)[2 * idx], hi = reinterpret_cast<const float4*>(scr)[2 * idx + 1];
         if (e < e_end)

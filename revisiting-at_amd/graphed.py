@@ -1,0 +1,151 @@
+"""hipGraph replay of the APGD attack (``apgd_train(..., graph=True)`` / ``APGD_GRAPH=1``).
+
+Why.  One adversarial-training step of ConvNeXt-T enqueues ~900 kernels from Python (autograd functions + ctypes), 40-50 ms
+of host time against 50-57 ms of GPU time: every kernel gain shrinks into that wall, and eight rank processes share one
+host.  The attack is 3/5 of those launches, has static shapes and performs no host synchronisation
+(``autopgd_train_clean.py:123-371`` on the device, ``apgd._apgd_core``), so it is captured once and replayed.
+
+How.  The third call with a given (model, input signature, arguments) runs ``_apgd_core`` under stream capture.  The
+Linf-update launches (K1) are NOT captured: ``_apgd_core`` hands them to the recorder as closures, which cuts the capture
+into ``n_iter + 1`` graph segments with the K1 launches between them - ``bench.py`` brackets exactly those launches with HIP
+events on the launch stream for its ``roofline`` object, which a node inside a graph does not allow.  A replay is then
+``n_iter + 1`` graph launches and ``n_iter`` kernel launches.
+
+What a replay reads.  The caller's ``x`` / ``y`` are copied into the static input buffers; model PARAMETERS are read in
+place by the captured kernels, and every derived copy of a parameter (fragment-packed MLP weights, bf16 casts, transposed
+filters: ``ops._cached``) is rebuilt INSIDE the graph from the live parameter - during capture ``ops`` uses a capture-local
+cache - so an optimizer step between two replays needs no host-side refresh and nothing can go stale.  Results are returned
+as fresh tensors (clones of the graph's static outputs), as ``apgd_train`` promises.
+
+Capture failures (an operator that synchronises, a library that refuses capture) fall back to the eager loop with a warning:
+same kernels, same results, only the host cost differs.
+"""
+from __future__ import annotations
+
+import warnings
+import weakref
+
+import torch
+
+from . import apgd, ops
+
+WARMUP_CALLS = 2                 # eager calls before the capture (library handles, kernel attributes, autotuned choices)
+STATS = {"captures": 0, "replays": 0, "eager": 0, "failed": 0}
+_programs = {}
+
+
+class _Recorder:
+    """Cuts one pass of ``_apgd_core`` into graph segments separated by eager closures."""
+
+    def __init__(self):
+        self.pool = torch.cuda.graph_pool_handle()
+        self.steps = []                                      # torch.cuda.CUDAGraph | callable
+        self._g = None
+
+    def begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool)
+
+    def end(self):
+        g, self._g = self._g, None
+        g.capture_end()
+        self.steps.append(g)
+
+    def abort(self):
+        """After an exception inside the capture: leave capture mode, whatever state the graph is in."""
+        g, self._g = self._g, None
+        if g is not None:
+            try:
+                g.capture_end()
+            except Exception:                                # noqa: BLE001 - the capture is already invalid
+                pass
+
+    def eager(self, fn):
+        self.end()
+        self.steps.append(fn)
+        self.begin()
+
+
+class _Program:
+    def __init__(self, model, x, y, norm, eps, n_iter, kind, soft):
+        self.model_ref = weakref.ref(model)
+        self.x = torch.empty_like(x)
+        self.y = torch.empty_like(y)
+        self.x.copy_(x)
+        self.y.copy_(y)
+        self.derived = {}                                    # capture-local ops._cached entries (kept alive with the graphs)
+        rec = _Recorder()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        prev = ops._CAPTURE_CACHE
+        ops._CAPTURE_CACHE = self.derived
+        try:
+            with torch.cuda.stream(side):
+                rec.begin()
+                try:
+                    self.out = apgd._apgd_core(model, self.x, self.y, norm, eps, n_iter, kind, soft=soft, rec=rec)
+                except BaseException:
+                    rec.abort()
+                    raise
+                rec.end()
+        finally:
+            ops._CAPTURE_CACHE = prev
+        torch.cuda.current_stream().wait_stream(side)
+        self.steps = rec.steps
+        self.n_graphs = sum(isinstance(s, torch.cuda.CUDAGraph) for s in self.steps)
+
+    def __call__(self, x, y):
+        self.x.copy_(x)
+        self.y.copy_(y)
+        for s in self.steps:
+            if isinstance(s, torch.cuda.CUDAGraph):
+                s.replay()
+            else:
+                s()
+        x_best, acc, loss_best, x_best_adv = self.out
+        return x_best.clone(), acc.clone(), loss_best.clone(), x_best_adv.clone()
+
+
+def _signature(model, x, y, norm, eps, n_iter, kind, soft):
+    ac = (torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
+    return (id(model), tuple(x.shape), tuple(x.stride()), x.dtype, x.device.index, tuple(y.shape), y.dtype, norm, float(eps),
+            int(n_iter), int(kind), bool(soft), ac, ops.MODE, apgd.USE_SIGN_SINK)
+
+
+def reset():
+    """Drop every captured program (tests; after replacing a model's parameters by new tensors)."""
+    _programs.clear()
+
+
+def run(model, x, y, norm, eps, n_iter, kind, soft):
+    """``_apgd_core`` with graph replay: eager for the first ``WARMUP_CALLS`` calls of a signature, captured on the next."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and isinstance(y, torch.Tensor) and y.is_cuda):
+        return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft)     # raises the usual errors
+    x = x.detach()
+    if not apgd._dense_rows(x):
+        x = x.contiguous()
+    y = y.detach()
+    key = _signature(model, x, y, norm, eps, n_iter, kind, soft)
+    ent = _programs.get(key)
+    if ent is None:
+        ent = _programs[key] = {"calls": 0, "prog": None, "failed": False}
+    prog = ent["prog"]
+    if prog is not None and prog.model_ref() is not model:   # id() of a dead model handed to a new one
+        ent.update(calls=0, prog=None, failed=False)
+        prog = None
+    if prog is None:
+        if ent["failed"] or ent["calls"] < WARMUP_CALLS:
+            ent["calls"] += 1
+            STATS["eager"] += 1
+            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft)
+        try:
+            prog = ent["prog"] = _Program(model, x, y, norm, eps, n_iter, kind, soft)
+            STATS["captures"] += 1
+        except Exception as e:                               # noqa: BLE001 - any capture failure means "run eagerly"
+            ent["failed"] = True
+            STATS["failed"] += 1
+            warnings.warn(f"APGD graph capture failed ({type(e).__name__}: {e}); this signature runs eagerly")
+            torch.cuda.synchronize()
+            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft)
+    STATS["replays"] += 1
+    return prog(x, y)

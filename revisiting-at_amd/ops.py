@@ -752,10 +752,23 @@ def load_gemm_table(path=None):
         return False
 
 
+# Set (to a dict) while graphed.py captures the attack into hipGraphs: derived weight copies are then built INSIDE the capture,
+# once per capture, from the live parameters - a replay re-packs them on the device and never reads a copy made before the last
+# optimizer step - and the ordinary cache is neither read nor written.
+_CAPTURE_CACHE = None
+
+
 def _cached(params, tag, fn):
     """Derived copies of parameters (bf16 casts, MFMA-fragment packing), rebuilt only when a parameter changes
     (optimizer steps bump ``_version``); the attack's forwards and the train forward share them.  Entries hold weak
     references: ``id()`` and even the storage address of a dead parameter can be handed to a new one."""
+    if _CAPTURE_CACHE is not None:
+        ckey = tuple(id(q) for q in params) + (tag,)
+        hit = _CAPTURE_CACHE.get(ckey)
+        if hit is None:
+            with torch.no_grad():
+                hit = _CAPTURE_CACHE[ckey] = (fn(*[q.detach() for q in params]), params)     # params kept alive: ids stay unique
+        return hit[0]
     key = tuple(id(q) for q in params) + (tag,)
     ver = (_WEIGHTS_EPOCH,) + tuple((q._version, q.data_ptr()) for q in params)
     hit = _wcache.get(key)

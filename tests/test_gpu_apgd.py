@@ -225,6 +225,39 @@ def test_linf_step_full_size_properties(lib):
     assert torch.equal(o2, out)
 
 
+def test_linf_step_full_size_with_int8_gradient_signs(lib):
+    """The PRODUCT form of K1 at BASELINE config #2's size (B = 256, 3x224x224): gradient signs as int8, both the general
+    (a = 0.75) and the first-iteration (x_adv_old is x_adv) launch.  Bit-exact vs the oracle on a strided sample of rows AND vs
+    the fp32-gradient launch on every element; eps-ball / box on everything."""
+    eps, B, E = 4 / 255, 256, 3 * 224 * 224
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(B, E, device="cuda", generator=gen)
+    xa = (x + (torch.rand(B, E, device="cuda", generator=gen) * 2 - 1) * eps).clamp(0, 1)
+    xo = (x + (torch.rand(B, E, device="cuda", generator=gen) * 2 - 1) * eps).clamp(0, 1)
+    g = torch.randn(B, E, device="cuda", generator=gen) * 1e-3
+    g[:, ::7] = 0.0                                          # exact zeros: sign 0
+    g[:, 5::11] = -0.0
+    g[3, :100] = float("nan")                                # sign(NaN) = 0 in the reference's torch.sign
+    sg = torch.sign(torch.nan_to_num(g, nan=0.0)).to(torch.int8)
+    step = torch.full((B,), 2 * eps, device="cuda")
+    step[::3] /= 2
+    step[::5] /= 4
+    for a, old in ((0.75, xo), (1.0, xa)):
+        o8, o32 = torch.empty_like(x), torch.empty_like(x)
+        assert lib.apgd_linf_step_f32(x.data_ptr(), xa.data_ptr(), old.data_ptr(), sg.data_ptr(), 3, step.data_ptr(),
+                                      o8.data_ptr(), None, B, E, eps, a, S()) == 0
+        assert lib.apgd_linf_step_f32(x.data_ptr(), xa.data_ptr(), old.data_ptr(), g.data_ptr(), 0, step.data_ptr(),
+                                      o32.data_ptr(), None, B, E, eps, a, S()) == 0
+        assert torch.equal(o8.view(torch.int32), o32.view(torch.int32)), a          # every element, bit for bit
+        sl = slice(3, 256, 41)
+        want = O.linf_step(*(t[sl].cpu().numpy() for t in (x, xa, old, g, step)), eps, a)
+        assert bits_equal(o8[sl].cpu().numpy(), want), a
+        chk = torch.empty(B, 3, device="cuda")
+        assert lib.apgd_check_imgs_f32(o8.data_ptr(), x.data_ptr(), chk.data_ptr(), B, E, S()) == 0
+        chk = chk.cpu().numpy()
+        assert chk[:, 0].max() <= np.float32(eps) * (1 + 2e-7) + 6e-8 and chk[:, 1].min() >= 0 and chk[:, 2].max() <= 1
+
+
 # --------------------------------------------------------------------------- K2 loss / pred / dlogits
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,C", [(1, 2), (5, 10), (33, 1000), (256, 1000), (3, 63), (4, 65)])

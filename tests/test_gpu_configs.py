@@ -9,7 +9,10 @@ never exercised against the oracle, plus the whole adversarial-training step (SU
   cfg #4  ConvNeXt-L-CvSt, APGD-3, 320x320                      utils_architecture.py:264-269
   a11     3 full AT steps vs a CPU oracle step                  main.py:961-997, 395-459, 882-887
 
-Tolerances.  fp32 (no autocast): logits <= 1e-4, input gradient <= 1e-3 relative L2.  bf16 autocast: the error of the
+Tolerances (round 3: every bar at <= ~3x the value measured on MI355X, gpurun_out/test_metrics.jsonl - round 2's were 10-100x
+looser than what the kernels deliver, wide enough for a dropped residual gradient to pass).  fp32 (no autocast): logits <= 5e-6,
+input gradient <= 6e-5 relative L2 (measured 5e-7 ... 1.5e-6 / 1.2e-5 ... 1.8e-5), attack loss <= 5e-7 (6e-8 ... 1.4e-7), >= 99.99 %
+identical pixels.  bf16 autocast: the error of the
 hand-written path against the fp32 oracle must not exceed max(1e-2, 1.5 x the error of the plain bf16 library composition of
 the same weights) - i.e. north_star's 1e-2, relaxed only where bf16 itself (not our kernels) cannot do better over a
 60-kernel-deep chain; the measured values are appended to gpurun_out/test_metrics.jsonl.  Adversarial images: the attack
@@ -100,7 +103,10 @@ def product_fwd_grad(R, prod, x, y, autocast, mode="hip", monkeypatch=None):
     return logits.detach().float().cpu(), g.detach().float().cpu()
 
 
-def check_model_parity(R, monkeypatch, name, arch, res, nb, fp32_bars=(1e-4, 1e-3)):
+FP32_BARS = (5e-6, 6e-5)            # relative L2 of logits / input gradient vs the pinned oracle, fp32
+
+
+def check_model_parity(R, monkeypatch, name, arch, res, nb, fp32_bars=FP32_BARS):
     ref, prod = build_pair(R, arch, res)
     g = torch.Generator().manual_seed(5)
     x = torch.rand(nb, 3, res, res, generator=g)
@@ -160,19 +166,32 @@ def test_cfg2_convnext_tiny_cvst_224_vs_oracle(R, monkeypatch):
     a32 = attack_both(R, ref, prod, x, y, 2, autocast=False)
     a16 = attack_both(R, ref, prod, x, y, 2, autocast=True)
     note("cfg2_attack", fp32=a32, bf16=a16)
-    assert a32["same"] >= 0.99 and a32["acc_equal"] and a32["loss_rel"] <= 1e-3, a32
-    assert a16["same"] >= 0.90 and a16["loss_rel"] <= 5e-2, a16
+    assert a32["same"] >= 0.9999 and a32["acc_equal"] and a32["loss_rel"] <= 5e-7, a32
+    assert a16["same"] >= 0.95 and a16["acc_equal"] and a16["loss_rel"] <= 3e-3, a16          # measured 0.970 / 7e-4
+    replay_is_bit_exact(R, prod, x, y, 2, autocast=True)
+
+
+@pytest.mark.parametrize("nb", [3, 5])
+def test_cfg2_convnext_tiny_cvst_224_ragged_batches(R, monkeypatch, nb):
+    """The same configuration at batch sizes that leave ragged tiles everywhere (3 and 5 images: 9408 / 15680 rows at 56x56 are
+    not multiples of the 128-row workgroups, 147 / 245 rows at 7x7 not even of a wavefront's 32): model parity at the fp32 and
+    bf16 bars, and the bf16 attack replayed bit for bit through the oracle in both gradient modes."""
+    ref, prod, x, y = check_model_parity(R, monkeypatch, f"cfg2_model_b{nb}", "convnext_tiny", 224, nb)
+    monkeypatch.setattr(R.ops, "MODE", "hip")
+    a16 = attack_both(R, ref, prod, x, y, 2, autocast=True)
+    note(f"cfg2_attack_b{nb}", bf16=a16)
+    assert a16["same"] >= 0.95 and a16["loss_rel"] <= 3e-3, a16
     replay_is_bit_exact(R, prod, x, y, 2, autocast=True)
 
 
 # ------------------------------------------------------------------------------------------------ cfg #4
 def test_cfg4_convnext_large_cvst_320_apgd3_vs_oracle(R, monkeypatch):
     """80x80x192 / 40x40x384 / 20x20x768 / 10x10x1536 maps: stage 0 leaves the 56x56 rolling depthwise kernel's shape."""
-    ref, prod, x, y = check_model_parity(R, monkeypatch, "cfg4_model", "convnext_large", 320, 2, fp32_bars=(2e-4, 2e-3))
+    ref, prod, x, y = check_model_parity(R, monkeypatch, "cfg4_model", "convnext_large", 320, 2)
     monkeypatch.setattr(R.ops, "MODE", "hip")
     a16 = attack_both(R, ref, prod, x, y, 3, autocast=True)
     note("cfg4_attack", bf16=a16)
-    assert a16["same"] >= 0.85 and a16["loss_rel"] <= 5e-2, a16                    # three sign steps compound the flips
+    assert a16["same"] >= 0.97 and a16["acc_equal"] and a16["loss_rel"] <= 3e-3, a16   # measured 0.993 / 6e-4 (three sign steps)
     replay_is_bit_exact(R, prod, x, y, 3, autocast=True)
 
 
@@ -184,12 +203,13 @@ def test_cfg1_convnext_iso_cvst_64_apgd2_vs_oracle(R, monkeypatch):
     a32 = attack_both(R, ref, prod, x, y, 2, autocast=False)
     a16 = attack_both(R, ref, prod, x, y, 2, autocast=True)
     note("cfg1_attack", fp32=a32, bf16=a16)
-    assert a32["same"] >= 0.99 and a32["acc_equal"] and a32["loss_rel"] <= 1e-3, a32
-    assert a16["same"] >= 0.90 and a16["loss_rel"] <= 5e-2, a16
+    assert a32["same"] >= 0.9999 and a32["acc_equal"] and a32["loss_rel"] <= 5e-7, a32
+    assert a16["same"] >= 0.95 and a16["acc_equal"] and a16["loss_rel"] <= 3e-3, a16          # measured 0.974 / 4e-4
     replay_is_bit_exact(R, prod, x, y, 2, autocast=True)
     # the reference's plumbing config runs L2 as well (secondary norm)
     l2 = attack_both(R, ref, prod, x, y, 2, autocast=False, norm="L2", eps=2.0)
     note("cfg1_attack_l2", fp32=l2)
+    assert l2["acc_equal"] and l2["loss_rel"] <= 5e-7, l2      # (L2 iterates are real-valued: pixels agree to rounding, not bit for bit)
 
 
 # ------------------------------------------------------------------------------------------------ cfg #3
@@ -202,18 +222,18 @@ def test_cfg3_vit_cvst_vs_oracle_vittimm(R, monkeypatch, arch):
         monkeypatch.setattr(R.ops, "MODE", "hip")
         a16 = attack_both(R, ref, prod, x, y, 2, autocast=True)
         note("cfg3_attack", bf16=a16)
-        assert a16["same"] >= 0.90 and a16["loss_rel"] <= 5e-2, a16
+        assert a16["same"] >= 0.97 and a16["acc_equal"] and a16["loss_rel"] <= 3e-3, a16      # measured 0.991 / 1.0e-3
 
 
 def test_convnext_base_cvst_convblock3_vs_oracle(R, monkeypatch):
     """ConvNeXt-B-CvSt (ConvBlock3 stem, widths 128/256/512/1024: BASELINE config #5's model); the bf16 attack runs the
     C = 128 / 256 stages on the Hpre forward / input-gradient pair."""
-    ref, prod, x, y = check_model_parity(R, monkeypatch, "convnext_base_model", "convnext_base", 224, 2, fp32_bars=(2e-4, 2e-3))
+    ref, prod, x, y = check_model_parity(R, monkeypatch, "convnext_base_model", "convnext_base", 224, 2)
     monkeypatch.setattr(R.ops, "MODE", "hip")
     assert R.ops._use_hpre_block(128) and R.ops._use_hpre_block(256)
     a16 = attack_both(R, ref, prod, x, y, 2, autocast=True)
     note("convnext_base_attack", bf16=a16)
-    assert a16["same"] >= 0.90 and a16["loss_rel"] <= 5e-2, a16
+    assert a16["same"] >= 0.97 and a16["acc_equal"] and a16["loss_rel"] <= 3e-3, a16          # measured 0.993 / 4e-4
     # (the ConvBlock3 stem's stride-1 convolution runs MIOpen's backward-data kernel, which is not reproducible run to run:
     # each run must replay bit for bit, two runs of two images may differ in a few per cent of the pixels)
     replay_is_bit_exact(R, prod, x, y, 2, autocast=True, agree_bar=0.90)
@@ -342,11 +362,13 @@ def test_at_train_step_matches_oracle_step(R, amp):
             expect = d * prev[k] + (1 - d) * traj[k_step][k]
             torch.testing.assert_close(emas[k_step][k], expect, rtol=1e-5, atol=1e-7)
         prev = emas[k_step]
+    # bars at <= 3x the measured values (fp32: loss 1.2e-5, gradient 3.7e-5, cosines 0.999997 / 0.99997; bf16: 4.7e-3, 6.2e-3,
+    # 0.9984 / 0.9976) - round 2 asserted 1e-3 / 5e-3 / 0.98 and 3e-2 / 1e-1 / 0.80
     if amp is None:
-        assert loss_rel <= 1e-3 and g_rel <= 5e-3 and cos >= 0.98 and ema_cos >= 0.98, (loss_rel, g_rel, cos, ema_cos)
+        assert loss_rel <= 4e-5 and g_rel <= 1.2e-4 and cos >= 0.9999 and ema_cos >= 0.9999, (loss_rel, g_rel, cos, ema_cos)
     else:
-        assert loss_rel <= 3e-2 and g_rel <= 1e-1 and cos >= 0.80 and ema_cos >= 0.80, (loss_rel, g_rel, cos, ema_cos)
-    assert 0.9 <= float(upd_p.norm() / upd_o.norm()) <= 1.1
+        assert loss_rel <= 1.5e-2 and g_rel <= 2e-2 and cos >= 0.99 and ema_cos >= 0.99, (loss_rel, g_rel, cos, ema_cos)
+    assert 0.99 <= float(upd_p.norm() / upd_o.norm()) <= 1.01
 
 
 # ------------------------------------------------------------------------------------------------ (f) rows on the device

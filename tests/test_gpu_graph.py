@@ -1,0 +1,107 @@
+"""hipGraph replay of the attack (``apgd_train(graph=True)``, ``revisiting-at_amd/graphed.py``) against the eager loop: same
+kernels, so the results must be IDENTICAL bit for bit - on fresh inputs, after an optimizer step changed the parameters (the
+graph re-packs every derived weight copy on the device), and inside whole adversarial-training steps."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+EPS = 4 / 255
+
+
+@pytest.fixture(scope="module")
+def R():
+    import revisiting_at_amd as R
+    assert torch.cuda.is_available()
+    R._lib.load()
+    return R
+
+
+def small_convnext(R, seed=0):
+    torch.manual_seed(seed)
+    A = R.architecture
+    m = A.ConvNeXt(depths=(1, 1, 2, 1), dims=(96, 192, 384, 768), num_classes=10)
+    m.stem = A.ConvBlock1(48)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("gamma"):
+                p.fill_(0.5)
+    return m.cuda().to(memory_format=torch.channels_last).eval()
+
+
+def same(a, b):
+    return all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+@pytest.mark.parametrize("norm,eps", [("Linf", EPS), ("L2", 2.0)])
+def test_graph_replay_is_bit_identical_to_the_eager_attack(R, norm, eps):
+    R.graphed.reset()
+    model = small_convnext(R)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    stats0 = dict(R.graphed.STATS)
+    outs = []
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        for call in range(5):
+            x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
+            y = torch.randint(0, 10, (4,), device="cuda", generator=g)
+            got = R.apgd_train(model, x, y, norm=norm, eps=eps, n_iter=2, graph=True)
+            want = R.apgd_train(model, x, y, norm=norm, eps=eps, n_iter=2, graph=False)
+            torch.cuda.synchronize()
+            assert same(got, want), (norm, call)
+            assert got[0].data_ptr() != x.data_ptr() and float((got[0] - x).abs().max()) > 0
+            outs.append(got[0])
+            if call == 3:                                    # an "optimizer step": every parameter moves, in place
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.mul_(1.0 + 0.05 * torch.randn((), device="cuda", generator=g))
+                R.ops.invalidate_weight_cache()
+    st = R.graphed.STATS
+    assert st["captures"] - stats0["captures"] == 1 and st["replays"] - stats0["replays"] == 3 and st["failed"] == stats0["failed"]
+    assert not torch.equal(outs[2], outs[3])                 # fresh tensors per call, not views of the static buffers
+
+
+def test_graph_replay_returns_fresh_tensors_and_keeps_the_memory_format(R):
+    R.graphed.reset()
+    model = small_convnext(R, 1)
+    x = torch.rand(2, 3, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 10, (2,), device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        res = [R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=3, graph=True) for _ in range(4)]
+        ref = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=3)
+    assert all(same(r, ref) for r in res)
+    assert res[2][0].data_ptr() != res[3][0].data_ptr()
+    assert res[3][0].is_contiguous(memory_format=torch.channels_last) and res[3][1].dtype == torch.bool
+
+
+def test_graph_mode_leaves_error_behaviour_alone(R):
+    model = small_convnext(R, 2)
+    with pytest.raises(R._lib.ApgdHipError):
+        R.apgd_train(model, torch.rand(2, 3, 64, 64), torch.zeros(2, dtype=torch.long), norm="Linf", eps=EPS, n_iter=2, graph=True)
+    with pytest.raises(NotImplementedError):
+        R.apgd_train(model, torch.rand(2, 3, 64, 64, device="cuda"), torch.zeros(2, dtype=torch.long, device="cuda"), norm="Linf",
+                     eps=EPS, n_iter=2, use_rs=True, graph=True)
+
+
+def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R):
+    """Six full AT steps (attack + train forward / backward + AdamW + EMA) with adv.graph = 1 and 0 from the same seeds: the same
+    loss trajectory and the same final parameters, bit for bit - the replayed attack reads the parameters the optimizer just wrote."""
+    def run(graph):
+        R.graphed.reset()
+        torch.manual_seed(5)
+        A = R.architecture
+        m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
+        m.stem = A.ConvBlock1(48)
+        tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=graph), "cuda", lr=1e-3,
+                           amp_dtype=torch.bfloat16, ema=True)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        losses = []
+        for _ in range(6):
+            x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
+            y = torch.randint(0, 10, (4,), device="cuda", generator=g)
+            losses.append(float(tr.step(x, y)))
+        return losses, [p.detach().clone() for p in tr.inner.parameters()]
+    l1, p1 = run(1)
+    assert R.graphed.STATS["replays"] >= 4
+    l0, p0 = run(0)
+    assert l1 == l0, (l1, l0)
+    assert all(torch.equal(a, b) for a, b in zip(p1, p0))
