@@ -455,7 +455,9 @@ def main():
                 "kernel": ("linf_step_vec4_kernel" if form == "general" else "linf_step_first_vec4_kernel")
                           + f" (apgd_linf_step_f32, {'int8 sign' if gbytes == 1 else 'fp32'} gradient)",
                 "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bpe * n_elem,
-                "bytes_moved": moved_bpe * n_elem, "moved_GBs": round(moved_bpe * n_elem / (avg_ms * 1e-3) / 1e9, 1)}
+                "bytes_moved": moved_bpe * n_elem, "moved_GBs": round(moved_bpe * n_elem / (avg_ms * 1e-3) / 1e9, 1),
+                # the PHYSICAL reading: bytes the kernel is designed to move (= the PMC traffic) / time / 8 TB/s
+                "frac_moved": round(moved_bpe * n_elem / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     roof = k1_entry(lambda i: i > 0, K1_BYTES_PER_ELEM, "general")
     first = k1_entry(lambda i: i == 0, K1_BYTES_PER_ELEM_IT0, "first")

@@ -218,6 +218,23 @@ int cnx_attention_bwd_supported(int32_t N, int32_t head_dim);
 int cnx_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dvec,
                       int64_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream);
 
+/* bf16 GEMM with a fused epilogue (csrc/gemm_kernels.hip) for the pointwise convolutions / linears without a fused-block kernel:
+ * models/convnext.py:42-46 (pwconv1 / act / pwconv2 / gamma / residual) at the widths and passes the fused kernels do not cover,
+ * the stage downsample convolutions :76-83 in GEMM form, and the qkv / proj / fc1 / fc2 linears of the transformer blocks
+ * (utils_architecture.py:271-301; timm Block).  These ran as hipBLASLt GEMMs between one-pass kernels.
+ *     acc[m, n] = sum_k A[m, k] * B[n, k]          A [M, K] bf16 (row stride lda), B [N, K] bf16 (row stride ldb): both K-contiguous,
+ *                                                  i.e. B is an nn.Linear weight as stored (or a transposed copy for input gradients)
+ *   epilogue 0 (bias)        D = bf16(acc + bias)
+ *   epilogue 1 (bias, GELU)  z = bf16(acc + bias);  D = bf16(GELU(z));  z_out (nullable, row stride ldz) = z
+ *   epilogue 2 (scale, res.) y = bf16(acc + bias);  D = R + gamma * y  (D, R fp32 or bf16; gamma NULL = 1; R NULL = 0);  z_out (nullable) = y
+ *   epilogue 3 (GELU')       D = bf16(bf16(acc) * GELU'(z_in))        (z_in [M, N] bf16, row stride ldz)
+ * bias [N] fp32 (rounded to bf16, as the autocast linear adds it) or NULL.  fp32 accumulation; exact-erf GELU / GELU' with the
+ * polynomials of the fused block kernels.  Needs K % 64 == 0, N % 4 == 0, 16-byte aligned rows (cnx_gemm_nt_supported). */
+int cnx_gemm_nt_supported(int64_t M, int32_t N, int32_t K);
+int cnx_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* D, int64_t ldd, int d_dtype, int64_t M, int32_t N,
+                int32_t K, int32_t epilogue, const float* bias, const float* gamma, const void* R, int64_t ldr, int r_dtype,
+                void* z_out, const void* z_in, int64_t ldz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "cnx_layernorm_bwd_add": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32,
                                         _i32, _p]),
     "cnx_layernorm_fwd_patch2": (C.c_int, [_p, C.c_int, _p, _p, C.c_float, _p, C.c_int, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_gemm_nt_supported": (C.c_int, [_i64, _i32, _i32]),
+    "cnx_gemm_nt": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, C.c_int, _i64, _i32, _i32, _i32, _p, _p, _p, _i64, C.c_int, _p, _p, _i64, _p]),
     "cnx_layernorm_bwd_patch2": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32,
                                            _p]),
 }

@@ -81,14 +81,18 @@ inline int launch_status() { return static_cast<int>(hipGetLastError()); }
 #ifndef BLK_GLDS_ASM
 #define BLK_GLDS_ASM 1
 #endif
-__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* ldst) {
+// The source is split into a wave-uniform base (SGPR pair: weights + slice + piece offsets, scalar arithmetic) and the lane's
+// 16 l byte offset (one loop-invariant VGPR): a per-lane 64-bit source pointer cost a v_lshl_add_u64 and the scalar work to
+// feed it per piece - with M0 saved and restored around every load that was ~10 instructions per KiB in loops that are bound by
+// instruction issue (10 instructions per MFMA, 51 cycles per MFMA: profiles/r03_fused_mlp_issue.md).  Nothing else in these
+// kernels uses M0 (no other LDS-DMA, no indexed register access), so it is set and left.
+// `ldst` is the LDS BYTE ADDRESS (lds_addr(ptr) once per kernel + integer offsets: a pointer cast per piece carries a null test).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)p)); }
+__device__ __forceinline__ void glds16(const unsigned char* ubase, uint32_t lane_off, uint32_t ldst) {
 #if BLK_GLDS_ASM
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)ldst)));
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(ubase), "v"(lane_off), "s"(ldst) : "memory");
 #else
-  __builtin_amdgcn_global_load_lds((glb_ptr_t)gsrc, (lds_ptr_t)ldst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)(ubase + lane_off), (__attribute__((address_space(3))) void*)(uintptr_t)ldst, 16, 0, 0);
 #endif
 }
 
@@ -329,22 +333,23 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
 #endif
 
   // ---- weight stream: slice s -> ring slot s % DEPTH, 1 KiB pieces, piece = round*4 + wave
-  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf) + lane * 16;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf);    // wave-uniform; the lane's part is lane16
+  const uint32_t lane16 = lane * 16, ring0 = __builtin_amdgcn_readfirstlane(lds_addr(ring));
 #define DMA_SLICE(S)                                                                                       \
   {                                                                                                        \
     const unsigned char* gs = wsrc + static_cast<long>(S) * G::FWD_SLICE;                                  \
-    unsigned char* ls = ring + ((S) % G::DEPTH) * G::FWD_SLICE;                                            \
+    const uint32_t ls = ring0 + ((S) % G::DEPTH) * G::FWD_SLICE;                                           \
     _Pragma("unroll") for (int i = 0; i < G::FWD_ROUNDS; ++i) {                                            \
       const int piece = i * 4 + wave;                                                                      \
-      glds16(gs + piece * 1024, ls + piece * 1024); \
+      glds16(gs + piece * 1024, lane16, ls + piece * 1024); \
     }                                                                                                      \
   }
 #define DMA_PIECE(S, R)                                                                                    \
   {                                                                                                        \
     const unsigned char* gs = wsrc + static_cast<long>(S) * G::FWD_SLICE;                                  \
-    unsigned char* ls = ring + ((S) % G::DEPTH) * G::FWD_SLICE;                                            \
+    const uint32_t ls = ring0 + ((S) % G::DEPTH) * G::FWD_SLICE;                                           \
     const int piece = (R) * 4 + wave;                                                                      \
-    glds16(gs + piece * 1024, ls + piece * 1024); \
+    glds16(gs + piece * 1024, lane16, ls + piece * 1024); \
   }
   if (DBG(p, 16) && blockIdx.x < 1024) {                // timing experiment: de-phase the co-resident workgroups of the first round
     const int steps = ((blockIdx.x >> 8) & 3) * (p.dbg >> 8);
@@ -839,15 +844,16 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
   const int l32 = lane & 31, half = lane >> 5;
   const long m0 = static_cast<long>(blockIdx.x) * G::BM + wave * 32;
 
-  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wb) + lane * 16;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wb);    // wave-uniform; the lane's part is lane16
+  const uint32_t lane16 = lane * 16, ring0 = __builtin_amdgcn_readfirstlane(lds_addr(ring));
 #define DMA_SLICE(S)                                                                                       \
   {                                                                                                        \
     const unsigned char* gs = wsrc + static_cast<long>(S) * G::SLICE + LP0 * 1024;                         \
-    unsigned char* ls = ring + ((S) % G::DEPTH) * LSLICE;                                                  \
+    const uint32_t ls = ring0 + ((S) % G::DEPTH) * LSLICE;                                                 \
     _Pragma("unroll") for (int i = 0; i < LROUNDS; ++i) {                                                  \
       const int piece = i * G::WAVES + wave;                                                               \
       if (piece < LPIECES)                                                                                 \
-        glds16(gs + piece * 1024, ls + piece * 1024); \
+        glds16(gs + piece * 1024, lane16, ls + piece * 1024); \
     }                                                                                                      \
   }
   if constexpr (!HPRE) {                                  // (the pipelined loops below arrange their ring differently)
@@ -932,8 +938,8 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
 #define H_DMA_PIECE(L, Q)                                                                                      \
     {                                                                                                          \
       const int q_ = (Q) * G::WAVES + wave;                /* compact piece: < KS W2^T of block L, else GEMM3 of block L-1 */ \
-      const int blk_ = q_ < G::KS ? ((L) < G::NHB ? (L) : G::NHB - 1) : ((L) > 0 ? (L) - 1 : 0);              \
-      glds16(wsrc + static_cast<long>(blk_) * G::SLICE + (LP0 + q_) * 1024, ring + ((L) % G::DEPTH) * LSLICE + q_ * 1024);   \
+      const int blk_ = q_ < G::KS ? ((L) < G::NHB ? (L) : G::NHB - 1) : ((L) > 0 ? (L) - 1 : 0);   /* (steady iterations: 0 < L < NHB) */ \
+      glds16(wsrc + static_cast<long>(blk_) * G::SLICE + (LP0 + q_) * 1024, lane16, ring0 + ((L) % G::DEPTH) * LSLICE + q_ * 1024);   \
     }
 #define H_LOAD_HPRE(DST, T)                                                                                    \
     {                                                                                                          \
@@ -1039,7 +1045,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
     {                                                                                                          \
       const int q_ = (Q) * G::WAVES + wave;                /* piece < 2 KS: W1 / W2^T of block L, else GEMM3 of block L-1 */ \
       const int blk_ = q_ < NG ? ((L) < G::NHB ? (L) : G::NHB - 1) : ((L) > 0 ? (L) - 1 : 0);                  \
-      glds16(wsrc + static_cast<long>(blk_) * G::SLICE + q_ * 1024, ring + ((L) % G::DEPTH) * G::SLICE + q_ * 1024); \
+      glds16(wsrc + static_cast<long>(blk_) * G::SLICE + q_ * 1024, lane16, ring0 + ((L) % G::DEPTH) * G::SLICE + q_ * 1024); \
     }
 #define R_BIAS(Z, T)                                                                                           \
     _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                                         \
@@ -1161,7 +1167,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
       if (i % DMA_EVERY == 0 && i / DMA_EVERY < LROUNDS && s + 2 < G::NHB) {
         const int piece = (i / DMA_EVERY) * G::WAVES + wave;
         if (piece < LPIECES)
-          glds16(wsrc + static_cast<long>(s + 2) * G::SLICE + piece * 1024, ring + ((s + 2) % G::DEPTH) * LSLICE + piece * 1024);
+          glds16(wsrc + static_cast<long>(s + 2) * G::SLICE + piece * 1024, lane16, ring0 + ((s + 2) % G::DEPTH) * LSLICE + piece * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

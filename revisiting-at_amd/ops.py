@@ -352,14 +352,16 @@ class _DownsampleLnConv(torch.autograd.Function):
         _lib.check(lib.cnx_layernorm_fwd_patch2(x.data_ptr(), _code(x), lw.data_ptr(), lb.data_ptr(), eps, yp.data_ptr(), _code(yp),
                                                 mean.data_ptr(), rstd.data_ptr(), N, H, W, C, _stream()), "cnx_layernorm_fwd_patch2")
         wp = _cached((weight,), "patch2_bf16", lambda w: w.permute(0, 2, 3, 1).reshape(Co, 4 * C).to(torch.bfloat16).contiguous())
-        if bias is not None:
+        if _gemm_ok(yp, wp):
+            out = _gemm_nt(yp, wp, EPI_BIAS, bias=_f32(bias) if bias is not None else None)
+        elif bias is not None:
             bb = _cached((bias,), "bf16", lambda b: b.to(torch.bfloat16).contiguous())
             out = torch.addmm(bb, yp, wp.t())
         else:
             out = yp @ wp.t()
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, lw, mean, rstd, yp, wp)
-            ctx.has_bias = bias is not None
+            ctx.has_bias, ctx.weight = bias is not None, weight
         return out.view(N, H // 2, W // 2, Co)
 
     @staticmethod
@@ -374,7 +376,12 @@ class _DownsampleLnConv(torch.autograd.Function):
         gb = g2 if g2.dtype == torch.bfloat16 else g2.to(torch.bfloat16)
         gb = gb.contiguous()
         dx = dlw = dlb = dwt = db = None
-        dyp = gb @ wp                                                            # [Mo, 4C] in patch form
+        if _gemm_dims_ok(gb, Co, 4 * C):                                         # [Mo, 4C] in patch form
+            wpt = _cached((ctx.weight,), "patch2_bf16_t",
+                          lambda w: w.permute(0, 2, 3, 1).reshape(Co, 4 * C).to(torch.bfloat16).t().contiguous())
+            dyp = _gemm_nt(gb, wpt, EPI_BIAS)
+        else:
+            dyp = gb @ wp
         dx = torch.empty_like(x)
         ws = None
         if want_p:
@@ -807,6 +814,51 @@ def _sum_parts(part):
     return out
 
 
+# ------------------------------------------------------------------------------ hand-written GEMM with fused epilogues
+# "hip" (default): forward / input-gradient GEMMs of the library-path blocks, the downsample layers and the ViT linears run on
+# cnx_gemm_nt (csrc/gemm_kernels.hip) with bias / GELU / layer scale + residual / GELU' in the epilogue; "lib": hipBLASLt GEMMs
+# between one-pass kernels, as in round 2 (A/B timing).  Weight gradients (contraction over M) stay split-K library GEMMs.
+_GEMM_MODE = os.environ.get("APGD_GEMM", "hip")
+EPI_BIAS, EPI_BIAS_GELU, EPI_SCALE_RES, EPI_GELU_GRAD = 0, 1, 2, 3
+
+
+def _gemm_ok(a, w_nk):
+    """cnx_gemm_nt takes ``a`` [M, K] and ``w_nk`` [N, K]: bf16, unit inner stride, 16-byte rows, K % 64 == 0, N % 4 == 0."""
+    return (MODE != "eager" and _GEMM_MODE == "hip" and a.is_cuda and a.dtype == torch.bfloat16 and w_nk.dtype == torch.bfloat16
+            and a.dim() == 2 and w_nk.dim() == 2 and a.stride(1) == 1 and w_nk.stride(1) == 1 and a.shape[1] == w_nk.shape[1]
+            and a.shape[1] % 64 == 0 and w_nk.shape[0] % 4 == 0 and a.stride(0) % 8 == 0 and w_nk.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and w_nk.data_ptr() % 16 == 0 and a.shape[0] > 0)
+
+
+def _gemm_dims_ok(a, K, N):
+    """The same test for an operand pair that does not exist yet: ``a`` is a bf16 row matrix of ours, the weight copy will be
+    a fresh contiguous [N, K] bf16 tensor."""
+    return (MODE != "eager" and _GEMM_MODE == "hip" and a.is_cuda and a.dtype == torch.bfloat16 and K % 64 == 0 and N % 4 == 0
+            and a.shape[0] > 0)
+
+
+def _gemm_nt(a, w_nk, epi=EPI_BIAS, bias=None, gamma=None, resid=None, out_dtype=torch.bfloat16, z_out=None, z_in=None):
+    """``epilogue(a @ w_nk^T)`` through ``cnx_gemm_nt`` (see include/convnext_hip.h).  ``bias`` / ``gamma`` fp32 [N]."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w_nk.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=out_dtype)
+    z = z_out if z_out is not None else z_in
+    _lib.check(lib.cnx_gemm_nt(a.data_ptr(), a.stride(0), w_nk.data_ptr(), w_nk.stride(0), out.data_ptr(), N, _code(out), M, N, K, epi,
+                               _lib.ptr(bias), _lib.ptr(gamma), _lib.ptr(resid), N, _code(resid) if resid is not None else 0,
+                               _lib.ptr(z_out), _lib.ptr(z_in), z.stride(0) if z is not None else N, _stream()), "cnx_gemm_nt")
+    return out
+
+
+def _bf16(w):
+    return _cached((w,), "bf16", lambda t: t.to(torch.bfloat16).contiguous())
+
+
+def _bf16_t(w):
+    """[out, in] weight -> its transpose [in, out] in bf16: the K-contiguous B operand of an input-gradient GEMM."""
+    return _cached((w,), "bf16_t", lambda t: t.to(torch.bfloat16).t().contiguous())
+
+
 # split-K factor of the weight-gradient GEMMs.  Measured on MI355X (tools/wgrad_bench.py, bmm + partial sum): the optimum puts
 # about one 192 x 192 output tile on every CU, S * N1 * N2 ~ 256 * 192 * 192, over the whole range of shapes of the model
 # (S = 4 for 768 x 3072 at M = 12 544 ... S = 256 for 384 x 96 at M = 802 816); two shapes sit one step below the rule.
@@ -870,6 +922,25 @@ def _gelu_bf16(x):
     return y
 
 
+def _mlp_input_grads(lib, dos, hpre, w1, w2, w1b, w2b, db1, ws, M, C, want_da):
+    """``dHpre = (dO W2) * GELU'(Hpre)`` (+ ``d(b1)`` column sums when ``db1`` is given) and ``da = dHpre W1``: two GEMMs with the
+    GELU' in the first one's epilogue (``cnx_gemm_nt``), or library GEMMs around ``cnx_gelu_bwd_colsum``."""
+    if _gemm_dims_ok(dos, C, 4 * C) and _gemm_dims_ok(hpre, 4 * C, C) and dos.is_contiguous() and hpre.is_contiguous():
+        dhpre = _gemm_nt(dos, _bf16_t(w2), EPI_GELU_GRAD, z_in=hpre)                 # B = W2^T [4C, C]
+        if db1 is not None:                                  # training pass: d(b1) = column sums of dHpre (one read)
+            zeros = torch.empty(4 * C, device=dos.device, dtype=torch.float32)
+            _lib.check(lib.cnx_scale_residual_bwd(dhpre.data_ptr(), _code(dhpre), None, None, None, zeros.data_ptr(), db1.data_ptr(),
+                                                  ws.data_ptr(), M, 4 * C, _stream()), "cnx_scale_residual_bwd(colsum)")
+        da = _gemm_nt(dhpre, _bf16_t(w1), EPI_BIAS) if want_da else None             # B = W1^T [C, 4C]
+        return dhpre, da
+    dh = dos @ w2b                                                               # [M, 4C]
+    dhpre = torch.empty_like(dh)
+    _lib.check(lib.cnx_gelu_bwd_colsum(dh.data_ptr(), hpre.data_ptr(), dhpre.data_ptr(), _lib.ptr(db1), _lib.ptr(ws), M, 4 * C,
+                                       _stream()), "cnx_gelu_bwd_colsum")
+    del dh
+    return dhpre, ((dhpre @ w1b) if want_da else None)
+
+
 class _MlpResidual(torch.autograd.Function):
     """``xs + gamma * fc2(GELU(fc1(h)))`` for the second half of a transformer block (timm ``Block.forward``:
     ``x + ls2(mlp(norm2(x)))``, ``Mlp`` = Linear, GELU, Linear): the two linears are library GEMMs with the bias in their
@@ -888,13 +959,24 @@ class _MlpResidual(torch.autograd.Function):
         b1b = _cached((b1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
         b2b = _cached((b2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
         gf = _f32(gamma) if gamma is not None else None
-        hpre = torch.addmm(b1b, h2, w1b.t())                                     # [M, 4C]
-        hg = _gelu_bf16(hpre)
-        y2 = torch.addmm(b2b, hg, w2b.t())                                       # [M, C] bf16, pre-gamma
-        out = torch.empty(xs.shape, device=xs.device, dtype=torch.float32)
-        _lib.check(lib.cnx_scale_residual(xs.data_ptr(), _code(xs), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out), M, C,
-                                          _stream()), "cnx_scale_residual")
-        ctx.save_for_backward(h2, hpre, hg, y2 if gf is not None else None, w1b, w2b, gf)
+        need_grad = any(ctx.needs_input_grad)
+        if _gemm_ok(h2, w1b) and _gemm_dims_ok(h2, 4 * C, C):
+            # fc1 + bias + GELU and fc2 + bias + layer scale + residual: two kernels, nothing element-wise between or after them
+            hpre = torch.empty(M, 4 * C, device=h.device, dtype=torch.bfloat16) if need_grad else None
+            hg = _gemm_nt(h2, w1b, EPI_BIAS_GELU, bias=_f32(b1), z_out=hpre)
+            y2 = torch.empty(M, C, device=h.device, dtype=torch.bfloat16) if (need_grad and gf is not None) else None
+            out = _gemm_nt(hg, w2b, EPI_SCALE_RES, bias=_f32(b2), gamma=gf, resid=xs.reshape(M, C), out_dtype=torch.float32,
+                           z_out=y2).view(xs.shape)
+        else:
+            hpre = torch.addmm(b1b, h2, w1b.t())                                 # [M, 4C]
+            hg = _gelu_bf16(hpre)
+            y2 = torch.addmm(b2b, hg, w2b.t())                                   # [M, C] bf16, pre-gamma
+            out = torch.empty(xs.shape, device=xs.device, dtype=torch.float32)
+            _lib.check(lib.cnx_scale_residual(xs.data_ptr(), _code(xs), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out), M, C,
+                                              _stream()), "cnx_scale_residual")
+        if need_grad:
+            ctx.save_for_backward(h2, hpre, hg, y2 if gf is not None else None, w1b, w2b, gf)
+            ctx.w1, ctx.w2 = w1, w2
         ctx.M, ctx.C, ctx.xs_dtype, ctx.h_shape = M, C, xs.dtype, h.shape
         return out
 
@@ -923,13 +1005,9 @@ class _MlpResidual(torch.autograd.Function):
             _lib.check(lib.cnx_scale_residual_bwd(g.data_ptr(), _code(g), _lib.ptr(y2) if want_p else None, _lib.ptr(gf), dos.data_ptr(),
                                                   _lib.ptr(dgamma), _lib.ptr(db2), _lib.ptr(ws), M, C, _stream()),
                        "cnx_scale_residual_bwd")
-            dh = dos @ w2b                                                       # [M, 4C]
-            dhpre = torch.empty_like(dh)
-            _lib.check(lib.cnx_gelu_bwd_colsum(dh.data_ptr(), hpre.data_ptr(), dhpre.data_ptr(), _lib.ptr(db1), _lib.ptr(ws), M,
-                                               4 * C, _stream()), "cnx_gelu_bwd_colsum")
-            del dh
-            if nig[1]:
-                dhin = (dhpre @ w1b).view(ctx.h_shape)
+            dhpre, dhin = _mlp_input_grads(lib, dos, hpre, ctx.w1, ctx.w2, w1b, w2b, db1, ws, M, C, nig[1])
+            if dhin is not None:
+                dhin = dhin.view(ctx.h_shape)
             if want_p:
                 dw2 = _wgrad(dos, hg)
                 dw1 = _wgrad(dhpre, h2)
@@ -949,10 +1027,13 @@ class _LinearLib(torch.autograd.Function):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         wb = _cached((w,), "bf16", lambda t: t.to(torch.bfloat16).contiguous())
-        bb = _cached((b,), "bf16", lambda t: t.to(torch.bfloat16).contiguous())
-        y = torch.addmm(bb, x2, wb.t())
+        if _gemm_ok(x2, wb):
+            y = _gemm_nt(x2, wb, EPI_BIAS, bias=_f32(b))
+        else:
+            bb = _cached((b,), "bf16", lambda t: t.to(torch.bfloat16).contiguous())
+            y = torch.addmm(bb, x2, wb.t())
         ctx.save_for_backward(x2, wb)
-        ctx.x_shape = x.shape
+        ctx.x_shape, ctx.w = x.shape, w
         return y.view(x.shape[:-1] + (w.shape[0],))
 
     @staticmethod
@@ -964,7 +1045,12 @@ class _LinearLib(torch.autograd.Function):
         if dy2.dtype != torch.bfloat16 or not dy2.is_contiguous():
             dy2 = dy2.to(torch.bfloat16).contiguous()
         M = dy2.shape[0]
-        dx = (dy2 @ wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _gemm_dims_ok(dy2, N, wb.shape[1]):
+                dx = _gemm_nt(dy2, _bf16_t(ctx.w), EPI_BIAS).view(ctx.x_shape)    # B = W^T [in, out]
+            else:
+                dx = (dy2 @ wb).view(ctx.x_shape)
         dw = db = None
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY:
             dw = _wgrad(dy2, x2)
@@ -1093,15 +1179,24 @@ class _BlockFused(torch.autograd.Function):
             wb_ = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
             b1b = _cached((b1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
             b2b = _cached((b2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-            hpre = torch.addmm(b1b, a, wa.t())                                   # [M, 4C]
-            h = _gelu_bf16(hpre)
-            y2 = torch.addmm(b2b, h, wb_.t())                                    # [M, C] bf16, pre-gamma
-            _lib.check(lib.cnx_scale_residual(x.data_ptr(), _code(x), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out),
-                                              M, C, _stream()), "cnx_scale_residual")
+            if _gemm_ok(a, wa) and _gemm_dims_ok(a, 4 * C, C):
+                # fc1 + bias + GELU (+ Hpre for the backward) and fc2 + bias + gamma + residual: two kernels (cnx_gemm_nt)
+                hpre = torch.empty(M, 4 * C, device=x.device, dtype=torch.bfloat16) if need_grad else None
+                h = _gemm_nt(a, wa, EPI_BIAS_GELU, bias=b1f, z_out=hpre)
+                y2 = torch.empty(M, C, device=x.device, dtype=torch.bfloat16) if need_p else None
+                _lib.check(lib.cnx_gemm_nt(h.data_ptr(), 4 * C, wb_.data_ptr(), 4 * C, out.data_ptr(), C, _code(out), M, C, 4 * C,
+                                           EPI_SCALE_RES, b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), C, _code(x), _lib.ptr(y2), None,
+                                           C, _stream()), "cnx_gemm_nt")
+            else:
+                hpre = torch.addmm(b1b, a, wa.t())                               # [M, 4C]
+                h = _gelu_bf16(hpre)
+                y2 = torch.addmm(b2b, h, wb_.t())                                # [M, C] bf16, pre-gamma
+                _lib.check(lib.cnx_scale_residual(x.data_ptr(), _code(x), y2.data_ptr(), _lib.ptr(gf), out.data_ptr(), _code(out),
+                                                  M, C, _stream()), "cnx_scale_residual")
         if need_grad:
             ctx.fused = fused
             ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, wb_, b1f, gf, y2, a, hpre, h)
-            ctx.has_dw_bias, ctx.eps = dw_b is not None, eps
+            ctx.has_dw_bias, ctx.eps, ctx.w1, ctx.w2 = dw_b is not None, eps, w1, w2
         return out
 
     @staticmethod
@@ -1182,15 +1277,10 @@ class _BlockFused(torch.autograd.Function):
                 db2 = torch.empty(C, device=x.device, dtype=torch.float32)
                 db1 = torch.empty(4 * C, device=x.device, dtype=torch.float32)
                 ws = torch.empty(lib.cnx_colsum_ws_floats(4 * C), device=x.device, dtype=torch.float32)
-            _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2.data_ptr(), _lib.ptr(gf), dos.data_ptr(),
-                                                  _lib.ptr(dgamma), _lib.ptr(db2), _lib.ptr(ws), M, C, _stream()),
+            _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), _lib.ptr(y2) if want_p else None, _lib.ptr(gf),
+                                                  dos.data_ptr(), _lib.ptr(dgamma), _lib.ptr(db2), _lib.ptr(ws), M, C, _stream()),
                        "cnx_scale_residual_bwd")
-            dh = dos @ w2b                                                       # [M, 4C]
-            dhpre = torch.empty_like(dh)
-            _lib.check(lib.cnx_gelu_bwd_colsum(dh.data_ptr(), hpre.data_ptr(), dhpre.data_ptr(), _lib.ptr(db1), _lib.ptr(ws), M,
-                                               4 * C, _stream()), "cnx_gelu_bwd_colsum")
-            del dh
-            da = dhpre @ w1b                                                     # [M, C] bf16
+            dhpre, da = _mlp_input_grads(lib, dos, hpre, ctx.w1, ctx.w2, w1b, w2b, db1, ws, M, C, True)   # da [M, C] bf16
             if want_p:
                 dw2 = _wgrad(dos, h)
                 dw1 = _wgrad(dhpre, a_s)

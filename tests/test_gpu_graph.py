@@ -84,7 +84,8 @@ def test_graph_mode_leaves_error_behaviour_alone(R):
 
 def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R):
     """Six full AT steps (attack + train forward / backward + AdamW + EMA) with adv.graph = 1 and 0 from the same seeds: the same
-    loss trajectory and the same final parameters, bit for bit - the replayed attack reads the parameters the optimizer just wrote."""
+    loss trajectory and the same final parameters (to the run-to-run noise of the library's backward kernels) - the replayed
+    attack reads the parameters the optimizer just wrote."""
     def run(graph):
         R.graphed.reset()
         torch.manual_seed(5)
@@ -103,5 +104,9 @@ def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R):
     l1, p1 = run(1)
     assert R.graphed.STATS["replays"] >= 4
     l0, p0 = run(0)
-    assert l1 == l0, (l1, l0)
-    assert all(torch.equal(a, b) for a, b in zip(p1, p0))
+    # the attack is bit-reproducible (test above), the TRAINING backward is not: the library's convolution filter-gradient kernels
+    # differ in the last bits from run to run (profiles/r02_determinism.log) - compare at that level
+    assert max(abs(a - b) for a, b in zip(l1, l0)) <= 2e-3 * max(abs(v) for v in l0), (l1, l0)
+    num = sum(float((a.float() - b.float()).pow(2).sum()) for a, b in zip(p1, p0))
+    den = sum(float(b.float().pow(2).sum()) for b in p0)
+    assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
