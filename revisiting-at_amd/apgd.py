@@ -40,6 +40,9 @@ USE_SIGN_SINK = True
 # default of apgd_train(graph=None): hipGraph replay of the attack (graphed.py)
 GRAPH_DEFAULT = os.environ.get("APGD_GRAPH", "0") not in ("0", "")
 
+# models whose first backward through the sink showed a second consumer of the attack iterate (see _model_fwd_bwd)
+_SINK_REFUSED = set()
+
 # losses the reference's criterion_dict names (autopgd_train_clean.py:113-114)
 criterion_names = ("ce", "softloss", "dlr", "dlr-targeted")
 
@@ -148,12 +151,23 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
         if dl.shape != logits.shape or dl.dtype != logits.dtype:
             raise _lib.ApgdHipError("dlogits/logits mismatch")
         # the sink is opened for Linf only: the L2 step needs the gradient's values
-        sink = ops.grad_sign_sink(x_in) if (sign_ok and USE_SIGN_SINK) else contextlib.nullcontext()
+        use_sink = sign_ok and USE_SIGN_SINK and id(model) not in _SINK_REFUSED
+        sink = ops.grad_sign_sink(x_in) if use_sink else contextlib.nullcontext()
         with ops.input_grad_only(), sink:
             grad = torch.autograd.grad([logits], [x_in], grad_outputs=[dl.view_as(logits)])[0].detach()
         x_in.requires_grad_(False)
         if getattr(sink, "signs", None) is not None:
-            return sink.signs                                # int8 sign(grad), x_in's shape and (contiguous) layout
+            # The sink handed autograd a stride-0 zero in place of the stem's input gradient.  If that is ALL autograd returns,
+            # the stem convolution was the only consumer of the iterate and its signs are the gradient's signs.  Anything else
+            # (a dense tensor: autograd summed a second path from the raw input - an input skip, an ensemble sharing x) means
+            # the signs are not the whole story: this model is taken off the sink and the call repeated on the fp32 path.
+            if all(st == 0 for st in grad.stride()) or grad.numel() == 0:
+                return sink.signs                            # int8 sign(grad), x_in's shape and (contiguous) layout
+            import warnings
+            warnings.warn("the attack iterate feeds more than the ConvStem's first convolution: gradient-sign sink disabled for "
+                          "this model (fp32 input gradient through autograd)")
+            _SINK_REFUSED.add(id(model))
+            return _model_fwd_bwd(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, False)
         if grad.stride() != x_in.stride():
             g2 = torch.empty_like(x_in, dtype=grad.dtype)
             g2.copy_(grad)

@@ -69,7 +69,10 @@ def apgd_l1(model, x, y, eps, n_iter, soft, is_train, verbose, fwd_bwd, ApgdWork
         raise _lib.ApgdHipError(f"attack state is fp32 (got {x.dtype})")
     lib = _lib.load()
     n_iter = int(n_iter)
-    x = x.detach().contiguous()                                       # the reference's L1 branch is NCHW-contiguous only (:240)
+    # the L1 branch works on NCHW-contiguous iterates (the reference's own :240 reshapes them); a channels_last input gets its
+    # results back in its own memory format, as apgd_train promises
+    cl = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+    x = x.detach().contiguous()
     B = x.shape[0]
     E = x[0].numel() if B > 0 else 0
     stream = stream_ptr()
@@ -104,7 +107,8 @@ def apgd_l1(model, x, y, eps, n_iter, soft, is_train, verbose, fwd_bwd, ApgdWork
                                          ws.loss_steps.data_ptr(), ws.flags.data_ptr(), B, max(n_iter, 1), i, 0, 1, 0.75, stream),
                    "apgd_state_update")
         _lib.check(lib.apgd_track_rows(ws.flags.data_ptr(), cur.data_ptr(), grad.data_ptr(), ws.x_best.data_ptr(), grad_best.data_ptr(),
-                                       ws.x_best_adv.data_ptr(), grad.element_size(), B, E, 0, stream), "apgd_track_rows")
+                                       ws.x_best_adv.data_ptr(), grad.element_size(), B, E, int(last), stream),
+                   "apgd_track_rows")                                  # (final: the dead grad_best copy of the last iteration is skipped)
         counter3 += 1
         if counter3 == k:                                              # :351-362: adapt the sparsity
             sp_curr = (ws.x_best != x).view(B, -1).sum(1).to(torch.float32)
@@ -120,4 +124,7 @@ def apgd_l1(model, x, y, eps, n_iter, soft, is_train, verbose, fwd_bwd, ApgdWork
         if verbose:
             print('iteration: {} - best loss: {:.6f} - robust accuracy: {:.2%} - step size: {:.5f} - topk: {:.2f}'.format(
                 i, ws.loss_best.sum().item(), ws.acc.float().mean().item(), step_size.mean().item(), (topk.mean() * E).item()))
-    return ws.x_best, ws.acc.view(torch.bool), ws.loss_best, ws.x_best_adv
+    xb, xba = ws.x_best, ws.x_best_adv
+    if cl:
+        xb, xba = xb.contiguous(memory_format=torch.channels_last), xba.contiguous(memory_format=torch.channels_last)
+    return xb, ws.acc.view(torch.bool), ws.loss_best, xba

@@ -559,10 +559,13 @@ __device__ __forceinline__ void copy_bytes(void* __restrict__ dst, const void* _
     const uint4* s = static_cast<const uint4*>(src); uint4* d = static_cast<uint4*>(dst);
     const int64_t n = nbytes >> 4;
     for (int64_t v = first; v < n; v += stride) d[v] = s[v];
-  } else {
+  } else if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | static_cast<uintptr_t>(nbytes)) & 1) == 0) {
     const uint16_t* s = static_cast<const uint16_t*>(src); uint16_t* d = static_cast<uint16_t*>(dst);
     const int64_t n = nbytes >> 1;
     for (int64_t v = first; v < n; v += stride) d[v] = s[v];
+  } else {                                // int8 sign rows of odd length (E odd): rows start on odd addresses, copy bytes
+    const uint8_t* s = static_cast<const uint8_t*>(src); uint8_t* d = static_cast<uint8_t*>(dst);
+    for (int64_t v = first; v < nbytes; v += stride) d[v] = s[v];
   }
 }
 

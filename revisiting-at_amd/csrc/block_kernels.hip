@@ -259,7 +259,8 @@ struct Geo {
 #define BLK_FWD96_DEPTH 3
 #endif
   static constexpr int DEPTH = (C <= 96) ? BLK_FWD96_DEPTH : 3;   // ring slots (DEPTH - 1 slices in flight ahead of the one being read)
-  static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 24 * C;   // + b1 (4C), b2 (C), gamma (C) fp32
+  static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 32 * C;   // + b1 (4C), b2 (C), gamma (C), ln_w (C), ln_b (C) fp32
+  static_assert(FWD_LDS <= 160 * 1024, "ring + constants must fit the CU's LDS");
   static constexpr int BM = 128;                    // rows per workgroup
   // PIPE: the hidden loop is software-pipelined inside every wavefront - GEMM1 of hidden block t runs while the (unpacked) GELU
   // of block t-1 is evaluated - and the packed weights carry one more slice: slice t = [W1(t) | W2(t-1)], t = 0..NHB.
@@ -355,13 +356,18 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     const int steps = ((blockIdx.x >> 8) & 3) * (p.dbg >> 8);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
   }
-#pragma unroll
-  for (int s0 = 0; s0 < G::DEPTH - 1; ++s0) DMA_SLICE(s0)
-
+  // ---- prologue order (round 3): the per-channel constants go to LDS and this lane's half row of u into registers FIRST, the
+  //      weight DMA of the first two slices is issued behind them.  The DMA loads are inline asm the compiler does not count:
+  //      any wait it inserts for one of ITS loads issued after them also waits for them (in-order return) - round 2 issued the
+  //      96 KB of DMA first and every wavefront sat in `vmcnt(3)` for its u row until both slices had landed, then fetched the
+  //      LayerNorm weights from global memory in C/64 rounds of eight loads and a vmcnt(0) each (13.6 us of a 95 us workgroup at
+  //      C = 384, tools/blk_trace.py).
   for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
-  for (int i = tid; i < C; i += 256) {                                  // epilogue constants: b2, gamma (1 when absent)
+  for (int i = tid; i < C; i += 256) {                                  // b2, gamma (1 when absent), LayerNorm weight / bias
     b1s[4 * C + i] = p.b2[i];
     b1s[5 * C + i] = p.gamma ? p.gamma[i] : 1.0f;
+    b1s[6 * C + i] = p.ln_w ? p.ln_w[i] : 1.0f;
+    b1s[7 * C + i] = p.ln_w ? p.ln_b[i] : 0.0f;
   }
 
   // ---- this lane's half row of u  ->  (LayerNorm)  ->  GEMM1 B-operand fragments
@@ -374,6 +380,12 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) raw[ks] = up[ks];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)                                  // the row is in registers before the DMA is issued
+      asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+#pragma unroll
+    for (int s0 = 0; s0 < G::DEPTH - 1; ++s0) DMA_SLICE(s0)
+    __syncthreads();                                                    // constants visible (LDS only: the DMA is not waited for)
     if (p.ln_w) {
       float s = 0.f;
 #pragma unroll
@@ -398,8 +410,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       ss += __shfl_xor(ss, 32, 64);
       const float rstd = rsqrtf(ss * (1.0f / C) + p.eps);
       if (p.mean && half == 0 && row_ok) { p.mean[row] = mean; p.rstd[row] = rstd; }
-      const float4* lw = reinterpret_cast<const float4*>(p.ln_w + half * (C / 2));
-      const float4* lb = reinterpret_cast<const float4*>(p.ln_b + half * (C / 2));
+      const float4* lw = reinterpret_cast<const float4*>(b1s + 6 * C + half * (C / 2));     // LDS: a half-wave reads one address
+      const float4* lb = reinterpret_cast<const float4*>(b1s + 7 * C + half * (C / 2));
 #pragma unroll
       for (int ks = 0; ks < G::KS; ++ks) {
         const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
@@ -417,10 +429,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       }
     } else {
 #pragma unroll
-      for (int ks = 0; ks < G::KS; ++ks) {
-        asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));   // opaque: never re-loaded in the loop
-        af[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
-      }
+      for (int ks = 0; ks < G::KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
     }
   }
 

@@ -77,10 +77,9 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
 }
 
 // one global_load_lds_dwordx4: 64 lanes x 16 bytes -> 1 KiB of LDS at the wave-uniform address `dst` (see block_kernels.hip glds16)
+// (M0 is set and left: nothing else in this kernel uses it)
 __device__ __forceinline__ void glds16(const unsigned char* gsrc, uint32_t dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "memory");
 }
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RES = 2, EPI_GELU_GRAD = 3 };
@@ -174,17 +173,33 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
 
   const int nt = p.K / BK;
   STAGE_LOAD(0)
+  // one K step = 4 k-steps of 6 MFMAs; the 5 fragments of k-step ks + 1 are read while the MFMAs of k-step ks run (two register
+  // sets, the order pinned: MFMA, read, MFMA, read, ...) - left to itself the compiler issued each k-step's reads right in
+  // front of its first MFMA and the LDS latency (~130 cycles) was exposed four times per K step
+#define FRAG_READ(AF, BF, KS)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) AF[i] = *reinterpret_cast<const bf16x8*>(sb_ + a_base + i * 4096 + foff[KS]); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) BF[j] = *reinterpret_cast<const bf16x8*>(sb_ + b_base + j * 4096 + foff[KS]);
+#define KSTEP(AF, BF, AN, BN_, KS)                                                                             \
+    if ((KS) < 3) { FRAG_READ(AN, BN_, ((KS) < 3 ? (KS) + 1 : 3)) }                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                            \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i], BF[j], acc[i][j], 0, 0, 0);                 \
+    if ((KS) < 3) {                                                                                            \
+      _Pragma("unroll") for (int q_ = 0; q_ < 5; ++q_) {                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                     \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+    }
 #define COMPUTE(T)                                                                                             \
   {                                                                                                            \
     const unsigned char* sb_ = lds + ((T) & 1) * G::STAGE;                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                         \
-      bf16x8 af_[2], bf_[3];                                                                                   \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) af_[i] = *reinterpret_cast<const bf16x8*>(sb_ + a_base + i * 4096 + foff[ks]); \
-      _Pragma("unroll") for (int j = 0; j < 3; ++j) bf_[j] = *reinterpret_cast<const bf16x8*>(sb_ + b_base + j * 4096 + foff[ks]); \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                          \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_[i], bf_[j], acc[i][j], 0, 0, 0);             \
-    }                                                                                                          \
+    bf16x8 fa0[2], fb0[3], fa1[2], fb1[3];                                                                     \
+    FRAG_READ(fa0, fb0, 0)                                                                                     \
+    KSTEP(fa0, fb0, fa1, fb1, 0)                                                                               \
+    KSTEP(fa1, fb1, fa0, fb0, 1)                                                                               \
+    KSTEP(fa0, fb0, fa1, fb1, 2)                                                                               \
+    KSTEP(fa1, fb1, fa0, fb0, 3)                                                                               \
   }
   for (int t = 0; t + 1 < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // stage t has landed (this wavefront's pieces)
@@ -196,6 +211,8 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   __builtin_amdgcn_s_barrier();
   COMPUTE(nt - 1)
 #undef COMPUTE
+#undef KSTEP
+#undef FRAG_READ
 #undef STAGE_LOAD
   __syncthreads();                                                          // the ring is dead: epilogue scratch
 

@@ -169,6 +169,24 @@ def test_track_rows_moves_int8_sign_rows(lib):
         assert torch.equal(xa[b], xb0[b] if rs else xa0[b])
 
 
+def test_track_rows_moves_int8_sign_rows_of_odd_length(lib):
+    """grad_elt = 1 with an odd row length (E = 3*5*5): every second row starts on an odd address - the copy must be byte
+    exact, last byte of each row included (round-2 advice: the 2-byte fallback dropped it)."""
+    B, E = 5, 3 * 5 * 5
+    g = torch.Generator(device="cuda").manual_seed(4)
+    flags = torch.tensor([1, 4, 5, 0, 1], device="cuda", dtype=torch.uint8)
+    xa, xb, xba = (torch.rand(B, E, device="cuda", generator=g) for _ in range(3))
+    gr = torch.randint(-1, 2, (B, E), device="cuda", generator=g, dtype=torch.int8)
+    gb = torch.randint(-1, 2, (B, E), device="cuda", generator=g, dtype=torch.int8)
+    gr0, gb0 = gr.clone(), gb.clone()
+    assert lib.apgd_track_rows(flags.data_ptr(), xa.data_ptr(), gr.data_ptr(), xb.data_ptr(), gb.data_ptr(), xba.data_ptr(), 1, B, E,
+                               0, S()) == 0
+    for b, f in enumerate(flags.tolist()):
+        nb, rs = bool(f & 1), bool(f & 4) and not bool(f & 1)
+        assert torch.equal(gb[b], gr0[b] if nb else gb0[b]), b
+        assert torch.equal(gr[b], gb0[b] if rs else gr0[b]), b
+
+
 def test_linf_step_unaligned_rows(lib):
     eps, B, E = 8 / 255, 3, 64
     x, xa, xo, g, step = _step_inputs(B, E + 1, 5, eps)

@@ -404,3 +404,112 @@ def test_pos_embed_interpolation_on_device_matches_reference_fixture(R):
     for res in (320, 256):
         got = R.architecture.interpolate_pos_encoding(pe, res, old_img_size=224, patch_size=16)
         np.testing.assert_allclose(got.cpu().numpy(), d[f"out_{res}"], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ cfg #5, assembled
+def test_cfg5_standard_evaluation_on_convnext_base_replays_through_the_oracle(R, monkeypatch):
+    """BASELINE config #5 as ``AA_eval.py:226-239`` drives it: ``run_standard_evaluation`` (APGD-CE, then APGD-T on what is still
+    robust) on the ConvNeXt-B-CvSt PRODUCT model in fp32, 100 iterations, 2 target classes, 8 images at 224x224.  Every attack run
+    of the evaluation is recorded (start point, logits, sign of the input gradient per model call) and replayed through the pinned
+    numpy oracle: iterates, ``acc`` and ``loss_best`` must come out bit for bit, and the evaluation's bookkeeping (who is still
+    robust, which adversarial is kept, the counts) must be what the oracle's results imply."""
+    from revisiting_at_amd import aa_eval as AE
+    torch.manual_seed(0)
+    model = randomize(R.get_new_model("convnext_base", pretrained=False, not_original=True), 0)
+    model = model.cuda().to(memory_format=torch.channels_last).eval()
+    n, K, eps = 8, 100, EPS
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(n, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        y = model(x.cuda()).argmax(1).cpu()
+    y[5] = (y[5] + 1) % 1000                                               # one clean error: never attacked
+
+    calls = []
+    orig_attack, orig_rs = AE.apgd_attack, AE.random_start
+
+    def rs(xx, e, norm="Linf", generator=None):
+        out = orig_rs(xx, e, norm, generator)
+        calls[-1]["x_init"] = out.detach().cpu().numpy()
+        return out
+
+    def attack(m, xi, yi, norm, e, n_iter, loss, yt, use_rs, gen):
+        rec = {"x": xi.cpu().numpy(), "y": yi.cpu().numpy(), "loss": loss, "yt": None if yt is None else yt.cpu().numpy(),
+               "logits": [], "signs": []}
+        calls.append(rec)
+
+        class Tap(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.view_as(t)
+
+            @staticmethod
+            def backward(ctx, gr):
+                rec["signs"].append(torch.sign(gr).to(torch.int8).cpu().numpy())   # all the Linf update reads (:221)
+                return gr
+
+        class Rec(torch.nn.Module):
+            def forward(self, t):
+                o = m(Tap.apply(t) if t.requires_grad else t)
+                rec["logits"].append(o.detach().float().cpu().numpy())
+                return o
+        out = orig_attack(Rec().eval(), xi, yi, norm, e, n_iter, loss, yt, use_rs, gen)
+        rec["out"] = [t.cpu().numpy() for t in out]                          # x_best_adv, acc, loss_best, x_best
+        return out
+
+    # per-sample losses as the device computed them: at 100 iterations the iterates oscillate and their losses tie to the last
+    # bits, where two correct cross-entropy implementations order them differently (DESIGN.md section 2, "a note on ties") - the
+    # oracle is driven by the device's own losses, as in the bit-exact golden tests
+    orig_lp = R.apgd._loss_pred
+
+    def loss_pred(logits, y_hard, y_soft, loss_out, pred_out, want_dl, kind=0, *a):
+        dl = orig_lp(logits, y_hard, y_soft, loss_out, pred_out, want_dl, kind, *a)
+        calls[-1].setdefault("losses", []).append(loss_out.clone())
+        return dl
+
+    monkeypatch.setattr(R.apgd, "_loss_pred", loss_pred)
+    monkeypatch.setattr(AE, "apgd_attack", attack)
+    monkeypatch.setattr(AE, "random_start", rs)
+    monkeypatch.setattr(R.apgd, "USE_SIGN_SINK", False)                      # fp32 gradients through autograd: the tap sees them
+    x_adv, st = AE.run_standard_evaluation(model, x, y, bs=8, eps=eps, n_iter=K, n_target_classes=2, seed=3, device="cuda")
+    torch.cuda.synchronize()
+    assert [c["loss"] for c in calls][:1] == ["ce"] and 1 <= len(calls) <= 3
+    assert all(c["loss"] == "dlr-targeted" for c in calls[1:])
+
+    class Replay:
+        def __init__(self, c):
+            self.c, self.n = c, 0
+
+        def __call__(self, x_adv_np, need_grad):
+            i = self.n
+            self.n += 1
+            gsign = self.c["signs"][i].astype(np.float32) if need_grad else None
+            return self.c["logits"][i], gsign, self.c["losses"][i].cpu().numpy()
+
+    # the evaluation's bookkeeping, re-derived from the oracle's results
+    with torch.no_grad():
+        clean_logits = model(x.cuda()).float().cpu()
+    robust = (clean_logits.argmax(1) == y).numpy()
+    assert st["clean_correct"] == int(robust.sum()) == n - 1
+    want_adv = x.numpy().copy()
+    order = clean_logits.argsort(dim=1, descending=True).numpy()
+    for ci, c in enumerate(calls):
+        idx = np.nonzero(robust)[0]
+        assert np.array_equal(c["x"], x.numpy()[idx]) and np.array_equal(c["y"], y.numpy()[idx])
+        if c["loss"] == "dlr-targeted":
+            assert np.array_equal(c["yt"], order[idx, ci])                   # ci = 1, 2 -> the 2nd / 3rd most likely class
+        assert len(c["logits"]) == K + 1 and len(c["signs"]) == K
+        assert len(c["losses"]) == K + 1
+        oxb, oacc, olb, oxba, _ = O.apgd_train_oracle(Replay(c), c["x"], c["y"], "Linf", eps, K, loss=c["loss"], y_target=c["yt"],
+                                                      x_init=c["x_init"], use_model_loss=True)
+        xba, acc, lb, xb = c["out"]
+        assert np.array_equal(xb, oxb) and np.array_equal(xba, oxba), f"attack {ci}: iterates differ from the oracle replay"
+        assert np.array_equal(acc, oacc), f"attack {ci}"
+        np.testing.assert_allclose(lb, olb, rtol=1e-5, atol=3e-7)
+        assert float(np.abs(oxba - c["x"]).max()) <= eps * (1 + 1e-6) + 1e-7
+        broken = ~oacc
+        want_adv[idx[broken]] = oxba[broken]
+        robust[idx[broken]] = False
+    assert st["robust"] == int(robust.sum()) and st["n"] == n
+    assert np.array_equal(x_adv.numpy(), want_adv)
+    assert np.array_equal(x_adv.numpy()[5], x.numpy()[5])                    # the clean error was never touched
+    note("cfg5_assembled", attacks=len(calls), robust=int(robust.sum()), clean_correct=int(st["clean_correct"]))

@@ -110,3 +110,37 @@ def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R):
     num = sum(float((a.float() - b.float()).pow(2).sum()) for a, b in zip(p1, p0))
     den = sum(float(b.float().pow(2).sum()) for b in p0)
     assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+
+
+def test_sign_sink_steps_aside_when_the_iterate_has_a_second_consumer(R):
+    """Round-2 advice: the int8 gradient-sign sink assumed the stem convolution is the ONLY consumer of the attack iterate.  A
+    model with an input skip gets the fp32 gradient instead (detected on the first backward, which is repeated), and its attack
+    equals the attack with the sink switched off."""
+    import warnings
+    base = small_convnext(R, 3)
+
+    class WithSkip(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+            self.skip = torch.nn.Linear(3, 10).cuda()
+
+        def forward(self, x):
+            return self.m(x) + self.skip(x.mean((2, 3)))
+
+    model = WithSkip(base).eval()
+    x = torch.rand(4, 3, 64, 64, device="cuda")
+    y = torch.randint(0, 10, (4,), device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2)
+        assert any("sink disabled" in str(m.message) for m in w)
+        assert id(model) in R.apgd._SINK_REFUSED
+        saved = R.apgd.USE_SIGN_SINK
+        try:
+            R.apgd.USE_SIGN_SINK = False
+            want = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2)
+        finally:
+            R.apgd.USE_SIGN_SINK = saved
+    assert same(got, want)
