@@ -446,14 +446,16 @@ def main():
             return None
         avg_ms = sum(t for t, _ in ev) / len(ev)
         gbytes = ev[0][1]
+        blk = gbytes == 1 and R.ops.SIGN_BLOCKED and (3 * args.res * args.res) % 1024 == 0    # the stem's blocked sign order
         moved_bpe = alg_bpe - 4 + gbytes
         ach = alg_bpe * n_elem / (avg_ms * 1e-3) / 1e9
-        tr = traffic_tab.get(f"{form}_{'i8' if gbytes == 1 else 'f32'}", {})
+        tr = traffic_tab.get(f"{form}_{('i8blk' if blk else 'i8') if gbytes == 1 else 'f32'}", {})
         traffic = tr.get("hbm_bytes_per_launch") if n_elem * alg_bpe == tr.get("algorithmic_bytes_per_launch") else None
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": ("linf_step_vec4_kernel" if form == "general" else "linf_step_first_vec4_kernel")
-                          + f" (apgd_linf_step_f32, {'int8 sign' if gbytes == 1 else 'fp32'} gradient)",
+                "kernel": (("linf_step_i8blk_kernel<false>" if form == "general" else "linf_step_i8blk_kernel<true>") if blk else
+                           ("linf_step_vec4_kernel" if form == "general" else "linf_step_first_vec4_kernel"))
+                          + f" (apgd_linf_step_f32, {('blocked int8 sign' if blk else 'int8 sign') if gbytes == 1 else 'fp32'} gradient)",
                 "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bpe * n_elem,
                 "bytes_moved": moved_bpe * n_elem, "moved_GBs": round(moved_bpe * n_elem / (avg_ms * 1e-3) / 1e9, 1),
                 # the PHYSICAL reading: bytes the kernel is designed to move (= the PMC traffic) / time / 8 TB/s
@@ -467,7 +469,7 @@ def main():
         roof["first_iter"] = first
 
     extra = {"host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3), "package_power": power_stats,
-             "attack_graph": dict(R.graphed.STATS, enabled=bool(args.graph))}
+             "attack_graph": dict(R.graphed.STATS, enabled=bool(args.graph)), "gemm_mode": R.ops._GEMM_MODE}
     if args.attack_only or True:
         # attack-only throughput (same tensors, eval mode), a few repetitions
         base = trainer.inner.base_model

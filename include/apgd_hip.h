@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define APGD_HIP_VERSION 10400 /* major*10000 + minor*100 + patch */
+#define APGD_HIP_VERSION 10500 /* major*10000 + minor*100 + patch */
 
 #define APGD_OK 0
 #define APGD_ERR_NULL (-1)    /* required pointer is NULL */
@@ -44,6 +44,11 @@ extern "C" {
 #define APGD_BF16 1
 #define APGD_F16 2
 #define APGD_I8 3 /* gradient SIGNS {-1, 0, +1} as int8: all the Linf step uses of the gradient (autopgd_train_clean.py:221) */
+/* the same signs in BLOCKED order (apgd_linf_step_f32 only; E % 1024 == 0): inside every group of 1024 elements of a sample,
+ * element g*1024 + (u*64 + l)*4 + j (u < 4, l < 64, j < 4) is stored at byte g*1024 + l*16 + u*4 + j - a lane of the update
+ * kernel reads the signs of its four float4 chunks with one 16-byte load (cnx_stem_conv_dgrad_sign_blk writes this order;
+ * apgd_track_rows moves whole rows and does not care) */
+#define APGD_I8_BLK 4
 
 /* bits of the per-sample flag byte produced by apgd_state_update */
 #define APGD_FLAG_NEW_BEST 1u  /* loss_indiv > loss_best          (autopgd_train_clean.py:321)      */

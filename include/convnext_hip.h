@@ -100,6 +100,11 @@ int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx,
  * sign is taken of the same fp32 accumulator cnx_stem_conv_dgrad stores: identical decisions. */
 int cnx_stem_conv_dgrad_sign(const void* dy, const void* wq, int8_t* sign_out,
                              int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
+/* The same signs in the BLOCKED order apgd_linf_step_f32(grad_dtype = APGD_I8_BLK) reads (apgd_hip.h): inside every group of
+ * 1024 elements of a sample, element g*1024 + (u*64 + l)*4 + j (u < 4, l < 64, j < 4) is stored at byte g*1024 + l*16 + u*4 + j,
+ * so that a lane of the update kernel finds the signs of its four float4 chunks in ONE 16-byte load.  Needs 3*H*W % 1024 == 0. */
+int cnx_stem_conv_dgrad_sign_blk(const void* dy, const void* wq, int8_t* sign_out,
+                                 int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
 
 /* Element-wise tails of the MLP for widths that run their GEMMs in the library (models/convnext.py:44-49 and their
  * backward), one pass each, per-channel parameter gradients accumulated on the way (deterministic two-stage sums;

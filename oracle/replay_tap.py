@@ -45,7 +45,9 @@ def record_attack(R, model, x, y, norm, eps, K, autocast=True, sink=False, **kw)
     orig_exit = cls.__exit__
 
     def exit_and_record(self, *exc):
-        src = self.signs if self.signs is not None else last.get("g")
+        # (the product may hand the update kernel its signs in a blocked order - include/apgd_hip.h APGD_I8_BLK; the oracle reads
+        #  element order)
+        src = R.ops.signs_to_linear(self.signs) if self.signs is not None else last.get("g")
         rec["grads"].append(src.detach().float().cpu().numpy().reshape(tuple(self.x_in.shape)))
         rec.setdefault("sink_used", []).append(self.signs is not None)
         return orig_exit(self, *exc)

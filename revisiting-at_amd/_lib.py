@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libapgd_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
-F32, BF16, F16, I8 = 0, 1, 2, 3
+F32, BF16, F16, I8, I8_BLK = 0, 1, 2, 3, 4
 FLAG_NEW_BEST, FLAG_MISCLS, FLAG_HALVE = 1, 2, 4
 
 _p, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "cnx_stem_conv_ln_gelu_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_dgrad": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_dgrad_sign": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_stem_conv_dgrad_sign_blk": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_colsum_ws_floats": (C.c_int64, [_i32]),
     "cnx_sum_parts_bf16": (C.c_int, [_p, _p, _i64, _i64, _p]),
     "cnx_scale_residual": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int, _i64, _i32, _p]),

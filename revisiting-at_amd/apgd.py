@@ -137,7 +137,7 @@ class ApgdWorkspace:
 
 
 def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace, loss_out, pred_out,
-                   need_grad: bool, kind: int = 0, y_target=None, sign_ok: bool = False):
+                   need_grad: bool, kind: int = 0, y_target=None, sign_ok: bool = False, sign_blocked: bool = False):
     """One model call of the attack: forward, K2, and (optionally) the input gradient.
 
     ``autopgd_train_clean.py:174-192`` (first call) and ``:266-287`` (in-loop calls; the last
@@ -152,7 +152,7 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
             raise _lib.ApgdHipError("dlogits/logits mismatch")
         # the sink is opened for Linf only: the L2 step needs the gradient's values
         use_sink = sign_ok and USE_SIGN_SINK and id(model) not in _SINK_REFUSED
-        sink = ops.grad_sign_sink(x_in) if use_sink else contextlib.nullcontext()
+        sink = ops.grad_sign_sink(x_in, blocked=sign_blocked) if use_sink else contextlib.nullcontext()
         with ops.input_grad_only(), sink:
             grad = torch.autograd.grad([logits], [x_in], grad_outputs=[dl.view_as(logits)])[0].detach()
         x_in.requires_grad_(False)
@@ -167,7 +167,7 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
             warnings.warn("the attack iterate feeds more than the ConvStem's first convolution: gradient-sign sink disabled for "
                           "this model (fp32 input gradient through autograd)")
             _SINK_REFUSED.add(id(model))
-            return _model_fwd_bwd(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, False)
+            return _model_fwd_bwd(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, False, False)
         if grad.stride() != x_in.stride():
             g2 = torch.empty_like(x_in, dtype=grad.dtype)
             g2.copy_(grad)
@@ -271,7 +271,7 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
 
     # first forward/backward: acc, loss_best are written directly by the loss kernel (:194-200)
     sign_ok = norm == 'Linf'
-    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok)
+    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok, sign_ok)
     grad_best = torch.empty_like(grad)                                       # :189
     grad_best.copy_(grad)
     ws.loss_best_last.copy_(ws.loss_best)                                    # :200
@@ -287,9 +287,10 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
                 if PROFILE_EVENTS is not None:
                     ev0 = torch.cuda.Event(enable_timing=True)
                     ev0.record()
-                _lib.check(lib.apgd_linf_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(),
-                                                  _lib.dtype_code(grad.dtype), step_size.data_ptr(), out.data_ptr(), None, B, E,
-                                                  eps, a, _stream_ptr()), "apgd_linf_step_f32")   # :214-226
+                g_code = _lib.I8_BLK if getattr(grad, "apgd_blocked", False) else _lib.dtype_code(grad.dtype)
+                _lib.check(lib.apgd_linf_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
+                                                  step_size.data_ptr(), out.data_ptr(), None, B, E, eps, a, _stream_ptr()),
+                           "apgd_linf_step_f32")                             # :214-226
                 if PROFILE_EVENTS is not None:
                     ev1 = torch.cuda.Event(enable_timing=True)
                     ev1.record()
@@ -307,10 +308,12 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
         old, cur = cur, out                                                  # :215, 260 (buffer rotation)
 
         last = i == n_iter - 1
-        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind, y_target, sign_ok)   # :266-287
+        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind, y_target, sign_ok, sign_ok)   # :266-287
         if g_new is not None:
             if g_new.dtype != grad_best.dtype:               # a model that switches gradient form mid-attack
                 g_new = torch.sign(g_new).to(grad_best.dtype) if grad_best.dtype == torch.int8 else g_new.to(grad_best.dtype)
+                if getattr(grad, "apgd_blocked", False):     # grad_best rows are in blocked order: so must be the new gradient
+                    g_new = ops.signs_to_blocked(g_new)
             grad = g_new
 
         do_check = i in sched                                                # :329

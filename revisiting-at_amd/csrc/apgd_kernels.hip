@@ -258,6 +258,47 @@ __global__ __launch_bounds__(kBlock) void linf_step_vec4_kernel(
   }
 }
 
+// Blocked int8 signs (APGD_I8_BLK; E % 1024 == 0).  A wavefront owns one group of 1024 elements of a sample = 256 float4 chunks:
+// lane l takes chunks u*64 + l (u = 0..3), so every fp32 load / store is one fully coalesced KiB per wavefront, and finds the
+// signs of all four chunks in ONE 16-byte load at byte l*16 of the group (the order cnx_stem_conv_dgrad_sign_blk writes) - a
+// KiB per wavefront instead of four 256-byte requests.  FIRST: iteration 0 (x_adv_old is x_adv, a = 1: linf_elem_first).
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void linf_step_i8blk_kernel(
+    const float* __restrict__ x, const float* __restrict__ xa, const float* __restrict__ xo, const int8_t* __restrict__ g,
+    const float* __restrict__ step, float* __restrict__ out, int64_t E, float eps, float a, float oma) {
+  const int64_t b = blockIdx.y;
+  const float st = step[b];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t grp = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x / kWave);
+  if (grp >= (E >> 10)) return;
+  const int64_t row = b * E + (grp << 10);
+  const uint4 sg = *reinterpret_cast<const uint4*>(g + row + lane * 16);
+  const uint32_t sw[4] = {sg.x, sg.y, sg.z, sg.w};
+  float4 X[4], A[4], O[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t v = ((row >> 2) + u * 64 + lane);
+    X[u] = ld4(x, v, false);
+    A[u] = ld4(xa, v, false);
+    if (!FIRST) O[u] = ld4(xo, v, false);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t t = sw[u];
+    const float g0 = static_cast<float>(static_cast<int8_t>(t & 0xffu)), g1 = static_cast<float>(static_cast<int8_t>((t >> 8) & 0xffu));
+    const float g2 = static_cast<float>(static_cast<int8_t>((t >> 16) & 0xffu)), g3 = static_cast<float>(static_cast<int8_t>(t >> 24));
+    float4 r;
+    if (FIRST) {
+      r.x = linf_elem_first(X[u].x, A[u].x, g0, st, eps); r.y = linf_elem_first(X[u].y, A[u].y, g1, st, eps);
+      r.z = linf_elem_first(X[u].z, A[u].z, g2, st, eps); r.w = linf_elem_first(X[u].w, A[u].w, g3, st, eps);
+    } else {
+      r.x = linf_elem(X[u].x, A[u].x, O[u].x, g0, st, eps, a, oma); r.y = linf_elem(X[u].y, A[u].y, O[u].y, g1, st, eps, a, oma);
+      r.z = linf_elem(X[u].z, A[u].z, O[u].z, g2, st, eps, a, oma); r.w = linf_elem(X[u].w, A[u].w, O[u].w, g3, st, eps, a, oma);
+    }
+    st4(out, (row >> 2) + u * 64 + lane, r, false);
+  }
+}
+
 // scalar fallback for rows that are not 16-byte tileable (E % 4 != 0 or unaligned views)
 template <typename GT>
 __global__ __launch_bounds__(kBlock) void linf_step_scalar_kernel(
@@ -733,10 +774,23 @@ int apgd_linf_step_f32_ex(const float* x, const float* x_adv, const float* x_adv
   if (B < 0 || E < 0) return APGD_ERR_SIZE;
   if (B == 0 || E == 0) return APGD_OK;
   if (!x || !x_adv || !x_adv_old || !grad || !step_size || !out) return APGD_ERR_NULL;
-  if (grad_dtype != APGD_F32 && grad_dtype != APGD_BF16 && grad_dtype != APGD_I8) return APGD_ERR_DTYPE;
+  if (grad_dtype != APGD_F32 && grad_dtype != APGD_BF16 && grad_dtype != APGD_I8 && grad_dtype != APGD_I8_BLK) return APGD_ERR_DTYPE;
   if (B > 65535) return APGD_ERR_SIZE;
   if (out == x || out == x_adv || out == x_adv_old || out == grad) return APGD_ERR_ARG;
   hipStream_t s = as_stream(stream);
+  if (grad_dtype == APGD_I8_BLK) {
+    // blocked signs: whole 1024-element groups, 16-byte aligned streams, no bf16 copy of the result
+    if (E % 1024 != 0 || out_bf16 || !(aligned16(x) && aligned16(x_adv) && aligned16(x_adv_old) && aligned16(out) && aligned16(grad)))
+      return APGD_ERR_ARG;
+    const dim3 grid(static_cast<unsigned>(((E >> 10) + kBlock / kWave - 1) / (kBlock / kWave)), static_cast<unsigned>(B));
+    const float oma = static_cast<float>(1.0 - static_cast<double>(a));
+    const auto* gs = static_cast<const int8_t*>(grad);
+    if (x_adv_old == x_adv && a == 1.0f)
+      hipLaunchKernelGGL(linf_step_i8blk_kernel<true>, grid, dim3(kBlock), 0, s, x, x_adv, x_adv_old, gs, step_size, out, E, eps, a, oma);
+    else
+      hipLaunchKernelGGL(linf_step_i8blk_kernel<false>, grid, dim3(kBlock), 0, s, x, x_adv, x_adv_old, gs, step_size, out, E, eps, a, oma);
+    return launch_status();
+  }
   const int galign = grad_dtype == APGD_F32 ? 16 : (grad_dtype == APGD_BF16 ? 8 : 4);
   const bool vec = (E % 4 == 0) && aligned16(x) && aligned16(x_adv) && aligned16(x_adv_old) && aligned16(out) &&
                    (reinterpret_cast<uintptr_t>(grad) % galign == 0) &&

@@ -82,6 +82,13 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, uint32_t dst) 
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// 0 (default): the LDS-DMA two-stage ring; 1: operands staged through registers, three stages deep on the same two LDS buffers
+// (see the main loop).  Measured on MI355X (tools/gemm_bench.py, both builds in one run): 440 - 800 vs 480 - 870 TFLOP/s - like
+// the five-deep ring of 32-k stages it is no faster, i.e. the depth of the prefetch is not what bounds this kernel (profiles/r03_gemm.md).
+#ifndef GEMM_REGSTAGE
+#define GEMM_REGSTAGE 0
+#endif
+
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RES = 2, EPI_GELU_GRAD = 3 };
 
 struct GemmArgs {
@@ -114,7 +121,7 @@ template <int BM, int EPI, typename TD, typename TR>
 __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt_kernel(const GemmArgs p) {
   using G = Geo<BM>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)lds));
+  [[maybe_unused]] const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)lds));
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % G::WAVES_M, wn = wave / G::WAVES_M;
@@ -130,7 +137,8 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
 
   // ---- DMA source addresses of this lane: instruction q of a stage covers tile rows 8 * (q * WAVES + wave) ... + 7 of A (then B)
   const int r8 = lane >> 3, sl = lane & 7;                                   // row inside the 8-row group, LDS chunk inside the row
-  const unsigned char* src[G::INSTR];
+  const unsigned char* src[G::INSTR];                                        // LDS-DMA form: swizzled source chunk
+  const unsigned char* lsrc[G::INSTR];                                       // register-staged form: the lane's own chunk (coalesced rows)
 #pragma unroll
   for (int q = 0; q < G::INSTR; ++q) {
     const int j = q * G::WAVES + wave;                                       // 8-row group of the stage
@@ -141,10 +149,12 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
       long gr = m0 + row;
       if (gr >= p.M) gr = p.M - 1;
       src[q] = reinterpret_cast<const unsigned char*>(p.A + gr * p.lda) + chunk * 16;
+      lsrc[q] = reinterpret_cast<const unsigned char*>(p.A + gr * p.lda) + sl * 16;
     } else {
       int gr = n0 + row;
       if (gr >= p.N) gr = p.N - 1;
       src[q] = reinterpret_cast<const unsigned char*>(p.B + static_cast<long>(gr) * p.ldb) + chunk * 16;
+      lsrc[q] = reinterpret_cast<const unsigned char*>(p.B + static_cast<long>(gr) * p.ldb) + sl * 16;
     }
   }
 #define STAGE_LOAD(T)                                                                                          \
@@ -172,7 +182,6 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nt = p.K / BK;
-  STAGE_LOAD(0)
   // one K step = 4 k-steps of 6 MFMAs; the 5 fragments of k-step ks + 1 are read while the MFMAs of k-step ks run (two register
   // sets, the order pinned: MFMA, read, MFMA, read, ...) - left to itself the compiler issued each k-step's reads right in
   // front of its first MFMA and the LDS latency (~130 cycles) was exposed four times per K step
@@ -201,6 +210,45 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
     KSTEP(fa0, fb0, fa1, fb1, 2)                                                                               \
     KSTEP(fa1, fb1, fa0, fb0, 3)                                                                               \
   }
+#if GEMM_REGSTAGE
+  // ---- register-staged pipeline, three stages deep on two LDS buffers: stage t is consumed from LDS while stage t + 1 sits in
+  //      registers (its loads were issued one whole iteration earlier) and is written to the other buffer at the top of the
+  //      iteration, and the loads of stage t + 2 are issued right behind that write.  A CU always has a stage (56 KB) of loads in
+  //      flight, where the LDS-DMA two-stage ring below drains its loads at every K step (vmcnt(0) + barrier).  The swizzle moves
+  //      to the LDS write address.  (Not faster: see GEMM_REGSTAGE above.)
+  bf16x8 stg[G::INSTR];                                                      // (a native vector type: an array of uint4 structs went to scratch)
+  uint32_t woff[G::INSTR];                                                   // LDS byte offset of this lane's chunk inside a stage
+#pragma unroll
+  for (int q = 0; q < G::INSTR; ++q) {
+    const int j = q * G::WAVES + wave;
+    const int row = (j < G::A_INSTR ? j : j - G::A_INSTR) * 8 + r8;
+    woff[q] = j * 1024 + r8 * 128 + ((sl ^ ((row >> 1) & 7)) * 16);
+  }
+#define RS_LOAD(T)                                                                                             \
+  {                                                                                                            \
+    const long ko_ = static_cast<long>(T) * (BK * 2);                                                          \
+    _Pragma("unroll") for (int q = 0; q < G::INSTR; ++q) stg[q] = *reinterpret_cast<const bf16x8*>(lsrc[q] + ko_); \
+  }
+#define RS_WRITE(T)                                                                                            \
+  {                                                                                                            \
+    unsigned char* wb_ = lds + ((T) & 1) * G::STAGE;                                                           \
+    _Pragma("unroll") for (int q = 0; q < G::INSTR; ++q) *reinterpret_cast<bf16x8*>(wb_ + woff[q]) = stg[q];    \
+  }
+  RS_LOAD(0)
+  RS_WRITE(0)
+  if (nt > 1) { RS_LOAD(1) }
+  __syncthreads();
+  for (int t = 0; t + 1 < nt; ++t) {
+    RS_WRITE(t + 1)                                                         // buffer (t + 1) & 1: last read in iteration t - 1
+    if (t + 2 < nt) { RS_LOAD(t + 2) }
+    COMPUTE(t)
+    __syncthreads();                                                        // stage t + 1 visible; buffer t & 1 free
+  }
+  COMPUTE(nt - 1)
+#undef RS_LOAD
+#undef RS_WRITE
+#else
+  STAGE_LOAD(0)
   for (int t = 0; t + 1 < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // stage t has landed (this wavefront's pieces)
     __builtin_amdgcn_s_barrier();                                          // ... everyone's; and nobody reads stage t - 1 any more
@@ -210,6 +258,7 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   COMPUTE(nt - 1)
+#endif
 #undef COMPUTE
 #undef KSTEP
 #undef FRAG_READ

@@ -201,17 +201,23 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
 
 // TO = float: the input gradient itself;  TO = int8_t: its SIGN {-1, 0, +1} (sign(NaN) = 0, as torch.sign on the
 // reference's path) - all the Linf update reads of the gradient (autopgd_train_clean.py:221), a quarter of the bytes.
-template <typename TO>
-__device__ __forceinline__ void st_pair(TO* p, float a, float b) {
+// BLK (int8 signs only): the "blocked" order the Linf update kernel reads 16 signs per lane in (apgd_hip.h, APGD_I8_BLK) - inside
+// every group of 1024 elements of a sample, bits [2..9] of the element index, (u : 2 bits, lane : 6 bits), are stored as
+// (lane, u): element g*1024 + (u*64 + lane)*4 + j lives at byte g*1024 + lane*16 + u*4 + j.  Pairs (j even, j + 1) stay adjacent.
+__device__ __forceinline__ long blk_index(long e) {
+  return (e & ~1023L) | (((e >> 2) & 63) << 4) | (((e >> 8) & 3) << 2) | (e & 3);
+}
+template <typename TO, bool BLK>
+__device__ __forceinline__ void st_pair(TO* base, long e, float a, float b) {
   if constexpr (sizeof(TO) == 4) {
-    *reinterpret_cast<float2*>(p) = make_float2(a, b);
+    *reinterpret_cast<float2*>(base + e) = make_float2(a, b);
   } else {
     const int sa = (a > 0.f) - (a < 0.f), sb = (b > 0.f) - (b < 0.f);
-    *reinterpret_cast<uint16_t*>(p) = static_cast<uint16_t>((sa & 0xff) | ((sb & 0xff) << 8));
+    *reinterpret_cast<uint16_t*>(base + (BLK ? blk_index(e) : e)) = static_cast<uint16_t>((sa & 0xff) | ((sb & 0xff) << 8));
   }
 }
 
-template <int P, typename TO>
+template <int P, typename TO, bool BLK = false>
 __global__ __launch_bounds__(256) void stem_conv_dgrad_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ wq,
                                                               TO* __restrict__ dx, long total, int H, int W, int OH, int OW) {
   using G = StemGeo<P>;
@@ -246,13 +252,13 @@ __global__ __launch_bounds__(256) void stem_conv_dgrad_kernel(const uint16_t* __
       if (half == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          st_pair(xn + (0L * H + 2 * a + i) * W + 2 * b, acc[2 * i], acc[2 * i + 1]);            // ci = 0: o = 0..3
-          st_pair(xn + (2L * H + 2 * a + i) * W + 2 * b, acc[4 + 2 * i], acc[4 + 2 * i + 1]);    // ci = 2: o = 8..11
+          st_pair<TO, BLK>(xn, (0L * H + 2 * a + i) * W + 2 * b, acc[2 * i], acc[2 * i + 1]);            // ci = 0: o = 0..3
+          st_pair<TO, BLK>(xn, (2L * H + 2 * a + i) * W + 2 * b, acc[4 + 2 * i], acc[4 + 2 * i + 1]);    // ci = 2: o = 8..11
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          st_pair(xn + (1L * H + 2 * a + i) * W + 2 * b, acc[2 * i], acc[2 * i + 1]);            // ci = 1: o = 4..7
+          st_pair<TO, BLK>(xn, (1L * H + 2 * a + i) * W + 2 * b, acc[2 * i], acc[2 * i + 1]);            // ci = 1: o = 4..7
       }
     }
   }
@@ -325,7 +331,7 @@ int cnx_stem_conv_ln_gelu_fwd(const float* x, const void* wq, const float* bias,
   return launch_status();
 }
 
-static int stem_dgrad_impl(const void* dy, const void* wq, void* dx, bool sign, int64_t N, int32_t H, int32_t W, int32_t P, void* stream) {
+static int stem_dgrad_impl(const void* dy, const void* wq, void* dx, int sign, int64_t N, int32_t H, int32_t W, int32_t P, void* stream) {
   if (N < 0 || H <= 0 || W <= 0) return APGD_ERR_SIZE;
   if (N == 0) return APGD_OK;
   if (!dy || !wq || !dx) return APGD_ERR_NULL;
@@ -338,7 +344,13 @@ static int stem_dgrad_impl(const void* dy, const void* wq, void* dx, bool sign, 
   hipStream_t s = as_stream(stream);
   const auto* d = static_cast<const uint16_t*>(dy);
   const auto* q = static_cast<const uint16_t*>(wq);
-  if (sign) {
+  if (sign == 2) {                                   // blocked sign order (groups of 1024 elements per sample)
+    if ((3L * H * W) % 1024 != 0) return APGD_ERR_ARG;
+    auto* o = static_cast<int8_t*>(dx);
+    if (P == 48) hipLaunchKernelGGL((stem_conv_dgrad_kernel<48, int8_t, true>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+    else if (P == 64) hipLaunchKernelGGL((stem_conv_dgrad_kernel<64, int8_t, true>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+    else hipLaunchKernelGGL((stem_conv_dgrad_kernel<96, int8_t, true>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
+  } else if (sign) {
     auto* o = static_cast<int8_t*>(dx);
     if (P == 48) hipLaunchKernelGGL((stem_conv_dgrad_kernel<48, int8_t>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
     else if (P == 64) hipLaunchKernelGGL((stem_conv_dgrad_kernel<64, int8_t>), grid, block, 0, s, d, q, o, total, H, W, OH, OW);
@@ -353,12 +365,17 @@ static int stem_dgrad_impl(const void* dy, const void* wq, void* dx, bool sign, 
 }
 
 int cnx_stem_conv_dgrad(const void* dy, const void* wq, float* dx, int64_t N, int32_t H, int32_t W, int32_t P, void* stream) {
-  return stem_dgrad_impl(dy, wq, dx, false, N, H, W, P, stream);
+  return stem_dgrad_impl(dy, wq, dx, 0, N, H, W, P, stream);
 }
 
 int cnx_stem_conv_dgrad_sign(const void* dy, const void* wq, int8_t* sign_out, int64_t N, int32_t H, int32_t W, int32_t P,
                              void* stream) {
-  return stem_dgrad_impl(dy, wq, sign_out, true, N, H, W, P, stream);
+  return stem_dgrad_impl(dy, wq, sign_out, 1, N, H, W, P, stream);
+}
+
+int cnx_stem_conv_dgrad_sign_blk(const void* dy, const void* wq, int8_t* sign_out, int64_t N, int32_t H, int32_t W, int32_t P,
+                                 void* stream) {
+  return stem_dgrad_impl(dy, wq, sign_out, 2, N, H, W, P, stream);
 }
 
 }  // extern "C"

@@ -77,12 +77,17 @@ class grad_sign_sink:
     """``with grad_sign_sink(x_in) as sink: autograd.grad(...)`` - afterwards ``sink.signs`` is the int8 sign tensor
     (same shape / layout as ``x_in``) if the stem kernel produced it, else None (the caller uses autograd's gradient)."""
 
-    def __init__(self, x_in):
+    def __init__(self, x_in, blocked=False):
         self.x_in, self.signs, self._buf = x_in, None, None
+        # blocked=True (the Linf APGD loop asks for it): the sign order of include/apgd_hip.h, APGD_I8_BLK - the update kernel then
+        # reads 16 signs per lane in one load.  Whole 1024-element groups per sample only; ``signs.apgd_blocked`` tells the
+        # attack which dtype code to pass.  Other users of the sink (fgsm) get element order.
+        self.blocked = bool(blocked) and SIGN_BLOCKED and x_in.dim() >= 2 and x_in.shape[0] > 0 and x_in[0].numel() % 1024 == 0
 
     def buffer(self):
         if self._buf is None:
             self._buf = torch.empty(self.x_in.shape, device=self.x_in.device, dtype=torch.int8)
+            self._buf.apgd_blocked = self.blocked
         return self._buf
 
     def __enter__(self):
@@ -95,6 +100,29 @@ class grad_sign_sink:
         global _SIGN_SINK
         _SIGN_SINK = self._prev
         return False
+
+
+# Measured (tools/k1_ab.py, B = 256 x 3 x 224 x 224, alternating launches): the blocked order is 2.5 % SLOWER than element order (119.6 vs
+# 116.6 us warm, 129.6 vs 127.4 us behind a 512 MB copy) - the int8 stream's request count was not what holds the update kernel at
+# 0.64 - 0.70 of 8 TB/s of moved bytes - so it is off by default (APGD_SIGN_BLOCKED=1 enables it; kernels and tests stay).
+SIGN_BLOCKED = os.environ.get("APGD_SIGN_BLOCKED", "0") != "0"
+
+
+def signs_to_linear(t):
+    """Blocked int8 signs (``cnx_stem_conv_dgrad_sign_blk``) -> element order; a tensor without the ``apgd_blocked`` mark is
+    returned as it is.  For tests / replay: element g*1024 + (u*64 + l)*4 + j is stored at byte g*1024 + l*16 + u*4 + j."""
+    if not getattr(t, "apgd_blocked", False):
+        return t
+    B = t.shape[0]
+    return t.reshape(B, -1, 64, 4, 4).permute(0, 1, 3, 2, 4).reshape(t.shape)
+
+
+def signs_to_blocked(t):
+    """Inverse of ``signs_to_linear`` for a linear int8 tensor [B, ...] with numel per sample % 1024 == 0 (tests)."""
+    B = t.shape[0]
+    out = t.reshape(B, -1, 4, 64, 4).permute(0, 1, 3, 2, 4).reshape(t.shape).contiguous()
+    out.apgd_blocked = True
+    return out
 
 
 def _sink_for(x):
@@ -111,8 +139,8 @@ def _stem_dgrad(lib, x, gr, wq, N, H, W, P):
     sk = _sink_for(x)
     if sk is not None:
         buf = sk.buffer()
-        _lib.check(lib.cnx_stem_conv_dgrad_sign(gr.data_ptr(), wq.data_ptr(), buf.data_ptr(), N, H, W, P, _stream()),
-                   "cnx_stem_conv_dgrad_sign")
+        fn = lib.cnx_stem_conv_dgrad_sign_blk if sk.blocked else lib.cnx_stem_conv_dgrad_sign
+        _lib.check(fn(gr.data_ptr(), wq.data_ptr(), buf.data_ptr(), N, H, W, P, _stream()), "cnx_stem_conv_dgrad_sign")
         sk.signs = buf
         return torch.zeros((), device=x.device, dtype=x.dtype).expand(x.shape)
     dx = torch.empty_like(x)
@@ -352,7 +380,7 @@ class _DownsampleLnConv(torch.autograd.Function):
         _lib.check(lib.cnx_layernorm_fwd_patch2(x.data_ptr(), _code(x), lw.data_ptr(), lb.data_ptr(), eps, yp.data_ptr(), _code(yp),
                                                 mean.data_ptr(), rstd.data_ptr(), N, H, W, C, _stream()), "cnx_layernorm_fwd_patch2")
         wp = _cached((weight,), "patch2_bf16", lambda w: w.permute(0, 2, 3, 1).reshape(Co, 4 * C).to(torch.bfloat16).contiguous())
-        if _gemm_ok(yp, wp):
+        if _gemm_ok(yp, wp, "downsample"):
             out = _gemm_nt(yp, wp, EPI_BIAS, bias=_f32(bias) if bias is not None else None)
         elif bias is not None:
             bb = _cached((bias,), "bf16", lambda b: b.to(torch.bfloat16).contiguous())
@@ -376,7 +404,7 @@ class _DownsampleLnConv(torch.autograd.Function):
         gb = g2 if g2.dtype == torch.bfloat16 else g2.to(torch.bfloat16)
         gb = gb.contiguous()
         dx = dlw = dlb = dwt = db = None
-        if _gemm_dims_ok(gb, Co, 4 * C):                                         # [Mo, 4C] in patch form
+        if _gemm_dims_ok(gb, Co, 4 * C, "downsample"):                           # [Mo, 4C] in patch form
             wpt = _cached((ctx.weight,), "patch2_bf16_t",
                           lambda w: w.permute(0, 2, 3, 1).reshape(Co, 4 * C).to(torch.bfloat16).t().contiguous())
             dyp = _gemm_nt(gb, wpt, EPI_BIAS)
@@ -815,26 +843,38 @@ def _sum_parts(part):
 
 
 # ------------------------------------------------------------------------------ hand-written GEMM with fused epilogues
-# "hip" (default): forward / input-gradient GEMMs of the library-path blocks, the downsample layers and the ViT linears run on
-# cnx_gemm_nt (csrc/gemm_kernels.hip) with bias / GELU / layer scale + residual / GELU' in the epilogue; "lib": hipBLASLt GEMMs
-# between one-pass kernels, as in round 2 (A/B timing).  Weight gradients (contraction over M) stay split-K library GEMMs.
-_GEMM_MODE = os.environ.get("APGD_GEMM", "hip")
+# APGD_GEMM selects where cnx_gemm_nt (csrc/gemm_kernels.hip: bias / GELU / layer scale + residual / GELU' in the epilogue) replaces
+# the hipBLASLt GEMM + one-pass kernels of round 2:
+#   "hip"  : every forward / input-gradient GEMM of the library-path ConvNeXt blocks, the downsample layers and the ViT linears;
+#   "auto" : (default) only where it measured at least as fast in the step on MI355X - the stage downsample layers (K = 4C <= 1536,
+#            N <= 768: 49 - 77 us against 55 - 90 us).  At the MLP shapes the kernel reaches 480 - 860 TFLOP/s against the library's
+#            530 - 1240: it is bound by what a CU ingests from L2 (15 B / cycle / CU measured, 110 FLOP per staged byte at 256 x 192
+#            tiles; profiles/r03_gemm.md), and the AT step was 3 ms slower with it everywhere;
+#   "lib"  : nowhere (A/B timing).
+# Weight gradients (contraction over M) are split-K library GEMMs in every mode.
+_GEMM_MODE = os.environ.get("APGD_GEMM", "auto")
 EPI_BIAS, EPI_BIAS_GELU, EPI_SCALE_RES, EPI_GELU_GRAD = 0, 1, 2, 3
 
 
-def _gemm_ok(a, w_nk):
+def _gemm_on(site):
+    """Is cnx_gemm_nt enabled for this call site ("mlp", "linear", "downsample", "direct")?"""
+    if MODE == "eager" or _GEMM_MODE == "lib":
+        return False
+    return _GEMM_MODE == "hip" or site in ("downsample", "direct")
+
+
+def _gemm_ok(a, w_nk, site="direct"):
     """cnx_gemm_nt takes ``a`` [M, K] and ``w_nk`` [N, K]: bf16, unit inner stride, 16-byte rows, K % 64 == 0, N % 4 == 0."""
-    return (MODE != "eager" and _GEMM_MODE == "hip" and a.is_cuda and a.dtype == torch.bfloat16 and w_nk.dtype == torch.bfloat16
+    return (_gemm_on(site) and a.is_cuda and a.dtype == torch.bfloat16 and w_nk.dtype == torch.bfloat16
             and a.dim() == 2 and w_nk.dim() == 2 and a.stride(1) == 1 and w_nk.stride(1) == 1 and a.shape[1] == w_nk.shape[1]
             and a.shape[1] % 64 == 0 and w_nk.shape[0] % 4 == 0 and a.stride(0) % 8 == 0 and w_nk.stride(0) % 8 == 0
             and a.data_ptr() % 16 == 0 and w_nk.data_ptr() % 16 == 0 and a.shape[0] > 0)
 
 
-def _gemm_dims_ok(a, K, N):
+def _gemm_dims_ok(a, K, N, site="direct"):
     """The same test for an operand pair that does not exist yet: ``a`` is a bf16 row matrix of ours, the weight copy will be
     a fresh contiguous [N, K] bf16 tensor."""
-    return (MODE != "eager" and _GEMM_MODE == "hip" and a.is_cuda and a.dtype == torch.bfloat16 and K % 64 == 0 and N % 4 == 0
-            and a.shape[0] > 0)
+    return (_gemm_on(site) and a.is_cuda and a.dtype == torch.bfloat16 and K % 64 == 0 and N % 4 == 0 and a.shape[0] > 0)
 
 
 def _gemm_nt(a, w_nk, epi=EPI_BIAS, bias=None, gamma=None, resid=None, out_dtype=torch.bfloat16, z_out=None, z_in=None):
@@ -925,7 +965,7 @@ def _gelu_bf16(x):
 def _mlp_input_grads(lib, dos, hpre, w1, w2, w1b, w2b, db1, ws, M, C, want_da):
     """``dHpre = (dO W2) * GELU'(Hpre)`` (+ ``d(b1)`` column sums when ``db1`` is given) and ``da = dHpre W1``: two GEMMs with the
     GELU' in the first one's epilogue (``cnx_gemm_nt``), or library GEMMs around ``cnx_gelu_bwd_colsum``."""
-    if _gemm_dims_ok(dos, C, 4 * C) and _gemm_dims_ok(hpre, 4 * C, C) and dos.is_contiguous() and hpre.is_contiguous():
+    if _gemm_dims_ok(dos, C, 4 * C, "mlp") and _gemm_dims_ok(hpre, 4 * C, C, "mlp") and dos.is_contiguous() and hpre.is_contiguous():
         dhpre = _gemm_nt(dos, _bf16_t(w2), EPI_GELU_GRAD, z_in=hpre)                 # B = W2^T [4C, C]
         if db1 is not None:                                  # training pass: d(b1) = column sums of dHpre (one read)
             zeros = torch.empty(4 * C, device=dos.device, dtype=torch.float32)
@@ -960,7 +1000,7 @@ class _MlpResidual(torch.autograd.Function):
         b2b = _cached((b2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
         gf = _f32(gamma) if gamma is not None else None
         need_grad = any(ctx.needs_input_grad)
-        if _gemm_ok(h2, w1b) and _gemm_dims_ok(h2, 4 * C, C):
+        if _gemm_ok(h2, w1b, "mlp") and _gemm_dims_ok(h2, 4 * C, C, "mlp"):
             # fc1 + bias + GELU and fc2 + bias + layer scale + residual: two kernels, nothing element-wise between or after them
             hpre = torch.empty(M, 4 * C, device=h.device, dtype=torch.bfloat16) if need_grad else None
             hg = _gemm_nt(h2, w1b, EPI_BIAS_GELU, bias=_f32(b1), z_out=hpre)
@@ -1027,7 +1067,7 @@ class _LinearLib(torch.autograd.Function):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         wb = _cached((w,), "bf16", lambda t: t.to(torch.bfloat16).contiguous())
-        if _gemm_ok(x2, wb):
+        if _gemm_ok(x2, wb, "linear"):
             y = _gemm_nt(x2, wb, EPI_BIAS, bias=_f32(b))
         else:
             bb = _cached((b,), "bf16", lambda t: t.to(torch.bfloat16).contiguous())
@@ -1047,7 +1087,7 @@ class _LinearLib(torch.autograd.Function):
         M = dy2.shape[0]
         dx = None
         if ctx.needs_input_grad[0]:
-            if _gemm_dims_ok(dy2, N, wb.shape[1]):
+            if _gemm_dims_ok(dy2, N, wb.shape[1], "linear"):
                 dx = _gemm_nt(dy2, _bf16_t(ctx.w), EPI_BIAS).view(ctx.x_shape)    # B = W^T [in, out]
             else:
                 dx = (dy2 @ wb).view(ctx.x_shape)
@@ -1179,7 +1219,7 @@ class _BlockFused(torch.autograd.Function):
             wb_ = _cached((w2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
             b1b = _cached((b1,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
             b2b = _cached((b2,), "bf16", lambda w: w.to(torch.bfloat16).contiguous())
-            if _gemm_ok(a, wa) and _gemm_dims_ok(a, 4 * C, C):
+            if _gemm_ok(a, wa, "mlp") and _gemm_dims_ok(a, 4 * C, C, "mlp"):
                 # fc1 + bias + GELU (+ Hpre for the backward) and fc2 + bias + gamma + residual: two kernels (cnx_gemm_nt)
                 hpre = torch.empty(M, 4 * C, device=x.device, dtype=torch.bfloat16) if need_grad else None
                 h = _gemm_nt(a, wa, EPI_BIAS_GELU, bias=b1f, z_out=hpre)

@@ -169,6 +169,33 @@ def test_track_rows_moves_int8_sign_rows(lib):
         assert torch.equal(xa[b], xb0[b] if rs else xa0[b])
 
 
+@pytest.mark.parametrize("B,E", [(1, 1024), (3, 3 * 32 * 32), (5, 3 * 64 * 64), (2, 7 * 1024)])
+@pytest.mark.parametrize("a", [1.0, 0.75])
+def test_linf_step_with_blocked_int8_signs_is_bit_identical(lib, B, E, a):
+    """grad_dtype = APGD_I8_BLK (include/apgd_hip.h): the signs permuted inside 1024-element groups give the bits of the element-order
+    int8 call and of the oracle, in the general and the first-iteration form; sizes that are not whole groups are refused."""
+    import revisiting_at_amd as R
+    eps = 4 / 255
+    x, xa, xo, g, step = _step_inputs(B, E, B * 31 + E, eps)
+    if a == 1.0:
+        xo = xa.copy()
+    want = O.linf_step(x, xa, xo, g, step, eps, a)
+    sg = np.zeros(g.shape, np.int8)
+    sg[g > 0] = 1
+    sg[g < 0] = -1
+    xd, xad, xod, sd = map(dev, (x, xa, xo, step))
+    sb = R.ops.signs_to_blocked(torch.from_numpy(sg).cuda())
+    assert not torch.equal(sb, torch.from_numpy(sg).cuda()) and torch.equal(R.ops.signs_to_linear(sb).cpu(), torch.from_numpy(sg))
+    out = torch.zeros_like(xd)
+    xo_ptr = xad.data_ptr() if a == 1.0 else xod.data_ptr()
+    assert lib.apgd_linf_step_f32(xd.data_ptr(), xad.data_ptr(), xo_ptr, sb.data_ptr(), 4, sd.data_ptr(), out.data_ptr(), None, B, E,
+                                  eps, a, S()) == 0
+    assert bits_equal(out.cpu().numpy(), want)
+    bad = torch.zeros(B, E + 4, device="cuda")
+    assert lib.apgd_linf_step_f32(bad.data_ptr(), bad.data_ptr(), bad.data_ptr(), sb.data_ptr(), 4, sd.data_ptr(), out.data_ptr(), None,
+                                  B, E + 4, eps, a, S()) == -4
+
+
 def test_track_rows_moves_int8_sign_rows_of_odd_length(lib):
     """grad_elt = 1 with an odd row length (E = 3*5*5): every second row starts on an odd address - the copy must be byte
     exact, last byte of each row included (round-2 advice: the 2-byte fallback dropped it)."""
@@ -267,6 +294,14 @@ def test_linf_step_full_size_with_int8_gradient_signs(lib):
         assert lib.apgd_linf_step_f32(x.data_ptr(), xa.data_ptr(), old.data_ptr(), g.data_ptr(), 0, step.data_ptr(),
                                       o32.data_ptr(), None, B, E, eps, a, S()) == 0
         assert torch.equal(o8.view(torch.int32), o32.view(torch.int32)), a          # every element, bit for bit
+        # ... and in the BLOCKED sign order the product's stem kernel writes (APGD_I8_BLK: 16 signs per lane in one load)
+        import revisiting_at_amd as R
+        sb = R.ops.signs_to_blocked(sg)
+        assert torch.equal(R.ops.signs_to_linear(sb), sg)
+        ob = torch.empty_like(x)
+        assert lib.apgd_linf_step_f32(x.data_ptr(), xa.data_ptr(), old.data_ptr(), sb.data_ptr(), 4, step.data_ptr(),
+                                      ob.data_ptr(), None, B, E, eps, a, S()) == 0
+        assert torch.equal(ob.view(torch.int32), o32.view(torch.int32)), ("blocked", a)
         sl = slice(3, 256, 41)
         want = O.linf_step(*(t[sl].cpu().numpy() for t in (x, xa, old, g, step)), eps, a)
         assert bits_equal(o8[sl].cpu().numpy(), want), a

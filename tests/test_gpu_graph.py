@@ -144,3 +144,25 @@ def test_sign_sink_steps_aside_when_the_iterate_has_a_second_consumer(R):
         finally:
             R.apgd.USE_SIGN_SINK = saved
     assert same(got, want)
+
+
+def test_attack_with_the_blocked_sign_order_equals_the_default(R, monkeypatch):
+    """APGD_SIGN_BLOCKED=1 (off by default: measured 2.5 % slower): the stem kernel writes the signs in the blocked order, the
+    update kernel reads them with grad_dtype = APGD_I8_BLK - same adversarials bit for bit, and the recorded signs (un-permuted
+    by the tap) replay through the oracle."""
+    from oracle import apgd_oracle as O
+    from oracle import replay_tap as T
+    model = small_convnext(R, 4)
+    x = torch.rand(4, 3, 64, 64, device="cuda")                # 3 * 64 * 64 = 12 groups of 1024
+    y = torch.randint(0, 10, (4,), device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        want = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=3)
+    monkeypatch.setattr(R.ops, "SIGN_BLOCKED", True)
+    seen = []
+    orig = R._lib.load().apgd_linf_step_f32
+    out, lo, gr, used = T.record_attack(R, model, x, y, "Linf", EPS, 3, autocast=True, sink=True)
+    assert used and all(used)
+    assert same(out, want)
+    T.check_replay(O, out, lo, gr, x, y, "Linf", EPS, 3)
+    sk = R.ops.grad_sign_sink(x, blocked=True)
+    assert sk.blocked and sk.buffer().apgd_blocked

@@ -792,6 +792,16 @@ def test_stem_dgrad_sign_is_the_sign_of_the_stem_dgrad(R, P, N, H, W):
     assert lib.cnx_stem_conv_dgrad_sign(dy.data_ptr(), wq.data_ptr(), sg.data_ptr(), N, H, W, P, S()) == 0
     assert torch.equal(sg, torch.sign(dx).to(torch.int8))
     assert int((sg == 0).sum()) > 0 and int((sg == 1).sum()) > 0 and int((sg == -1).sum()) > 0
+    # the blocked order for the Linf update kernel (APGD_I8_BLK): the same signs, permuted inside 1024-element groups per sample
+    sb = torch.full((N, 3, H, W), 9, device="cuda", dtype=torch.int8)
+    rc = lib.cnx_stem_conv_dgrad_sign_blk(dy.data_ptr(), wq.data_ptr(), sb.data_ptr(), N, H, W, P, S())
+    if (3 * H * W) % 1024 == 0:
+        assert rc == 0
+        sb.apgd_blocked = True
+        assert torch.equal(R.ops.signs_to_linear(sb), sg)
+        assert torch.equal(R.ops.signs_to_blocked(sg), sb)
+    else:
+        assert rc == -4
 
 
 @pytest.mark.gpu

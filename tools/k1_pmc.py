@@ -21,7 +21,8 @@ sg = torch.sign(gr).to(torch.int8)
 step = torch.full((B,), 2 * eps, device="cuda")
 out = torch.empty_like(x)
 S = torch.cuda.current_stream().cuda_stream
-for grad, code in ((gr, 0), (sg, 3)):
+sb = R.ops.signs_to_blocked(sg)                      # the order the product's stem kernel writes (APGD_I8_BLK)
+for grad, code in ((gr, 0), (sg, 3), (sb, 4)):
     for _ in range(10):
         assert lib.apgd_linf_step_f32(x.data_ptr(), xa.data_ptr(), xo.data_ptr(), grad.data_ptr(), code, step.data_ptr(),
                                       out.data_ptr(), None, B, E, eps, 0.75, S) == 0

@@ -46,7 +46,8 @@ w_cal = pick(write, "copyBuffer") / TENSOR_KIB if any("copyBuffer" in k for k in
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/k1_pmc.py; B=256, E=150528",
        "fetch_calibration": f_cal, "write_calibration": w_cal, "variants": {}}
 forms = {"general_f32": ("linf_step_vec4_kernel<float", 20), "general_i8": ("linf_step_vec4_kernel<signed char", 17),
-         "first_f32": ("linf_step_first_vec4_kernel<float", 16), "first_i8": ("linf_step_first_vec4_kernel<signed char", 13)}
+         "first_f32": ("linf_step_first_vec4_kernel<float", 16), "first_i8": ("linf_step_first_vec4_kernel<signed char", 13),
+         "general_i8blk": ("linf_step_i8blk_kernel<false>", 17), "first_i8blk": ("linf_step_i8blk_kernel<true>", 13)}
 for key, (sub, bpe) in forms.items():
     try:
         fk, wk = pick(fetch, sub), pick(write, sub)
