@@ -179,6 +179,63 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
     return None
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.index, n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _SIDE_STREAMS[key]
+
+
+def _model_fwd_bwd_split(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind=0, y_target=None, sign_ok=False,
+                         sign_blocked=False, splits=1):
+    """``_model_fwd_bwd`` with the batch cut into ``splits`` chunks that run on their own HIP streams (fork / join around the call).
+
+    The attack treats samples independently and the model is in eval mode, so the chunks are independent problems with
+    identical per-sample results; what changes is how the GPU is filled: at the late stages of ConvNeXt-T a kernel has 392
+    (C = 384) or 98 (C = 768) workgroups for 256 CUs, and two streams let the tail of one chunk's kernel overlap the next
+    kernel of the other (round 2 measured 185 -> 152 us per C = 384 forward this way and dropped it because the HOST could not
+    feed two streams; under graph replay - graphed.py, the only caller with splits > 1 - there is no host in the loop)."""
+    B = x_in.shape[0]
+    if splits <= 1 or B < 2 * splits:
+        return _model_fwd_bwd(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, sign_ok, sign_blocked)
+    main = torch.cuda.current_stream()
+    streams = _side_streams(x_in.device, splits)
+    cuts = [B * i // splits for i in range(splits + 1)]
+    full = None
+    if need_grad:                                            # allocated on the calling stream, before the fork
+        sink_expected = sign_ok and USE_SIGN_SINK and id(model) not in _SINK_REFUSED
+        full = torch.empty(x_in.shape, device=x_in.device, dtype=torch.int8 if sink_expected else torch.float32)
+        if x_in.dim() == 4 and not x_in.is_contiguous():
+            full = torch.empty_like(x_in, dtype=full.dtype)
+    parts = []
+    for h, st in enumerate(streams):
+        a, b = cuts[h], cuts[h + 1]
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            g = _model_fwd_bwd(model, x_in[a:b], None if y_hard is None else y_hard[a:b], None if y_soft is None else y_soft[a:b], ws,
+                               loss_out[a:b], pred_out[a:b], need_grad, kind, None if y_target is None else y_target[a:b], sign_ok,
+                               sign_blocked)
+            if g is not None and g.dtype == full.dtype:
+                full[a:b].copy_(g)
+            parts.append(g)
+    for st in streams:
+        main.wait_stream(st)
+    if not need_grad:
+        return None
+    if any(g.dtype != full.dtype for g in parts):            # a chunk left the sign sink (second consumer detected): fp32 for all
+        if all(g.dtype == parts[0].dtype for g in parts):
+            full = torch.cat(parts, 0)
+        else:
+            full = torch.cat([g.float() if g.dtype == torch.int8 and not getattr(g, "apgd_blocked", False) else ops.signs_to_linear(g).float()
+                              for g in parts], 0)
+    elif full.dtype == torch.int8 and getattr(parts[0], "apgd_blocked", False):
+        full.apgd_blocked = True
+    return full
+
+
 def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
                verbose=False, mixup=None, is_train=True, graph=None):
     """Drop-in for the reference's ``apgd_train`` (``autopgd_train_clean.py:123-124``).
@@ -222,7 +279,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
     return _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=mixup is not None, verbose=verbose)
 
 
-def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, y_target=None, x_init=None, rec=None):
+def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, y_target=None, x_init=None, rec=None, splits=1):
     """The device loop shared by ``apgd_train`` and the evaluation attacks (``aa_eval.apgd_attack``).
 
     ``x_init`` (optional) replaces the clean image as the start point (AutoAttack's random start); the ball stays
@@ -271,7 +328,7 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
 
     # first forward/backward: acc, loss_best are written directly by the loss kernel (:194-200)
     sign_ok = norm == 'Linf'
-    grad = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok, sign_ok)
+    grad = _model_fwd_bwd_split(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok, sign_ok, splits)
     grad_best = torch.empty_like(grad)                                       # :189
     grad_best.copy_(grad)
     ws.loss_best_last.copy_(ws.loss_best)                                    # :200
@@ -308,7 +365,8 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
         old, cur = cur, out                                                  # :215, 260 (buffer rotation)
 
         last = i == n_iter - 1
-        g_new = _model_fwd_bwd(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind, y_target, sign_ok, sign_ok)   # :266-287
+        g_new = _model_fwd_bwd_split(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind, y_target, sign_ok, sign_ok,
+                                     splits)                                 # :266-287
         if g_new is not None:
             if g_new.dtype != grad_best.dtype:               # a model that switches gradient form mid-attack
                 g_new = torch.sign(g_new).to(grad_best.dtype) if grad_best.dtype == torch.int8 else g_new.to(grad_best.dtype)

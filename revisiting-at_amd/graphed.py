@@ -22,6 +22,7 @@ same kernels, same results, only the host cost differs.
 """
 from __future__ import annotations
 
+import os
 import warnings
 import weakref
 
@@ -30,6 +31,9 @@ import torch
 from . import apgd, ops
 
 WARMUP_CALLS = 2                 # eager calls before the capture (library handles, kernel attributes, autotuned choices)
+# batch chunks the model calls of a captured attack are cut into, each on its own stream (apgd._model_fwd_bwd_split): fills the CUs
+# the late stages' small kernels leave idle; costs nothing on the host once captured.  APGD_ATTACK_STREAMS=1: one stream.
+STREAMS = int(os.environ.get("APGD_ATTACK_STREAMS", "2"))
 STATS = {"captures": 0, "replays": 0, "eager": 0, "failed": 0}
 _programs = {}
 
@@ -83,7 +87,7 @@ class _Program:
             with torch.cuda.stream(side):
                 rec.begin()
                 try:
-                    self.out = apgd._apgd_core(model, self.x, self.y, norm, eps, n_iter, kind, soft=soft, rec=rec)
+                    self.out = apgd._apgd_core(model, self.x, self.y, norm, eps, n_iter, kind, soft=soft, rec=rec, splits=STREAMS)
                 except BaseException:
                     rec.abort()
                     raise
@@ -109,7 +113,7 @@ class _Program:
 def _signature(model, x, y, norm, eps, n_iter, kind, soft):
     ac = (torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
     return (id(model), tuple(x.shape), tuple(x.stride()), x.dtype, x.device.index, tuple(y.shape), y.dtype, norm, float(eps),
-            int(n_iter), int(kind), bool(soft), ac, ops.MODE, apgd.USE_SIGN_SINK)
+            int(n_iter), int(kind), bool(soft), ac, ops.MODE, apgd.USE_SIGN_SINK, STREAMS)
 
 
 def reset():
@@ -137,7 +141,8 @@ def run(model, x, y, norm, eps, n_iter, kind, soft):
         if ent["failed"] or ent["calls"] < WARMUP_CALLS:
             ent["calls"] += 1
             STATS["eager"] += 1
-            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft)
+            # (same batch chunks as the capture will use: every kernel / library shape is initialised before it)
+            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=1 if ent["failed"] else STREAMS)
         try:
             prog = ent["prog"] = _Program(model, x, y, norm, eps, n_iter, kind, soft)
             STATS["captures"] += 1
