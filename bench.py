@@ -54,6 +54,9 @@ def parse():
     p.add_argument("--attack-only", action="store_true", help="time only apgd_train (extra info line on stderr)")
     p.add_argument("--no-other-configs", action="store_true", help="skip the informational runs of BASELINE configs #3-#5")
     p.add_argument("--graph", type=int, default=1, help="1: the attack is replayed from hipGraphs (adv.graph, graphed.py); 0: eager")
+    p.add_argument("--other-configs", default=None, help="which informational configurations (cfg3,cfg4,cfg5) to run after the timed "
+                   "region; default: all three, none with --no-cpu-baseline / --no-other-configs")
+    p.add_argument("--graph-train", type=int, default=1, help="1 (with --graph 1, one GPU): the training pass is replayed from a hipGraph too")
     return p.parse_args()
 
 
@@ -183,10 +186,10 @@ def model_kernel_rooflines(R, dev, B, iters=10):
     return out
 
 
-def other_configs(R, dev, graph=1):
+def other_configs(R, dev, graph=1, which=("cfg3", "cfg4", "cfg5")):
     """Single-GPU, per-GPU-batch numbers of the other BASELINE.json configurations (informational, after the timed region):
     #3 ViT-B-CvSt APGD-2 AT @224 (per-GPU batch 256), #4 ConvNeXt-L-CvSt APGD-3 AT @320 (per-GPU batch 128),
-    #5 100-step APGD-CE evaluation attack on ConvNeXt-B-CvSt @224 (batch 32, fp32 as AA_eval.py runs it)."""
+    #5 the 100-step APGD-CE + APGD-T evaluation (`run_standard_evaluation`) on ConvNeXt-B-CvSt @224 (batch 100, fp32 as AA_eval.py runs it)."""
     import torch
     out = {}
 
@@ -211,34 +214,51 @@ def other_configs(R, dev, graph=1):
         return {"img_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "per_gpu_batch": batch, "res": res,
                 "n_iter": n_iter, "steps": steps}
 
+    def note(msg):
+        print(f"[bench other_configs +{time.perf_counter() - t_start:.0f}s] {msg}", file=sys.stderr, flush=True)
+    t_start = time.perf_counter()
     for key, cfg in (("cfg3_vit_b_cvst_apgd2_at_224", ("vit_b", 224, 256, 2)),
                      ("cfg4_convnext_large_cvst_apgd3_at_320", ("convnext_large", 320, 128, 3))):
+        if key[:4] not in which:
+            continue
         try:
             out[key] = at_step(*cfg)
         except Exception as e:                               # informational: never fail the headline line over it
             out[key] = "unavailable: %r" % (e,)
+        note(f"{key}: {out[key]}")
+    if "cfg5" not in which:
+        return out
     try:
         torch.manual_seed(0)
         model = R.get_new_model("convnext_base", pretrained=False, not_original=True).to(dev).to(memory_format=torch.channels_last).eval()
         g = torch.Generator(device=dev).manual_seed(9)
-        x = torch.rand(32, 3, 224, 224, device=dev, generator=g)
+        bs = 100                                             # AA_eval.py's batch for the large models (BASELINE.json config #5)
+        x = torch.rand(bs, 3, 224, 224, device=dev, generator=g)
         with torch.no_grad():
-            y = model(x).argmax(1)                           # every point starts robust: the attack runs on all of them
+            y = model(x).argmax(1)                           # every point starts robust: APGD-CE runs on all of them
         # warm-up at the SAME batch size: MIOpen's find mode times every solver (its naive kernels included, 4 - 10 ms each)
-        # the first time it meets a convolution shape - ~10 s for this model's twelve fp32 problems, which a warm-up at
+        # the first time it meets a convolution shape - ~10 s for this model's fp32 problems, which a warm-up at
         # another batch size leaves inside the timed run (round 2's first cfg5 figure, 2.4 img/s, was mostly that)
         R.aa_eval.apgd_attack(model, x, y, "Linf", 4 / 255, 2, "ce", None, True, g)
         torch.cuda.synchronize()
+        note("cfg5 warm-up done")
         t0 = time.perf_counter()
-        R.aa_eval.apgd_attack(model, x, y, "Linf", 4 / 255, 100, "ce", None, True, g)
+        # the config as AA_eval.py:226-239 drives it: APGD-CE, then APGD-T x 9 target classes on the points still robust.
+        # (A random-init model is broken by APGD-CE almost everywhere, so the targeted runs see few points, each with a batch
+        # size the libraries have not met: `attack_runs` / `sample_iters` say what the evaluation amounted to.)
+        _, st = R.run_standard_evaluation(model, x, y, bs=bs, norm="Linf", eps=4 / 255, attacks_to_run=("apgd-ce", "apgd-t"),
+                                          n_iter=100, n_target_classes=9, verbose=bool(os.environ.get("APGD_BENCH_VERBOSE")))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out["cfg5_convnext_base_cvst_apgd_ce_100step_eval_224"] = {"img_s": round(32 / dt, 2), "s_per_batch": round(dt, 3),
-                                                                   "batch": 32, "n_iter": 100, "dtype": "f32"}
+        out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"] = {
+            "img_s": round(bs / dt, 2), "s_per_batch": round(dt, 3), "batch": bs, "n_iter": 100, "dtype": "f32",
+            "attack_runs": st["attack_runs"], "sample_iters": st["sample_iters"],
+            "sample_iters_per_s": round(st["sample_iters"] / dt, 1), "robust_after": st["robust"]}
         del model
         torch.cuda.empty_cache()
     except Exception as e:
-        out["cfg5_convnext_base_cvst_apgd_ce_100step_eval_224"] = "unavailable: %r" % (e,)
+        out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"] = "unavailable: %r" % (e,)
+    note(f"cfg5: {out['cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224']}")
     return out
 
 
@@ -390,7 +410,8 @@ def main():
     adv = R.AdvConfig(attack="apgd", norm="Linf", eps=args.eps, n_iter=args.n_iter, graph=args.graph)
     trainer = R.ATTrainStep(model, args.arch, adv, dev, lr=1e-3, distributed=world > 1, channels_last=True,
                             amp_dtype=torch.bfloat16, ema=True, mixup=object() if args.soft_labels else None,
-                            soft_targets=args.soft_labels, gemm_table=True)
+                            soft_targets=args.soft_labels, gemm_table=True,
+                            graph_train=bool(args.graph) and bool(args.graph_train))
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch
     x = torch.rand(B, 3, args.res, args.res, device=dev, generator=g)        # synthetic 224x224x3 batch in [0,1)
@@ -405,7 +426,8 @@ def main():
         torch.cuda.synchronize()
 
     # the attack's hipGraphs are captured on its third call (graphed.WARMUP_CALLS eager calls first): never inside the timed region
-    n_warm = max(args.warmup, R.graphed.WARMUP_CALLS + 1) if args.graph else args.warmup
+    # ... and the training pass on the step after TRAIN_GRAPH_WARMUP eager ones
+    n_warm = max(args.warmup, R.graphed.WARMUP_CALLS + 1, R.train_step.TRAIN_GRAPH_WARMUP + 1) if args.graph else args.warmup
     for _ in range(n_warm):
         trainer.step(x, y)
     sync()
@@ -469,7 +491,9 @@ def main():
         roof["first_iter"] = first
 
     extra = {"host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3), "package_power": power_stats,
-             "attack_graph": dict(R.graphed.STATS, enabled=bool(args.graph)), "gemm_mode": R.ops._GEMM_MODE}
+             "attack_graph": dict(R.graphed.STATS, enabled=bool(args.graph)), "gemm_mode": R.ops._GEMM_MODE,
+             "train_graph": {"enabled": bool(trainer.graph_train),
+                             "captured": sum(v is not None for v in trainer._tg.values()), "failed": sum(v is None for v in trainer._tg.values())}}
     if args.attack_only or True:
         # attack-only throughput (same tensors, eval mode), a few repetitions
         base = trainer.inner.base_model
@@ -492,10 +516,10 @@ def main():
             except Exception as e:                       # informational only: never fail the bench line over it
                 extra["model_kernel_rooflines"] = "unavailable: %r" % (e,)
         if (rank == 0 and world == 1 and args.arch == "convnext_tiny" and R.ops.MODE != "eager" and not args.no_other_configs
-                and not args.no_cpu_baseline):
+                and (args.other_configs is not None or not args.no_cpu_baseline)):
             del trainer, model, base, x, y
             torch.cuda.empty_cache()
-            extra["other_configs"] = other_configs(R, dev, args.graph)
+            extra["other_configs"] = other_configs(R, dev, args.graph, tuple((args.other_configs or "cfg3,cfg4,cfg5").split(",")))
         extra["ops_mode"] = R.ops.MODE
         extra["device"] = torch.cuda.get_device_name(dev)
 

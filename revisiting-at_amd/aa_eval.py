@@ -77,7 +77,8 @@ def run_standard_evaluation(model, x, y, bs=200, norm='Linf', eps=4. / 255.,
 
     ``x`` [n,3,H,W] fp32 in [0,1] and ``y`` [n] may live on the host (as in AA_eval.py:116); this rank evaluates
     samples ``rank::world`` in batches of ``bs`` on ``device``.  Returns ``(x_adv_shard, stats)`` with
-    ``stats = {'n', 'clean_correct', 'robust'}`` (counts on this rank; see ``robust_accuracy``).
+    ``stats = {'n', 'clean_correct', 'robust', 'attack_runs', 'sample_iters'}`` (counts on this rank; see ``robust_accuracy``;
+    the last two say how much work the evaluation was: APGD runs started, and samples x iterations they covered).
     """
     assert not model.training
     for a in attacks_to_run:
@@ -92,7 +93,7 @@ def run_standard_evaluation(model, x, y, bs=200, norm='Linf', eps=4. / 255.,
     n = xs.shape[0]
     x_adv_all = xs.clone()
     gen = torch.Generator(device=device).manual_seed(seed * 1000003 + rank)
-    clean_correct = robust_total = 0
+    clean_correct = robust_total = attack_runs = sample_iters = 0
     ctx = torch.autocast('cuda', dtype=amp_dtype) if amp_dtype is not None else torch.autocast('cuda', enabled=False)
     for b0 in range(0, n, bs):
         xb = xs[b0:b0 + bs].to(device, non_blocking=True).float().contiguous()
@@ -111,6 +112,8 @@ def run_standard_evaluation(model, x, y, bs=200, norm='Linf', eps=4. / 255.,
                     if idx.numel() == 0:
                         break
                     xi, yi = xb[idx].contiguous(), yb[idx]
+                    attack_runs += 1
+                    sample_iters += int(idx.numel()) * n_iter
                     if tc is None:
                         xa, acc, _, _ = apgd_attack(model, xi, yi, norm, eps, n_iter, 'ce', None, True, gen)
                     else:
@@ -127,7 +130,8 @@ def run_standard_evaluation(model, x, y, bs=200, norm='Linf', eps=4. / 255.,
                               f"robust {int(robust.sum())}/{xb.shape[0]}")
         robust_total += int(robust.sum())
         x_adv_all[b0:b0 + bs] = x_adv.to(x_adv_all.device)
-    return x_adv_all, {'n': n, 'clean_correct': clean_correct, 'robust': robust_total}
+    return x_adv_all, {'n': n, 'clean_correct': clean_correct, 'robust': robust_total, 'attack_runs': attack_runs,
+                       'sample_iters': sample_iters}
 
 
 def robust_accuracy(stats: dict, device=None) -> Tuple[float, float]:

@@ -13,13 +13,17 @@
 // input gradients), which is the MFMA fragment order of v_mfma_f32_32x32x16_bf16 for BOTH operands: lane (row = l & 31,
 // half = l >> 5) holds 8 consecutive k of its row.
 //
-// Decomposition.  Workgroup tile BM x 192 (every N of the models is a multiple of 192 = 6 x 32), BM = 256 (8 wavefronts, 4 x 2)
-// or 128 (4 wavefronts, 2 x 2); wavefront tile 64 x 96 = 2 x 3 MFMA blocks, 96 accumulator registers; K in steps of 64.
+// Decomposition.  Workgroup tiles 256 x 256 (N a multiple of 256 and >= 512 tiles), 256 x 192 (every N of the models is a
+// multiple of 192 = 6 x 32) or 128 x 192 (small grids); 8 (4) wavefronts of 64 x BN/2 = 2 x 4 (2 x 3) MFMA blocks, 128 (96)
+// accumulator registers; K in steps of 64.  The kernel is bound by the rate at which a CU takes operand bytes from L2 (~15 B /
+// cycle, profiles/r03_gemm.md), so the FLOP per staged byte of the tile (128 at 256 x 256, 110 at 256 x 192) is what counts.
 // Staging: global_load_lds_dwordx4 (1 KiB = 8 rows x 128 B per instruction, no registers) into a two-stage ring, stage t + 1 in
-// flight while stage t is consumed, one barrier per K step.  LDS rows are 128 B, so a 32-row fragment read would put a
-// ds_read_b128 lane group on two 16-byte slots; the 16-byte chunk index is XOR-ed with (row >> 1) & 7 - applied to the per-lane
-// SOURCE address of the DMA (its LDS destination is lane-linear) and to the read address - which spreads the 16 rows of a lane
-// group over all 16 slots of the 256-byte bank row.
+// flight while stage t is consumed (its DMA instructions dealt over the four k-steps of stage t), one barrier per K step.  LDS rows
+// are 128 B, so a 32-row fragment read would put a ds_read_b128 lane group on two 16-byte slots; the 16-byte chunk index is
+// XOR-ed with (row >> 1) & 7 - applied to the per-lane SOURCE address of the DMA (its LDS destination is lane-linear) and to the
+// read address - which spreads the 16 rows of a lane group over all 16 slots of the 256-byte bank row.
+// Tile order: XCD-aware (block b runs on XCD b % 8: XCD x works through the x-th contiguous eighth of the tile list) and in
+// panels of a few column tiles, so that the B rows an XCD keeps re-reading stay in its 4 MB L2 (see the kernel).
 // Epilogue: the accumulators go through the (dead) staging ring so that every lane stores 16 contiguous bytes of an output row.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -81,12 +85,25 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
 __device__ __forceinline__ void glds16(const unsigned char* gsrc, uint32_t dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "memory");
 }
+// the same with the non-temporal hint (tuning experiment GEMM_NT_A: the A rows are streamed, the B rows are the reused operand)
+__device__ __forceinline__ void glds16_nt(const unsigned char* gsrc, uint32_t dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(dst) : "memory");
+}
+#ifndef GEMM_NT_A
+#define GEMM_NT_A 0
+#endif
 
 // 0 (default): the LDS-DMA two-stage ring; 1: operands staged through registers, three stages deep on the same two LDS buffers
 // (see the main loop).  Measured on MI355X (tools/gemm_bench.py, both builds in one run): 440 - 800 vs 480 - 870 TFLOP/s - like
 // the five-deep ring of 32-k stages it is no faster, i.e. the depth of the prefetch is not what bounds this kernel (profiles/r03_gemm.md).
 #ifndef GEMM_REGSTAGE
 #define GEMM_REGSTAGE 0
+#endif
+
+// 1: the DMA instructions of stage t + 1 are dealt over the four k-steps of stage t instead of being issued in one burst behind the
+// barrier (every CU of the chip bursts at about the same time: the L2s see 56 - 64 KB requests per CU, then nothing)
+#ifndef GEMM_SPREAD
+#define GEMM_SPREAD 1
 #endif
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RES = 2, EPI_GELU_GRAD = 3 };
@@ -101,25 +118,29 @@ struct GemmArgs {
   uint16_t* Zout; long ldz;        // EPI_BIAS_GELU: pre-activation out (or NULL); EPI_SCALE_RES: Y = bf16(acc + b) out (or NULL)
   const uint16_t* Zin;             // EPI_GELU_GRAD: pre-activation [M, N] (row stride ldz)
   long M; int N, K;
+  int pw;                          // column tiles per panel of the tile order (see the kernel)
 };
 
-constexpr int BN = 192, BK = 64, WN = 96, WM = 64;
+constexpr int BK = 64;
 
-template <int BM>
+template <int BM, int BN, int WM>
 struct Geo {
+  static constexpr int WN = BN / 2, NI = WM / 32, NJ = WN / 32;              // wavefront tile WM x WN = NI x NJ MFMA blocks
   static constexpr int WAVES_M = BM / WM, WAVES = WAVES_M * (BN / WN), THREADS = WAVES * 64;
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   static constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;                   // 1 KiB DMA instructions per stage
   static constexpr int INSTR = (A_INSTR + B_INSTR) / WAVES;                  // per wavefront
   static_assert((A_INSTR + B_INSTR) % WAVES == 0 && A_INSTR % WAVES == 0, "whole DMA instructions per wavefront, A before B");
   static constexpr int LDS = 2 * STAGE;
-  // epilogue: 32 rows x 96 columns fp32 per wavefront and pass
+  // epilogue: 32 rows x WN columns fp32 per wavefront and pass
   static_assert(WAVES * 32 * WN * 4 <= LDS, "the epilogue tile reuses the staging ring");
+  static_assert(LDS <= 160 * 1024, "LDS of a CU");
 };
 
-template <int BM, int EPI, typename TD, typename TR>
-__global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt_kernel(const GemmArgs p) {
-  using G = Geo<BM>;
+template <int BM, int BN, int WM, int EPI, typename TD, typename TR>
+__global__ __launch_bounds__((Geo<BM, BN, WM>::THREADS), (Geo<BM, BN, WM>::WAVES == 8 ? 2 : 1)) void gemm_nt_kernel(const GemmArgs p) {
+  using G = Geo<BM, BN, WM>;
+  constexpr int WN = G::WN, NI = G::NI, NJ = G::NJ;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   [[maybe_unused]] const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)lds));
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
@@ -132,8 +153,28 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   const long nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7;
   const long xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
   const long tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-  const long m0 = (tile / n_tiles_n) * BM;
-  const int n0 = static_cast<int>(tile % n_tiles_n) * BN;
+  // ... in PANELS of p.pw column tiles, row by row inside a panel: the B rows of a panel (pw x 192 x K bf16) are what an XCD's
+  // 32 workgroups re-read for every row tile, and they have to stay in its 4 MB L2 next to the A rows streaming through - with
+  // whole rows of column tiles (pw = N / 192) the 4.7 MB weight of a 3072 x 768 layer came back from the fabric for every pair of
+  // row tiles (L2 hit rate 68 %)
+  const long n_tiles_m = (p.M + BM - 1) / BM;
+  const long tpp = n_tiles_m * p.pw, full = n_tiles_n / p.pw;
+  long trow; int tcol;
+  {
+    const long pn = tile / tpp;
+    if (pn < full) {
+      const long w = tile - pn * tpp;
+      trow = w / p.pw;
+      tcol = static_cast<int>(pn * p.pw + (w - trow * p.pw));
+    } else {
+      const int wl = n_tiles_n - static_cast<int>(full) * p.pw;
+      const long w = tile - full * tpp;
+      trow = w / wl;
+      tcol = static_cast<int>(full * p.pw + (w - trow * wl));
+    }
+  }
+  const long m0 = trow * BM;
+  const int n0 = tcol * BN;
 
   // ---- DMA source addresses of this lane: instruction q of a stage covers tile rows 8 * (q * WAVES + wave) ... + 7 of A (then B)
   const int r8 = lane >> 3, sl = lane & 7;                                   // row inside the 8-row group, LDS chunk inside the row
@@ -161,7 +202,8 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   {                                                                                                            \
     const uint32_t sb_ = lds0 + ((T) & 1) * G::STAGE;                                                          \
     _Pragma("unroll") for (int q = 0; q < G::INSTR; ++q)                                                       \
-      glds16(src[q] + static_cast<long>(T) * (BK * 2), sb_ + (q * G::WAVES + wave) * 1024);                    \
+      if (GEMM_NT_A && q < G::A_INSTR / G::WAVES) glds16_nt(src[q] + static_cast<long>(T) * (BK * 2), sb_ + (q * G::WAVES + wave) * 1024); \
+      else glds16(src[q] + static_cast<long>(T) * (BK * 2), sb_ + (q * G::WAVES + wave) * 1024);               \
   }
 
   // ---- fragment read offsets: chunk (2 ks + half) ^ ((row >> 1) & 7) of row l32 (+ 32-row block offsets, multiples of 16 rows)
@@ -173,11 +215,11 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   }
   const int a_base = wm * (WM * 128), b_base = G::A_BYTES + wn * (WN * 128);
 
-  f32x16 acc[2][3];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -186,24 +228,34 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   // sets, the order pinned: MFMA, read, MFMA, read, ...) - left to itself the compiler issued each k-step's reads right in
   // front of its first MFMA and the LDS latency (~130 cycles) was exposed four times per K step
 #define FRAG_READ(AF, BF, KS)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) AF[i] = *reinterpret_cast<const bf16x8*>(sb_ + a_base + i * 4096 + foff[KS]); \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) BF[j] = *reinterpret_cast<const bf16x8*>(sb_ + b_base + j * 4096 + foff[KS]);
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) AF[i] = *reinterpret_cast<const bf16x8*>(sb_ + a_base + i * 4096 + foff[KS]); \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) BF[j] = *reinterpret_cast<const bf16x8*>(sb_ + b_base + j * 4096 + foff[KS]);
+#define STAGE_LOAD_PART(T, KS)                                                                                 \
+  {                                                                                                            \
+    const uint32_t sl_ = lds0 + ((T) & 1) * G::STAGE;                                                          \
+    _Pragma("unroll") for (int q = (KS) * G::INSTR / 4; q < ((KS) + 1) * G::INSTR / 4; ++q)                    \
+      if (GEMM_NT_A && q < G::A_INSTR / G::WAVES) glds16_nt(src[q] + static_cast<long>(T) * (BK * 2), sl_ + (q * G::WAVES + wave) * 1024); \
+      else glds16(src[q] + static_cast<long>(T) * (BK * 2), sl_ + (q * G::WAVES + wave) * 1024);               \
+  }
 #define KSTEP(AF, BF, AN, BN_, KS)                                                                             \
+    if (GEMM_SPREAD && pre_) STAGE_LOAD_PART(tn_, KS)                                                          \
     if ((KS) < 3) { FRAG_READ(AN, BN_, ((KS) < 3 ? (KS) + 1 : 3)) }                                            \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
-      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                            \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                             \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                           \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i], BF[j], acc[i][j], 0, 0, 0);                 \
     if ((KS) < 3) {                                                                                            \
-      _Pragma("unroll") for (int q_ = 0; q_ < 5; ++q_) {                                                       \
+      _Pragma("unroll") for (int q_ = 0; q_ < NI + NJ; ++q_) {                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                     \
       }                                                                                                        \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+      __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ - NI - NJ, 0);                                       \
     }
-#define COMPUTE(T)                                                                                             \
+#define COMPUTE(T, PRE)                                                                                        \
   {                                                                                                            \
     const unsigned char* sb_ = lds + ((T) & 1) * G::STAGE;                                                     \
-    bf16x8 fa0[2], fb0[3], fa1[2], fb1[3];                                                                     \
+    [[maybe_unused]] const bool pre_ = (PRE);                                                                  \
+    [[maybe_unused]] const int tn_ = (T) + 1;                                                                  \
+    bf16x8 fa0[NI], fb0[NJ], fa1[NI], fb1[NJ];                                                                 \
     FRAG_READ(fa0, fb0, 0)                                                                                     \
     KSTEP(fa0, fb0, fa1, fb1, 0)                                                                               \
     KSTEP(fa1, fb1, fa0, fb0, 1)                                                                               \
@@ -241,10 +293,10 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   for (int t = 0; t + 1 < nt; ++t) {
     RS_WRITE(t + 1)                                                         // buffer (t + 1) & 1: last read in iteration t - 1
     if (t + 2 < nt) { RS_LOAD(t + 2) }
-    COMPUTE(t)
+    COMPUTE(t, false)
     __syncthreads();                                                        // stage t + 1 visible; buffer t & 1 free
   }
-  COMPUTE(nt - 1)
+  COMPUTE(nt - 1, false)
 #undef RS_LOAD
 #undef RS_WRITE
 #else
@@ -252,36 +304,41 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   for (int t = 0; t + 1 < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // stage t has landed (this wavefront's pieces)
     __builtin_amdgcn_s_barrier();                                          // ... everyone's; and nobody reads stage t - 1 any more
+#if GEMM_SPREAD
+    COMPUTE(t, true)
+#else
     STAGE_LOAD(t + 1)
-    COMPUTE(t)
+    COMPUTE(t, false)
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  COMPUTE(nt - 1)
+  COMPUTE(nt - 1, false)
 #endif
 #undef COMPUTE
 #undef KSTEP
+#undef STAGE_LOAD_PART
 #undef FRAG_READ
 #undef STAGE_LOAD
   __syncthreads();                                                          // the ring is dead: epilogue scratch
 
-  // ---- epilogue.  acc[i][j][r] = C[wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half][wn*96 + j*32 + l32].  Two passes (i = 0, 1) of 32
-  //      rows x 96 columns through 12 KiB of LDS per wavefront (fp32), read back as 4-column chunks of a row: 24 chunks per row,
-  //      768 per pass, 12 per lane - a row's chunks sit in consecutive lanes, so loads and stores are contiguous runs.
+  // ---- epilogue.  acc[i][j][r] = C[wm*WM + i*32 + (r&3) + 8*(r>>2) + 4*half][wn*WN + j*32 + l32].  NI passes (i = 0, 1, ..) of 32
+  //      rows x WN columns through 32 x WN x 4 bytes of LDS per wavefront (fp32), read back as 4-column chunks of a row (WN / 4
+  //      per row, WN / 8 per lane and pass) - a row's chunks sit in consecutive lanes, so loads and stores are contiguous runs.
   float* scr = reinterpret_cast<float*>(lds) + wave * (32 * WN);
   const int ncol0 = n0 + wn * WN;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * WN + j * 32 + l32] = acc[i][j][r];
     __builtin_amdgcn_wave_barrier();
     const long mrow0 = m0 + wm * WM + i * 32;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      const int idx = c * 64 + lane, rr = idx / 24, c4 = (idx - rr * 24) * 4;
+    for (int c = 0; c < WN / 8; ++c) {                                       // 32 x WN / 4 chunks per pass, 64 lanes
+      const int idx = c * 64 + lane, rr = idx / (WN / 4), c4 = (idx - rr * (WN / 4)) * 4;
       const long m = mrow0 + rr;
       const int n = ncol0 + c4;
       if (m >= p.M || n >= p.N) continue;                                    // (N is a multiple of 4: whole chunks)
@@ -333,10 +390,10 @@ __global__ __launch_bounds__(Geo<BM>::THREADS, (BM == 256 ? 2 : 1)) void gemm_nt
   }
 }
 
-template <int BM, int EPI, typename TD, typename TR>
+template <int BM, int BN, int WM, int EPI, typename TD, typename TR>
 int launch(const GemmArgs& a, hipStream_t s) {
-  using G = Geo<BM>;
-  auto kfn = gemm_nt_kernel<BM, EPI, TD, TR>;
+  using G = Geo<BM, BN, WM>;
+  auto kfn = gemm_nt_kernel<BM, BN, WM, EPI, TD, TR>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -347,16 +404,17 @@ int launch(const GemmArgs& a, hipStream_t s) {
   return launch_status();
 }
 
-template <int BM>
+template <int BM, int BN, int WM>
 int dispatch(const GemmArgs& a, int epi, int d_dtype, int r_dtype, hipStream_t s) {
   switch (epi) {
-    case EPI_BIAS: return launch<BM, EPI_BIAS, uint16_t, uint16_t>(a, s);
-    case EPI_BIAS_GELU: return launch<BM, EPI_BIAS_GELU, uint16_t, uint16_t>(a, s);
-    case EPI_GELU_GRAD: return launch<BM, EPI_GELU_GRAD, uint16_t, uint16_t>(a, s);
+    case EPI_BIAS: return launch<BM, BN, WM, EPI_BIAS, uint16_t, uint16_t>(a, s);
+    case EPI_BIAS_GELU: return launch<BM, BN, WM, EPI_BIAS_GELU, uint16_t, uint16_t>(a, s);
+    case EPI_GELU_GRAD: return launch<BM, BN, WM, EPI_GELU_GRAD, uint16_t, uint16_t>(a, s);
     case EPI_SCALE_RES:
-      if (d_dtype == APGD_F32) return r_dtype == APGD_F32 ? launch<BM, EPI_SCALE_RES, float, float>(a, s)
-                                                          : launch<BM, EPI_SCALE_RES, float, uint16_t>(a, s);
-      return r_dtype == APGD_F32 ? launch<BM, EPI_SCALE_RES, uint16_t, float>(a, s) : launch<BM, EPI_SCALE_RES, uint16_t, uint16_t>(a, s);
+      if (d_dtype == APGD_F32) return r_dtype == APGD_F32 ? launch<BM, BN, WM, EPI_SCALE_RES, float, float>(a, s)
+                                                          : launch<BM, BN, WM, EPI_SCALE_RES, float, uint16_t>(a, s);
+      return r_dtype == APGD_F32 ? launch<BM, BN, WM, EPI_SCALE_RES, uint16_t, float>(a, s)
+                                 : launch<BM, BN, WM, EPI_SCALE_RES, uint16_t, uint16_t>(a, s);
     default: return APGD_ERR_ARG;
   }
 }
@@ -389,12 +447,25 @@ int cnx_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* D,
   a.D = D; a.ldd = ldd; a.bias = bias; a.gamma = gamma; a.R = R; a.ldr = ldr;
   a.Zout = static_cast<uint16_t*>(z_out); a.Zin = static_cast<const uint16_t*>(z_in); a.ldz = ldz;
   a.M = M; a.N = N; a.K = K;
-  // 256-row tiles (two wavefronts per SIMD) when they give the chip at least ~3 rounds of workgroups, else 128-row tiles
-  const long t256 = ((M + 255) / 256) * ((N + BN - 1) / BN);
+  // tile: 256 x 256 (128 FLOP per staged byte) where N is a multiple of 256 and the grid still has >= ~2 rounds of workgroups;
+  // else 256 x 192 (every N of the models is a multiple of 192) when that gives >= ~3 rounds; else 128 x 192
   static const int bm_env = getenv("APGD_GEMM_BM") ? atoi(getenv("APGD_GEMM_BM")) : 0;      // tuning experiments only
-  const bool big = bm_env ? bm_env == 256 : t256 >= 768;
-  if (big) return dispatch<256>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
-  return dispatch<128>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
+  static const int bn_env = getenv("APGD_GEMM_BN") ? atoi(getenv("APGD_GEMM_BN")) : 0;
+  static const int pw_env = getenv("APGD_GEMM_PW") ? atoi(getenv("APGD_GEMM_PW")) : 0;
+  const long rows256 = (M + 255) / 256;
+  int bn = (N % 256 == 0 && rows256 * (N / 256) >= 512) ? 256 : 192;
+  if (bn_env == 192 || bn_env == 256) bn = bn_env;
+  const int ntn = (N + bn - 1) / bn;
+  const bool big = bn == 256 || (bm_env ? bm_env == 256 : rows256 * ntn >= 768);
+  // panel width: the widest whose B rows (pw x BN x K bf16) take at most ~1.5 MB of an XCD's 4 MB L2
+  int pw = static_cast<int>((1536L * 1024) / (static_cast<long>(bn) * K * 2));
+  if (pw_env > 0) pw = pw_env;
+  a.pw = pw < 1 ? 1 : (pw > ntn ? ntn : pw);
+  static const int w4_env = getenv("APGD_GEMM_W4") ? atoi(getenv("APGD_GEMM_W4")) : 0;       // 1: 256 x 256 on four wavefronts of 128 x 128
+  if (bn == 256 && w4_env) return dispatch<256, 256, 128>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
+  if (bn == 256) return dispatch<256, 256, 64>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
+  if (big) return dispatch<256, 192, 64>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
+  return dispatch<128, 192, 64>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
 }
 
 }  // extern "C"

@@ -355,8 +355,12 @@ __global__ __launch_bounds__(512) void dwconv7x7_dot2_kernel(const TI* __restric
   // ---- staging: unit = (row, pair m, 4-channel group): two 4-channel loads (padded cols 2m, 2m+1) -> 4 packed dwords
   constexpr int kSR = 4;
   const int row_units = P2 * (kDC / 4);
-  for (int tr0 = 0; tr0 < (DW_DBG(dbg, 2) ? 0 : TH + 6); tr0 += kSR) {       // dbg 2: timing experiment, no staging
-    for (int i = tid; i < row_units; i += nthr) {
+  // (all (row group, unit) pairs dealt over the whole workgroup: at 14x14 a row group is 88 units for 256 threads, and walking
+  //  the five row groups one after the other exposed the load latency five times with two thirds of the threads idle)
+  const int n_rg = (TH + 6 + kSR - 1) / kSR;
+  {
+    for (int j = tid; j < (DW_DBG(dbg, 2) ? 0 : n_rg * row_units); j += nthr) {   // dbg 2: timing experiment, no staging
+      const int rg = j / row_units, i = j - rg * row_units, tr0 = rg * kSR;
       const int m = i / (kDC / 4), l4 = i - m * (kDC / 4);
       const int w0 = 2 * m - 3, w1 = w0 + 1;
       float4 v0[kSR], v1[kSR];

@@ -35,10 +35,13 @@ def iteration_lrs(epoch, iters, **kw):
     return np.interp(np.arange(iters), [0, iters], [get_cosine_lr(epoch, **kw), get_cosine_lr(epoch + 1, **kw)])
 
 
-def create_optimizer(model: nn.Module, arch: str, weight_decay: float = 0.05):
+def create_optimizer(model: nn.Module, arch: str, weight_decay: float = 0.05, capturable: bool = False):
     """AdamW(betas=(0.9, 0.95)) with the reference's two parameter groups (``main.py:395-459``):
     for convnext/resnet archs the names containing ``bn`` or ``.bias`` are not decayed (LayerNorm
-    weights and gammas ARE); otherwise 1-D parameters and biases are not decayed."""
+    weights and gammas ARE); otherwise 1-D parameters and biases are not decayed.
+
+    ``capturable``: step counters and the learning rate are device tensors, so the update can be part of a hipGraph
+    (``ATTrainStep(graph_train=True)``); the arithmetic is the same."""
     named = [(k, v) for k, v in model.named_parameters() if v.requires_grad]
     if 'convnext' in arch or 'resnet' in arch:
         excluded = ['bn', '.bias']
@@ -48,6 +51,10 @@ def create_optimizer(model: nn.Module, arch: str, weight_decay: float = 0.05):
         no_decay = [v for k, v in named if v.ndim <= 1 or k.endswith('.bias')]
         decay = [v for k, v in named if not (v.ndim <= 1 or k.endswith('.bias'))]
     groups = [{'params': no_decay, 'weight_decay': 0.}, {'params': decay, 'weight_decay': weight_decay}]
+    if capturable:
+        dev = decay[0].device
+        return torch.optim.AdamW(groups, lr=torch.tensor(1e-3, dtype=torch.float32, device=dev), betas=(0.9, 0.95), fused=True,
+                                 capturable=True)
     return torch.optim.AdamW(groups, betas=(0.9, 0.95), fused=decay[0].is_cuda)
 
 
@@ -112,14 +119,68 @@ def setup_distributed():
     return rank, local, world
 
 
+class _TrainPassGraph:
+    """The training pass of one step - forward of the adversarial batch, loss, backward, AdamW, EMA (``main.py:985-997``) -
+    captured once as a hipGraph and replayed: ~350 kernel launches through Python autograd functions become one graph
+    launch.  Same capture rules as ``graphed._Program``: parameters (and their ``.grad``, allocated in the graph's pool by
+    the captured backward) are read and written in place, derived weight copies are rebuilt inside the graph."""
+
+    def __init__(self, step: "ATTrainStep", x, target):
+        self.x = torch.empty_like(x)
+        self.t = torch.empty_like(target)
+        self.x.copy_(x)
+        self.t.copy_(target)
+        self.derived = {}
+        self.graph = torch.cuda.CUDAGraph()
+        step.optimizer.zero_grad(set_to_none=True)             # the captured backward allocates every .grad in the graph's pool
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        prev = ops._CAPTURE_CACHE
+        ops._CAPTURE_CACHE = self.derived
+        try:
+            with torch.cuda.stream(side):
+                self.graph.capture_begin()
+                try:
+                    self.loss = step._train_pass(self.x, self.t)
+                except BaseException:
+                    try:
+                        self.graph.capture_end()
+                    except Exception:                          # noqa: BLE001 - the capture is already invalid
+                        pass
+                    raise
+                self.graph.capture_end()
+        finally:
+            ops._CAPTURE_CACHE = prev
+        torch.cuda.current_stream().wait_stream(side)
+
+    def __call__(self, x, target):
+        self.x.copy_(x)
+        self.t.copy_(target)
+        self.graph.replay()
+        return self.loss.clone()
+
+
+TRAIN_GRAPH_WARMUP = 3            # eager steps per batch shape before its training pass is captured (the attack's graphs: step 3)
+
+
 class ATTrainStep:
-    """Builds ``DDP(WrappedModel(model, apgd))`` + optimizer (+EMA) and runs single steps."""
+    """Builds ``DDP(WrappedModel(model, apgd))`` + optimizer (+EMA) and runs single steps.
+
+    ``graph_train`` (default: on when ``adv.graph`` is set, on one GPU): after ``TRAIN_GRAPH_WARMUP`` eager steps the
+    training pass is replayed from a hipGraph (``_TrainPassGraph``); it needs static batch shapes - a batch of another shape
+    runs eagerly.  Under DDP the pass stays eager (the gradient all-reduce is fired from autograd hooks)."""
 
     def __init__(self, model: nn.Module, arch: str, adv: AdvConfig, device, lr: float = 1e-3,
                  weight_decay: float = 0.05, distributed: bool = False, channels_last: bool = True,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ema: bool = True, mixup=None,
-                 soft_targets: bool = False, perturb=None, gemm_table: bool = False, ema_decay: float = 0.9999):
+                 soft_targets: bool = False, perturb=None, gemm_table: bool = False, ema_decay: float = 0.9999,
+                 graph_train: Optional[bool] = None):
         self.device = torch.device(device)
+        if graph_train is None:
+            graph_train = bool(getattr(adv, "graph", 0)) and os.environ.get("APGD_GRAPH_TRAIN", "1") != "0"
+        self.graph_train = bool(graph_train) and not distributed and self.device.type == 'cuda'
+        self._tg = {}                                                      # (shapes, dtypes) -> _TrainPassGraph | None (failed)
+        self._tg_seen = {}                                                 # (shapes, dtypes) -> eager steps so far
         if gemm_table and self.device.type == 'cuda':
             # opt-in: points PyTorch's process-wide TunableOp at the shipped, read-only hipBLASLt solution table
             ops.load_gemm_table()
@@ -140,7 +201,7 @@ class ATTrainStep:
             wrapped = nn.parallel.DistributedDataParallel(wrapped, device_ids=ids, broadcast_buffers=False,
                                                           gradient_as_bucket_view=True)
         self.model = wrapped
-        self.optimizer = create_optimizer(self.inner, arch, weight_decay)
+        self.optimizer = create_optimizer(self.inner, arch, weight_decay, capturable=self.graph_train)
         self.loss = (lambda o, t: torch.sum(-t * torch.log_softmax(o.float(), dim=-1), dim=-1).mean()) \
             if soft_targets else nn.CrossEntropyLoss()                     # SoftTargetCrossEntropy / CE (main.py:461-466)
         self.amp_dtype = amp_dtype
@@ -150,11 +211,70 @@ class ATTrainStep:
             self.inner.set_perturb(True)                                   # main.py:950-954
         self.model.train()
 
-    def step(self, images, target, lr: Optional[float] = None):
+    def _set_lr(self, lr):
         for g in self.optimizer.param_groups:                              # main.py:973-974
-            g['lr'] = self.lr if lr is None else lr
+            if isinstance(g['lr'], torch.Tensor):
+                g['lr'].fill_(lr)                                          # capturable optimizer: the graph reads this tensor
+            else:
+                g['lr'] = lr
+
+    def _train_pass(self, x_adv, target):
+        """forward - loss - backward - AdamW - EMA on an already perturbed batch (what ``_TrainPassGraph`` captures)."""
+        with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            output = self.inner.base_model(x_adv)                          # main.py:293 (WrappedModel.forward after the attack)
+            loss = self.loss(output, target)
+        loss.backward()
+        self.optimizer.step()
+        if self.ema is not None:
+            self.ema.update()
+        return loss.detach()
+
+    def _graph_step(self, images, target):
+        """The step with the training pass replayed from a hipGraph; None if this batch has to run eagerly."""
+        key = (tuple(images.shape), images.dtype, tuple(target.shape), target.dtype)
+        if key in self._tg and self._tg[key] is None:
+            return None
+        if key not in self._tg and self._tg_seen.get(key, 0) < TRAIN_GRAPH_WARMUP:
+            self._tg_seen[key] = self._tg_seen.get(key, 0) + 1            # libraries meet every shape outside a capture first
+            return None
+        base = self.inner.base_model
+        if self.perturb:                                                   # WrappedModel.forward, main.py:276-292 (under the
+            base.eval()                                                    # step's autocast, as main.py:985 has it)
+            with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                z = self.inner.perturb(base, images, target)
+            base.train()
+            if isinstance(z, (tuple, list)):
+                z = z[0]
+        else:
+            z = images
+        prog = self._tg.get(key)
+        if prog is None:
+            try:
+                prog = self._tg[key] = _TrainPassGraph(self, z, target)
+            except Exception as e:                                         # noqa: BLE001 - any capture failure means "run eagerly"
+                import warnings
+                warnings.warn(f"training-pass graph capture failed ({type(e).__name__}: {e}); this batch shape runs eagerly")
+                self._tg[key] = None
+                torch.cuda.synchronize()
+                self.optimizer.zero_grad(set_to_none=True)
+                loss = self._train_pass(z, target)
+                ops.invalidate_weight_cache()
+                return loss
+        loss = prog(z, target)
+        ops.invalidate_weight_cache()                                      # eager consumers of packed / bf16 weight copies
+        return loss
+
+    def step(self, images, target, lr: Optional[float] = None):
+        self._set_lr(self.lr if lr is None else lr)
         if self.mixup_fn is not None:
             images, target = self.mixup_fn(images, target)                 # main.py:965-966 (soft labels [B, n_cls])
+        if self.graph_train and images.is_cuda:
+            loss = self._graph_step(images, target)
+            if loss is not None:
+                return loss
+        return self._eager_step(images, target)
+
+    def _eager_step(self, images, target):
         self.optimizer.zero_grad(set_to_none=True)                         # main.py:984
         with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             output = self.model(images, target) if self.perturb else self.model(images)   # main.py:985-989

@@ -1,4 +1,4 @@
-"""cnx_gemm_nt (csrc/gemm_kernels.hip) against fp32 torch references of the same arithmetic: the four epilogues, both tile
+"""cnx_gemm_nt (csrc/gemm_kernels.hip) against fp32 torch references of the same arithmetic: the four epilogues, the three tile
 configurations, ragged M / N, strided operands, and the operators that route through it (``ops.mlp_residual``, ``ops.linear_lib``,
 the library-path ConvNeXt block, the downsample layer) against their hipBLASLt composition (``APGD_GEMM=lib`` path)."""
 import numpy as np
@@ -25,7 +25,8 @@ def rel(a, b):
     return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
 
 
-SHAPES = [(256 * 100, 1536, 384),      # 800 tiles of 256 x 192: the 8-wavefront configuration
+SHAPES = [(256 * 100 + 37, 1536, 384), # 606 tiles of 256 x 256 (N a multiple of 256, >= 512 tiles), ragged last row tile
+          (256 * 120, 1344, 128),      # 840 tiles of 256 x 192: the other 8-wavefront configuration
           (12544, 768, 3072),          # 128-row tiles, long K
           (1000, 192, 64), (777, 196, 128), (33, 4, 64), (4099, 388, 448)]
 
@@ -48,7 +49,7 @@ def test_gemm_bias_and_gelu_epilogues(R, M, N, K):
     assert float((h.float() - F.gelu(z.float())).abs().max()) <= 2e-2 * float(z.float().abs().max())
 
 
-@pytest.mark.parametrize("M,N,K", SHAPES[:4])
+@pytest.mark.parametrize("M,N,K", SHAPES[:5])
 @pytest.mark.parametrize("rdt,odt", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16)])
 def test_gemm_scale_residual_epilogue(R, M, N, K, rdt, odt):
     O = R.ops
@@ -68,7 +69,7 @@ def test_gemm_scale_residual_epilogue(R, M, N, K, rdt, odt):
     assert rel(out2, r.float() + y.float()) <= (3e-3 if odt == torch.float32 else 6e-3)
 
 
-@pytest.mark.parametrize("M,N,K", SHAPES[:4])
+@pytest.mark.parametrize("M,N,K", SHAPES[:5])
 def test_gemm_gelu_grad_epilogue(R, M, N, K):
     O = R.ops
     g = torch.Generator(device="cuda").manual_seed(11)

@@ -82,10 +82,14 @@ def test_graph_mode_leaves_error_behaviour_alone(R):
                      eps=EPS, n_iter=2, use_rs=True, graph=True)
 
 
-def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R):
-    """Six full AT steps (attack + train forward / backward + AdamW + EMA) with adv.graph = 1 and 0 from the same seeds: the same
-    loss trajectory and the same final parameters (to the run-to-run noise of the library's backward kernels) - the replayed
-    attack reads the parameters the optimizer just wrote."""
+@pytest.mark.parametrize("graph_train", [False, True])
+def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R, graph_train):
+    """Seven full AT steps (attack + train forward / backward + AdamW + EMA, a different learning rate at every step) with
+    adv.graph = 1 and 0 from the same seeds: the same loss trajectory, the same final parameters and the same EMA copy (to the
+    run-to-run noise of the library's backward kernels) - the replayed attack reads the parameters the optimizer just wrote.
+    ``graph_train``: the training pass is replayed from a hipGraph too (from the fourth step on), with the capturable AdamW."""
+    lrs = [1e-3, 8e-4, 1.2e-3, 5e-4, 9e-4, 1e-3, 7e-4]
+
     def run(graph):
         R.graphed.reset()
         torch.manual_seed(5)
@@ -93,23 +97,56 @@ def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R):
         m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
         m.stem = A.ConvBlock1(48)
         tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=graph), "cuda", lr=1e-3,
-                           amp_dtype=torch.bfloat16, ema=True)
+                           amp_dtype=torch.bfloat16, ema=True, ema_decay=0.9, graph_train=bool(graph) and graph_train)
         g = torch.Generator(device="cuda").manual_seed(9)
         losses = []
-        for _ in range(6):
+        for lr in lrs:
             x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
             y = torch.randint(0, 10, (4,), device="cuda", generator=g)
-            losses.append(float(tr.step(x, y)))
-        return losses, [p.detach().clone() for p in tr.inner.parameters()]
-    l1, p1 = run(1)
+            losses.append(float(tr.step(x, y, lr=lr)))
+        if graph and graph_train:
+            assert [v is not None for v in tr._tg.values()] == [True], "the training pass was not captured"
+        else:
+            assert not tr._tg
+        return losses, [p.detach().clone() for p in tr.inner.parameters()], [v.detach().clone() for v in tr.ema.ema]
+    l1, p1, e1 = run(1)
     assert R.graphed.STATS["replays"] >= 4
-    l0, p0 = run(0)
+    l0, p0, e0 = run(0)
     # the attack is bit-reproducible (test above), the TRAINING backward is not: the library's convolution filter-gradient kernels
     # differ in the last bits from run to run (profiles/r02_determinism.log) - compare at that level
     assert max(abs(a - b) for a, b in zip(l1, l0)) <= 2e-3 * max(abs(v) for v in l0), (l1, l0)
-    num = sum(float((a.float() - b.float()).pow(2).sum()) for a, b in zip(p1, p0))
-    den = sum(float(b.float().pow(2).sum()) for b in p0)
-    assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+    for got, want in ((p1, p0), (e1, e0)):
+        num = sum(float((a.float() - b.float()).pow(2).sum()) for a, b in zip(got, want))
+        den = sum(float(b.float().pow(2).sum()) for b in want)
+        assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+
+
+def test_training_pass_graph_runs_other_batch_shapes_eagerly_and_keeps_training(R):
+    """A batch of another shape after the capture (the last, short batch of an epoch) runs through the eager step with the same
+    optimizer state, and the next full batch replays again; both move the parameters."""
+    R.graphed.reset()
+    torch.manual_seed(6)
+    A = R.architecture
+    m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
+    m.stem = A.ConvBlock1(48)
+    tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=1), "cuda", lr=1e-3,
+                       amp_dtype=torch.bfloat16, ema=True)
+    assert tr.graph_train
+    g = torch.Generator(device="cuda").manual_seed(10)
+
+    def batch(n):
+        return torch.rand(n, 3, 64, 64, device="cuda", generator=g), torch.randint(0, 10, (n,), device="cuda", generator=g)
+    for _ in range(5):
+        tr.step(*batch(4))
+    w = next(iter(tr.inner.parameters()))
+    before = w.detach().clone()
+    l_short = tr.step(*batch(3))                               # second shape: eager (it would be captured after three such steps)
+    mid = w.detach().clone()
+    l_full = tr.step(*batch(4))
+    after = w.detach().clone()
+    assert torch.isfinite(l_short) and torch.isfinite(l_full)
+    assert not torch.equal(before, mid) and not torch.equal(mid, after)
+    assert sum(v is not None for v in tr._tg.values()) >= 1
 
 
 def test_sign_sink_steps_aside_when_the_iterate_has_a_second_consumer(R):
