@@ -136,7 +136,7 @@ class ApgdWorkspace:
         self.flags = torch.empty(B, device=dev, dtype=torch.uint8)
 
 
-def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace, loss_out, pred_out,
+def _model_fwd_bwd_inner(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace, loss_out, pred_out,
                    need_grad: bool, kind: int = 0, y_target=None, sign_ok: bool = False, sign_blocked: bool = False):
     """One model call of the attack: forward, K2, and (optionally) the input gradient.
 
@@ -167,7 +167,7 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
             warnings.warn("the attack iterate feeds more than the ConvStem's first convolution: gradient-sign sink disabled for "
                           "this model (fp32 input gradient through autograd)")
             _SINK_REFUSED.add(id(model))
-            return _model_fwd_bwd(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, False, False)
+            return _model_fwd_bwd_inner(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, False, False)
         if grad.stride() != x_in.stride():
             g2 = torch.empty_like(x_in, dtype=grad.dtype)
             g2.copy_(grad)
@@ -177,6 +177,10 @@ def _model_fwd_bwd(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace,
         logits = model(x_in)
     _loss_pred(logits, y_hard, y_soft, loss_out, pred_out, False, kind, *(() if y_target is None else (y_target,)))
     return None
+
+
+def _model_fwd_bwd(*args, **kw):
+    return _model_fwd_bwd_inner(*args, **kw)
 
 
 _SIDE_STREAMS = {}
@@ -214,7 +218,7 @@ def _model_fwd_bwd_split(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, ne
     for h, st in enumerate(streams):
         a, b = cuts[h], cuts[h + 1]
         st.wait_stream(main)
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(st), ops.attack_pass():       # chunks overlap: no library GEMMs in them (see ops.attack_pass)
             g = _model_fwd_bwd(model, x_in[a:b], None if y_hard is None else y_hard[a:b], None if y_soft is None else y_soft[a:b], ws,
                                loss_out[a:b], pred_out[a:b], need_grad, kind, None if y_target is None else y_target[a:b], sign_ok,
                                sign_blocked)

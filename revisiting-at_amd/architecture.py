@@ -267,6 +267,10 @@ class ConvNeXt(nn.Module):
     def __init__(self, depths=(3, 3, 9, 3), dims=(96, 192, 384, 768), num_classes=1000, ls_init_value=1e-6):
         super().__init__()
         self.num_classes, self.num_features = num_classes, dims[-1]
+        # graphed.py: a captured attack on this model runs as two batch chunks on two streams.  Pays on the narrow pyramids
+        # (ConvNeXt-T / -S: the late stages' kernels have 98 - 392 workgroups for 256 CUs); the wide ones and the isotropic /
+        # transformer models are GEMM-bound at every depth and keep one stream (and the library's GEMMs, measured faster there)
+        self.apgd_two_streams = max(dims) <= 768
         self.stem = nn.Sequential(nn.Conv2d(3, dims[0], kernel_size=4, stride=4), LayerNorm2d(dims[0], eps=1e-6))
         self.stages = nn.Sequential(*[ConvNeXtStage(dims[max(i - 1, 0)], dims[i], depths[i], i == 0, ls_init_value)
                                       for i in range(4)])
@@ -398,6 +402,7 @@ class PatchEmbed(nn.Module):
 
 
 class VisionTransformer(nn.Module):
+
     def __init__(self, img_size=224, patch_size=16, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
                  init_values=None, no_embed_class=False):
         super().__init__()

@@ -85,13 +85,6 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
 __device__ __forceinline__ void glds16(const unsigned char* gsrc, uint32_t dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "memory");
 }
-// the same with the non-temporal hint (tuning experiment GEMM_NT_A: the A rows are streamed, the B rows are the reused operand)
-__device__ __forceinline__ void glds16_nt(const unsigned char* gsrc, uint32_t dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(dst) : "memory");
-}
-#ifndef GEMM_NT_A
-#define GEMM_NT_A 0
-#endif
 
 // 0 (default): the LDS-DMA two-stage ring; 1: operands staged through registers, three stages deep on the same two LDS buffers
 // (see the main loop).  Measured on MI355X (tools/gemm_bench.py, both builds in one run): 440 - 800 vs 480 - 870 TFLOP/s - like
@@ -202,8 +195,7 @@ __global__ __launch_bounds__((Geo<BM, BN, WM>::THREADS), (Geo<BM, BN, WM>::WAVES
   {                                                                                                            \
     const uint32_t sb_ = lds0 + ((T) & 1) * G::STAGE;                                                          \
     _Pragma("unroll") for (int q = 0; q < G::INSTR; ++q)                                                       \
-      if (GEMM_NT_A && q < G::A_INSTR / G::WAVES) glds16_nt(src[q] + static_cast<long>(T) * (BK * 2), sb_ + (q * G::WAVES + wave) * 1024); \
-      else glds16(src[q] + static_cast<long>(T) * (BK * 2), sb_ + (q * G::WAVES + wave) * 1024);               \
+      glds16(src[q] + static_cast<long>(T) * (BK * 2), sb_ + (q * G::WAVES + wave) * 1024);                    \
   }
 
   // ---- fragment read offsets: chunk (2 ks + half) ^ ((row >> 1) & 7) of row l32 (+ 32-row block offsets, multiples of 16 rows)
@@ -234,8 +226,7 @@ __global__ __launch_bounds__((Geo<BM, BN, WM>::THREADS), (Geo<BM, BN, WM>::WAVES
   {                                                                                                            \
     const uint32_t sl_ = lds0 + ((T) & 1) * G::STAGE;                                                          \
     _Pragma("unroll") for (int q = (KS) * G::INSTR / 4; q < ((KS) + 1) * G::INSTR / 4; ++q)                    \
-      if (GEMM_NT_A && q < G::A_INSTR / G::WAVES) glds16_nt(src[q] + static_cast<long>(T) * (BK * 2), sl_ + (q * G::WAVES + wave) * 1024); \
-      else glds16(src[q] + static_cast<long>(T) * (BK * 2), sl_ + (q * G::WAVES + wave) * 1024);               \
+      glds16(src[q] + static_cast<long>(T) * (BK * 2), sl_ + (q * G::WAVES + wave) * 1024);                    \
   }
 #define KSTEP(AF, BF, AN, BN_, KS)                                                                             \
     if (GEMM_SPREAD && pre_) STAGE_LOAD_PART(tn_, KS)                                                          \
@@ -461,8 +452,8 @@ int cnx_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* D,
   int pw = static_cast<int>((1536L * 1024) / (static_cast<long>(bn) * K * 2));
   if (pw_env > 0) pw = pw_env;
   a.pw = pw < 1 ? 1 : (pw > ntn ? ntn : pw);
-  static const int w4_env = getenv("APGD_GEMM_W4") ? atoi(getenv("APGD_GEMM_W4")) : 0;       // 1: 256 x 256 on four wavefronts of 128 x 128
-  if (bn == 256 && w4_env) return dispatch<256, 256, 128>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
+  // (the wavefront-tile height is a template parameter: 256 x 256 on FOUR wavefronts of 128 x 128 - 256 accumulator registers,
+  //  half the fragment reads per MFMA, one wavefront per SIMD - measured 25 - 40 % slower than eight of 64 x 128)
   if (bn == 256) return dispatch<256, 256, 64>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
   if (big) return dispatch<256, 192, 64>(a, epilogue, d_dtype, r_dtype, as_stream(stream));
   return dispatch<128, 192, 64>(a, epilogue, d_dtype, r_dtype, as_stream(stream));

@@ -34,6 +34,18 @@ WARMUP_CALLS = 2                 # eager calls before the capture (library handl
 # batch chunks the model calls of a captured attack are cut into, each on its own stream (apgd._model_fwd_bwd_split): fills the CUs
 # the late stages' small kernels leave idle; costs nothing on the host once captured.  APGD_ATTACK_STREAMS=1: one stream.
 STREAMS = int(os.environ.get("APGD_ATTACK_STREAMS", "2"))
+
+
+def _streams(model):
+    """Chunks / streams of a captured attack: two for the models that ask for it (``apgd_two_streams``: the narrow ConvNeXt
+    pyramids), else one.  With more than one stream the attack's GEMMs all run on cnx_gemm_nt (``ops.attack_pass``): two of the
+    library's stream-K GEMMs in flight at once deadlocked the GPU (ViT-B shapes, round 3) - hence never with APGD_GEMM=lib /
+    APGD_OPS=eager, and never for a model that is not built from ``architecture``'s classes."""
+    if ops._GEMM_MODE == "lib" or ops.MODE == "eager" or STREAMS <= 1:
+        return 1
+    return STREAMS if any(getattr(m, "apgd_two_streams", False) for m in model.modules()) else 1
+
+
 STATS = {"captures": 0, "replays": 0, "eager": 0, "failed": 0}
 _programs = {}
 
@@ -87,7 +99,7 @@ class _Program:
             with torch.cuda.stream(side):
                 rec.begin()
                 try:
-                    self.out = apgd._apgd_core(model, self.x, self.y, norm, eps, n_iter, kind, soft=soft, rec=rec, splits=STREAMS)
+                    self.out = apgd._apgd_core(model, self.x, self.y, norm, eps, n_iter, kind, soft=soft, rec=rec, splits=_streams(model))
                 except BaseException:
                     rec.abort()
                     raise
@@ -113,7 +125,7 @@ class _Program:
 def _signature(model, x, y, norm, eps, n_iter, kind, soft):
     ac = (torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
     return (id(model), tuple(x.shape), tuple(x.stride()), x.dtype, x.device.index, tuple(y.shape), y.dtype, norm, float(eps),
-            int(n_iter), int(kind), bool(soft), ac, ops.MODE, apgd.USE_SIGN_SINK, STREAMS)
+            int(n_iter), int(kind), bool(soft), ac, ops.MODE, apgd.USE_SIGN_SINK, _streams(model))
 
 
 def reset():
@@ -142,7 +154,7 @@ def run(model, x, y, norm, eps, n_iter, kind, soft):
             ent["calls"] += 1
             STATS["eager"] += 1
             # (same batch chunks as the capture will use: every kernel / library shape is initialised before it)
-            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=1 if ent["failed"] else STREAMS)
+            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=1 if ent["failed"] else _streams(model))
         try:
             prog = ent["prog"] = _Program(model, x, y, norm, eps, n_iter, kind, soft)
             STATS["captures"] += 1

@@ -66,6 +66,26 @@ class attack_forward:
         return False
 
 
+# Set by apgd._model_fwd_bwd_split around the model calls of an attack whose batch chunks run on SEVERAL streams (graph replay of
+# the narrow ConvNeXt pyramids).  Under APGD_GEMM=auto those calls' pointwise convolutions / linears then all run on cnx_gemm_nt:
+# two of the library's stream-K GEMMs in flight at once deadlocked the GPU (ViT-B shapes, hipBLASLt ``..._SK3_...`` solutions
+# spinning on a shared synchroniser), so overlapping chunks keep the library's GEMMs out of their streams.
+_ATTACK_PASS = False
+
+
+class attack_pass:
+    def __enter__(self):
+        global _ATTACK_PASS
+        self._prev = _ATTACK_PASS
+        _ATTACK_PASS = True
+        return self
+
+    def __exit__(self, *exc):
+        global _ATTACK_PASS
+        _ATTACK_PASS = self._prev
+        return False
+
+
 # Gradient-sign sink of the Linf attack.  ``step_size * sign(grad)`` (autopgd_train_clean.py:221) is the only use the Linf
 # update makes of the input gradient, so when the layer that produces it is our own first stem convolution AND its input
 # is the attack iterate itself, the attack hands it an int8 buffer: the kernel stores sign(dx) (a quarter of the bytes)
@@ -856,17 +876,28 @@ _GEMM_MODE = os.environ.get("APGD_GEMM", "auto")
 EPI_BIAS, EPI_BIAS_GELU, EPI_SCALE_RES, EPI_GELU_GRAD = 0, 1, 2, 3
 
 
-def _gemm_on(site):
-    """Is cnx_gemm_nt enabled for this call site ("mlp", "linear", "downsample", "direct")?"""
+# auto policy, "mlp" / "linear" sites of the TRAINING pass: cnx_gemm_nt up to this many (rows x wider dimension); 0 = never
+# (default).  Kernel for kernel it equals the library on the ConvNeXt-T / -S layers (50176 x 1536 at C = 384, 12544 x 3072 at
+# C = 768: +0.6 ms per step in the kernel trace, hipBLASLt 12 % -> 6 % of the step) but the un-profiled step was 2 ms slower with
+# it in three interleaved runs (55.3 / 53.3 / 55.5 ms, 8e7 / 0 / 8e7), and on the larger problems (ViT-B 50432 x 3072, ConvNeXt-L)
+# the library's kernels are 15 - 20 % ahead (profiles/r03_gemm.md) - so the training pass keeps the library
+_GEMM_AUTO_MAX = int(float(os.environ.get("APGD_GEMM_AUTO_MAX", "0")))
+
+
+def _gemm_on(site, M=0, N=0, K=0):
+    """Is cnx_gemm_nt enabled for this call site ("mlp", "linear", "downsample", "direct") and problem size?"""
     if MODE == "eager" or _GEMM_MODE == "lib":
         return False
-    return _GEMM_MODE == "hip" or site in ("downsample", "direct")
+    if _GEMM_MODE == "hip" or site in ("downsample", "direct") or _ATTACK_PASS:
+        return True
+    return 0 < M * max(N, K) <= _GEMM_AUTO_MAX
 
 
 def _gemm_ok(a, w_nk, site="direct"):
     """cnx_gemm_nt takes ``a`` [M, K] and ``w_nk`` [N, K]: bf16, unit inner stride, 16-byte rows, K % 64 == 0, N % 4 == 0."""
-    return (_gemm_on(site) and a.is_cuda and a.dtype == torch.bfloat16 and w_nk.dtype == torch.bfloat16
-            and a.dim() == 2 and w_nk.dim() == 2 and a.stride(1) == 1 and w_nk.stride(1) == 1 and a.shape[1] == w_nk.shape[1]
+    return (a.dim() == 2 and w_nk.dim() == 2 and _gemm_on(site, a.shape[0], w_nk.shape[0], a.shape[1])
+            and a.is_cuda and a.dtype == torch.bfloat16 and w_nk.dtype == torch.bfloat16
+            and a.stride(1) == 1 and w_nk.stride(1) == 1 and a.shape[1] == w_nk.shape[1]
             and a.shape[1] % 64 == 0 and w_nk.shape[0] % 4 == 0 and a.stride(0) % 8 == 0 and w_nk.stride(0) % 8 == 0
             and a.data_ptr() % 16 == 0 and w_nk.data_ptr() % 16 == 0 and a.shape[0] > 0)
 
@@ -874,7 +905,8 @@ def _gemm_ok(a, w_nk, site="direct"):
 def _gemm_dims_ok(a, K, N, site="direct"):
     """The same test for an operand pair that does not exist yet: ``a`` is a bf16 row matrix of ours, the weight copy will be
     a fresh contiguous [N, K] bf16 tensor."""
-    return (_gemm_on(site) and a.is_cuda and a.dtype == torch.bfloat16 and K % 64 == 0 and N % 4 == 0 and a.shape[0] > 0)
+    return (_gemm_on(site, a.shape[0], N, K) and a.is_cuda and a.dtype == torch.bfloat16 and K % 64 == 0 and N % 4 == 0
+            and a.shape[0] > 0)
 
 
 def _gemm_nt(a, w_nk, epi=EPI_BIAS, bias=None, gamma=None, resid=None, out_dtype=torch.bfloat16, z_out=None, z_in=None):
