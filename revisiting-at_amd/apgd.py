@@ -19,6 +19,7 @@ There is no CPU fallback: CPU tensors or a missing ``libapgd_hip.so`` raise.
 from __future__ import annotations
 
 import contextlib
+import weakref
 import math
 import os
 from typing import List, Optional, Tuple
@@ -179,8 +180,30 @@ def _model_fwd_bwd_inner(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWork
     return None
 
 
-def _model_fwd_bwd(*args, **kw):
-    return _model_fwd_bwd_inner(*args, **kw)
+_TWO_STREAM = weakref.WeakKeyDictionary()
+
+
+def two_stream_model(model) -> bool:
+    """Does this model ask for the two-stream form of a captured attack (``architecture.ConvNeXt.apgd_two_streams``: the narrow
+    pyramids)?  Such a model's attack calls ALWAYS run their GEMMs on cnx_gemm_nt (``ops.attack_pass``), chunked or not, graph
+    or eager: overlapping chunks must not contain library GEMMs, and the eager attack has to stay bit-identical to the replay."""
+    try:
+        return _TWO_STREAM[model]
+    except (KeyError, TypeError):
+        pass
+    v = bool(isinstance(model, torch.nn.Module) and any(getattr(m, "apgd_two_streams", False) for m in model.modules()))
+    try:
+        _TWO_STREAM[model] = v
+    except TypeError:
+        pass
+    return v
+
+
+def _model_fwd_bwd(model, *args, **kw):
+    if two_stream_model(model):
+        with ops.attack_pass():
+            return _model_fwd_bwd_inner(model, *args, **kw)
+    return _model_fwd_bwd_inner(model, *args, **kw)
 
 
 _SIDE_STREAMS = {}
@@ -218,7 +241,7 @@ def _model_fwd_bwd_split(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, ne
     for h, st in enumerate(streams):
         a, b = cuts[h], cuts[h + 1]
         st.wait_stream(main)
-        with torch.cuda.stream(st), ops.attack_pass():       # chunks overlap: no library GEMMs in them (see ops.attack_pass)
+        with torch.cuda.stream(st):                          # (chunks overlap: two_stream_model keeps library GEMMs out of them)
             g = _model_fwd_bwd(model, x_in[a:b], None if y_hard is None else y_hard[a:b], None if y_soft is None else y_soft[a:b], ws,
                                loss_out[a:b], pred_out[a:b], need_grad, kind, None if y_target is None else y_target[a:b], sign_ok,
                                sign_blocked)

@@ -43,7 +43,7 @@ def _streams(model):
     APGD_OPS=eager, and never for a model that is not built from ``architecture``'s classes."""
     if ops._GEMM_MODE == "lib" or ops.MODE == "eager" or STREAMS <= 1:
         return 1
-    return STREAMS if any(getattr(m, "apgd_two_streams", False) for m in model.modules()) else 1
+    return STREAMS if apgd.two_stream_model(model) else 1
 
 
 STATS = {"captures": 0, "replays": 0, "eager": 0, "failed": 0}
@@ -118,8 +118,30 @@ class _Program:
                 s.replay()
             else:
                 s()
+        if BORROW:                                           # the caller consumes the results before the next call (borrow_outputs)
+            return self.out
         x_best, acc, loss_best, x_best_adv = self.out
         return x_best.clone(), acc.clone(), loss_best.clone(), x_best_adv.clone()
+
+
+BORROW = False
+
+
+class borrow_outputs:
+    """Inside this context a replayed attack returns its graph's static output tensors themselves instead of fresh copies
+    (two 154 MB clones at the headline shapes): for a caller that consumes them before the next attack call - ``ATTrainStep``,
+    whose training-pass graph reads ``x_best`` in place."""
+
+    def __enter__(self):
+        global BORROW
+        self._prev = BORROW
+        BORROW = True
+        return self
+
+    def __exit__(self, *exc):
+        global BORROW
+        BORROW = self._prev
+        return False
 
 
 def _signature(model, x, y, norm, eps, n_iter, kind, soft):

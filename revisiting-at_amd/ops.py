@@ -66,10 +66,11 @@ class attack_forward:
         return False
 
 
-# Set by apgd._model_fwd_bwd_split around the model calls of an attack whose batch chunks run on SEVERAL streams (graph replay of
-# the narrow ConvNeXt pyramids).  Under APGD_GEMM=auto those calls' pointwise convolutions / linears then all run on cnx_gemm_nt:
-# two of the library's stream-K GEMMs in flight at once deadlocked the GPU (ViT-B shapes, hipBLASLt ``..._SK3_...`` solutions
-# spinning on a shared synchroniser), so overlapping chunks keep the library's GEMMs out of their streams.
+# Set by apgd._model_fwd_bwd around every model call of the attack on a model whose captured attack runs as batch chunks on
+# SEVERAL streams (apgd.two_stream_model: the narrow ConvNeXt pyramids).  Under APGD_GEMM=auto those calls' pointwise convolutions /
+# linears all run on cnx_gemm_nt: two of the library's stream-K GEMMs in flight at once deadlocked the GPU (ViT-B shapes,
+# hipBLASLt ``..._SK3_...`` solutions spinning on a shared synchroniser), so overlapping chunks keep the library's GEMMs out of
+# their streams - and the eager attack of the same model takes the same kernels, so that replay and eager loop stay bit-identical.
 _ATTACK_PASS = False
 
 

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import graphed, ops
 from .config import AdvConfig, wrap_model_for_at
 
 
@@ -125,10 +125,13 @@ class _TrainPassGraph:
     launch.  Same capture rules as ``graphed._Program``: parameters (and their ``.grad``, allocated in the graph's pool by
     the captured backward) are read and written in place, derived weight copies are rebuilt inside the graph."""
 
-    def __init__(self, step: "ATTrainStep", x, target):
-        self.x = torch.empty_like(x)
+    def __init__(self, step: "ATTrainStep", x, target, x_is_static: bool = False):
+        # x_is_static: x is the static output of the attack's own graph (graphed.borrow_outputs) - the same tensor at every
+        # step, read in place; anything else is copied into a buffer of this graph
+        self.x = x if x_is_static else torch.empty_like(x)
         self.t = torch.empty_like(target)
-        self.x.copy_(x)
+        if not x_is_static:
+            self.x.copy_(x)
         self.t.copy_(target)
         self.derived = {}
         self.graph = torch.cuda.CUDAGraph()
@@ -154,7 +157,8 @@ class _TrainPassGraph:
         torch.cuda.current_stream().wait_stream(side)
 
     def __call__(self, x, target):
-        self.x.copy_(x)
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x)
         self.t.copy_(target)
         self.graph.replay()
         return self.loss.clone()
@@ -238,9 +242,11 @@ class ATTrainStep:
             self._tg_seen[key] = self._tg_seen.get(key, 0) + 1            # libraries meet every shape outside a capture first
             return None
         base = self.inner.base_model
+        replays0 = graphed.STATS["replays"]
         if self.perturb:                                                   # WrappedModel.forward, main.py:276-292 (under the
             base.eval()                                                    # step's autocast, as main.py:985 has it)
-            with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None), \
+                    graphed.borrow_outputs():
                 z = self.inner.perturb(base, images, target)
             base.train()
             if isinstance(z, (tuple, list)):
@@ -250,7 +256,8 @@ class ATTrainStep:
         prog = self._tg.get(key)
         if prog is None:
             try:
-                prog = self._tg[key] = _TrainPassGraph(self, z, target)
+                # (a replayed attack under borrow_outputs hands out its graph's own static tensor: stable address)
+                prog = self._tg[key] = _TrainPassGraph(self, z, target, x_is_static=graphed.STATS["replays"] > replays0)
             except Exception as e:                                         # noqa: BLE001 - any capture failure means "run eagerly"
                 import warnings
                 warnings.warn(f"training-pass graph capture failed ({type(e).__name__}: {e}); this batch shape runs eagerly")

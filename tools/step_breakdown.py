@@ -57,6 +57,16 @@ lines = [f"step window {(t1 - t0) / 1e6:.2f} ms, GPU busy {tot / 1e6:.2f} ms, {s
          "| ms | % | calls | avg us | kernel |", "|---|---|---|---|---|"]
 for n, (c, t) in sorted(grp.items(), key=lambda kv: -kv[1][1])[: a.top]:
     lines.append(f"| {t / 1e6:.2f} | {100 * t / tot:.1f} | {c} | {t / c / 1e3:.1f} | `{n}` |")
+# idle time of the device around every APGD-update launch of the window (the attack's graph segments end / begin there) and the
+# largest gaps anywhere: how much of the window is launch latency rather than kernels
+win = [(s_, e_, n_) for s_, e_, n_ in rows if t0 <= s_ < t1]
+busy_until, gaps = t0, []
+for s_, e_, n_ in win:
+    if s_ > busy_until:
+        gaps.append((s_ - busy_until, n_))
+    busy_until = max(busy_until, e_)
+lines += ["", f"idle inside the window: {sum(g for g, _ in gaps) / 1e3:.1f} us in {len(gaps)} gaps; largest: "
+          + ", ".join(f"{g / 1e3:.1f} us before `{short(n_)[:40]}`" for g, n_ in sorted(gaps, reverse=True)[:6])]
 out = "\n".join(lines)
 print(out)
 if a.md:
