@@ -1955,7 +1955,12 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
       return launch_status();
     }
     DwMulti mp;
-    if (dw_multi_plan(N, H, W, C, x_dtype == APGD_F32 ? 4 : 2, out_dtype == APGD_F32 ? 4 : 2, &mp)) {
+    // (the input gradient with the fp32 residual gradient added, bf16 -> fp32 + add, at 14x14: the multi-image kernel holds the add
+    //  operand of the next image in registers on top of its filter and prefetch registers - one wavefront per SIMD - and the
+    //  whole-image tile kernel below, four per SIMD, is ahead since its staging was spread over the workgroup: 68 vs 81 us at
+    //  14x14x384 x 256, 42 vs 55 us x 128; at 7x7 the two are level)
+    const bool tile_ahead = out_dtype == APGD_F32 && add != nullptr && H * W >= 144;
+    if (!tile_ahead && dw_multi_plan(N, H, W, C, x_dtype == APGD_F32 ? 4 : 2, out_dtype == APGD_F32 ? 4 : 2, &mp)) {
       const dim3 grid(static_cast<unsigned>(static_cast<long>((N + mp.ipw - 1) / mp.ipw) * (C / kDC))), block(mp.threads);
 #define DWM_LAUNCH(TI, TO, UU)                                                                                        \
   {                                                                                                                   \

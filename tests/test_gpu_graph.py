@@ -203,3 +203,24 @@ def test_attack_with_the_blocked_sign_order_equals_the_default(R, monkeypatch):
     T.check_replay(O, out, lo, gr, x, y, "Linf", EPS, 3)
     sk = R.ops.grad_sign_sink(x, blocked=True)
     assert sk.blocked and sk.buffer().apgd_blocked
+
+
+def test_a_model_that_is_not_built_from_our_classes_is_replayed_on_one_stream(R):
+    """Any eval-mode model can be captured; only the models that ask for it (``ConvNeXt.apgd_two_streams``) get the two-stream form -
+    a plain torch model's library GEMMs must never overlap - and its replay equals its eager attack."""
+    R.graphed.reset()
+    torch.manual_seed(11)
+    plain = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, stride=2, padding=1), torch.nn.GELU(), torch.nn.Flatten(),
+                                torch.nn.Linear(16 * 16 * 16, 10)).cuda().eval()
+    assert R.graphed._streams(plain) == 1 and not R.apgd.two_stream_model(plain)
+    assert R.graphed._streams(small_convnext(R)) == max(1, R.graphed.STREAMS)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    before = R.graphed.STATS["replays"]
+    for call in range(5):
+        x = torch.rand(6, 3, 32, 32, device="cuda", generator=g)
+        y = torch.randint(0, 10, (6,), device="cuda", generator=g)
+        got = R.apgd_train(plain, x, y, norm="Linf", eps=EPS, n_iter=3, graph=True)
+        want = R.apgd_train(plain, x, y, norm="Linf", eps=EPS, n_iter=3, graph=False)
+        torch.cuda.synchronize()
+        assert same(got, want), call
+    assert R.graphed.STATS["replays"] - before == 3
