@@ -50,6 +50,16 @@ STATS = {"captures": 0, "replays": 0, "eager": 0, "failed": 0}
 _programs = {}
 
 
+def capture_mode():
+    """hipStreamCaptureMode of our captures.  "global" (torch's default) makes an unsafe runtime call from ANY thread an error
+    while a capture is open - including the event queries of the RCCL watchdog thread of a multi-GPU rank, which polls the
+    gradient all-reduce of the previous step while this step's attack is being captured (the host runs ahead of the device).
+    With a process group up, captures therefore use "thread_local" (only the capturing thread is policed), after a device
+    synchronisation that leaves the watchdog nothing to poll."""
+    import torch.distributed as dist
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 class _Recorder:
     """Cuts one pass of ``_apgd_core`` into graph segments separated by eager closures."""
 
@@ -57,10 +67,11 @@ class _Recorder:
         self.pool = torch.cuda.graph_pool_handle()
         self.steps = []                                      # torch.cuda.CUDAGraph | callable
         self._g = None
+        self.mode = capture_mode()
 
     def begin(self):
         self._g = torch.cuda.CUDAGraph()
-        self._g.capture_begin(pool=self.pool)
+        self._g.capture_begin(pool=self.pool, capture_error_mode=self.mode)
 
     def end(self):
         g, self._g = self._g, None
@@ -91,6 +102,8 @@ class _Program:
         self.y.copy_(y)
         self.derived = {}                                    # capture-local ops._cached entries (kept alive with the graphs)
         rec = _Recorder()
+        if rec.mode != "global":
+            torch.cuda.synchronize()                         # collectives of earlier steps are done: nothing for a watchdog to poll
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         prev = ops._CAPTURE_CACHE

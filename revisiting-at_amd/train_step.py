@@ -142,7 +142,7 @@ class _TrainPassGraph:
         ops._CAPTURE_CACHE = self.derived
         try:
             with torch.cuda.stream(side):
-                self.graph.capture_begin()
+                self.graph.capture_begin(capture_error_mode=graphed.capture_mode())
                 try:
                     self.loss = step._train_pass(self.x, self.t)
                 except BaseException:

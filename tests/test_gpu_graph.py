@@ -224,3 +224,30 @@ def test_a_model_that_is_not_built_from_our_classes_is_replayed_on_one_stream(R)
         torch.cuda.synchronize()
         assert same(got, want), call
     assert R.graphed.STATS["replays"] - before == 3
+
+
+def test_thread_local_capture_mode_of_multi_gpu_ranks_replays_the_same(R, monkeypatch):
+    """With a process group up (RCCL ranks) the captures use hipStreamCaptureModeThreadLocal so that the communicator's watchdog
+    thread may keep polling events (graphed.capture_mode); forced here on the single-process box: same replays, bit for bit, for
+    the attack and for a training step."""
+    monkeypatch.setattr(R.graphed, "capture_mode", lambda: "thread_local")
+    R.graphed.reset()
+    model = small_convnext(R, 4)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        for call in range(4):
+            x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
+            y = torch.randint(0, 10, (4,), device="cuda", generator=g)
+            got = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2, graph=True)
+            want = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2, graph=False)
+            torch.cuda.synchronize()
+            assert same(got, want), call
+    torch.manual_seed(5)
+    A = R.architecture
+    m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
+    m.stem = A.ConvBlock1(48)
+    tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=1), "cuda", lr=1e-3,
+                       amp_dtype=torch.bfloat16, ema=True)
+    for _ in range(6):
+        loss = tr.step(torch.rand(4, 3, 64, 64, device="cuda", generator=g), torch.randint(0, 10, (4,), device="cuda", generator=g))
+    assert torch.isfinite(loss) and [v is not None for v in tr._tg.values()] == [True]
