@@ -501,6 +501,15 @@ def main():
     extra = {"host_enqueue_ms_per_step": round(head[len(head) // 2] * 1e3, 3),
              "host_loop_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3), "package_power": power_stats,
              "attack_graph": dict(R.graphed.STATS, enabled=bool(args.graph)), "gemm_mode": R.ops._GEMM_MODE,
+             # what the host issues per steady-state step: graph launches (attack segments + the training pass), the K1 kernel
+             # launches between the attack's segments, input copies; the device executes ~1250 kernels per step from them
+             # (profiles/r03_step.md).  Eager steps issue ~900 kernel launches from Python instead.
+             "host_launches_per_step": ({"graph_launches": sum(pr.n_graphs for en in R.graphed._programs.values()
+                                                                 for pr in [en.get("prog")] if pr is not None)
+                                         + sum(v is not None for v in trainer._tg.values()),
+                                         "kernel_launches": sum(len(pr.steps) - pr.n_graphs for en in R.graphed._programs.values()
+                                                                for pr in [en.get("prog")] if pr is not None),
+                                         "copies": 3} if args.graph else None),
              "train_graph": {"enabled": bool(trainer.graph_train),
                              "captured": sum(v is not None for v in trainer._tg.values()), "failed": sum(v is None for v in trainer._tg.values())}}
     if args.attack_only or True:
