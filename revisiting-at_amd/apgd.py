@@ -238,16 +238,20 @@ def _model_fwd_bwd_split(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, ne
         if x_in.dim() == 4 and not x_in.is_contiguous():
             full = torch.empty_like(x_in, dtype=full.dtype)
     parts = []
-    for h, st in enumerate(streams):
-        a, b = cuts[h], cuts[h + 1]
-        st.wait_stream(main)
-        with torch.cuda.stream(st):                          # (chunks overlap: two_stream_model keeps library GEMMs out of them)
-            g = _model_fwd_bwd(model, x_in[a:b], None if y_hard is None else y_hard[a:b], None if y_soft is None else y_soft[a:b], ws,
-                               loss_out[a:b], pred_out[a:b], need_grad, kind, None if y_target is None else y_target[a:b], sign_ok,
-                               sign_blocked)
-            if g is not None and g.dtype == full.dtype:
-                full[a:b].copy_(g)
-            parts.append(g)
+    ops._CHUNKED = True                                      # derived weight copies made by one chunk are awaited by the other (ops._cached)
+    try:
+        for h, st in enumerate(streams):
+            a, b = cuts[h], cuts[h + 1]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):                      # (chunks overlap: two_stream_model keeps library GEMMs out of them)
+                g = _model_fwd_bwd(model, x_in[a:b], None if y_hard is None else y_hard[a:b], None if y_soft is None else y_soft[a:b],
+                                   ws, loss_out[a:b], pred_out[a:b], need_grad, kind, None if y_target is None else y_target[a:b],
+                                   sign_ok, sign_blocked)
+                if g is not None and g.dtype == full.dtype:
+                    full[a:b].copy_(g)
+                parts.append(g)
+    finally:
+        ops._CHUNKED = False
     for st in streams:
         main.wait_stream(st)
     if not need_grad:

@@ -90,6 +90,7 @@ class _Recorder:
     def eager(self, fn):
         self.end()
         self.steps.append(fn)
+        ops._CAPTURE_SEG += 1                                # derived copies of earlier segments need no cross-stream wait (ops._cached)
         self.begin()
 
 

@@ -814,6 +814,21 @@ def load_gemm_table(path=None):
 _CAPTURE_CACHE = None
 
 
+# Number of the graph segment being captured (graphed._Recorder bumps it at every cut): a derived copy made in an EARLIER segment is
+# complete by stream order when a later segment runs; one made in the SAME segment on another stream has to be waited for.
+_CAPTURE_SEG = 0
+_CHUNKED = False                                             # set by apgd._model_fwd_bwd_split while batch chunks run on several streams
+
+
+def _await_producer(ev, st):
+    """A derived copy is made on the stream that asks for it first.  When the attack's batch chunks run on two streams, the other
+    chunk finds it in the cache moments later - its stream has to wait for the kernels that are still writing it (without this
+    the second chunk could read the packed weights of the PREVIOUS optimizer step, or a mix)."""
+    cur = torch.cuda.current_stream()
+    if st is not None and cur != st:
+        cur.wait_event(ev)
+
+
 def _cached(params, tag, fn):
     """Derived copies of parameters (bf16 casts, MFMA-fragment packing), rebuilt only when a parameter changes
     (optimizer steps bump ``_version``); the attack's forwards and the train forward share them.  Entries hold weak
@@ -823,12 +838,22 @@ def _cached(params, tag, fn):
         hit = _CAPTURE_CACHE.get(ckey)
         if hit is None:
             with torch.no_grad():
-                hit = _CAPTURE_CACHE[ckey] = (fn(*[q.detach() for q in params]), params)     # params kept alive: ids stay unique
+                val = fn(*[q.detach() for q in params])
+            ev = st = None
+            if _CHUNKED:
+                st = torch.cuda.current_stream()
+                ev = torch.cuda.Event()
+                ev.record(st)
+            hit = _CAPTURE_CACHE[ckey] = (val, params, ev, st, _CAPTURE_SEG)                 # params kept alive: ids stay unique
+        elif _CHUNKED and hit[4] == _CAPTURE_SEG:
+            _await_producer(hit[2], hit[3])
         return hit[0]
     key = tuple(id(q) for q in params) + (tag,)
     ver = (_WEIGHTS_EPOCH,) + tuple((q._version, q.data_ptr()) for q in params)
     hit = _wcache.get(key)
     if hit is not None and hit[0] == ver and all(r() is q for r, q in zip(hit[2], params)):
+        if _CHUNKED:
+            _await_producer(hit[3], hit[4])
         return hit[1]
     CACHE_STATS["miss"] += 1
     with torch.no_grad():
@@ -836,7 +861,12 @@ def _cached(params, tag, fn):
     if len(_wcache) > 4096:                      # dead entries of models that no longer exist
         for k in [k for k, v in _wcache.items() if any(r() is None for r in v[2])]:
             del _wcache[k]
-    _wcache[key] = (ver, val, tuple(weakref.ref(q) for q in params))
+    ev = st = None
+    if _CHUNKED and val.is_cuda:
+        st = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(st)
+    _wcache[key] = (ver, val, tuple(weakref.ref(q) for q in params), ev, st)
     return val
 
 
