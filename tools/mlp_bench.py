@@ -87,6 +87,9 @@ if "fwd" in args.what.split(","):
     merr = float((mean[rows] - mu).abs().max())
     med, mn = timeit(run)
     nbytes = M * C * (2 + x.element_size() + 4)
+    import hashlib
+    sha = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16] + "/" + hashlib.sha256(mean.cpu().numpy().tobytes()).hexdigest()[:8]
+    res["fwd_out_sha"] = sha
     res["fwd"] = {"med_us": round(med, 1), "min_us": round(mn, 1), "TFLOPs": round(flops / med / 1e6, 1), "mfma_frac": round(flops / med / 1e6 / 2500, 4),
                   "GBs": round(nbytes / med / 1e3, 1), "max_rel_err": err, "mean_err": merr}
 if "bwd_in" in args.what.split(","):
