@@ -59,7 +59,13 @@ def parse():
     p.add_argument("--settle-steps", type=int, default=45, help="after the timed region: keep stepping until this many steps have run in "
                    "all (~2.4 s at the headline configuration), then time K more steps as extra.settled_window (the operating "
                    "point of the package settles ~2 s into the load); 0: skip")
-    p.add_argument("--graph-train", type=int, default=1, help="1 (with --graph 1, one GPU): the training pass is replayed from a hipGraph too")
+    p.add_argument("--graph-train", type=int, default=1, help="1 (with --graph 1): the training pass is replayed from hipGraphs too")
+    p.add_argument("--ddp-path", type=int, default=None, help="1: gradients through the flat buffers of train_step.FlatGradSync (two-call "
+                   "backward, all-reduces between the graph segments) - the path every N > 1 rank takes; on one GPU the collectives "
+                   "are no-ops, so N = 1 and N > 1 run the same code.  Default: 1 when --gpus > 1, else 0 (one backward call, one graph)")
+    p.add_argument("--grad-sync", default=None, choices=("flat", "ddp"), help="N > 1: 'flat' (default) or torch DDP (eager training pass)")
+    p.add_argument("--strict", action="store_true", help="exit non-zero if any informational measurement (other_configs, model_kernel_"
+                   "rooflines) failed; the failures are always visible as {'error': ...} entries and in extra.errors")
     return p.parse_args()
 
 
@@ -226,8 +232,10 @@ def other_configs(R, dev, graph=1, which=("cfg3", "cfg4", "cfg5")):
             continue
         try:
             out[key] = at_step(*cfg)
-        except Exception as e:                               # informational: never fail the headline line over it
-            out[key] = "unavailable: %r" % (e,)
+        except Exception as e:                               # informational: the headline line still prints; --strict fails the run
+            out[key] = {"error": repr(e)}
+        R.graphed.reset()                                    # the captured programs' graph pools go with the configuration
+        torch.cuda.empty_cache()
         note(f"{key}: {out[key]}")
     if "cfg5" not in which:
         return out
@@ -256,13 +264,46 @@ def other_configs(R, dev, graph=1, which=("cfg3", "cfg4", "cfg5")):
         out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"] = {
             "img_s": round(bs / dt, 2), "s_per_batch": round(dt, 3), "batch": bs, "n_iter": 100, "dtype": "f32",
             "attack_runs": st["attack_runs"], "sample_iters": st["sample_iters"],
-            "sample_iters_per_s": round(st["sample_iters"] / dt, 1), "robust_after": st["robust"]}
+            "sample_iters_per_s": round(st["sample_iters"] / dt, 1), "robust_after": st["robust"],
+            # a random-init model has no point left after APGD-CE at eps = 4/255: the line then times the CE leg alone
+            "legs": "CE + T" if st["attack_runs"] >= 2 else "CE only (no point survived APGD-CE: the targeted runs had nothing to attack)"}
+        # the same evaluation at an eps small enough that about half the points survive APGD-CE, so that the targeted leg
+        # (dlr-targeted on the product model, targets from the clean logits, still-robust subset) is inside a timed figure too
+        try:
+            eps_t = cfg5_eps_with_survivors(R, model, x, y, g)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, st2 = R.run_standard_evaluation(model, x, y, bs=bs, norm="Linf", eps=eps_t, attacks_to_run=("apgd-ce", "apgd-t"),
+                                               n_iter=100, n_target_classes=2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"]["with_targeted_leg"] = {
+                "eps": eps_t, "n_target_classes": 2, "attack_runs": st2["attack_runs"], "sample_iters": st2["sample_iters"],
+                "sample_iters_per_s": round(st2["sample_iters"] / dt2, 1), "robust_after": st2["robust"], "s_per_batch": round(dt2, 3)}
+        except Exception as e:
+            out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"]["with_targeted_leg"] = {"error": repr(e)}
         del model
         torch.cuda.empty_cache()
     except Exception as e:
-        out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"] = "unavailable: %r" % (e,)
+        out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"] = {"error": repr(e)}
     note(f"cfg5: {out['cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224']}")
     return out
+
+
+def cfg5_eps_with_survivors(R, model, x, y, gen, n_iter=20):
+    """An eps at which roughly half of the batch survives APGD-CE: bisection over short (20-iteration) runs, downwards from 4/255."""
+    lo, hi, eps = 0.0, 4 / 255, 4 / 255
+    for _ in range(7):
+        eps = 0.5 * (lo + hi)
+        _, acc, _, _ = R.aa_eval.apgd_attack(model, x, y, "Linf", eps, n_iter, "ce", None, True, gen)
+        frac = float(acc.float().mean())
+        if 0.3 <= frac <= 0.7:
+            break
+        if frac > 0.7:
+            lo = eps
+        else:
+            hi = eps
+    return eps
 
 
 def spawn_ranks(args, child_argv=None, ndev=None) -> int:
@@ -411,10 +452,14 @@ def main():
 
     model = R.get_new_model(args.arch, pretrained=False, not_original=True)
     adv = R.AdvConfig(attack="apgd", norm="Linf", eps=args.eps, n_iter=args.n_iter, graph=args.graph)
+    ddp_path = (world > 1) if args.ddp_path is None else bool(args.ddp_path)
+    grad_sync = args.grad_sync or ("flat" if ddp_path else None)
+    if world > 1 and grad_sync is None:
+        raise SystemExit("bench.py: N > 1 ranks need a gradient exchange (--ddp-path 1 or --grad-sync ddp)")
     trainer = R.ATTrainStep(model, args.arch, adv, dev, lr=1e-3, distributed=world > 1, channels_last=True,
                             amp_dtype=torch.bfloat16, ema=True, mixup=object() if args.soft_labels else None,
                             soft_targets=args.soft_labels, gemm_table=True,
-                            graph_train=bool(args.graph) and bool(args.graph_train))
+                            graph_train=bool(args.graph) and bool(args.graph_train), grad_sync=grad_sync)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch
     x = torch.rand(B, 3, args.res, args.res, device=dev, generator=g)        # synthetic 224x224x3 batch in [0,1)
@@ -479,6 +524,10 @@ def main():
         ach = alg_bpe * n_elem / (avg_ms * 1e-3) / 1e9
         tr = traffic_tab.get(f"{form}_{('i8blk' if blk else 'i8') if gbytes == 1 else 'f32'}", {})
         traffic = tr.get("hbm_bytes_per_launch") if n_elem * alg_bpe == tr.get("algorithmic_bytes_per_launch") else None
+        if traffic is None and rank == 0:
+            print(f"bench.py: roofline.traffic is null for the {form} K1 form - profiles/k1_traffic.json holds PMC passes of the headline "
+                  f"shape only ({tr.get('algorithmic_bytes_per_launch')} algorithmic bytes per launch; this run: {int(n_elem * alg_bpe)}); "
+                  "re-run tools/k1_traffic.py for this shape", file=sys.stderr)
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": (("linf_step_i8blk_kernel<false>" if form == "general" else "linf_step_i8blk_kernel<true>") if blk else
@@ -542,13 +591,18 @@ def main():
              # (profiles/r03_step.md).  Eager steps issue ~900 kernel launches from Python instead.
              "host_launches_per_step": ({"graph_launches": sum(pr.n_graphs for en in R.graphed._programs.values()
                                                                  for pr in [en.get("prog")] if pr is not None)
-                                         + sum(v is not None for v in trainer._tg.values()),
+                                         + sum(v.n_graphs for v in trainer._tg.values() if v is not None),
                                          "kernel_launches": sum(len(pr.steps) - pr.n_graphs for en in R.graphed._programs.values()
                                                                 for pr in [en.get("prog")] if pr is not None),
+                                         "collectives": (sum(len(v.steps) - v.n_graphs for v in trainer._tg.values() if v is not None)
+                                                         if world > 1 else 0),
                                          "copies": 3} if args.graph else None),
              "train_graph": {"enabled": bool(trainer.graph_train),
-                             "captured": sum(v is not None for v in trainer._tg.values()), "failed": sum(v is None for v in trainer._tg.values())}}
-    if args.attack_only or True:
+                             "captured": sum(v is not None for v in trainer._tg.values()), "failed": sum(v is None for v in trainer._tg.values())},
+             # how the ranks' gradients meet: "flat" = train_step.FlatGradSync (same replayed step at every N), "ddp" = torch DDP
+             "grad_sync": {"path": grad_sync, "allreduce_bytes_per_step": trainer.sync.bytes_per_step if trainer.sync else None,
+                           "groups_MB": [round(4e-6 * b.numel(), 1) for b in trainer.sync.flat] if trainer.sync else None}}
+    if True:
         # attack-only throughput (same tensors, eval mode), a few repetitions
         base = trainer.inner.base_model
         base.eval()
@@ -567,11 +621,12 @@ def main():
         if rank == 0 and world == 1 and args.arch.startswith("convnext") and R.ops.MODE != "eager":
             try:
                 extra["model_kernel_rooflines"] = model_kernel_rooflines(R, dev, B)
-            except Exception as e:                       # informational only: never fail the bench line over it
-                extra["model_kernel_rooflines"] = "unavailable: %r" % (e,)
+            except Exception as e:                       # informational: the line still prints; --strict fails the run
+                extra["model_kernel_rooflines"] = {"error": repr(e)}
         if (rank == 0 and world == 1 and args.arch == "convnext_tiny" and R.ops.MODE != "eager" and not args.no_other_configs
                 and (args.other_configs is not None or not args.no_cpu_baseline)):
             del trainer, model, base, x, y
+            R.graphed.reset()                            # the headline model's captured attack (its graph pool) goes first
             torch.cuda.empty_cache()
             extra["other_configs"] = other_configs(R, dev, args.graph, tuple((args.other_configs or "cfg3,cfg4,cfg5").split(",")))
         extra["ops_mode"] = R.ops.MODE
@@ -580,6 +635,14 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
+
+    def errors_in(o, path=""):
+        if isinstance(o, dict):
+            return ([path] if "error" in o else []) + [e for k, v in o.items() for e in errors_in(v, f"{path}/{k}")]
+        if isinstance(o, list):
+            return [e for i, v in enumerate(o) for e in errors_in(v, f"{path}[{i}]")]
+        return []
+    extra["errors"] = errors_in(extra)
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -593,7 +656,7 @@ def main():
             "config": {"workload": f"{args.arch}-CvSt APGD-{args.n_iter} adversarial-training step, eps={args.eps:.6f} Linf, "
                                    f"{args.res}x{args.res}x3 fp32 inputs, bf16 autocast, per-GPU batch {B}, "
                                    f"{'soft (mixup-style)' if args.soft_labels else 'hard'} labels, AdamW + EMA, "
-                                   f"{'DDP over RCCL' if world > 1 else 'single GPU'}",
+                                   f"{('batch sharded over ' + str(world) + ' ranks, gradient all-reduce over RCCL') if world > 1 else 'single GPU'}",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "extra": extra,
         }
@@ -601,6 +664,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if args.strict and extra["errors"]:
+        print(f"bench.py --strict: failed measurements: {extra['errors']}", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

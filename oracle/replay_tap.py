@@ -11,10 +11,26 @@ import numpy as np
 import torch
 
 
-def record_attack(R, model, x, y, norm, eps, K, autocast=True, sink=False, **kw):
+def _merge_chunks(items, B):
+    """Records of a call that ran as batch chunks (one entry per chunk, in batch order) -> one entry per model call."""
+    out, cur = [], []
+    for a in items:
+        cur.append(a)
+        n = sum(c.shape[0] for c in cur)
+        assert n <= B, "chunk records do not add up to the batch"
+        if n == B:
+            out.append(cur[0] if len(cur) == 1 else np.concatenate(cur, 0))
+            cur = []
+    assert not cur
+    return out
+
+
+def record_attack(R, model, x, y, norm, eps, K, autocast=True, sink=False, splits=1, **kw):
     """Run R.apgd_train on cuda tensors x, y; returns (outputs, logits [K+1, B, classes], grads [K+1, *x.shape]) as numpy.
     sink=True: the product default (int8 signs straight from the stem kernel when the model surface supports it); the recorded
-    'gradient' is then the sign tensor itself, which is all the Linf update reads (autopgd_train_clean.py:221)."""
+    'gradient' is then the sign tensor itself, which is all the Linf update reads (autopgd_train_clean.py:221).
+    splits > 1: the eager form of what a captured two-stream attack replays - the model calls as batch chunks on their own
+    streams, every GEMM on cnx_gemm_nt (apgd._apgd_core(splits=, attack_gemm=True)); the chunks' records are joined per call."""
     rec = {"logits": [], "grads": []}
     last = {}
 
@@ -59,11 +75,18 @@ def record_attack(R, model, x, y, norm, eps, K, autocast=True, sink=False, **kw)
             cls.__exit__ = exit_and_record
         ctx = torch.autocast("cuda", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
         with ctx:
-            out = R.apgd_train(Rec(model).eval(), x, y, norm=norm, eps=eps, n_iter=K, **kw)
+            if splits > 1:
+                assert not kw
+                out = R.apgd._apgd_core(Rec(model).eval(), x, y, norm, eps, K, 0, splits=splits, attack_gemm=True)
+            else:
+                out = R.apgd_train(Rec(model).eval(), x, y, norm=norm, eps=eps, n_iter=K, **kw)
         torch.cuda.synchronize()
     finally:
         cls.__exit__ = orig_exit
         R.apgd.USE_SIGN_SINK = saved
+    if splits > 1:
+        rec["logits"] = _merge_chunks(rec["logits"], x.shape[0])
+        rec["grads"] = _merge_chunks(rec["grads"], x.shape[0])
     return out, np.stack(rec["logits"]), np.stack(rec["grads"]), rec.get("sink_used", [])
 
 

@@ -41,8 +41,16 @@ USE_SIGN_SINK = True
 # default of apgd_train(graph=None): hipGraph replay of the attack (graphed.py)
 GRAPH_DEFAULT = os.environ.get("APGD_GRAPH", "0") not in ("0", "")
 
-# models whose first backward through the sink showed a second consumer of the attack iterate (see _model_fwd_bwd)
-_SINK_REFUSED = set()
+# models whose first backward through the sink showed a second consumer of the attack iterate (see _model_fwd_bwd); weak: the id of
+# a dead model may be handed to a new one, which must get the sink again
+_SINK_REFUSED = weakref.WeakSet()
+
+
+def _sink_refused(model) -> bool:
+    try:
+        return model in _SINK_REFUSED
+    except TypeError:                                        # not weak-referenceable: never recorded
+        return False
 
 # losses the reference's criterion_dict names (autopgd_train_clean.py:113-114)
 criterion_names = ("ce", "softloss", "dlr", "dlr-targeted")
@@ -152,7 +160,7 @@ def _model_fwd_bwd_inner(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWork
         if dl.shape != logits.shape or dl.dtype != logits.dtype:
             raise _lib.ApgdHipError("dlogits/logits mismatch")
         # the sink is opened for Linf only: the L2 step needs the gradient's values
-        use_sink = sign_ok and USE_SIGN_SINK and id(model) not in _SINK_REFUSED
+        use_sink = sign_ok and USE_SIGN_SINK and not _sink_refused(model)
         sink = ops.grad_sign_sink(x_in, blocked=sign_blocked) if use_sink else contextlib.nullcontext()
         with ops.input_grad_only(), sink:
             grad = torch.autograd.grad([logits], [x_in], grad_outputs=[dl.view_as(logits)])[0].detach()
@@ -167,7 +175,10 @@ def _model_fwd_bwd_inner(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWork
             import warnings
             warnings.warn("the attack iterate feeds more than the ConvStem's first convolution: gradient-sign sink disabled for "
                           "this model (fp32 input gradient through autograd)")
-            _SINK_REFUSED.add(id(model))
+            try:
+                _SINK_REFUSED.add(model)
+            except TypeError:
+                pass
             return _model_fwd_bwd_inner(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, False, False)
         if grad.stride() != x_in.stride():
             g2 = torch.empty_like(x_in, dtype=grad.dtype)
@@ -185,8 +196,9 @@ _TWO_STREAM = weakref.WeakKeyDictionary()
 
 def two_stream_model(model) -> bool:
     """Does this model ask for the two-stream form of a captured attack (``architecture.ConvNeXt.apgd_two_streams``: the narrow
-    pyramids)?  Such a model's attack calls ALWAYS run their GEMMs on cnx_gemm_nt (``ops.attack_pass``), chunked or not, graph
-    or eager: overlapping chunks must not contain library GEMMs, and the eager attack has to stay bit-identical to the replay."""
+    pyramids)?  When such a model's attack runs as overlapping batch chunks - and in every call ``graphed.run`` makes for it, warm-up
+    or replay, so that they agree bit for bit - its GEMMs all run on cnx_gemm_nt (``ops.attack_pass``): overlapping chunks must not
+    contain library GEMMs.  The plain eager attack (``graph=False``, the default) keeps the library's GEMMs where they are faster."""
     try:
         return _TWO_STREAM[model]
     except (KeyError, TypeError):
@@ -199,8 +211,8 @@ def two_stream_model(model) -> bool:
     return v
 
 
-def _model_fwd_bwd(model, *args, **kw):
-    if two_stream_model(model):
+def _model_fwd_bwd(model, *args, attack_gemm=False, **kw):
+    if attack_gemm:
         with ops.attack_pass():
             return _model_fwd_bwd_inner(model, *args, **kw)
     return _model_fwd_bwd_inner(model, *args, **kw)
@@ -217,7 +229,7 @@ def _side_streams(device, n):
 
 
 def _model_fwd_bwd_split(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind=0, y_target=None, sign_ok=False,
-                         sign_blocked=False, splits=1):
+                         sign_blocked=False, splits=1, attack_gemm=False):
     """``_model_fwd_bwd`` with the batch cut into ``splits`` chunks that run on their own HIP streams (fork / join around the call).
 
     The attack treats samples independently and the model is in eval mode, so the chunks are independent problems with
@@ -227,13 +239,16 @@ def _model_fwd_bwd_split(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, ne
     feed two streams; under graph replay - graphed.py, the only caller with splits > 1 - there is no host in the loop)."""
     B = x_in.shape[0]
     if splits <= 1 or B < 2 * splits:
-        return _model_fwd_bwd(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, sign_ok, sign_blocked)
+        return _model_fwd_bwd(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, need_grad, kind, y_target, sign_ok, sign_blocked,
+                              attack_gemm=attack_gemm)
+    if not attack_gemm:
+        raise _lib.ApgdHipError("overlapping batch chunks need the attack's GEMMs on cnx_gemm_nt (attack_gemm=True)")
     main = torch.cuda.current_stream()
     streams = _side_streams(x_in.device, splits)
     cuts = [B * i // splits for i in range(splits + 1)]
     full = None
     if need_grad:                                            # allocated on the calling stream, before the fork
-        sink_expected = sign_ok and USE_SIGN_SINK and id(model) not in _SINK_REFUSED
+        sink_expected = sign_ok and USE_SIGN_SINK and not _sink_refused(model)
         full = torch.empty(x_in.shape, device=x_in.device, dtype=torch.int8 if sink_expected else torch.float32)
         if x_in.dim() == 4 and not x_in.is_contiguous():
             full = torch.empty_like(x_in, dtype=full.dtype)
@@ -246,7 +261,7 @@ def _model_fwd_bwd_split(model, x_in, y_hard, y_soft, ws, loss_out, pred_out, ne
             with torch.cuda.stream(st):                      # (chunks overlap: two_stream_model keeps library GEMMs out of them)
                 g = _model_fwd_bwd(model, x_in[a:b], None if y_hard is None else y_hard[a:b], None if y_soft is None else y_soft[a:b],
                                    ws, loss_out[a:b], pred_out[a:b], need_grad, kind, None if y_target is None else y_target[a:b],
-                                   sign_ok, sign_blocked)
+                                   sign_ok, sign_blocked, attack_gemm=True)
                 if g is not None and g.dtype == full.dtype:
                     full[a:b].copy_(g)
                 parts.append(g)
@@ -310,13 +325,18 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss='ce',
     return _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=mixup is not None, verbose=verbose)
 
 
-def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, y_target=None, x_init=None, rec=None, splits=1):
+def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, y_target=None, x_init=None, rec=None, splits=1,
+               attack_gemm=None):
     """The device loop shared by ``apgd_train`` and the evaluation attacks (``aa_eval.apgd_attack``).
 
     ``x_init`` (optional) replaces the clean image as the start point (AutoAttack's random start); the ball stays
     centred on ``x``.  ``kind`` 2 = targeted DLR with ``y_target``.  ``rec`` (``graphed._Recorder``) is set while the loop is
     being captured into hipGraph segments: the update-kernel launches are handed to it as closures and stay outside the graphs.
+    ``splits`` > 1: the model calls run as that many batch chunks on their own streams; ``attack_gemm`` (default: ``splits > 1``):
+    every GEMM of the model calls on cnx_gemm_nt (``ops.attack_pass``) - ``graphed.run`` sets it for all its calls of a two-stream model.
     """
+    if attack_gemm is None:
+        attack_gemm = splits > 1
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise _lib.ApgdHipError("apgd_train needs a device (MI355X) tensor; there is no CPU fallback")
     if x.dtype != torch.float32:
@@ -359,7 +379,8 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
 
     # first forward/backward: acc, loss_best are written directly by the loss kernel (:194-200)
     sign_ok = norm == 'Linf'
-    grad = _model_fwd_bwd_split(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok, sign_ok, splits)
+    grad = _model_fwd_bwd_split(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok, sign_ok, splits,
+                                attack_gemm)
     grad_best = torch.empty_like(grad)                                       # :189
     grad_best.copy_(grad)
     ws.loss_best_last.copy_(ws.loss_best)                                    # :200
@@ -397,7 +418,7 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
 
         last = i == n_iter - 1
         g_new = _model_fwd_bwd_split(model, cur, y_hard, y_soft, ws, ws.loss, ws.pred, not last, kind, y_target, sign_ok, sign_ok,
-                                     splits)                                 # :266-287
+                                     splits, attack_gemm)                    # :266-287
         if g_new is not None:
             if g_new.dtype != grad_best.dtype:               # a model that switches gradient form mid-attack
                 g_new = torch.sign(g_new).to(grad_best.dtype) if grad_best.dtype == torch.int8 else g_new.to(grad_best.dtype)

@@ -257,7 +257,13 @@ class _Head(nn.Module):
 
     def forward(self, x):
         x = x.mean((-2, -1), keepdim=True)           # global_pool
-        return self.fc(self.norm(x).flatten(1))
+        h = self.norm(x).flatten(1)
+        if (ops._ATTACK_PASS and h.is_cuda and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            # inside the attack of a two-stream model no GEMM may be the library's (graphed._streams): the classifier too runs
+            # on cnx_gemm_nt (autocast would hand nn.Linear the same bf16 operands)
+            return ops.linear_lib(h.to(torch.bfloat16).contiguous(), self.fc.weight, self.fc.bias)
+        return self.fc(h)
 
 
 class ConvNeXt(nn.Module):
@@ -283,6 +289,12 @@ class ConvNeXt(nn.Module):
 
     def forward_head(self, x):
         return self.head(x)
+
+    def ddp_cut(self):
+        """``train_step.FlatGradSync``: (module whose output splits the backward, modules behind it).  Stages 2, 3 and the head hold
+        95 % of ConvNeXt-T's parameter bytes and their gradients are complete after less than half of the backward: their
+        all-reduce runs under the backward of stages 1, 0 and the stem."""
+        return self.stages[1], [self.stages[2], self.stages[3], self.norm_pre, self.head]
 
     def forward(self, x):
         return self.forward_head(self.forward_features(x))
@@ -325,6 +337,10 @@ class ConvNeXtIsotropic(nn.Module):
 
     def forward_features(self, x):
         return self.norm(self.blocks(self.stem(x)).mean((-2, -1)))
+
+    def ddp_cut(self):
+        k = len(self.blocks) // 2                     # equal blocks: the second half's gradients go out under the first half's backward
+        return self.blocks[k - 1], [*self.blocks[k:], self.norm, self.head]
 
     def forward(self, x):
         return self.head(self.forward_features(x))
@@ -429,6 +445,10 @@ class VisionTransformer(nn.Module):
 
     def forward_features(self, x):
         return self.norm(self.blocks(self._pos_embed(self.patch_embed(x))))
+
+    def ddp_cut(self):
+        k = len(self.blocks) // 2
+        return self.blocks[k - 1], [*self.blocks[k:], self.norm, self.head]
 
     def forward(self, x):
         return self.head(self.forward_features(x)[:, 0])

@@ -721,7 +721,7 @@ template <int C>
 int launch_blk_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
   using G = Geo<C>;
   const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(256);
-#define BLK_LAUNCH(TX, TO) { if (a.hpre) { if constexpr (G::PIPE) BLK_LAUNCH_WS(TX, TO, true) } else BLK_LAUNCH_WS(TX, TO, false) }
+#define BLK_LAUNCH(TX, TO) { if (a.hpre) { if constexpr (G::PIPE) BLK_LAUNCH_WS(TX, TO, true) else return APGD_ERR_ARG; } else BLK_LAUNCH_WS(TX, TO, false) }
 #define BLK_LAUNCH_WS(TX, TO, WSV)                                                                               \
   {                                                                                                              \
     auto kfn = blk_mlp_fwd_kernel<C, TX, TO, WSV>;                                                               \

@@ -86,12 +86,8 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, uint32_t dst) 
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "memory");
 }
 
-// 0 (default): the LDS-DMA two-stage ring; 1: operands staged through registers, three stages deep on the same two LDS buffers
-// (see the main loop).  Measured on MI355X (tools/gemm_bench.py, both builds in one run): 440 - 800 vs 480 - 870 TFLOP/s - like
-// the five-deep ring of 32-k stages it is no faster, i.e. the depth of the prefetch is not what bounds this kernel (profiles/r03_gemm.md).
-#ifndef GEMM_REGSTAGE
-#define GEMM_REGSTAGE 0
-#endif
+// (Measured and dropped in round 3, profiles/r03_gemm.md: operands staged through registers three stages deep on the same two LDS
+//  buffers, 440 - 800 vs 480 - 870 TFLOP/s; a five-deep ring of 32-k stages: the depth of the prefetch does not bound this kernel.)
 
 // 1: the DMA instructions of stage t + 1 are dealt over the four k-steps of stage t instead of being issued in one burst behind the
 // barrier (every CU of the chip bursts at about the same time: the L2s see 56 - 64 KB requests per CU, then nothing)
@@ -171,8 +167,7 @@ __global__ __launch_bounds__((Geo<BM, BN, WM>::THREADS), (Geo<BM, BN, WM>::WAVES
 
   // ---- DMA source addresses of this lane: instruction q of a stage covers tile rows 8 * (q * WAVES + wave) ... + 7 of A (then B)
   const int r8 = lane >> 3, sl = lane & 7;                                   // row inside the 8-row group, LDS chunk inside the row
-  const unsigned char* src[G::INSTR];                                        // LDS-DMA form: swizzled source chunk
-  const unsigned char* lsrc[G::INSTR];                                       // register-staged form: the lane's own chunk (coalesced rows)
+  const unsigned char* src[G::INSTR];                                        // swizzled source chunk of the LDS-DMA
 #pragma unroll
   for (int q = 0; q < G::INSTR; ++q) {
     const int j = q * G::WAVES + wave;                                       // 8-row group of the stage
@@ -183,12 +178,10 @@ __global__ __launch_bounds__((Geo<BM, BN, WM>::THREADS), (Geo<BM, BN, WM>::WAVES
       long gr = m0 + row;
       if (gr >= p.M) gr = p.M - 1;
       src[q] = reinterpret_cast<const unsigned char*>(p.A + gr * p.lda) + chunk * 16;
-      lsrc[q] = reinterpret_cast<const unsigned char*>(p.A + gr * p.lda) + sl * 16;
     } else {
       int gr = n0 + row;
       if (gr >= p.N) gr = p.N - 1;
       src[q] = reinterpret_cast<const unsigned char*>(p.B + static_cast<long>(gr) * p.ldb) + chunk * 16;
-      lsrc[q] = reinterpret_cast<const unsigned char*>(p.B + static_cast<long>(gr) * p.ldb) + sl * 16;
     }
   }
 #define STAGE_LOAD(T)                                                                                          \
@@ -253,44 +246,6 @@ __global__ __launch_bounds__((Geo<BM, BN, WM>::THREADS), (Geo<BM, BN, WM>::WAVES
     KSTEP(fa0, fb0, fa1, fb1, 2)                                                                               \
     KSTEP(fa1, fb1, fa0, fb0, 3)                                                                               \
   }
-#if GEMM_REGSTAGE
-  // ---- register-staged pipeline, three stages deep on two LDS buffers: stage t is consumed from LDS while stage t + 1 sits in
-  //      registers (its loads were issued one whole iteration earlier) and is written to the other buffer at the top of the
-  //      iteration, and the loads of stage t + 2 are issued right behind that write.  A CU always has a stage (56 KB) of loads in
-  //      flight, where the LDS-DMA two-stage ring below drains its loads at every K step (vmcnt(0) + barrier).  The swizzle moves
-  //      to the LDS write address.  (Not faster: see GEMM_REGSTAGE above.)
-  bf16x8 stg[G::INSTR];                                                      // (a native vector type: an array of uint4 structs went to scratch)
-  uint32_t woff[G::INSTR];                                                   // LDS byte offset of this lane's chunk inside a stage
-#pragma unroll
-  for (int q = 0; q < G::INSTR; ++q) {
-    const int j = q * G::WAVES + wave;
-    const int row = (j < G::A_INSTR ? j : j - G::A_INSTR) * 8 + r8;
-    woff[q] = j * 1024 + r8 * 128 + ((sl ^ ((row >> 1) & 7)) * 16);
-  }
-#define RS_LOAD(T)                                                                                             \
-  {                                                                                                            \
-    const long ko_ = static_cast<long>(T) * (BK * 2);                                                          \
-    _Pragma("unroll") for (int q = 0; q < G::INSTR; ++q) stg[q] = *reinterpret_cast<const bf16x8*>(lsrc[q] + ko_); \
-  }
-#define RS_WRITE(T)                                                                                            \
-  {                                                                                                            \
-    unsigned char* wb_ = lds + ((T) & 1) * G::STAGE;                                                           \
-    _Pragma("unroll") for (int q = 0; q < G::INSTR; ++q) *reinterpret_cast<bf16x8*>(wb_ + woff[q]) = stg[q];    \
-  }
-  RS_LOAD(0)
-  RS_WRITE(0)
-  if (nt > 1) { RS_LOAD(1) }
-  __syncthreads();
-  for (int t = 0; t + 1 < nt; ++t) {
-    RS_WRITE(t + 1)                                                         // buffer (t + 1) & 1: last read in iteration t - 1
-    if (t + 2 < nt) { RS_LOAD(t + 2) }
-    COMPUTE(t, false)
-    __syncthreads();                                                        // stage t + 1 visible; buffer t & 1 free
-  }
-  COMPUTE(nt - 1, false)
-#undef RS_LOAD
-#undef RS_WRITE
-#else
   STAGE_LOAD(0)
   for (int t = 0; t + 1 < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // stage t has landed (this wavefront's pieces)
@@ -305,7 +260,6 @@ __global__ __launch_bounds__((Geo<BM, BN, WM>::THREADS), (Geo<BM, BN, WM>::WAVES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   COMPUTE(nt - 1, false)
-#endif
 #undef COMPUTE
 #undef KSTEP
 #undef STAGE_LOAD_PART

@@ -1944,7 +1944,7 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
   }
 #define DWR_DISPATCH(TI, TO)                                                                                          \
   {                                                                                                                   \
-    if (rp.threads > 256) { if constexpr (sizeof(TI) == 2) DWR_LAUNCH(TI, TO, 1, kRollMaxThreads) } /* plan: bf16 inputs only */ \
+    if (rp.threads > 256) { if constexpr (sizeof(TI) == 2) DWR_LAUNCH(TI, TO, 1, kRollMaxThreads) else return APGD_ERR_ARG; } /* plan: bf16 inputs only */ \
     else if (rp.units == 1) DWR_LAUNCH(TI, TO, 1, 256) else DWR_LAUNCH(TI, TO, 2, 256)                                \
   }
       if (x_dtype == APGD_F32) DWR_DISPATCH(float, uint16_t)

@@ -27,6 +27,7 @@ import warnings
 import weakref
 
 import torch
+import torch.utils._python_dispatch
 
 from . import apgd, ops
 
@@ -40,14 +41,63 @@ def _streams(model):
     """Chunks / streams of a captured attack: two for the models that ask for it (``apgd_two_streams``: the narrow ConvNeXt
     pyramids), else one.  With more than one stream the attack's GEMMs all run on cnx_gemm_nt (``ops.attack_pass``): two of the
     library's stream-K GEMMs in flight at once deadlocked the GPU (ViT-B shapes, round 3) - hence never with APGD_GEMM=lib /
-    APGD_OPS=eager, and never for a model that is not built from ``architecture``'s classes."""
+    APGD_OPS=eager, never for a model that is not built from ``architecture``'s classes, and never outside bf16 autocast:
+    cnx_gemm_nt takes bf16 operands only, so under fp32 / fp16 every GEMM of the chunks would be the library's.  What this static
+    test cannot see (a layer whose shape fails the kernel's guards) the warm-up calls catch: ``_LibGemmWatch``."""
     if ops._GEMM_MODE == "lib" or ops.MODE == "eager" or STREAMS <= 1:
+        return 1
+    if not (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
         return 1
     return STREAMS if apgd.two_stream_model(model) else 1
 
 
-STATS = {"captures": 0, "replays": 0, "eager": 0, "failed": 0}
+class _LibGemmWatch(torch.utils._python_dispatch.TorchDispatchMode):
+    """Counts the library GEMMs (hipBLASLt / rocBLAS through ATen) a model call issues.  ``run`` puts the FIRST warm-up call of a
+    would-be two-stream signature under it, on one stream: if anything in the attack's model calls still reaches the library
+    although ``ops.attack_pass`` is on (a layer that fails cnx_gemm_nt's guards, a foreign submodule), the signature is
+    captured and run on ONE stream - overlapping chunks never contain a library GEMM."""
+    NAMES = ("mm", "addmm", "bmm", "baddbmm", "linear", "matmul", "_scaled_mm", "addmv", "mv")
+
+    def __init__(self):
+        super().__init__()
+        self.count = 0
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = getattr(func, "__name__", str(func)).split(".")[0]
+        if name in self.NAMES and any(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
+            self.count += 1
+        return func(*args, **(kwargs or {}))
+
+
+STATS = {"captures": 0, "replays": 0, "eager": 0, "failed": 0, "evicted": 0, "lib_gemm_one_stream": 0}
+# Captured programs, most recently used last.  Each holds a private graph pool (the attack state, the activations of its model
+# passes, packed weight copies: multi-GB at batch 256), so their number is bounded: beyond MAX_PROGRAMS the least recently used
+# capture is dropped (its signature starts over: warm-up calls, then a new capture), and a model's entries go when the model does.
+MAX_PROGRAMS = int(os.environ.get("APGD_GRAPH_MAX_PROGRAMS", "4"))
 _programs = {}
+_finalizers = {}
+
+
+def _drop_model(mid):
+    for k in [k for k in _programs if k[0] == mid]:
+        del _programs[k]
+    _finalizers.pop(mid, None)
+
+
+def _watch_model(model):
+    mid = id(model)
+    if mid not in _finalizers:
+        try:
+            _finalizers[mid] = weakref.finalize(model, _drop_model, mid)
+        except TypeError:                                    # not weak-referenceable: the id check in run() still applies
+            pass
+
+
+def _evict():
+    live = [k for k, e in _programs.items() if e["prog"] is not None]
+    while len(live) > MAX_PROGRAMS:
+        del _programs[live.pop(0)]                           # dicts keep insertion order; run() re-inserts on every use
+        STATS["evicted"] += 1
 
 
 def capture_mode():
@@ -95,7 +145,7 @@ class _Recorder:
 
 
 class _Program:
-    def __init__(self, model, x, y, norm, eps, n_iter, kind, soft):
+    def __init__(self, model, x, y, norm, eps, n_iter, kind, soft, splits):
         self.model_ref = weakref.ref(model)
         self.x = torch.empty_like(x)
         self.y = torch.empty_like(y)
@@ -113,7 +163,8 @@ class _Program:
             with torch.cuda.stream(side):
                 rec.begin()
                 try:
-                    self.out = apgd._apgd_core(model, self.x, self.y, norm, eps, n_iter, kind, soft=soft, rec=rec, splits=_streams(model))
+                    self.out = apgd._apgd_core(model, self.x, self.y, norm, eps, n_iter, kind, soft=soft, rec=rec, splits=splits,
+                                               attack_gemm=_attack_gemm(model))
                 except BaseException:
                     rec.abort()
                     raise
@@ -164,8 +215,14 @@ def _signature(model, x, y, norm, eps, n_iter, kind, soft):
             int(n_iter), int(kind), bool(soft), ac, ops.MODE, apgd.USE_SIGN_SINK, _streams(model))
 
 
+def _attack_gemm(model):
+    """Every call ``run`` makes for a would-be two-stream model - warm-up, capture, the eager fallback - keeps the attack's GEMMs
+    on cnx_gemm_nt, so that they all agree bit for bit whatever the number of streams turns out to be."""
+    return _streams(model) > 1
+
+
 def reset():
-    """Drop every captured program (tests; after replacing a model's parameters by new tensors)."""
+    """Drop every captured program (tests; after replacing a model's parameters by new tensors; bench.py between configurations)."""
     _programs.clear()
 
 
@@ -178,27 +235,42 @@ def run(model, x, y, norm, eps, n_iter, kind, soft):
         x = x.contiguous()
     y = y.detach()
     key = _signature(model, x, y, norm, eps, n_iter, kind, soft)
-    ent = _programs.get(key)
+    ent = _programs.pop(key, None)
     if ent is None:
-        ent = _programs[key] = {"calls": 0, "prog": None, "failed": False}
+        ent = {"calls": 0, "prog": None, "failed": False, "one_stream": False}
+        _watch_model(model)
+    _programs[key] = ent                                     # most recently used last
     prog = ent["prog"]
     if prog is not None and prog.model_ref() is not model:   # id() of a dead model handed to a new one
-        ent.update(calls=0, prog=None, failed=False)
+        ent.update(calls=0, prog=None, failed=False, one_stream=False)
         prog = None
+    ag = _attack_gemm(model)
     if prog is None:
+        splits = 1 if (ent["failed"] or ent["one_stream"]) else _streams(model)
         if ent["failed"] or ent["calls"] < WARMUP_CALLS:
             ent["calls"] += 1
             STATS["eager"] += 1
+            if splits > 1 and ent["calls"] == 1:
+                # first warm-up call of a two-stream signature: one stream, library GEMMs counted
+                with _LibGemmWatch() as watch:
+                    out = apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=1, attack_gemm=ag)
+                if watch.count:
+                    ent["one_stream"] = True
+                    STATS["lib_gemm_one_stream"] += 1
+                    warnings.warn(f"{watch.count} library GEMM calls inside the attack's model calls: this signature is captured on "
+                                  "one stream (overlapping chunks must not contain library GEMMs)")
+                return out
             # (same batch chunks as the capture will use: every kernel / library shape is initialised before it)
-            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=1 if ent["failed"] else _streams(model))
+            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=splits, attack_gemm=ag)
         try:
-            prog = ent["prog"] = _Program(model, x, y, norm, eps, n_iter, kind, soft)
+            prog = ent["prog"] = _Program(model, x, y, norm, eps, n_iter, kind, soft, splits)
             STATS["captures"] += 1
+            _evict()
         except Exception as e:                               # noqa: BLE001 - any capture failure means "run eagerly"
             ent["failed"] = True
             STATS["failed"] += 1
             warnings.warn(f"APGD graph capture failed ({type(e).__name__}: {e}); this signature runs eagerly")
             torch.cuda.synchronize()
-            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft)
+            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, attack_gemm=ag)
     STATS["replays"] += 1
     return prog(x, y)

@@ -119,11 +119,97 @@ def setup_distributed():
     return rank, local, world
 
 
+class FlatGradSync:
+    """The gradient exchange of the outer step (``main.py:889-890, 992``: DDP's bucketed all-reduce of the parameter gradients) without
+    autograd hooks, so that the training pass of a rank can be replayed from hipGraphs like the single-GPU one.
+
+    DDP fires its bucket reductions from hooks inside ``loss.backward()``; RCCL calls cannot sit inside a stream capture on this pool,
+    which round 3 answered by leaving every N > 1 rank on the eager pass (~350 Python launches, 30 - 40 ms of host per step, eight
+    ranks on one host).  Here the parameter gradients live in TWO flat fp32 buffers - ``late``: the parameters behind the model's
+    cut point (ConvNeXt-T: stages 2, 3 and the head = 95 % of the bytes, whose gradients are complete after ~45 % of the backward),
+    ``early``: the rest - every ``p.grad`` is a view into them, and the backward runs in two ``torch.autograd.grad`` calls split at the
+    cut activation.  The training pass becomes three graph segments with the collectives issued eagerly BETWEEN them:
+
+        [forward, loss, backward down to the cut]  -> all-reduce(late), asynchronous: runs on RCCL's stream under ...
+        [... the backward of the early stages]     -> all-reduce(early); wait for both
+        [AdamW, EMA]
+
+    One exchange per step and rank, 4 bytes per parameter, none inside the attack - the traffic ``north_star`` / SURVEY.md section
+    8e prescribe; the mean over ranks is RCCL's ``AVG`` (gloo: ``SUM`` then a division).  With one rank (or no process group) the
+    reductions are no-ops and the same code is the single-GPU step."""
+
+    def __init__(self, module: nn.Module, device):
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.backend = dist.get_backend() if self.world > 1 else None
+        params = [p for p in module.parameters() if p.requires_grad]
+        cut, late_mods = None, []
+        for m in module.modules():
+            if hasattr(m, "ddp_cut"):
+                cut, late_mods = m.ddp_cut()
+                break
+        late_ids = {id(p) for lm in late_mods for p in lm.parameters()}
+        self.cut = cut if late_ids else None
+        self.late = [p for p in params if id(p) in late_ids]
+        self.early = [p for p in params if id(p) not in late_ids]
+        self.flat, self.views = [], []
+        for group in (self.late, self.early):
+            n = sum(p.numel() for p in group)
+            buf = torch.zeros(n, device=device, dtype=torch.float32)
+            vs, o = [], 0
+            for p in group:
+                vs.append(buf[o:o + p.numel()].view(p.shape))
+                o += p.numel()
+            self.flat.append(buf)
+            self.views.append(vs)
+        for group, vs in zip((self.late, self.early), self.views):
+            for p, v in zip(group, vs):
+                if p.dtype != torch.float32:
+                    raise TypeError("FlatGradSync keeps fp32 gradients (the path's parameters are fp32, main.py:797)")
+                p.grad = v                                                 # for the optimizer; never set to None again
+        self._works = []
+        self.reduces = 0                                                   # collectives issued (tests, bench)
+        self.bytes_per_step = 4 * sum(b.numel() for b in self.flat)
+
+    @torch.no_grad()
+    def broadcast_parameters(self, module: nn.Module):
+        """Rank 0's parameters and buffers to every rank, once (what DDP's constructor does, ``main.py:889-890``)."""
+        if self.world > 1:
+            import torch.distributed as dist
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, 0)
+
+    @torch.no_grad()
+    def store(self, which: int, grads):
+        """Gradients of one group (``torch.autograd.grad`` output, None for an unused parameter) into its flat buffer."""
+        vs = self.views[which]
+        have = [(v, g) for v, g in zip(vs, grads) if g is not None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, g in zip(vs, grads):
+            if g is None:
+                v.zero_()
+
+    def start_reduce(self, which: int):
+        if self.world > 1 and self.flat[which].numel():
+            import torch.distributed as dist
+            op = dist.ReduceOp.AVG if self.backend == "nccl" else dist.ReduceOp.SUM
+            self._works.append((dist.all_reduce(self.flat[which], op=op, async_op=True), which))
+            self.reduces += 1
+
+    def wait(self):
+        for w, which in self._works:
+            w.wait()
+            if self.backend != "nccl":
+                self.flat[which].div_(self.world)
+        self._works = []
+
+
 class _TrainPassGraph:
     """The training pass of one step - forward of the adversarial batch, loss, backward, AdamW, EMA (``main.py:985-997``) -
-    captured once as a hipGraph and replayed: ~350 kernel launches through Python autograd functions become one graph
-    launch.  Same capture rules as ``graphed._Program``: parameters (and their ``.grad``, allocated in the graph's pool by
-    the captured backward) are read and written in place, derived weight copies are rebuilt inside the graph."""
+    captured once as hipGraph segments and replayed: ~350 kernel launches through Python autograd functions become one graph
+    launch (three with the gradient exchange of ``FlatGradSync`` issued eagerly between them).  Same capture rules as
+    ``graphed._Program``: parameters are read and written in place, derived weight copies are rebuilt inside the graph."""
 
     def __init__(self, step: "ATTrainStep", x, target, x_is_static: bool = False):
         # x_is_static: x is the static output of the attack's own graph (graphed.borrow_outputs) - the same tensor at every
@@ -134,33 +220,39 @@ class _TrainPassGraph:
             self.x.copy_(x)
         self.t.copy_(target)
         self.derived = {}
-        self.graph = torch.cuda.CUDAGraph()
-        step.optimizer.zero_grad(set_to_none=True)             # the captured backward allocates every .grad in the graph's pool
+        rec = graphed._Recorder()
+        if step.sync is None:
+            step.optimizer.zero_grad(set_to_none=True)         # the captured backward allocates every .grad in the graph's pool
+        if rec.mode != "global":
+            torch.cuda.synchronize()                           # nothing left for a communicator's watchdog thread to poll
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         prev = ops._CAPTURE_CACHE
         ops._CAPTURE_CACHE = self.derived
         try:
             with torch.cuda.stream(side):
-                self.graph.capture_begin(capture_error_mode=graphed.capture_mode())
+                rec.begin()
                 try:
-                    self.loss = step._train_pass(self.x, self.t)
+                    self.loss = step._train_pass(self.x, self.t, rec=rec)
                 except BaseException:
-                    try:
-                        self.graph.capture_end()
-                    except Exception:                          # noqa: BLE001 - the capture is already invalid
-                        pass
+                    rec.abort()
                     raise
-                self.graph.capture_end()
+                rec.end()
         finally:
             ops._CAPTURE_CACHE = prev
         torch.cuda.current_stream().wait_stream(side)
+        self.steps = rec.steps
+        self.n_graphs = sum(isinstance(s, torch.cuda.CUDAGraph) for s in self.steps)
 
     def __call__(self, x, target):
         if x.data_ptr() != self.x.data_ptr():
             self.x.copy_(x)
         self.t.copy_(target)
-        self.graph.replay()
+        for s in self.steps:
+            if isinstance(s, torch.cuda.CUDAGraph):
+                s.replay()
+            else:
+                s()
         return self.loss.clone()
 
 
@@ -170,19 +262,28 @@ TRAIN_GRAPH_WARMUP = 3            # eager steps per batch shape before its train
 class ATTrainStep:
     """Builds ``DDP(WrappedModel(model, apgd))`` + optimizer (+EMA) and runs single steps.
 
-    ``graph_train`` (default: on when ``adv.graph`` is set, on one GPU): after ``TRAIN_GRAPH_WARMUP`` eager steps the
-    training pass is replayed from a hipGraph (``_TrainPassGraph``); it needs static batch shapes - a batch of another shape
-    runs eagerly.  Under DDP the pass stays eager (the gradient all-reduce is fired from autograd hooks)."""
+    ``graph_train`` (default: on when ``adv.graph`` is set): after ``TRAIN_GRAPH_WARMUP`` eager steps the training pass is
+    replayed from hipGraphs (``_TrainPassGraph``); it needs static batch shapes - a batch of another shape runs eagerly.
+
+    ``grad_sync`` - how the gradients of the ranks meet when ``distributed``: ``"flat"`` (default): ``FlatGradSync`` - flat
+    gradient buffers, two asynchronous all-reduces issued between the graph segments of the training pass, so an N > 1 rank runs
+    the same replayed step as the single GPU; ``"ddp"``: ``torch.nn.parallel.DistributedDataParallel`` around the wrapped model
+    (``main.py:889-890`` literally; its hooks keep the training pass eager).  ``grad_sync="flat"`` with ``distributed=False`` runs
+    the N > 1 code path on one GPU (``bench.py --ddp-path 1``)."""
 
     def __init__(self, model: nn.Module, arch: str, adv: AdvConfig, device, lr: float = 1e-3,
                  weight_decay: float = 0.05, distributed: bool = False, channels_last: bool = True,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ema: bool = True, mixup=None,
                  soft_targets: bool = False, perturb=None, gemm_table: bool = False, ema_decay: float = 0.9999,
-                 graph_train: Optional[bool] = None):
+                 graph_train: Optional[bool] = None, grad_sync: Optional[str] = None):
         self.device = torch.device(device)
+        if grad_sync not in (None, "flat", "ddp"):
+            raise ValueError(f"grad_sync={grad_sync!r}")
+        if grad_sync is None and distributed:
+            grad_sync = "flat"
         if graph_train is None:
             graph_train = bool(getattr(adv, "graph", 0)) and os.environ.get("APGD_GRAPH_TRAIN", "1") != "0"
-        self.graph_train = bool(graph_train) and not distributed and self.device.type == 'cuda'
+        self.graph_train = bool(graph_train) and grad_sync != "ddp" and self.device.type == 'cuda'
         self._tg = {}                                                      # (shapes, dtypes) -> _TrainPassGraph | None (failed)
         self._tg_seen = {}                                                 # (shapes, dtypes) -> eager steps so far
         if gemm_table and self.device.type == 'cuda':
@@ -198,7 +299,12 @@ class ATTrainStep:
         self.ema = DeviceEma(wrapped, ema_decay) if ema else None                     # before DDP (main.py:882-887)
         self.perturb = adv.attack != 'none' or perturb is not None
         self.inner = wrapped
-        if distributed:
+        self.sync = None
+        if grad_sync == "flat":
+            self.sync = FlatGradSync(wrapped, self.device)
+            if distributed:
+                self.sync.broadcast_parameters(wrapped)
+        elif distributed:
             ids = [self.device.index] if self.device.type == 'cuda' else None
             # main.py:889-890.  The models of this path carry constant buffers only (ImageNormalizer mean / std), so the
             # per-forward buffer broadcast is dropped; gradients live in the all-reduce buckets (no copy in / out per step).
@@ -222,16 +328,68 @@ class ATTrainStep:
             else:
                 g['lr'] = lr
 
-    def _train_pass(self, x_adv, target):
-        """forward - loss - backward - AdamW - EMA on an already perturbed batch (what ``_TrainPassGraph`` captures)."""
-        with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-            output = self.inner.base_model(x_adv)                          # main.py:293 (WrappedModel.forward after the attack)
-            loss = self.loss(output, target)
-        loss.backward()
-        self.optimizer.step()
+    def _train_pass(self, x_adv, target, rec=None):
+        """forward - loss - backward - (gradient exchange) - AdamW - EMA on an already perturbed batch: what ``_TrainPassGraph``
+        captures (``rec``: its recorder; the collectives are handed to it as eager closures between graph segments)."""
+        sync = self.sync
+        stash = {}
+        hook = None
+        if sync is not None and sync.cut is not None:
+            hook = sync.cut.register_forward_hook(lambda m, i, o: stash.__setitem__("h", o))
+        try:
+            with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                output = self.inner.base_model(x_adv)                      # main.py:293 (WrappedModel.forward after the attack)
+                loss = self.loss(output, target)
+        finally:
+            if hook is not None:
+                hook.remove()
+        if sync is None:
+            loss.backward()                                                # main.py:992
+        else:
+            def between(fn):
+                if rec is not None:
+                    rec.eager(fn)
+                else:
+                    fn()
+            h = stash.get("h")
+            if isinstance(h, torch.Tensor) and h.requires_grad and sync.late and sync.early:
+                g1 = torch.autograd.grad([loss], sync.late + [h], allow_unused=True)
+                sync.store(0, g1[:-1])
+                between(lambda: sync.start_reduce(0))                      # ... runs under the backward of the early stages
+                g2 = torch.autograd.grad([h], sync.early, grad_outputs=[g1[-1]], allow_unused=True)
+                sync.store(1, g2)
+                del g1, g2
+            else:
+                g = torch.autograd.grad([loss], sync.late + sync.early, allow_unused=True)
+                sync.store(0, g[:len(sync.late)])
+                sync.store(1, g[len(sync.late):])
+                del g
+                between(lambda: sync.start_reduce(0))
+
+            def finish():
+                sync.start_reduce(1)
+                sync.wait()
+            between(finish)
+        self.optimizer.step()                                              # main.py:993
         if self.ema is not None:
-            self.ema.update()
+            self.ema.update()                                              # main.py:996-997
         return loss.detach()
+
+    def _perturbed(self, images, target, borrow=False):
+        """The first half of ``WrappedModel.forward`` (``main.py:276-292``): the attack in eval mode, under the step's autocast as
+        ``main.py:985`` has it; returns ``x_best`` (``borrow``: a replayed attack hands out its graph's static tensor itself)."""
+        if not self.perturb:
+            return images
+        import contextlib
+        base = self.inner.base_model
+        base.eval()
+        with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None), \
+                (graphed.borrow_outputs() if borrow else contextlib.nullcontext()):
+            z = self.inner.perturb(base, images, target)
+        base.train()
+        if isinstance(z, (tuple, list)):
+            z = z[0]
+        return z
 
     def _graph_step(self, images, target):
         """The step with the training pass replayed from a hipGraph; None if this batch has to run eagerly."""
@@ -241,18 +399,8 @@ class ATTrainStep:
         if key not in self._tg and self._tg_seen.get(key, 0) < TRAIN_GRAPH_WARMUP:
             self._tg_seen[key] = self._tg_seen.get(key, 0) + 1            # libraries meet every shape outside a capture first
             return None
-        base = self.inner.base_model
         replays0 = graphed.STATS["replays"]
-        if self.perturb:                                                   # WrappedModel.forward, main.py:276-292 (under the
-            base.eval()                                                    # step's autocast, as main.py:985 has it)
-            with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None), \
-                    graphed.borrow_outputs():
-                z = self.inner.perturb(base, images, target)
-            base.train()
-            if isinstance(z, (tuple, list)):
-                z = z[0]
-        else:
-            z = images
+        z = self._perturbed(images, target, borrow=True)
         prog = self._tg.get(key)
         if prog is None:
             try:
@@ -263,7 +411,8 @@ class ATTrainStep:
                 warnings.warn(f"training-pass graph capture failed ({type(e).__name__}: {e}); this batch shape runs eagerly")
                 self._tg[key] = None
                 torch.cuda.synchronize()
-                self.optimizer.zero_grad(set_to_none=True)
+                if self.sync is None:
+                    self.optimizer.zero_grad(set_to_none=True)
                 loss = self._train_pass(z, target)
                 ops.invalidate_weight_cache()
                 return loss
@@ -282,6 +431,10 @@ class ATTrainStep:
         return self._eager_step(images, target)
 
     def _eager_step(self, images, target):
+        if self.sync is not None:                                          # same pass as the replayed one, launched from Python
+            loss = self._train_pass(self._perturbed(images, target), target)
+            ops.invalidate_weight_cache()
+            return loss
         self.optimizer.zero_grad(set_to_none=True)                         # main.py:984
         with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             output = self.model(images, target) if self.perturb else self.model(images)   # main.py:985-989

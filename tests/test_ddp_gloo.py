@@ -22,8 +22,26 @@ def _free_port():
     return p
 
 
-def _model():
+class _CutNet(nn.Module):
+    """A model that names a cut point (``ddp_cut``, as architecture.ConvNeXt does): FlatGradSync then splits the backward there and
+    sends the late parameters' gradients out before the early part of the backward runs."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.GELU())
+        self.b = nn.Sequential(nn.Conv2d(8, 8, 3, padding=1), nn.GELU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 5))
+
+    def forward(self, x):
+        return self.b(self.a(x))
+
+    def ddp_cut(self):
+        return self.a, [self.b]
+
+
+def _model(kind="seq"):
     torch.manual_seed(0)
+    if kind == "cut":
+        return _CutNet()
     return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.GELU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 5))
 
 
@@ -42,7 +60,7 @@ def _data(n):
     return torch.rand(n, 3, 8, 8, generator=g), torch.randint(0, 5, (n,), generator=g)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, grad_sync="ddp", kind="seq"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
@@ -69,18 +87,26 @@ def _worker(rank, world, port, q):
             return _real(*a, **kw)
         setattr(dist, name, counted)
 
-    tr = R.ATTrainStep(_model(), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=True, channels_last=False,
-                       amp_dtype=None, ema=True, perturb=attack)
+    tr = R.ATTrainStep(_model(kind), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=True, channels_last=False,
+                       amp_dtype=None, ema=True, perturb=attack, grad_sync=grad_sync)
 
     def hook(_, bucket):
         st["hook_total"] += 1
         st["hook_in_attack"] += int(st["in_attack"])
         fut = dist.all_reduce(bucket.buffer().div_(world), async_op=True).get_future()
         return fut.then(lambda f: f.value()[0])
-    tr.model.register_comm_hook(None, hook)
+    if grad_sync == "ddp":
+        tr.model.register_comm_hook(None, hook)
+    else:
+        assert tr.sync is not None and tr.sync.world == world and not isinstance(tr.model, nn.parallel.DistributedDataParallel)
+        assert (tr.sync.cut is not None) == (kind == "cut") and bool(tr.sync.late) == (kind == "cut")
     x, y = _data(8)
     xs, ys = x[rank::world], y[rank::world]                 # DistributedSampler-style disjoint shards (main.py:567)
     losses = [float(tr.step(xs, ys)) for _ in range(3)]
+    if grad_sync == "flat":                                 # the flat path's exchanges are Python-level all-reduces (counted above)
+        st["hook_total"] = tr.sync.reduces
+        assert all(p.grad.data_ptr() == v.data_ptr() for g, vs in zip((tr.sync.late, tr.sync.early), tr.sync.views)
+                   for p, v in zip(g, vs)), "a parameter's .grad left the flat buffers"
     flat = torch.cat([p.detach().flatten() for p in tr.inner.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -93,11 +119,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_ddp_world2_matches_single_process():
+@pytest.mark.parametrize("grad_sync,kind", [("ddp", "seq"), ("flat", "seq"), ("flat", "cut")])
+def test_ddp_world2_matches_single_process(grad_sync, kind):
+    """``grad_sync="ddp"``: DistributedDataParallel as ``main.py:889-890``; ``"flat"`` (the default of ATTrainStep(distributed=True)):
+    ``FlatGradSync`` - flat gradient buffers and one / two asynchronous all-reduces per step between the segments of the training
+    pass (with a model that names a cut point: the late group goes out before the early backward runs)."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, grad_sync, kind)) for r in range(2)]
     for p in procs:
         p.start()
     res = q.get()
@@ -105,21 +135,38 @@ def test_ddp_world2_matches_single_process():
         p.join(60)
         assert p.exitcode == 0
     assert res["same"], "ranks diverged: gradients were not all-reduced"
-    assert res["training"] and res["keys"][0].startswith("module.base_model.")      # DDP(WrappedModel(model))
+    assert res["training"]
+    assert res["keys"][0].startswith("module.base_model." if grad_sync == "ddp" else "base_model.")   # DDP(WrappedModel(model)) / WrappedModel(model)
     assert res["ema_moved"]
     # no inter-rank traffic inside the attack; the only exchange is the gradient all-reduce of the
     # outer backward (>= 1 bucket per step, 3 steps)
     assert res["coll"]["hook_in_attack"] == 0 and res["coll"]["py_in_attack"] == 0, res["coll"]
-    assert res["coll"]["hook_total"] >= 3, res["coll"]
+    assert res["coll"]["hook_total"] >= (6 if kind == "cut" else 3), res["coll"]
     # single process, whole batch: DDP averages per-rank mean losses == mean over the full batch (equal shards)
     torch.set_num_threads(1)
-    tr = R.ATTrainStep(_model(), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=False, channels_last=False,
+    tr = R.ATTrainStep(_model(kind), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=False, channels_last=False,
                        amp_dtype=None, ema=False, perturb=_sign_attack)
     x, y = _data(8)
     for _ in range(3):
         tr.step(x, y)
     flat = torch.cat([p.detach().flatten() for p in tr.inner.parameters()])
     torch.testing.assert_close(res["params"], flat, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["seq", "cut"])
+def test_flat_gradient_path_on_one_rank_equals_the_plain_backward(kind):
+    """``grad_sync="flat"`` without a process group (``bench.py --ddp-path 1``): the two-call backward into the flat buffers is the
+    same training step as ``loss.backward()`` - identical parameters after three steps, bit for bit on the CPU."""
+    torch.set_num_threads(1)
+    x, y = _data(8)
+    out = []
+    for gs in (None, "flat"):
+        tr = R.ATTrainStep(_model(kind), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=False, channels_last=False,
+                           amp_dtype=None, ema=True, perturb=_sign_attack, grad_sync=gs)
+        losses = [float(tr.step(x, y)) for _ in range(3)]
+        out.append((losses, torch.cat([p.detach().flatten() for p in tr.inner.parameters()]), tr.ema.ema[0].clone()))
+        assert (tr.sync is not None) == (gs == "flat")
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
 
 
 def test_optimizer_groups_follow_reference_rules():

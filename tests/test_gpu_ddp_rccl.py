@@ -90,7 +90,7 @@ assert dist.get_backend() == os.environ.get("APGD_DIST_BACKEND", "nccl") and wor
 dev = torch.device("cuda", local)
 torch.manual_seed(0)
 A = R.architecture
-m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
+m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=12)
 m.stem = A.ConvBlock1(48)
 st = {"in_attack": False, "hook_in_attack": 0, "hook_total": 0}
 real_attack = R.build_perturb(R.AdvConfig(attack="apgd", n_iter=2))
@@ -100,22 +100,47 @@ def attack(model, x, y):
         return real_attack(model, x, y)
     finally:
         st["in_attack"] = False
-tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2), dev, lr=1e-3, distributed=True, ema=True,
-                   perturb=attack)
-def hook(_, bucket):
-    st["hook_total"] += 1
-    st["hook_in_attack"] += int(st["in_attack"])
-    buf = bucket.buffer().div_(world)
-    dist.all_reduce(buf)                      # synchronous: gloo's CUDA work objects have no future
-    fut = torch.futures.Future()
-    fut.set_result(buf)
-    return fut
-tr.model.register_comm_hook(None, hook)
+GS = os.environ.get("APGD_TEST_GRAD_SYNC", "flat")
+for name in ("all_reduce",):
+    real = getattr(dist, name)
+    def counted(*a, _real=real, **kw):
+        st["hook_total"] += 1
+        st["hook_in_attack"] += int(st["in_attack"])
+        return _real(*a, **kw)
+    setattr(dist, name, counted)
+tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, graph=1 if GS == "flat" else 0), dev, lr=1e-3,
+                   distributed=True, ema=True, perturb=attack if GS == "ddp" else None, grad_sync=GS)
+if GS == "ddp":
+    def hook(_, bucket):
+        st["hook_total"] += 1
+        st["hook_in_attack"] += int(st["in_attack"])
+        buf = bucket.buffer().div_(world)
+        dist.all_reduce(buf)                      # synchronous: gloo's CUDA work objects have no future
+        fut = torch.futures.Future()
+        fut.set_result(buf)
+        return fut
+    tr.model.register_comm_hook(None, hook)
+else:
+    # the product path of an N > 1 rank: FlatGradSync + graphs.  The attack (adv.graph=1) is replayed from hipGraphs, which cannot
+    # contain a Python-level collective; `in_attack` brackets the perturb call of every step
+    real_perturb = tr.inner.perturb
+    def bracketed(model, x, y):
+        st["in_attack"] = True
+        try:
+            return real_perturb(model, x, y)
+        finally:
+            st["in_attack"] = False
+    tr.inner.perturb = bracketed
 g = torch.Generator(device=dev).manual_seed(100 + rank)
 x = torch.rand(4, 3, 64, 64, device=dev, generator=g)
 y = torch.randint(0, 10, (4,), device=dev, generator=g)
-for _ in range(2):
+n_steps = 2 if GS == "ddp" else 6
+for _ in range(n_steps):
     tr.step(x, y)
+if GS == "flat":
+    st["train_graph_segments"] = [v.n_graphs for v in tr._tg.values() if v is not None]
+    st["reduces"] = tr.sync.reduces
+    st["attack_replays"] = R.graphed.STATS["replays"]
 flat = torch.cat([p.detach().flatten() for p in tr.inner.parameters()])
 other = [torch.zeros_like(flat) for _ in range(world)]
 dist.all_gather(other, flat)
@@ -127,7 +152,7 @@ dist.destroy_process_group()
 """
 
 
-def _run_two_ranks(tmp_path, backend):
+def _run_two_ranks(tmp_path, backend, grad_sync="flat"):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     with socket.socket() as sk:
@@ -136,7 +161,7 @@ def _run_two_ranks(tmp_path, backend):
     procs = []
     for r in range(2):
         env = dict(_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", APGD_DIST_BACKEND=backend)
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", APGD_DIST_BACKEND=backend, APGD_TEST_GRAD_SYNC=grad_sync)
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, text=True))
     out = procs[0].communicate(timeout=900)[0]
     for p in procs:
@@ -144,16 +169,67 @@ def _run_two_ranks(tmp_path, backend):
     return json.loads(out.strip().splitlines()[-1])
 
 
+def _check_flat(res):
+    # six steps: three eager, then the training pass captured as THREE graph segments (forward + late backward | early backward |
+    # AdamW + EMA) with the two all-reduces between them, replayed from then on; two exchanges per step, none inside the attack
+    assert res["same"] and res["hook_in_attack"] == 0, res
+    assert res["train_graph_segments"] == [3], res
+    assert res["reduces"] == 12 and res["hook_total"] >= 12 and res["attack_replays"] >= 3, res
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
 def test_two_rccl_ranks_keep_identical_parameters_and_no_collective_inside_the_attack(tmp_path):
-    res = _run_two_ranks(tmp_path, "nccl")
-    assert res["same"] and res["hook_in_attack"] == 0 and res["hook_total"] >= 2, res
+    _check_flat(_run_two_ranks(tmp_path, "nccl"))
 
 
 def test_two_ranks_on_one_gpu_with_the_product_model(tmp_path):
     """The 1-GPU box's stand-in for the RCCL run: two rank processes share cuda:0 over gloo (RCCL refuses two ranks per
-    device).  Everything except the transport is the product path: DDP(WrappedModel(ConvNeXt)) with the fused blocks, the HIP
-    attack with its gradient-sign sink inside DDP.forward, bf16 autocast, AdamW, EMA.  Parameters stay identical across the
-    ranks, and no bucket reduction fires inside the attack."""
-    res = _run_two_ranks(tmp_path, "gloo")
+    device).  Everything except the transport is the product path of an N > 1 rank: WrappedModel(ConvNeXt) with the fused blocks,
+    the HIP attack replayed from hipGraphs, bf16 autocast, the training pass replayed from three graph segments with
+    ``FlatGradSync``'s all-reduces between them, capturable AdamW, EMA.  Parameters stay identical across the ranks."""
+    _check_flat(_run_two_ranks(tmp_path, "gloo"))
+
+
+def test_two_ranks_on_one_gpu_with_torch_ddp(tmp_path):
+    """``grad_sync="ddp"`` (``main.py:889-890`` literally: DistributedDataParallel around the wrapped model, eager training pass):
+    identical parameters, and no bucket reduction fires inside the attack, which runs inside DDP.forward."""
+    res = _run_two_ranks(tmp_path, "gloo", "ddp")
     assert res["same"] and res["hook_in_attack"] == 0 and res["hook_total"] >= 2, res
+
+
+def test_flat_gradient_path_on_one_gpu_is_the_same_step_and_costs_the_host_little():
+    """``bench.py --ddp-path 1`` on one GPU: the N > 1 code (two-call backward into flat buffers, three graph segments; the
+    collectives are no-ops without a process group) trains like the one-graph step (to the run-to-run noise of the library's
+    filter-gradient kernels), and a replayed step() call stays a handful of launches: <= 5 ms of host time."""
+    import time
+    import revisiting_at_amd as R
+    R._lib.load()
+
+    def run(gs):
+        R.graphed.reset()
+        torch.manual_seed(5)
+        A = R.architecture
+        m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=12)
+        m.stem = A.ConvBlock1(48)
+        tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=4 / 255, graph=1), "cuda", lr=1e-3,
+                           amp_dtype=torch.bfloat16, ema=True, ema_decay=0.9, grad_sync=gs)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        losses, host = [], []
+        for i in range(8):
+            x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
+            y = torch.randint(0, 12, (4,), device="cuda", generator=g)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = tr.step(x, y)
+            host.append(time.perf_counter() - t0)
+            losses.append(float(loss))
+        segs = [v.n_graphs for v in tr._tg.values() if v is not None]
+        return losses, [p.detach().clone() for p in tr.inner.parameters()], segs, host
+    l1, p1, s1, h1 = run("flat")
+    l0, p0, s0, h0 = run(None)
+    assert s1 == [3] and s0 == [1], (s1, s0)
+    assert max(abs(a - b) for a, b in zip(l1, l0)) <= 2e-3 * max(abs(v) for v in l0), (l1, l0)
+    num = sum(float((a.float() - b.float()).pow(2).sum()) for a, b in zip(p1, p0))
+    den = sum(float(b.float().pow(2).sum()) for b in p0)
+    assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+    assert min(h1[5:]) <= 5e-3, h1

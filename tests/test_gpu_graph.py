@@ -17,10 +17,10 @@ def R():
     return R
 
 
-def small_convnext(R, seed=0):
+def small_convnext(R, seed=0, num_classes=12):
     torch.manual_seed(seed)
     A = R.architecture
-    m = A.ConvNeXt(depths=(1, 1, 2, 1), dims=(96, 192, 384, 768), num_classes=10)
+    m = A.ConvNeXt(depths=(1, 1, 2, 1), dims=(96, 192, 384, 768), num_classes=num_classes)
     m.stem = A.ConvBlock1(48)
     with torch.no_grad():
         for n, p in m.named_parameters():
@@ -33,6 +33,14 @@ def same(a, b):
     return all(torch.equal(u, v) for u, v in zip(a, b))
 
 
+def eager_like_graph(R, model, x, y, **kw):
+    """The eager loop with the GEMM policy ``graphed.run`` gives this model: a two-stream model's attack runs every GEMM on
+    cnx_gemm_nt (``ops.attack_pass``) in all of ``run``'s calls; the plain ``apgd_train(graph=False)`` keeps the library's."""
+    import contextlib
+    with (R.ops.attack_pass() if R.graphed._attack_gemm(model) else contextlib.nullcontext()):
+        return R.apgd_train(model, x, y, graph=False, **kw)
+
+
 @pytest.mark.parametrize("norm,eps", [("Linf", EPS), ("L2", 2.0)])
 def test_graph_replay_is_bit_identical_to_the_eager_attack(R, norm, eps):
     R.graphed.reset()
@@ -43,9 +51,9 @@ def test_graph_replay_is_bit_identical_to_the_eager_attack(R, norm, eps):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         for call in range(5):
             x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
-            y = torch.randint(0, 10, (4,), device="cuda", generator=g)
+            y = torch.randint(0, 12, (4,), device="cuda", generator=g)
             got = R.apgd_train(model, x, y, norm=norm, eps=eps, n_iter=2, graph=True)
-            want = R.apgd_train(model, x, y, norm=norm, eps=eps, n_iter=2, graph=False)
+            want = eager_like_graph(R, model, x, y, norm=norm, eps=eps, n_iter=2)
             torch.cuda.synchronize()
             assert same(got, want), (norm, call)
             assert got[0].data_ptr() != x.data_ptr() and float((got[0] - x).abs().max()) > 0
@@ -67,7 +75,7 @@ def test_graph_replay_returns_fresh_tensors_and_keeps_the_memory_format(R):
     y = torch.randint(0, 10, (2,), device="cuda")
     with torch.autocast("cuda", dtype=torch.bfloat16):
         res = [R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=3, graph=True) for _ in range(4)]
-        ref = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=3)
+        ref = eager_like_graph(R, model, x, y, norm="Linf", eps=EPS, n_iter=3)
     assert all(same(r, ref) for r in res)
     assert res[2][0].data_ptr() != res[3][0].data_ptr()
     assert res[3][0].is_contiguous(memory_format=torch.channels_last) and res[3][1].dtype == torch.bool
@@ -94,7 +102,7 @@ def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R, graph_train):
         R.graphed.reset()
         torch.manual_seed(5)
         A = R.architecture
-        m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
+        m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=12)
         m.stem = A.ConvBlock1(48)
         tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=graph), "cuda", lr=1e-3,
                            amp_dtype=torch.bfloat16, ema=True, ema_decay=0.9, graph_train=bool(graph) and graph_train)
@@ -127,7 +135,7 @@ def test_training_pass_graph_runs_other_batch_shapes_eagerly_and_keeps_training(
     R.graphed.reset()
     torch.manual_seed(6)
     A = R.architecture
-    m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
+    m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=12)
     m.stem = A.ConvBlock1(48)
     tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=1), "cuda", lr=1e-3,
                        amp_dtype=torch.bfloat16, ema=True)
@@ -173,7 +181,7 @@ def test_sign_sink_steps_aside_when_the_iterate_has_a_second_consumer(R):
             warnings.simplefilter("always")
             got = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2)
         assert any("sink disabled" in str(m.message) for m in w)
-        assert id(model) in R.apgd._SINK_REFUSED
+        assert model in R.apgd._SINK_REFUSED
         saved = R.apgd.USE_SIGN_SINK
         try:
             R.apgd.USE_SIGN_SINK = False
@@ -213,7 +221,11 @@ def test_a_model_that_is_not_built_from_our_classes_is_replayed_on_one_stream(R)
     plain = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, stride=2, padding=1), torch.nn.GELU(), torch.nn.Flatten(),
                                 torch.nn.Linear(16 * 16 * 16, 10)).cuda().eval()
     assert R.graphed._streams(plain) == 1 and not R.apgd.two_stream_model(plain)
-    assert R.graphed._streams(small_convnext(R)) == max(1, R.graphed.STREAMS)
+    assert R.graphed._streams(small_convnext(R)) == 1            # outside bf16 autocast: the chunks' GEMMs would be the library's
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert R.graphed._streams(small_convnext(R)) == max(1, R.graphed.STREAMS)
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert R.graphed._streams(small_convnext(R)) == 1
     g = torch.Generator(device="cuda").manual_seed(12)
     before = R.graphed.STATS["replays"]
     for call in range(5):
@@ -239,15 +251,141 @@ def test_thread_local_capture_mode_of_multi_gpu_ranks_replays_the_same(R, monkey
             x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
             y = torch.randint(0, 10, (4,), device="cuda", generator=g)
             got = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2, graph=True)
-            want = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2, graph=False)
+            want = eager_like_graph(R, model, x, y, norm="Linf", eps=EPS, n_iter=2)
             torch.cuda.synchronize()
             assert same(got, want), call
     torch.manual_seed(5)
     A = R.architecture
-    m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=10)
+    m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=12)
     m.stem = A.ConvBlock1(48)
     tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=1), "cuda", lr=1e-3,
                        amp_dtype=torch.bfloat16, ema=True)
     for _ in range(6):
         loss = tr.step(torch.rand(4, 3, 64, 64, device="cuda", generator=g), torch.randint(0, 10, (4,), device="cuda", generator=g))
     assert torch.isfinite(loss) and [v is not None for v in tr._tg.values()] == [True]
+
+
+# ------------------------------------------------------------------------------------------------ round 4: the benchmarked path itself
+def test_full_size_two_stream_replay_equals_the_eager_chunks_and_replays_through_the_oracle(R):
+    """The code path ``bench.py`` times, at its real shapes: convnext_tiny (ConvStem) at 224 x 224 under bf16 autocast, graph
+    replay with the model calls as two batch chunks on two streams, every attack GEMM on cnx_gemm_nt - here with an ODD batch of
+    33 (chunks of 16 and 17 images: ragged row tiles in every kernel, 56 x 56 maps at C = 96).  (1) The eager form of the same
+    program (``_apgd_core(splits=2, attack_gemm=True)``) is recorded - logits and the int8 gradient signs the stem kernel wrote,
+    per chunk - and the pinned numpy oracle driven by those numbers must reproduce its outputs bit for bit; (2) every replay of
+    the captured program equals it bit for bit; (3) both again after an in-place "optimizer step" (the replay re-packs the derived
+    weight copies on the device; a cross-stream race on them would show here)."""
+    from oracle import apgd_oracle as O
+    from oracle import replay_tap as T
+    R.graphed.reset()
+    torch.manual_seed(0)
+    model = R.get_new_model("convnext_tiny", pretrained=False, not_original=True)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gamma"):
+                p.fill_(0.3)                                      # blocks that matter (the init value is 1e-6)
+    model = model.cuda().to(memory_format=torch.channels_last).eval()
+    B, K = 33, 2
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.rand(B, 3, 224, 224, device="cuda", generator=g)
+    y = torch.randint(0, 1000, (B,), device="cuda", generator=g)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert R.graphed._streams(model) == 2
+    before = dict(R.graphed.STATS)
+    for phase in range(2):
+        want, lo, gr, used = T.record_attack(R, model, x, y, "Linf", EPS, K, autocast=True, sink=True, splits=2)
+        assert used and all(used), "the int8 sign sink was not used"
+        assert lo.shape == (K + 1, B, 1000) and gr.shape == (K,) + tuple(x.shape)
+        T.check_replay(O, want, lo, gr, x, y, "Linf", EPS, K)
+        assert float((want[0] - x).abs().max()) > 0
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            for call in range(4 if phase == 0 else 2):
+                got = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=K, graph=True)
+                torch.cuda.synchronize()
+                assert same(got, want), (phase, call)
+        if phase == 0:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.mul_(1.0 + 0.05 * torch.randn((), device="cuda", generator=g))
+            R.ops.invalidate_weight_cache()
+    st = R.graphed.STATS
+    assert st["captures"] - before["captures"] == 1 and st["replays"] - before["replays"] == 4
+    assert st["failed"] == before["failed"] and st["lib_gemm_one_stream"] == before["lib_gemm_one_stream"]
+    R.graphed.reset()
+
+
+def test_a_graphed_fp32_attack_on_a_two_stream_model_runs_on_one_stream(R, monkeypatch):
+    """Round-3 advice: cnx_gemm_nt takes bf16 operands only, so outside bf16 autocast the chunks of a two-stream model would run
+    the library's GEMMs concurrently - the condition that deadlocked the GPU.  ``_streams`` is 1 there; the capture asks
+    ``_apgd_core`` for one chunk and the replay equals the plain eager attack."""
+    R.graphed.reset()
+    model = small_convnext(R, 6)
+    seen = []
+    orig = R.apgd._apgd_core
+
+    def spy(*a, **kw):
+        seen.append((kw.get("splits", 1), kw.get("attack_gemm")))
+        return orig(*a, **kw)
+    monkeypatch.setattr(R.apgd, "_apgd_core", spy)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for call in range(4):
+        x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
+        y = torch.randint(0, 12, (4,), device="cuda", generator=g)
+        got = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2, graph=True)
+        want = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2, graph=False)
+        torch.cuda.synchronize()
+        assert same(got, want), call
+    assert seen and all(s == 1 and not ag for s, ag in seen), seen
+    assert R.graphed.STATS["captures"] >= 1
+    R.graphed.reset()
+
+
+def test_a_library_gemm_inside_the_attack_keeps_the_capture_on_one_stream(R):
+    """What ``_streams`` cannot see statically - a layer whose shape fails cnx_gemm_nt's guards (here a 10-class head: N % 4 != 0)
+    reaches hipBLASLt even under ``ops.attack_pass`` - the first warm-up call catches (``_LibGemmWatch``): the signature is
+    captured on ONE stream, with a warning, and still replays bit for bit."""
+    import warnings
+    R.graphed.reset()
+    model = small_convnext(R, 7, num_classes=10)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n0 = R.graphed.STATS["lib_gemm_one_stream"]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert R.graphed._streams(model) == 2
+        for call in range(4):
+            x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
+            y = torch.randint(0, 10, (4,), device="cuda", generator=g)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                got = R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=2, graph=True)
+            if call == 0:
+                assert any("library GEMM" in str(m.message) for m in w)
+            want = eager_like_graph(R, model, x, y, norm="Linf", eps=EPS, n_iter=2)
+            torch.cuda.synchronize()
+            assert same(got, want), call
+    assert R.graphed.STATS["lib_gemm_one_stream"] == n0 + 1
+    ent = [e for k, e in R.graphed._programs.items() if k[0] == id(model)]
+    assert len(ent) == 1 and ent[0]["one_stream"] and ent[0]["prog"] is not None
+    R.graphed.reset()
+
+
+def test_captured_programs_are_bounded_and_follow_the_model(R, monkeypatch):
+    """Round-3 advice: every captured signature owns a private graph pool (multi-GB at batch 256).  Their number is capped (LRU,
+    ``MAX_PROGRAMS``); a model's captures are dropped when the model is collected."""
+    import gc
+    R.graphed.reset()
+    monkeypatch.setattr(R.graphed, "MAX_PROGRAMS", 2)
+    model = small_convnext(R, 8)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ev0 = R.graphed.STATS["evicted"]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        for bsz in (2, 3, 4):                                   # three signatures, three captures: the first is evicted
+            x = torch.rand(bsz, 3, 64, 64, device="cuda", generator=g)
+            y = torch.randint(0, 12, (bsz,), device="cuda", generator=g)
+            for _ in range(3):
+                R.apgd_train(model, x, y, norm="Linf", eps=EPS, n_iter=1, graph=True)
+    live = [k for k, e in R.graphed._programs.items() if e["prog"] is not None]
+    assert len(live) == 2 and R.graphed.STATS["evicted"] == ev0 + 1
+    assert sorted(k[1][0] for k in live) == [3, 4]
+    mid = id(model)
+    del model, x, y
+    gc.collect()
+    assert not [k for k in R.graphed._programs if k[0] == mid]
