@@ -1,0 +1,289 @@
+// dwwin_kernels.hip — depthwise 7x7 on bf16 operands with a REGISTER sliding window (round 4; gfx950 / MI355X).
+// Reference arithmetic: /root/reference/models/convnext.py:28, 39 (`Conv2d(dim, dim, 7, padding=3, groups=dim)` under autocast:
+// bf16 inputs and weights, fp32 accumulation), forward and - with the 180-degree rotated filter - its input gradient, with the
+// residual gradient added in the same pass.
+//
+// Why another form.  The LDS-ring kernels of model_kernels.hip (dwconv7x7_roll / _multi) stage every input row through
+// registers into a pair-packed LDS ring and back, in workgroup-wide phases separated by barriers; with their prefetch registers
+// they sit at 220 - 256 VGPRs (+ up to 66 AGPRs): ONE or TWO wavefronts per SIMD, 4 - 8 per CU.  Round 3 measured them at half
+// of both of their bounds (56x56x96 forward 145 us against 73 us of HBM time and ~60 us of v_dot2 time): with so few wavefronts
+// nothing covers a phase's memory latency, and a CU never has the ~50 KB in flight that its share of the HBM bandwidth needs.
+//
+// Here a wavefront is on its own - no LDS, no barrier:
+//   * lane = (unit, channel): CH = 32 or 64 channels of one STRIP of 7 output columns (56, 28, 14 and 7 - every ConvNeXt map at 224 -
+//     are multiples of 7: no ragged strip, no idle lane; "unit" = strip of one image, a wavefront holds 64 / CH units).  NHWC
+//     memory gives every load / store instruction one full 128-byte (fp32) or 64-byte (bf16) run per unit and position.
+//   * the lane keeps a 7-row x 13-column window of ITS channel in 49 registers, packed as pairs of W-adjacent bf16 per dword
+//     (columns 7 s - 3 ... 7 s + 9 of strip s), walks DOWN a band of the image, and per output row issues 13 loads for the row
+//     that enters the window (one row ahead of its use), 7 x 28 v_dot2_f32_bf16 on the window, and the 7 stores of the finished row:
+//         even t = 2 q  : pairs q .. q+3 . {(f0,f1),(f2,f3),(f4,f5),(f6,0)}
+//         odd  t = 2 q+1: pairs q .. q+3 . {(0,f0),(f1,f2),(f3,f4),(f5,f6)}            (as the LDS kernels; no realignment)
+//   * ~150 registers: three wavefronts per SIMD, twelve per CU, each with its own loads in flight.
+// The price is the column halo (13 loads per 7 outputs: neighbouring strips sit in the same wavefront / workgroup, the re-reads
+// are L1 / L2 hits) and the 6 halo rows per band (XCD-aware item order keeps the bands of an image in one L2).
+//
+// Algorithmic bytes: forward fp32 -> bf16: 6 B per element; input gradient bf16 -> fp32 with the fp32
+// residual gradient added: 10 B per element.  HBM-bound: 56 x 56 x 96, batch 256: 462 / 771 MB.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "apgd_hip.h"
+#include "convnext_hip.h"
+#include "dw_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+constexpr int kT = 7;                 // output columns of a strip
+constexpr int kCols = kT + 6;         // input columns a strip reads (13)
+constexpr int kPairs = 7;             // window dwords per row: 14 columns, the last one always zero
+
+template <typename TI> struct RawRow { TI v[kCols]; };
+
+__device__ __forceinline__ void pack_row(uint32_t (&d)[kPairs], const RawRow<float>& r, const uint32_t (&m)[kPairs]) {
+#pragma unroll
+  for (int i = 0; i < kPairs; ++i) d[i] = pack2_bf16(r.v[2 * i], 2 * i + 1 < kCols ? r.v[2 * i + 1 < kCols ? 2 * i + 1 : 0] : 0.f) & m[i];
+}
+__device__ __forceinline__ void pack_row(uint32_t (&d)[kPairs], const RawRow<uint16_t>& r, const uint32_t (&m)[kPairs]) {
+#pragma unroll
+  for (int i = 0; i < kPairs; ++i) {
+    const uint32_t hi = 2 * i + 1 < kCols ? static_cast<uint32_t>(r.v[2 * i + 1 < kCols ? 2 * i + 1 : 0]) : 0u;
+    d[i] = (static_cast<uint32_t>(r.v[2 * i]) | (hi << 16)) & m[i];
+  }
+}
+
+__device__ __forceinline__ void store_out(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_out(uint16_t* p, float v) { *p = static_cast<uint16_t>(pack2_bf16(v, 0.f)); }
+
+struct WinArgs {
+  const void* x; const float* w49c; const float* bias; const float* add; void* out;
+  int N, H, W, C, flip;
+  int n_strips, n_sg, n_cg, band, n_bands;   // strips per image row, strip groups (of 64 / CH strips), channel groups, rows per band, bands
+  long items_per_cg, items_per_cg_real;      // wavefront work items of one channel group: N * n_bands * n_sg, padded to a multiple of 4
+};
+
+// One wavefront = one item: (image, band, channel group, strip group), strip group fastest.
+// RAGGED: W is not a multiple of 7 (the last strip's stores are predicated per column, its group may hold an idle unit).
+// Three wavefronts per SIMD (<= 168 registers) except for the add variants with per-unit masks in VGPRs (CH = 32) or ragged strips,
+// which need ~180 and take two.
+template <typename TI, typename TO, int CH, bool ADD, bool RAGGED>
+__global__ __launch_bounds__(256, (ADD && (RAGGED || CH == 32)) ? 2 : 3) void dwconv7x7_win_kernel(const WinArgs a) {
+  constexpr int UPW = 64 / CH;
+  const int lane = threadIdx.x & 63;
+  // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch); XCD k takes the k-th contiguous eighth of the item list,
+  // so that the bands / strips of an image - which share halo rows and columns - meet in one L2
+  long blk;
+  {
+    const long L = blockIdx.x, B = gridDim.x;
+    const long q = B / 8, r = B % 8, xcd = L % 8, k = L / 8;
+    blk = xcd * q + (xcd < r ? xcd : r) + k;
+  }
+  // (everything derived from the item is wave-uniform: say so, and the addresses below become SGPR base + one VGPR offset)
+  const long item = blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // item order: strip group fastest, then band, image, channel group slowest - the four wavefronts of a workgroup share ONE channel
+  // group (the launcher pads the items of a channel group to a multiple of four), whose packed filter they read from LDS, and an
+  // XCD's contiguous eighth of the list keeps the strips / bands of an image in one L2
+  const int cg = static_cast<int>(item / a.items_per_cg);
+  const long it = item % a.items_per_cg;
+  const bool item_ok = it < a.items_per_cg_real;
+  const int sg = static_cast<int>(it % a.n_sg);
+  const int bd = static_cast<int>((it / a.n_sg) % a.n_bands);
+  const long n = item_ok ? it / (static_cast<long>(a.n_sg) * a.n_bands) : 0;
+  const int H = a.H, W = a.W, C = a.C;
+  const int ul = lane / CH;                                                // unit of this lane inside the wavefront
+  const bool unit_ok = sg * UPW + ul < a.n_strips;                         // (an odd strip count leaves the last CH = 32 wavefront half idle)
+  const int ulc = unit_ok ? ul : a.n_strips - 1 - sg * UPW;               // an idle unit shadows the last strip (loads stay in range)
+  const int w0 = (sg * UPW + ulc) * kT;
+  const int c = cg * CH + (lane % CH);
+  const int r_begin = bd * a.band, r_end = min(H, r_begin + a.band);
+  const int n_rows = r_end - r_begin;
+  const long rs = static_cast<long>(W) * C;                               // row stride in elements
+
+  // ---- pair masks: window column j (0..12) is image column w0 - 3 + j; what lies outside the image is zero in the window,
+  //      whatever was loaded for it (the loads of such a column fetch a neighbouring row's element: valid memory, except in the
+  //      first / last row of the whole tensor, which take the clamped loads below)
+  uint32_t m[kPairs];
+#pragma unroll
+  for (int i = 0; i < kPairs; ++i) {
+    const int wl = w0 - 3 + 2 * i, wh = wl + 1;
+    m[i] = ((wl >= 0 && wl < W) ? 0x0000ffffu : 0u) | ((2 * i + 1 < kCols && wh >= 0 && wh < W) ? 0xffff0000u : 0u);
+  }
+  const uint32_t zero_m[kPairs] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+
+  // addresses = wave-uniform pointer (image, row, first column of the strip group, channel group, column j: scalar arithmetic)
+  //           + ONE per-lane element offset (unit inside the group, channel inside the group), the same for every load of the lane
+  const uint32_t voff = static_cast<uint32_t>(ulc * kT * C + (lane % CH));   // elements
+  // (byte offsets: `uniform pointer + zero-extended 32-bit VGPR` is what selects the SGPR-base addressing mode - one VGPR, no
+  //  per-load 64-bit address arithmetic; an ELEMENT index would be scaled after the extension and lose the form)
+  const uint32_t vb_in = voff * static_cast<uint32_t>(sizeof(TI)), vb_out = voff * static_cast<uint32_t>(sizeof(TO)), vb_add = voff * 4u;
+  const long goff = static_cast<long>(sg * UPW * kT - 3) * C + cg * CH;   // window column 0 of the group's first strip (may be < 0)
+  const TI* ximg = static_cast<const TI*>(a.x) + n * H * rs;
+  const long last_row = static_cast<long>(a.N) * H - 1;
+
+  auto load_row = [&](RawRow<TI>& r, int hrow) {                          // hrow: a row of this image, 0 <= hrow < H
+    const long grow = n * H + hrow;
+    const TI* prow = ximg + hrow * rs;
+    if (grow == 0 || grow == last_row) {                                  // (wave-uniform, rare) element index clamped into the row:
+      asm volatile("; first / last row of the tensor" ::: "memory");      // (a side effect: keeps this a branch - if-converted, the
+#pragma unroll                                                            //  common path's addresses become per-lane 64-bit selects)
+      for (int j = 0; j < kCols; ++j) {
+        const long idx = goff + static_cast<long>(voff) + static_cast<long>(j) * C;
+        r.v[j] = prow[idx < 0 ? 0 : (idx >= rs ? rs - 1 : idx)];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kCols; ++j)
+        r.v[j] = *reinterpret_cast<const TI*>(reinterpret_cast<const char*>(prow + goff + static_cast<long>(j) * C) + vb_in);
+    }
+  };
+
+  // ---- packed filter of the workgroup's channel group in LDS: wl[kh][parity][channel] = 4 dwords (16 bytes, one ds_read_b128 per
+  //      lane, conflict-free; the two units of a CH = 32 wavefront read the same addresses).  56 dwords per channel would be a
+  //      third of the register budget of three wavefronts per SIMD; here a filter row lives in registers only while it is used.
+  __shared__ uint4 wl[7 * 2 * CH];
+  for (int q = threadIdx.x; q < 7 * CH; q += 256) {
+    const int kh = q / CH, cc = q % CH;
+    float f[7];
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int tap = kh * 7 + kw;
+      f[kw] = a.w49c[(a.flip ? 48 - tap : tap) * C + cg * CH + cc];
+    }
+    wl[(kh * 2 + 0) * CH + cc] = make_uint4(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], 0.f));
+    wl[(kh * 2 + 1) * CH + cc] = make_uint4(pack2_bf16(0.f, f[0]), pack2_bf16(f[1], f[2]), pack2_bf16(f[3], f[4]), pack2_bf16(f[5], f[6]));
+  }
+  __syncthreads();
+  if (!item_ok) return;                                                   // (padding wavefront of the channel group's last workgroup)
+  // LDS byte address of this lane's channel; laundered through an empty asm in every step so that the filter reads are not
+  // loop-invariant to the compiler (it would hoist all 14 of them out of the row loop: 56 registers again)
+  typedef const __attribute__((address_space(3))) u32x4_t* lds_u4_t;
+  const uint32_t wl_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)wl)) +
+                           (lane % CH) * 16u;
+  const float b0 = a.bias ? a.bias[c] : 0.f;
+
+  // ---- window: slot k holds input row r_begin - 3 + j for j % 7 == k
+  uint32_t win[7][kPairs];
+  // prologue: input rows j = 0 .. 5 (rows r_begin - 3 .. r_begin + 2), three at a time; rows above / below the image are zeros
+#pragma unroll
+  for (int j0 = 0; j0 < 6; j0 += 3) {
+    RawRow<TI> raw[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) load_row(raw[jj], min(max(r_begin - 3 + j0 + jj, 0), H - 1));
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int hr = r_begin - 3 + j0 + jj;
+      if (hr >= 0 && hr < H) pack_row(win[j0 + jj], raw[jj], m);          // wave-uniform
+      else pack_row(win[j0 + jj], raw[jj], zero_m);
+    }
+  }
+  RawRow<TI> nx;                                                          // the row that enters the window next (input row j = i + 6)
+  load_row(nx, min(r_begin + 3, H - 1));
+
+  const long gout = static_cast<long>(sg * UPW * kT) * C + cg * CH;       // first output column of the group's first strip
+  TO* oimg = static_cast<TO*>(a.out) + n * H * rs + gout;
+  const float* aimg = ADD ? a.add + n * H * rs + gout : nullptr;
+
+  // ---- one output row.  P = i % 7 (compile time): window slots are register arrays, their indices must be static.
+#define DWWIN_STEP(P)                                                                                              \
+  {                                                                                                                \
+    const int h = min(r_begin + i + (P), H - 1);                                                                   \
+    const bool row_ok = i + (P) < n_rows;                                 /* wave-uniform */                       \
+    /* the row prefetched one step ago (input row h + 3) enters slot (P + 6) % 7 */                                \
+    if (h + 3 < H) pack_row(win[((P) + 6) % 7], nx, m);                                                            \
+    else pack_row(win[((P) + 6) % 7], nx, zero_m);                                                                 \
+    /* prefetch input row h + 4 for the next step; the add operand of this row */                                  \
+    load_row(nx, min(h + 4, H - 1));                                                                               \
+    float acc[kT];                                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[t] = b0;                                                    \
+    uint32_t wa = wl_addr;                                                                                         \
+    asm volatile("" : "+v"(wa));                                                                                   \
+    lds_u4_t wlane = reinterpret_cast<lds_u4_t>(static_cast<uintptr_t>(wa));                                       \
+    _Pragma("unroll") for (int kh = 0; kh < 7; ++kh) {                                                             \
+      const uint32_t(&d)[kPairs] = win[((P) + kh) % 7];                                                            \
+      const u32x4_t we4 = wlane[(kh * 2 + 0) * CH], wo4 = wlane[(kh * 2 + 1) * CH];                                \
+      const uint32_t we[4] = {we4.x, we4.y, we4.z, we4.w}, wo[4] = {wo4.x, wo4.y, wo4.z, wo4.w};                   \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                              \
+          acc[t] = dot2(d[t / 2 + e], (t & 1) ? wo[e] : we[e], acc[t]);                                            \
+      }                                                                                                            \
+    }                                                                                                              \
+    float av[kT];                                                                                                  \
+    if (ADD) {                /* after the arithmetic (compiler barrier): 7 registers less across the dot products */ \
+      asm volatile("" ::: "memory");                                                                               \
+      const float* ap = aimg + h * rs;                                                                             \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
+        if (RAGGED) av[t] = ap[voff + static_cast<long>(min(t, W - 1 - w0)) * C];                                  \
+        else av[t] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ap + static_cast<long>(t) * C) + vb_add); \
+      }                                                                                                            \
+    }                                                                                                              \
+    if (unit_ok && row_ok) {                                                                                       \
+      TO* op = oimg + h * rs;                                                                                      \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
+        if (!RAGGED || w0 + t < W)                                                                                 \
+          store_out(reinterpret_cast<TO*>(reinterpret_cast<char*>(op + static_cast<long>(t) * C) + vb_out), ADD ? acc[t] + av[t] : acc[t]); \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+
+  // (bands are multiples of 7 rows except possibly the last of an image: its surplus steps compute on clamped rows and store nothing)
+  for (int i = 0; i < n_rows; i += 7) {
+    DWWIN_STEP(0) DWWIN_STEP(1) DWWIN_STEP(2) DWWIN_STEP(3) DWWIN_STEP(4) DWWIN_STEP(5) DWWIN_STEP(6)
+  }
+#undef DWWIN_STEP
+}
+
+template <typename TI, typename TO, int CH, bool ADD>
+int launch_win(const WinArgs& a, hipStream_t s) {
+  const long blocks = a.items_per_cg / 4 * a.n_cg;
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (a.W % kT == 0) hipLaunchKernelGGL((dwconv7x7_win_kernel<TI, TO, CH, ADD, false>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((dwconv7x7_win_kernel<TI, TO, CH, ADD, true>), grid, block, 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace
+
+// -> APGD_OK / an error of the launch; -1 when this shape is not for the window kernel (the caller goes on to the LDS kernels)
+int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bias, const float* add, void* out, int out_dtype,
+                  int64_t N, int32_t H, int32_t W, int32_t C, int32_t flip, hipStream_t s) {
+  static const int on = getenv("APGD_DW_WIN") ? atoi(getenv("APGD_DW_WIN")) : 1;
+  if (!on || C % 32 != 0 || H < 1 || W < 7) return -1;
+  if (x_dtype == APGD_F32 && out_dtype == APGD_F32) return -1;             // the exact-fp32 path is not a bf16 kernel's business
+  if (add && x_dtype == APGD_F32) return -1;                                // (no caller: forward calls carry no add operand)
+  if (static_cast<long>(N) * H * W * C >= (1L << 31)) return -1;           // 32-bit per-lane element offsets inside an image / tensor
+  WinArgs a;
+  a.x = x; a.w49c = w49c; a.bias = bias; a.add = add; a.out = out;
+  a.N = static_cast<int>(N); a.H = H; a.W = W; a.C = C; a.flip = flip;
+  const int ch = (C % 64 == 0) ? 64 : 32;
+  a.n_strips = (W + kT - 1) / kT;
+  a.n_sg = (a.n_strips + (64 / ch) - 1) / (64 / ch);
+  a.n_cg = C / ch;
+  // rows per band: whole image for the small maps; for the large ones as few bands as give >= ~3 rounds of 12 wavefronts per CU
+  // (every band re-reads 6 halo rows)
+  static const int band_env = getenv("APGD_DW_WIN_BAND") ? atoi(getenv("APGD_DW_WIN_BAND")) : 0;
+  const long per_band_items = static_cast<long>(N) * a.n_cg * a.n_sg;
+  int n_bands = 1;
+  while (n_bands < 8 && per_band_items * n_bands < 3L * 256 * 12 && (H + n_bands) / (n_bands + 1) >= 7) ++n_bands;
+  a.band = band_env > 0 ? band_env : ((H + n_bands - 1) / n_bands + 6) / 7 * 7;   // whole groups of 7 rows (the kernel's unrolled window rotation)
+  a.n_bands = (H + a.band - 1) / a.band;
+  a.items_per_cg_real = static_cast<long>(N) * a.n_sg * a.n_bands;
+  a.items_per_cg = (a.items_per_cg_real + 3) / 4 * 4;
+#define WIN_GO(TI, TO, ADDV) return (ch == 64) ? launch_win<TI, TO, 64, ADDV>(a, s) : launch_win<TI, TO, 32, ADDV>(a, s);
+  if (x_dtype == APGD_F32) WIN_GO(float, uint16_t, false)
+  if (out_dtype == APGD_F32) { if (add) WIN_GO(uint16_t, float, true) else WIN_GO(uint16_t, float, false) }
+  if (add) WIN_GO(uint16_t, uint16_t, true)
+  WIN_GO(uint16_t, uint16_t, false)
+#undef WIN_GO
+}

@@ -12,6 +12,7 @@
 
 #include "apgd_hip.h"
 #include "convnext_hip.h"
+#include "dw_internal.h"
 
 // timing experiments (APGD_DW_DBG) are compiled in only with -DDW_ABLATE=1: a run-time flag test inside a stencil loop is a
 // branch per use (see profiles/r02_fused_mlp_study.md)
@@ -1881,6 +1882,11 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     return APGD_ERR_DTYPE;
   hipStream_t s = as_stream(stream);
   const bool all_f32 = x_dtype == APGD_F32 && out_dtype == APGD_F32;
+  {
+    // bf16 operands: the register-window kernel (dwwin_kernels.hip, round 4) takes every shape with C % 32 == 0
+    const int rc = dw_win_launch(x, x_dtype, w49c, bias, add, out, out_dtype, N, H, W, C, flip, s);
+    if (rc != -1) return rc;
+  }
   static const int dw_dbg = getenv("APGD_DW_DBG") ? atoi(getenv("APGD_DW_DBG")) : 0;   // timing experiments only
   // The packed-dot kernels fuse "+ add" only into an fp32 result.  A bf16 result with an add operand (the residual gradient
   // of a block whose input is bf16) goes to the strip kernel below, which honours it for every output type - never silently

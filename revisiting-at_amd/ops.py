@@ -1152,6 +1152,14 @@ class _LinearLib(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if _gemm_dims_ok(dy2, N, wb.shape[1], "linear"):
                 dx = _gemm_nt(dy2, _bf16_t(ctx.w), EPI_BIAS).view(ctx.x_shape)    # B = W^T [in, out]
+            elif N % 64 != 0 and _gemm_dims_ok(dy2, (N + 63) // 64 * 64, wb.shape[1], "linear"):
+                # a contraction length cnx_gemm_nt does not take (the 1000-class head: K = 1000): both operands zero-padded to the
+                # next multiple of 64 - a few KB at the head's row counts - so that no GEMM of an attack pass is the library's
+                Kp = (N + 63) // 64 * 64
+                dyp = torch.zeros(M, Kp, device=dy2.device, dtype=torch.bfloat16)
+                dyp[:, :N].copy_(dy2)
+                wtp = _cached((ctx.w,), "bf16_t_pad64", lambda t: F.pad(t.to(torch.bfloat16).t(), (0, Kp - N)).contiguous())
+                dx = _gemm_nt(dyp, wtp, EPI_BIAS).view(ctx.x_shape)
             else:
                 dx = (dy2 @ wb).view(ctx.x_shape)
         dw = db = None

@@ -158,7 +158,9 @@ class FlatGradSync:
             buf = torch.zeros(n, device=device, dtype=torch.float32)
             vs, o = [], 0
             for p in group:
-                vs.append(buf[o:o + p.numel()].view(p.shape))
+                # the parameter's own layout (channels_last convolution weights): the fused AdamW wants params and grads alike
+                dense = p.numel() > 0 and sum((sz - 1) * st for sz, st in zip(p.shape, p.stride())) + 1 == p.numel()
+                vs.append(buf[o:o + p.numel()].as_strided(p.shape, p.stride()) if dense else buf[o:o + p.numel()].view(p.shape))
                 o += p.numel()
             self.flat.append(buf)
             self.views.append(vs)

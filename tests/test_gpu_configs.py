@@ -514,7 +514,8 @@ def test_cfg5_standard_evaluation_on_convnext_base_replays_through_the_oracle(R,
     torch.cuda.synchronize()
     assert [c["loss"] for c in calls] == ["ce", "dlr-targeted", "dlr-targeted"], [c["loss"] for c in calls]
     assert st["attack_runs"] == 3
-    assert all(2 <= len(c["y"]) <= 5 for c in calls[1:]), [len(c["y"]) for c in calls]   # the targeted runs attack the survivors only
+    # the targeted runs attack the survivors only: 2 - 5 of the 7 after APGD-CE, then whoever the first targeted run left robust
+    assert 2 <= len(calls[1]["y"]) <= 5 and 1 <= len(calls[2]["y"]) <= len(calls[1]["y"]), [len(c["y"]) for c in calls]
 
     class Replay:
         def __init__(self, c):
