@@ -31,6 +31,12 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
                        const float* add, void* out, int out_dtype,
                        int64_t N, int32_t H, int32_t W, int32_t C, int32_t flip, void* stream);
 
+/* Which calls with a bf16 operand and C % 32 == 0 take the register-window kernel (csrc/dwwin_kernels.hip) instead of the LDS-ring
+ * kernels: 0 = none, 1 = the shapes where it measured ahead on MI355X (default; APGD_DW_WIN overrides the default at start-up),
+ * 2 = every shape it supports.  Same arithmetic either way (bf16 operands, fp32 accumulation; the summation order differs).
+ * Returns the previous setting; a negative `policy` only queries.  Process-wide, not synchronised: set it before launching. */
+int cnx_dwconv7x7_win_policy(int policy);
+
 /* Filter / bias gradient of the same convolution:
  *   dw49c[(kh*7+kw)*C + c] = sum_{n,h,w} dy[n,h,w,c] * x[n,h+kh-3,w+kw-3,c];  dbias[c] = sum dy.
  * Deterministic two-stage reduction; ws is scratch of cnx_dwconv7x7_wgrad_ws_floats(C) floats.  With a bf16 dy (the

@@ -72,14 +72,16 @@ struct WinArgs {
   int N, H, W, C, flip;
   int n_strips, n_sg, n_cg, band, n_bands;   // strips per image row, strip groups (of 64 / CH strips), channel groups, rows per band, bands
   long items_per_cg, items_per_cg_real;      // wavefront work items of one channel group: N * n_bands * n_sg, padded to a multiple of 4
+  int per_wave_cg;                           // 1: a workgroup = the n_cg channel groups of ONE (image, band, strip group), one wavefront each
 };
 
 // One wavefront = one item: (image, band, channel group, strip group), strip group fastest.
 // RAGGED: W is not a multiple of 7 (the last strip's stores are predicated per column, its group may hold an idle unit).
 // Three wavefronts per SIMD (<= 168 registers) except for the add variants with per-unit masks in VGPRs (CH = 32) or ragged strips,
 // which need ~180 and take two.
-template <typename TI, typename TO, int CH, bool ADD, bool RAGGED>
-__global__ __launch_bounds__(256, (ADD && (RAGGED || CH == 32)) ? 2 : 3) void dwconv7x7_win_kernel(const WinArgs a) {
+template <typename TI, typename TO, int CH, bool ADD, bool RAGGED, int R>
+__global__ __launch_bounds__(256, ((ADD && (RAGGED || CH == 32)) || (R == 2 && (CH == 32 || ADD || sizeof(TI) == 4))) ? 2 : 3)
+void dwconv7x7_win_kernel(const WinArgs a) {
   constexpr int UPW = 64 / CH;
   const int lane = threadIdx.x & 63;
   // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch); XCD k takes the k-th contiguous eighth of the item list,
@@ -91,12 +93,19 @@ __global__ __launch_bounds__(256, (ADD && (RAGGED || CH == 32)) ? 2 : 3) void dw
     blk = xcd * q + (xcd < r ? xcd : r) + k;
   }
   // (everything derived from the item is wave-uniform: say so, and the addresses below become SGPR base + one VGPR offset)
-  const long item = blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // item order: strip group fastest, then band, image, channel group slowest - the four wavefronts of a workgroup share ONE channel
-  // group (the launcher pads the items of a channel group to a multiple of four), whose packed filter they read from LDS, and an
-  // XCD's contiguous eighth of the list keeps the strips / bands of an image in one L2
-  const int cg = static_cast<int>(item / a.items_per_cg);
-  const long it = item % a.items_per_cg;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Two workgroup shapes:
+  //  * per_wave_cg (narrow tensors, n_cg <= 4: C = 96): the workgroup's wavefronts are the CHANNEL GROUPS of one (image, band, strip
+  //    group).  A 32-channel group is 128 bytes (fp32) / 64 bytes (bf16) of every position: read on its own, at another time than its
+  //    neighbours, it uses half / a quarter of every DRAM burst the position's 384 / 192 bytes sit in (PMC, profiles/r04_dwwin.md:
+  //    2.7 TB/s with the groups apart).  Together the wavefronts walk whole contiguous rows.  Each fills its own filter slot.
+  //  * shared (everything else): four wavefronts = four items of ONE channel group, whose packed filter they share; item order
+  //    strip group fastest, then band, image, channel group slowest (the launcher pads a group's items to a multiple of four).
+  // In both an XCD's contiguous eighth of the workgroup list keeps the strips / bands of an image in one L2.
+  int cg;
+  long it;
+  if (a.per_wave_cg) { cg = wave; it = blk; }
+  else { const long item = blk * 4 + wave; cg = static_cast<int>(item / a.items_per_cg); it = item % a.items_per_cg; }
   const bool item_ok = it < a.items_per_cg_real;
   const int sg = static_cast<int>(it % a.n_sg);
   const int bd = static_cast<int>((it / a.n_sg) % a.n_bands);
@@ -152,8 +161,9 @@ __global__ __launch_bounds__(256, (ADD && (RAGGED || CH == 32)) ? 2 : 3) void dw
   // ---- packed filter of the workgroup's channel group in LDS: wl[kh][parity][channel] = 4 dwords (16 bytes, one ds_read_b128 per
   //      lane, conflict-free; the two units of a CH = 32 wavefront read the same addresses).  56 dwords per channel would be a
   //      third of the register budget of three wavefronts per SIMD; here a filter row lives in registers only while it is used.
-  __shared__ uint4 wl[7 * 2 * CH];
-  for (int q = threadIdx.x; q < 7 * CH; q += 256) {
+  extern __shared__ uint4 wl_all[];                                       // [per_wave_cg ? n_cg : 1][7 * 2 * CH]
+  uint4* wl = wl_all + (a.per_wave_cg ? wave * (7 * 2 * CH) : 0);
+  for (int q = a.per_wave_cg ? lane : static_cast<int>(threadIdx.x); q < 7 * CH; q += a.per_wave_cg ? 64 : 256) {
     const int kh = q / CH, cc = q % CH;
     float f[7];
 #pragma unroll
@@ -173,8 +183,11 @@ __global__ __launch_bounds__(256, (ADD && (RAGGED || CH == 32)) ? 2 : 3) void dw
                            (lane % CH) * 16u;
   const float b0 = a.bias ? a.bias[c] : 0.f;
 
-  // ---- window: slot k holds input row r_begin - 3 + j for j % 7 == k
-  uint32_t win[7][kPairs];
+  // ---- window: NS = 6 + R slots; slot k holds input row r_begin - 3 + j for j % NS == k.  A step produces R output rows: with
+  //      R = 2 a wavefront has TWO rows of loads in flight (the latency of a row's loads is what a step waits for: profiles/
+  //      r04_dwwin.md) and every filter row fetched from LDS serves both output rows.
+  constexpr int NS = 6 + R;
+  uint32_t win[NS][kPairs];
   // prologue: input rows j = 0 .. 5 (rows r_begin - 3 .. r_begin + 2), three at a time; rows above / below the image are zeros
 #pragma unroll
   for (int j0 = 0; j0 < 6; j0 += 3) {
@@ -188,78 +201,127 @@ __global__ __launch_bounds__(256, (ADD && (RAGGED || CH == 32)) ? 2 : 3) void dw
       else pack_row(win[j0 + jj], raw[jj], zero_m);
     }
   }
-  RawRow<TI> nx;                                                          // the row that enters the window next (input row j = i + 6)
-  load_row(nx, min(r_begin + 3, H - 1));
+  RawRow<TI> nx[R];                                                       // the rows that enter the window next (input rows j = i + 6 ...)
+#pragma unroll
+  for (int r = 0; r < R; ++r) load_row(nx[r], min(r_begin + 3 + r, H - 1));
 
   const long gout = static_cast<long>(sg * UPW * kT) * C + cg * CH;       // first output column of the group's first strip
   TO* oimg = static_cast<TO*>(a.out) + n * H * rs + gout;
   const float* aimg = ADD ? a.add + n * H * rs + gout : nullptr;
 
-  // ---- one output row.  P = i % 7 (compile time): window slots are register arrays, their indices must be static.
+  // ---- one step = R output rows.  P = i % NS (compile time): window slots are register arrays, their indices must be static.
 #define DWWIN_STEP(P)                                                                                              \
   {                                                                                                                \
-    const int h = min(r_begin + i + (P), H - 1);                                                                   \
-    const bool row_ok = i + (P) < n_rows;                                 /* wave-uniform */                       \
-    /* the row prefetched one step ago (input row h + 3) enters slot (P + 6) % 7 */                                \
-    if (h + 3 < H) pack_row(win[((P) + 6) % 7], nx, m);                                                            \
-    else pack_row(win[((P) + 6) % 7], nx, zero_m);                                                                 \
-    /* prefetch input row h + 4 for the next step; the add operand of this row */                                  \
-    load_row(nx, min(h + 4, H - 1));                                                                               \
-    float acc[kT];                                                                                                 \
-    _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[t] = b0;                                                    \
+    const int h0 = r_begin + i + (P);                                     /* first output row of the step */        \
+    /* the rows prefetched one step ago (input rows h0 + 3 ...) enter slots (P + 6 ...) % NS */                     \
+    _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                \
+      if (h0 + 3 + r < H) pack_row(win[((P) + 6 + r) % NS], nx[r], m);                                             \
+      else pack_row(win[((P) + 6 + r) % NS], nx[r], zero_m);                                                       \
+    }                                                                                                              \
+    /* prefetch the input rows of the next step */                                                                 \
+    _Pragma("unroll") for (int r = 0; r < R; ++r) load_row(nx[r], min(h0 + 3 + R + r, H - 1));                     \
+    float acc[R][kT];                                                                                              \
+    _Pragma("unroll") for (int r = 0; r < R; ++r)                                                                  \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[r][t] = b0;                                               \
     uint32_t wa = wl_addr;                                                                                         \
     asm volatile("" : "+v"(wa));                                                                                   \
     lds_u4_t wlane = reinterpret_cast<lds_u4_t>(static_cast<uintptr_t>(wa));                                       \
+    /* window slot q of the step holds input row h0 - 3 + q: filter row kh = q - r of output row h0 + r */         \
     _Pragma("unroll") for (int kh = 0; kh < 7; ++kh) {                                                             \
-      const uint32_t(&d)[kPairs] = win[((P) + kh) % 7];                                                            \
       const u32x4_t we4 = wlane[(kh * 2 + 0) * CH], wo4 = wlane[(kh * 2 + 1) * CH];                                \
       const uint32_t we[4] = {we4.x, we4.y, we4.z, we4.w}, wo[4] = {wo4.x, wo4.y, wo4.z, wo4.w};                   \
-      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                              \
-          acc[t] = dot2(d[t / 2 + e], (t & 1) ? wo[e] : we[e], acc[t]);                                            \
+      _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                              \
+        const uint32_t(&d)[kPairs] = win[((P) + kh + r) % NS];                                                     \
+        _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                           \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                            \
+            acc[r][t] = dot2(d[t / 2 + e], (t & 1) ? wo[e] : we[e], acc[r][t]);                                    \
+        }                                                                                                          \
       }                                                                                                            \
     }                                                                                                              \
-    float av[kT];                                                                                                  \
-    if (ADD) {                /* after the arithmetic (compiler barrier): 7 registers less across the dot products */ \
-      asm volatile("" ::: "memory");                                                                               \
-      const float* ap = aimg + h * rs;                                                                             \
-      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
-        if (RAGGED) av[t] = ap[voff + static_cast<long>(min(t, W - 1 - w0)) * C];                                  \
-        else av[t] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ap + static_cast<long>(t) * C) + vb_add); \
+    _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                \
+      const int h = min(h0 + r, H - 1);                                                                            \
+      const bool row_ok = i + (P) + r < n_rows;                           /* wave-uniform */                       \
+      float av[kT];                                                                                                \
+      if (ADD) {              /* after the arithmetic (compiler barrier): 7 registers less across the dot products */ \
+        asm volatile("" ::: "memory");                                                                             \
+        const float* ap = aimg + h * rs;                                                                           \
+        _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                           \
+          if (RAGGED) av[t] = ap[voff + static_cast<long>(min(t, W - 1 - w0)) * C];                                \
+          else av[t] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ap + static_cast<long>(t) * C) + vb_add); \
+        }                                                                                                          \
       }                                                                                                            \
-    }                                                                                                              \
-    if (unit_ok && row_ok) {                                                                                       \
-      TO* op = oimg + h * rs;                                                                                      \
-      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
-        if (!RAGGED || w0 + t < W)                                                                                 \
-          store_out(reinterpret_cast<TO*>(reinterpret_cast<char*>(op + static_cast<long>(t) * C) + vb_out), ADD ? acc[t] + av[t] : acc[t]); \
+      if (unit_ok && row_ok) {                                                                                     \
+        TO* op = oimg + h * rs;                                                                                    \
+        _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                           \
+          if (!RAGGED || w0 + t < W)                                                                               \
+            store_out(reinterpret_cast<TO*>(reinterpret_cast<char*>(op + static_cast<long>(t) * C) + vb_out),      \
+                      ADD ? acc[r][t] + av[t] : acc[r][t]);                                                        \
+        }                                                                                                          \
       }                                                                                                            \
     }                                                                                                              \
   }
 
-  // (bands are multiples of 7 rows except possibly the last of an image: its surplus steps compute on clamped rows and store nothing)
-  for (int i = 0; i < n_rows; i += 7) {
-    DWWIN_STEP(0) DWWIN_STEP(1) DWWIN_STEP(2) DWWIN_STEP(3) DWWIN_STEP(4) DWWIN_STEP(5) DWWIN_STEP(6)
+  // (bands are multiples of NS rows except possibly the last of an image: its surplus steps compute on clamped rows and store nothing)
+  for (int i = 0; i < n_rows; i += NS) {
+    if constexpr (R == 1) {
+      DWWIN_STEP(0) DWWIN_STEP(1) DWWIN_STEP(2) DWWIN_STEP(3) DWWIN_STEP(4) DWWIN_STEP(5) DWWIN_STEP(6)
+    } else {
+      DWWIN_STEP(0) DWWIN_STEP(2) DWWIN_STEP(4) DWWIN_STEP(6)
+    }
   }
 #undef DWWIN_STEP
 }
 
 template <typename TI, typename TO, int CH, bool ADD>
-int launch_win(const WinArgs& a, hipStream_t s) {
-  const long blocks = a.items_per_cg / 4 * a.n_cg;
-  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-  if (a.W % kT == 0) hipLaunchKernelGGL((dwconv7x7_win_kernel<TI, TO, CH, ADD, false>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((dwconv7x7_win_kernel<TI, TO, CH, ADD, true>), grid, block, 0, s, a);
+int launch_win(const WinArgs& a, int rows_per_step, hipStream_t s) {
+  const long blocks = a.per_wave_cg ? a.items_per_cg : a.items_per_cg / 4 * a.n_cg;
+  const dim3 grid(static_cast<unsigned>(blocks)), block(a.per_wave_cg ? 64 * a.n_cg : 256);
+  const size_t lds = static_cast<size_t>(a.per_wave_cg ? a.n_cg : 1) * 7 * 2 * CH * sizeof(uint4);
+#define WIN_K(RG, RR) hipLaunchKernelGGL((dwconv7x7_win_kernel<TI, TO, CH, ADD, RG, RR>), grid, block, lds, s, a)
+  // (R = 2 - two output rows per step, two rows of loads in flight per wavefront - measured on MI355X: needs ~180 registers, i.e.
+  //  two wavefronts per SIMD, and is 10 - 40 % SLOWER than R = 1 at three (profiles/r04_dwwin.md): only R = 1 is instantiated)
+  (void)rows_per_step;
+  if (a.W % kT == 0) WIN_K(false, 1);
+  else WIN_K(true, 1);
+#undef WIN_K
   return static_cast<int>(hipGetLastError());
+}
+
+int& win_policy() {
+  static int p = getenv("APGD_DW_WIN") ? atoi(getenv("APGD_DW_WIN")) : 1;
+  return p;
 }
 
 }  // namespace
 
+extern "C" int cnx_dwconv7x7_win_policy(int policy) {
+  int& p = win_policy();
+  const int prev = p;
+  if (policy >= 0) p = policy > 2 ? 2 : policy;
+  return prev;
+}
+
 // -> APGD_OK / an error of the launch; -1 when this shape is not for the window kernel (the caller goes on to the LDS kernels)
 int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bias, const float* add, void* out, int out_dtype,
                   int64_t N, int32_t H, int32_t W, int32_t C, int32_t flip, hipStream_t s) {
-  static const int on = getenv("APGD_DW_WIN") ? atoi(getenv("APGD_DW_WIN")) : 1;
+  // policy (cnx_dwconv7x7_win_policy / APGD_DW_WIN): 0 = never, 1 = where it measured ahead of the LDS-ring kernels (default), 2 = every
+  // shape it supports
+  const int on = win_policy();
   if (!on || C % 32 != 0 || H < 1 || W < 7) return -1;
+  if (on == 1) {
+    // Measured on MI355X, batch 256 / 128 (profiles/r04_dwwin.md; us, window kernel vs LDS-ring kernels):
+    //   28x28x192: 71 vs 113 (fwd), 98 vs 135 (dgrad + add), 75 vs 96;   7x7x768: 24 vs 35, 25 vs 45;   14x14x384: 51 vs 63 (dgrad + add),
+    //   43 vs 49 (bf16 -> bf16), but 56 vs 49 for the fp32 -> bf16 forward;   56x56x96 (32-channel groups, half-wave runs of 128 / 64
+    //   bytes): 170 vs 155 and 236 vs 190 at batch 256 - behind - and 72 vs 83 (fwd) / 112 vs 101 (dgrad + add) at batch 128.
+    const long px = static_cast<long>(H) * W;
+    const bool wide32 = (C % 64 != 0);                                     // 32-channel groups
+    if (wide32 && px >= 2000) {                                            // 56x56x96
+      const bool fwd_small = x_dtype == APGD_F32 && N <= 128;
+      const bool plain_bf16 = x_dtype == APGD_BF16 && out_dtype == APGD_BF16 && !add;
+      if (!fwd_small && !plain_bf16) return -1;
+    }
+    if (!wide32 && px >= 150 && px < 400 && x_dtype == APGD_F32) return -1;   // 14x14 forward from fp32: the whole-image tile kernel
+  }
   if (x_dtype == APGD_F32 && out_dtype == APGD_F32) return -1;             // the exact-fp32 path is not a bf16 kernel's business
   if (add && x_dtype == APGD_F32) return -1;                                // (no caller: forward calls carry no add operand)
   if (static_cast<long>(N) * H * W * C >= (1L << 31)) return -1;           // 32-bit per-lane element offsets inside an image / tensor
@@ -276,11 +338,15 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   const long per_band_items = static_cast<long>(N) * a.n_cg * a.n_sg;
   int n_bands = 1;
   while (n_bands < 8 && per_band_items * n_bands < 3L * 256 * 12 && (H + n_bands) / (n_bands + 1) >= 7) ++n_bands;
-  a.band = band_env > 0 ? band_env : ((H + n_bands - 1) / n_bands + 6) / 7 * 7;   // whole groups of 7 rows (the kernel's unrolled window rotation)
+  const int rps = 1;                                                       // output rows per step
+  const int ns = 6 + rps;
+  a.band = band_env > 0 ? band_env : ((H + n_bands - 1) / n_bands + ns - 1) / ns * ns;   // whole groups of NS rows (the kernel's unrolled window rotation)
   a.n_bands = (H + a.band - 1) / a.band;
   a.items_per_cg_real = static_cast<long>(N) * a.n_sg * a.n_bands;
-  a.items_per_cg = (a.items_per_cg_real + 3) / 4 * 4;
-#define WIN_GO(TI, TO, ADDV) return (ch == 64) ? launch_win<TI, TO, 64, ADDV>(a, s) : launch_win<TI, TO, 32, ADDV>(a, s);
+  static const int pw_env = getenv("APGD_DW_WIN_PWCG") ? atoi(getenv("APGD_DW_WIN_PWCG")) : 0;   // measured: 3 - 15 % slower (profiles/r04_dwwin.md)
+  a.per_wave_cg = (pw_env && ch == 32 && a.n_cg >= 2 && a.n_cg <= 4) ? 1 : 0;
+  a.items_per_cg = a.per_wave_cg ? a.items_per_cg_real : (a.items_per_cg_real + 3) / 4 * 4;
+#define WIN_GO(TI, TO, ADDV) return (ch == 64) ? launch_win<TI, TO, 64, ADDV>(a, rps, s) : launch_win<TI, TO, 32, ADDV>(a, rps, s);
   if (x_dtype == APGD_F32) WIN_GO(float, uint16_t, false)
   if (out_dtype == APGD_F32) { if (add) WIN_GO(uint16_t, float, true) else WIN_GO(uint16_t, float, false) }
   if (add) WIN_GO(uint16_t, uint16_t, true)
