@@ -53,8 +53,25 @@ for n, (c, t) in agg.items():
     g[0] += c
     g[1] += t
 tot = sum(t for _, t in grp.values())
+GROUPS = (("fused LN+MLP (`blk_mlp_*`)", r"blk_mlp_"), ("depthwise 7x7 (forward, input gradient, filter gradient)", r"dwconv7x7"),
+          ("hipBLASLt / rocBLAS GEMMs", r"^hipBLASLt|Cijk_"), ("`cnx_gemm_nt`", r"gemm_nt_kernel"), ("LayerNorm kernels", r"layernorm_"),
+          ("element-wise tails around the library GEMMs + partial sums", r"gelu_|scale_residual|sum_parts|reduce_parts|colsum"),
+          ("ConvStem convolutions", r"stem_conv|conv2_"), ("attention", r"attn_"),
+          ("attack kernels (K1, loss, state, tracking, init)", r"linf_step|track_rows|state_update|ce_pred|init_kernel|l2_step|dlr"),
+          ("ATen copies / casts / optimizer / other", r""))
+gt = collections.OrderedDict((g, [0, 0]) for g, _ in GROUPS)
+for n, (c, t) in grp.items():
+    for g, pat in GROUPS:
+        if re.search(pat, n):
+            gt[g][0] += c
+            gt[g][1] += t
+            break
 lines = [f"step window {(t1 - t0) / 1e6:.2f} ms, GPU busy {tot / 1e6:.2f} ms, {sum(c for c, _ in grp.values())} launches", "",
-         "| ms | % | calls | avg us | kernel |", "|---|---|---|---|---|"]
+         "| ms | % | launches | group |", "|---|---|---|---|"]
+for g, (c, t) in sorted(gt.items(), key=lambda kv: -kv[1][1]):
+    if c:
+        lines.append(f"| {t / 1e6:.2f} | {100 * t / tot:.1f} | {c} | {g} |")
+lines += ["", "| ms | % | calls | avg us | kernel |", "|---|---|---|---|---|"]
 for n, (c, t) in sorted(grp.items(), key=lambda kv: -kv[1][1])[: a.top]:
     lines.append(f"| {t / 1e6:.2f} | {100 * t / tot:.1f} | {c} | {t / c / 1e3:.1f} | `{n}` |")
 # idle time of the device around every APGD-update launch of the window (the attack's graph segments end / begin there) and the
