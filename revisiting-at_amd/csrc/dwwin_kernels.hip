@@ -141,6 +141,15 @@ void dwconv7x7_win_kernel(const WinArgs a) {
   const TI* ximg = static_cast<const TI*>(a.x) + n * H * rs;
   const long last_row = static_cast<long>(a.N) * H - 1;
 
+  // Buffer addressing (raw buffer resources over the whole tensors): address = resource base + one per-lane 32-bit byte offset
+  // (VGPR) + a wave-uniform byte offset (SGPR, scalar arithmetic) - no per-load 64-bit vector address (the flat form cost one
+  // v_lshl_add_u64 and a register pair per load / store: 27 of ~280 VALU instructions per output row).  Nothing relies on the
+  // hardware's range check: every offset handed over is inside the tensor (the rows that could leave it take the clamped path).
+  const uint32_t tensor_elems = static_cast<uint32_t>(static_cast<long>(a.N) * H * rs);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, tensor_elems * static_cast<uint32_t>(sizeof(TI)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, tensor_elems * static_cast<uint32_t>(sizeof(TO)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.add), 0, ADD ? tensor_elems * 4u : 0u, 0x00020000);
+  const uint32_t img_elem = static_cast<uint32_t>(n * H * rs);             // first element of this image
   auto load_row = [&](RawRow<TI>& r, int hrow) {                          // hrow: a row of this image, 0 <= hrow < H
     const long grow = n * H + hrow;
     const TI* prow = ximg + hrow * rs;
@@ -152,9 +161,13 @@ void dwconv7x7_win_kernel(const WinArgs a) {
         r.v[j] = prow[idx < 0 ? 0 : (idx >= rs ? rs - 1 : idx)];
       }
     } else {
+      const uint32_t base = static_cast<uint32_t>(static_cast<long>(img_elem) + hrow * rs + goff);   // >= 0: not the tensor's first row
 #pragma unroll
-      for (int j = 0; j < kCols; ++j)
-        r.v[j] = *reinterpret_cast<const TI*>(reinterpret_cast<const char*>(prow + goff + static_cast<long>(j) * C) + vb_in);
+      for (int j = 0; j < kCols; ++j) {
+        const uint32_t so = (base + static_cast<uint32_t>(j) * static_cast<uint32_t>(C)) * static_cast<uint32_t>(sizeof(TI));
+        if constexpr (sizeof(TI) == 4) r.v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, vb_in, so, 0));
+        else r.v[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_x, vb_in, so, 0);
+      }
     }
   };
 
@@ -208,6 +221,7 @@ void dwconv7x7_win_kernel(const WinArgs a) {
   const long gout = static_cast<long>(sg * UPW * kT) * C + cg * CH;       // first output column of the group's first strip
   TO* oimg = static_cast<TO*>(a.out) + n * H * rs + gout;
   const float* aimg = ADD ? a.add + n * H * rs + gout : nullptr;
+  const uint32_t out_base = img_elem + static_cast<uint32_t>(gout);       // element index of the group's first output column, row 0
 
   // ---- one step = R output rows.  P = i % NS (compile time): window slots are register arrays, their indices must be static.
 #define DWWIN_STEP(P)                                                                                              \
@@ -247,15 +261,22 @@ void dwconv7x7_win_kernel(const WinArgs a) {
         const float* ap = aimg + h * rs;                                                                           \
         _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                           \
           if (RAGGED) av[t] = ap[voff + static_cast<long>(min(t, W - 1 - w0)) * C];                                \
-          else av[t] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ap + static_cast<long>(t) * C) + vb_add); \
+          else av[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, vb_add,                                  \
+                           (out_base + static_cast<uint32_t>(h * rs) + static_cast<uint32_t>(t) * static_cast<uint32_t>(C)) * 4u, 0)); \
         }                                                                                                          \
       }                                                                                                            \
       if (unit_ok && row_ok) {                                                                                     \
         TO* op = oimg + h * rs;                                                                                    \
         _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                           \
-          if (!RAGGED || w0 + t < W)                                                                               \
-            store_out(reinterpret_cast<TO*>(reinterpret_cast<char*>(op + static_cast<long>(t) * C) + vb_out),      \
-                      ADD ? acc[r][t] + av[t] : acc[r][t]);                                                        \
+          const float ov = ADD ? acc[r][t] + av[t] : acc[r][t];                                                    \
+          if (RAGGED) {                                                                                            \
+            if (w0 + t < W) store_out(reinterpret_cast<TO*>(reinterpret_cast<char*>(op + static_cast<long>(t) * C) + vb_out), ov); \
+          } else {                                                                                                 \
+            const uint32_t so = (out_base + static_cast<uint32_t>(h * rs) + static_cast<uint32_t>(t) * static_cast<uint32_t>(C)) * \
+                                static_cast<uint32_t>(sizeof(TO));                                                 \
+            if constexpr (sizeof(TO) == 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ov), rs_o, vb_out, so, 0);  \
+            else __builtin_amdgcn_raw_buffer_store_b16(static_cast<uint16_t>(pack2_bf16(ov, 0.f)), rs_o, vb_out, so, 0);     \
+          }                                                                                                        \
         }                                                                                                          \
       }                                                                                                            \
     }                                                                                                              \
@@ -309,22 +330,17 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   const int on = win_policy();
   if (!on || C % 32 != 0 || H < 1 || W < 7) return -1;
   if (on == 1) {
-    // Measured on MI355X, batch 256 / 128 (profiles/r04_dwwin.md; us, window kernel vs LDS-ring kernels):
-    //   28x28x192: 71 vs 113 (fwd), 98 vs 135 (dgrad + add), 75 vs 96;   7x7x768: 24 vs 35, 25 vs 45;   14x14x384: 51 vs 63 (dgrad + add),
-    //   43 vs 49 (bf16 -> bf16), but 56 vs 49 for the fp32 -> bf16 forward;   56x56x96 (32-channel groups, half-wave runs of 128 / 64
-    //   bytes): 170 vs 155 and 236 vs 190 at batch 256 - behind - and 72 vs 83 (fwd) / 112 vs 101 (dgrad + add) at batch 128.
+    // Measured on MI355X (profiles/r04_dwwin.md; us, window kernel vs LDS-ring kernels): ahead at every 64-channel-group shape -
+    // 28x28x192: 72 vs 113 (fwd), 96 vs 136 (dgrad + add);  14x14x384: 44 vs 49, 48 vs 63;  7x7x768: 24 vs 35, 26 vs 45 - and at
+    // 56x56x96 (32-channel groups: half-wave runs of 128 / 64 bytes, masks in VGPRs) for the batch-128 chunks of the two-stream
+    // attack (72 vs 83, 95 vs 101) and the plain bf16 calls (154 vs 159); at batch 256 its fp32 -> bf16 forward (166 - 172 vs 156)
+    // and input gradient + add (189 vs 187) stay with the LDS-ring kernel.
     const long px = static_cast<long>(H) * W;
-    const bool wide32 = (C % 64 != 0);                                     // 32-channel groups
-    if (wide32 && px >= 2000) {                                            // 56x56x96
-      const bool fwd_small = x_dtype == APGD_F32 && N <= 128;
-      const bool plain_bf16 = x_dtype == APGD_BF16 && out_dtype == APGD_BF16 && !add;
-      if (!fwd_small && !plain_bf16) return -1;
-    }
-    if (!wide32 && px >= 150 && px < 400 && x_dtype == APGD_F32 && N > 128) return -1;   // 14x14 forward from fp32 at full batch: the whole-image tile kernel (26 vs 34 us at batch 128)
+    if ((C % 64 != 0) && px >= 2000 && N > 128 && !(x_dtype == APGD_BF16 && out_dtype == APGD_BF16 && !add)) return -1;
   }
   if (x_dtype == APGD_F32 && out_dtype == APGD_F32) return -1;             // the exact-fp32 path is not a bf16 kernel's business
   if (add && x_dtype == APGD_F32) return -1;                                // (no caller: forward calls carry no add operand)
-  if (static_cast<long>(N) * H * W * C >= (1L << 31)) return -1;           // 32-bit per-lane element offsets inside an image / tensor
+  if (static_cast<long>(N) * H * W * C >= (1L << 30)) return -1;           // 32-bit BYTE offsets into the fp32 tensors (buffer addressing)
   WinArgs a;
   a.x = x; a.w49c = w49c; a.bias = bias; a.add = add; a.out = out;
   a.N = static_cast<int>(N); a.H = H; a.W = W; a.C = C; a.flip = flip;
