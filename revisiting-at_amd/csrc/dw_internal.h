@@ -7,3 +7,7 @@
 // -> APGD_OK (0) / a HIP launch error; -1 when the shape / dtype combination is not for the window kernel
 int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bias, const float* add, void* out, int out_dtype,
                   int64_t N, int32_t H, int32_t W, int32_t C, int32_t flip, hipStream_t s);
+
+// Filter / bias gradient partials ws[parts][50][C] by the register-window kernel: -> parts (> 0), 0 = shape not supported, < 0 = -(1 + HIP error)
+int dw_win_wgrad_launch(const void* x, int x_dtype, const void* dy, float* ws, int max_parts, int64_t N, int32_t H, int32_t W, int32_t C,
+                        hipStream_t s);

@@ -77,10 +77,10 @@ struct WinArgs {
 
 // One wavefront = one item: (image, band, channel group, strip group), strip group fastest.
 // RAGGED: W is not a multiple of 7 (the last strip's stores are predicated per column, its group may hold an idle unit).
-// Three wavefronts per SIMD (<= 168 registers) except for the add variants with per-unit masks in VGPRs (CH = 32) or ragged strips,
-// which need ~180 and take two.
+// Three wavefronts per SIMD (137 - 154 registers) except for the add variants with ragged strips or 32-channel groups (~180 registers, two:
+// capped at 168 the CH = 32 add variant measured 203 - 209 us against 189 at 56 x 56 x 96).
 template <typename TI, typename TO, int CH, bool ADD, bool RAGGED, int R>
-__global__ __launch_bounds__(256, ((ADD && (RAGGED || CH == 32)) || (R == 2 && (CH == 32 || ADD || sizeof(TI) == 4))) ? 2 : 3)
+__global__ __launch_bounds__(256, ((ADD && (RAGGED || CH == 32)) || R == 2) ? 2 : 3)
 void dwconv7x7_win_kernel(const WinArgs a) {
   constexpr int UPW = 64 / CH;
   const int lane = threadIdx.x & 63;
@@ -154,17 +154,23 @@ void dwconv7x7_win_kernel(const WinArgs a) {
     const long grow = n * H + hrow;
     const TI* prow = ximg + hrow * rs;
     if (grow == 0 || grow == last_row) {                                  // (wave-uniform, rare) element index clamped into the row:
-      asm volatile("; first / last row of the tensor" ::: "memory");      // (a side effect: keeps this a branch - if-converted, the
-#pragma unroll                                                            //  common path's addresses become per-lane 64-bit selects)
+      asm volatile("; first / last row of the tensor" ::: "memory");      // nothing outside the tensor is read.  (The asm keeps this a
+      const int row0 = static_cast<int>(img_elem) + hrow * static_cast<int>(rs);   // branch; 32-bit per-lane offsets, no 64-bit pointers:
+      const int rel0 = static_cast<int>(goff) + static_cast<int>(voff);            // the rare path must not set the kernel's register count)
+#pragma unroll
       for (int j = 0; j < kCols; ++j) {
-        const long idx = goff + static_cast<long>(voff) + static_cast<long>(j) * C;
-        r.v[j] = prow[idx < 0 ? 0 : (idx >= rs ? rs - 1 : idx)];
+        const int rel = min(max(rel0 + j * C, 0), static_cast<int>(rs) - 1);
+        const uint32_t vo = static_cast<uint32_t>(row0 + rel) * static_cast<uint32_t>(sizeof(TI));
+        if constexpr (sizeof(TI) == 4) r.v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, vo, 0, 0));
+        else r.v[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_x, vo, 0, 0);
       }
     } else {
       const uint32_t base = static_cast<uint32_t>(static_cast<long>(img_elem) + hrow * rs + goff);   // >= 0: not the tensor's first row
+      uint32_t Cs = static_cast<uint32_t>(C);                             // (opaque per call: the column offsets are recomputed by the scalar unit
+      asm volatile("" : "+s"(Cs));                                         //  instead of living in 13 SGPRs across the unrolled steps)
 #pragma unroll
       for (int j = 0; j < kCols; ++j) {
-        const uint32_t so = (base + static_cast<uint32_t>(j) * static_cast<uint32_t>(C)) * static_cast<uint32_t>(sizeof(TI));
+        const uint32_t so = (base + static_cast<uint32_t>(j) * Cs) * static_cast<uint32_t>(sizeof(TI));
         if constexpr (sizeof(TI) == 4) r.v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, vb_in, so, 0));
         else r.v[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_x, vb_in, so, 0);
       }
@@ -308,6 +314,188 @@ int launch_win(const WinArgs& a, int rows_per_step, hipStream_t s) {
   return static_cast<int>(hipGetLastError());
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Filter / bias gradient in the same form:  dw[kh][kw][c] = sum_{n,h,w} dy[n,h,w,c] x[n,h+kh-3,w+kw-3,c],  db[c] = sum dy.
+// lane = (strip of 7 columns, channel) keeps its 49 + 1 partial sums in registers next to the 7-row x window and walks down whole
+// images (one item = (image, strip group); a wavefront takes every (4 x parts)-th item of its channel group).  Per dy row: the 7
+// values of the strip are packed twice - D_q = (dy[2q], dy[2q+1]) and D'_q = (dy[2q-1], dy[2q]) - so that EVERY tap is four aligned
+// dot products on the window's pairs P_i = (X[2i], X[2i+1]) (X[j] = window column j = image column w0 - 3 + j):
+//     kw = 2e   : sum_t dy[t] X[t + kw] = sum_q D_q . P_{q+e}          kw = 2e + 1 : = sum_q D'_q . P_{q+e}        (q = 0..3)
+// (the LDS-ring kernels rebuild three misaligned x pairs with v_alignbit per pair step instead).  196 dot products per row, as the
+// forward.  At the end the two units of a CH = 32 wavefront are added (lane ^ 32), the workgroup's four wavefronts through LDS,
+// and one partial per workgroup goes to ws[part][50][C]; reduce_parts_kernel (model_kernels.hip) sums the parts in a fixed order.
+struct WinWgArgs {
+  const void* x; const uint16_t* dy; float* ws;
+  int N, H, W, C;
+  int n_strips, n_sg, n_cg, parts;           // strips per row, strip groups, channel groups, workgroups (= partial sums) per channel group
+  long items_per_cg;                         // N * n_sg
+};
+
+template <typename TX, int CH>
+__global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_win_kernel(const WinWgArgs a) {
+  constexpr int UPW = 64 / CH;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  long blk;
+  {
+    const long L = blockIdx.x, B = gridDim.x;
+    const long q = B / 8, r = B % 8, xcd = L % 8, k = L / 8;
+    blk = xcd * q + (xcd < r ? xcd : r) + k;
+  }
+  const int cg = static_cast<int>(blk / a.parts), part = static_cast<int>(blk % a.parts);
+  const int H = a.H, W = a.W, C = a.C;
+  const long rs = static_cast<long>(W) * C;
+  const int ul = lane / CH;
+  const uint32_t tensor_elems = static_cast<uint32_t>(static_cast<long>(a.N) * H * rs);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, tensor_elems * static_cast<uint32_t>(sizeof(TX)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dy), 0, tensor_elems * 2u, 0x00020000);
+  const long last_row = static_cast<long>(a.N) * H - 1;
+  const uint32_t zero_m[kPairs] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+
+  float acc[7][7], accb = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) acc[kh][kw] = 0.f;
+
+  for (long it = static_cast<long>(part) * 4 + wave; it < a.items_per_cg; it += static_cast<long>(a.parts) * 4) {
+    const int sg = static_cast<int>(it % a.n_sg);
+    const long n = it / a.n_sg;
+    const bool unit_ok = sg * UPW + ul < a.n_strips;
+    const int ulc = unit_ok ? ul : a.n_strips - 1 - sg * UPW;
+    const int w0 = (sg * UPW + ulc) * kT;
+    // pair masks (what lies outside the image is zero in the window): wave-uniform per unit, so they live in SGPRs and a CH = 32
+    // wavefront selects its unit's with one v_cndmask per use - seven VGPRs less than the forward kernel's per-lane array
+    uint32_t mu[UPW][kPairs];
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      const int su = min(sg * UPW + u, a.n_strips - 1) * kT;
+#pragma unroll
+      for (int i = 0; i < kPairs; ++i) {
+        const int wl = su - 3 + 2 * i, wh = wl + 1;
+        mu[u][i] = ((wl >= 0 && wl < W) ? 0x0000ffffu : 0u) | ((2 * i + 1 < kCols && wh >= 0 && wh < W) ? 0xffff0000u : 0u);
+      }
+    }
+    uint32_t m[kPairs];
+#pragma unroll
+    for (int i = 0; i < kPairs; ++i) m[i] = (UPW == 2 && ul) ? mu[UPW - 1][i] : mu[0][i];
+    const uint32_t dmask = unit_ok ? 0xffffffffu : 0u;                   // an idle unit contributes nothing
+    const uint32_t voff = static_cast<uint32_t>(ulc * kT * C + (lane % CH));
+    const uint32_t vb_x = voff * static_cast<uint32_t>(sizeof(TX)), vb_d = voff * 2u;
+    const long goff = static_cast<long>(sg * UPW * kT - 3) * C + cg * CH;
+    const uint32_t img_elem = static_cast<uint32_t>(n * H * rs);
+    const uint32_t dy_base = img_elem + static_cast<uint32_t>(static_cast<long>(sg * UPW * kT) * C + cg * CH);
+
+    auto load_row = [&](RawRow<TX>& r, int hrow) {
+      const long grow = n * H + hrow;
+      if (grow == 0 || grow == last_row) {
+        asm volatile("; first / last row of the tensor" ::: "memory");
+        const int row0 = static_cast<int>(img_elem) + hrow * static_cast<int>(rs);
+        const int rel0 = static_cast<int>(goff) + static_cast<int>(voff);
+#pragma unroll
+        for (int j = 0; j < kCols; ++j) {
+          const int rel = min(max(rel0 + j * C, 0), static_cast<int>(rs) - 1);
+          const uint32_t vo = static_cast<uint32_t>(row0 + rel) * static_cast<uint32_t>(sizeof(TX));
+          if constexpr (sizeof(TX) == 4) r.v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, vo, 0, 0));
+          else r.v[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_x, vo, 0, 0);
+        }
+      } else {
+        const uint32_t base = static_cast<uint32_t>(static_cast<long>(img_elem) + hrow * rs + goff);
+        uint32_t Cs = static_cast<uint32_t>(C);                           // (opaque per call: the 13 column offsets are recomputed by the scalar
+        asm volatile("" : "+s"(Cs));                                       //  unit instead of being kept in 13 SGPRs across the unrolled steps)
+#pragma unroll
+        for (int j = 0; j < kCols; ++j) {
+          const uint32_t so = (base + static_cast<uint32_t>(j) * Cs) * static_cast<uint32_t>(sizeof(TX));
+          if constexpr (sizeof(TX) == 4) r.v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, vb_x, so, 0));
+          else r.v[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_x, vb_x, so, 0);
+        }
+      }
+    };
+    auto load_dy = [&](uint16_t (&d)[kT], int hrow) {
+      const uint32_t base = dy_base + static_cast<uint32_t>(hrow * rs);
+      uint32_t Cs = static_cast<uint32_t>(C);
+      asm volatile("" : "+s"(Cs));
+#pragma unroll
+      for (int t = 0; t < kT; ++t)
+        d[t] = __builtin_amdgcn_raw_buffer_load_b16(rs_d, vb_d, (base + static_cast<uint32_t>(t) * Cs) * 2u, 0);
+    };
+
+    uint32_t win[7][kPairs];
+#pragma unroll
+    for (int j0 = 0; j0 < 6; j0 += 3) {
+      RawRow<TX> raw[3];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) load_row(raw[jj], min(max(j0 + jj - 3, 0), H - 1));
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const int hr = j0 + jj - 3;
+        if (hr >= 0 && hr < H) pack_row(win[j0 + jj], raw[jj], m);
+        else pack_row(win[j0 + jj], raw[jj], zero_m);
+      }
+    }
+    RawRow<TX> nx;
+    load_row(nx, min(3, H - 1));
+    uint16_t dn[kT];
+    load_dy(dn, 0);
+
+#define DWWG_STEP(P)                                                                                               \
+    {                                                                                                              \
+      const int h = min(i + (P), H - 1);                                                                           \
+      const bool row_ok = i + (P) < H;                                                                             \
+      if (h + 3 < H) pack_row(win[((P) + 6) % 7], nx, m);                                                          \
+      else pack_row(win[((P) + 6) % 7], nx, zero_m);                                                               \
+      const uint32_t rm = row_ok ? dmask : 0u;                                                                     \
+      uint32_t D[4], E[4];                                                                                         \
+      D[0] = (static_cast<uint32_t>(dn[0]) | (static_cast<uint32_t>(dn[1]) << 16)) & rm;                           \
+      D[1] = (static_cast<uint32_t>(dn[2]) | (static_cast<uint32_t>(dn[3]) << 16)) & rm;                           \
+      D[2] = (static_cast<uint32_t>(dn[4]) | (static_cast<uint32_t>(dn[5]) << 16)) & rm;                           \
+      D[3] = static_cast<uint32_t>(dn[6]) & rm;                                                                    \
+      E[0] = (static_cast<uint32_t>(dn[0]) << 16) & rm;                                                            \
+      E[1] = (static_cast<uint32_t>(dn[1]) | (static_cast<uint32_t>(dn[2]) << 16)) & rm;                           \
+      E[2] = (static_cast<uint32_t>(dn[3]) | (static_cast<uint32_t>(dn[4]) << 16)) & rm;                           \
+      E[3] = (static_cast<uint32_t>(dn[5]) | (static_cast<uint32_t>(dn[6]) << 16)) & rm;                           \
+      load_row(nx, min(h + 4, H - 1));                                                                             \
+      load_dy(dn, min(h + 1, H - 1));                                                                              \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) accb = dot2(D[q], 0x3f803f80u, accb);                          \
+      _Pragma("unroll") for (int kh = 0; kh < 7; ++kh) {                                                           \
+        const uint32_t(&d)[kPairs] = win[((P) + kh) % 7];                                                          \
+        _Pragma("unroll") for (int kw = 0; kw < 7; ++kw) {                                                         \
+          _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                            \
+            acc[kh][kw] = dot2((kw & 1) ? E[q] : D[q], d[q + kw / 2], acc[kh][kw]);                                \
+        }                                                                                                          \
+      }                                                                                                            \
+    }
+    for (int i = 0; i < H; i += 7) {
+      DWWG_STEP(0) DWWG_STEP(1) DWWG_STEP(2) DWWG_STEP(3) DWWG_STEP(4) DWWG_STEP(5) DWWG_STEP(6)
+    }
+#undef DWWG_STEP
+  }
+
+  // ---- the workgroup's partial: units of a wavefront (CH = 32), then the four wavefronts through LDS
+  __shared__ float red[4][50][CH];
+  if constexpr (UPW == 2) {
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) acc[kh][kw] += __shfl_xor(acc[kh][kw], 32, 64);
+    accb += __shfl_xor(accb, 32, 64);
+  }
+  if (lane < CH) {
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) red[wave][kh * 7 + kw][lane] = acc[kh][kw];
+    red[wave][49][lane] = accb;
+  }
+  __syncthreads();
+  float* pw = a.ws + static_cast<long>(part) * 50 * C + cg * CH;
+  for (int q = threadIdx.x; q < 50 * CH; q += 256) {
+    const int tap = q / CH, cc = q % CH;
+    pw[static_cast<long>(tap) * C + cc] = (red[0][tap][cc] + red[1][tap][cc]) + (red[2][tap][cc] + red[3][tap][cc]);
+  }
+}
+
 int& win_policy() {
   static int p = getenv("APGD_DW_WIN") ? atoi(getenv("APGD_DW_WIN")) : 1;
   return p;
@@ -368,4 +556,36 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   if (add) WIN_GO(uint16_t, uint16_t, true)
   WIN_GO(uint16_t, uint16_t, false)
 #undef WIN_GO
+}
+
+// Filter / bias gradient partials into ws[parts][50][C] (bf16 dy; x fp32 or bf16, rounded to bf16 as the convolution did).
+// -> number of parts written (the caller runs reduce_parts_kernel over them), a negative value = -(1 + HIP error), or 0 when this
+// shape is not for the window kernel.
+int dw_win_wgrad_launch(const void* x, int x_dtype, const void* dy, float* ws, int max_parts, int64_t N, int32_t H, int32_t W, int32_t C,
+                        hipStream_t s) {
+  if (win_policy() == 0 || C % 32 != 0 || W % kT != 0 || H < 1) return 0;
+  if (static_cast<long>(N) * H * W * C >= (1L << 30)) return 0;
+  WinWgArgs a;
+  a.x = x; a.dy = static_cast<const uint16_t*>(dy); a.ws = ws;
+  a.N = static_cast<int>(N); a.H = H; a.W = W; a.C = C;
+  const int ch = (C % 64 == 0) ? 64 : 32;
+  a.n_strips = W / kT;
+  a.n_sg = (a.n_strips + (64 / ch) - 1) / (64 / ch);
+  a.n_cg = C / ch;
+  a.items_per_cg = static_cast<long>(N) * a.n_sg;
+  // three wavefronts per SIMD = 768 workgroups of four on the chip; one partial sum per workgroup
+  long parts = (768 + a.n_cg - 1) / a.n_cg;
+  if (parts > max_parts) parts = max_parts;
+  if (parts * 4 > a.items_per_cg) parts = (a.items_per_cg + 3) / 4;
+  a.parts = static_cast<int>(parts < 1 ? 1 : parts);
+  const dim3 grid(static_cast<unsigned>(a.parts) * a.n_cg), block(256);
+  if (x_dtype == APGD_F32) {
+    if (ch == 64) hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<float, 64>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<float, 32>), grid, block, 0, s, a);
+  } else {
+    if (ch == 64) hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<uint16_t, 64>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<uint16_t, 32>), grid, block, 0, s, a);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? a.parts : -(1 + static_cast<int>(e));
 }

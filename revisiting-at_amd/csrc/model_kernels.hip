@@ -2065,6 +2065,16 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
   if (dy_dtype == APGD_BF16 && C % kDC == 0 && W <= 128) {
     // autocast path: bf16 output gradient; an fp32 x is rounded to bf16 (as the convolution itself did); packed dot products
     const int D2 = (W + 1) / 2, P2 = D2 + 3;
+    {
+      // register-window form (dwwin_kernels.hip, round 4): maps whose width is a multiple of 7
+      const int parts = dw_win_wgrad_launch(x, x_dtype, dy, ws, kWgradBlocks, N, H, W, C, s);
+      if (parts < 0) return -(parts + 1);
+      if (parts > 0) {
+        const int len = 50 * C;
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 15) / 16), dim3(256), 0, s, ws, dw49c, dbias, 49 * C, len, parts);
+        return launch_status();
+      }
+    }
     static const int wroll = getenv("APGD_DW_WROLL") ? atoi(getenv("APGD_DW_WROLL")) : 1;        // 0: tile kernel
     if (wroll && P2 * (kDC / 4) <= 256) {
       static const int rs_env = getenv("APGD_DW_WRS") ? atoi(getenv("APGD_DW_WRS")) : 0;         // tuning experiments only
