@@ -169,6 +169,28 @@ def test_flat_gradient_path_on_one_rank_equals_the_plain_backward(kind):
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
 
 
+def test_flat_gradient_views_keep_the_parameters_layout():
+    """The flat buffers hand every parameter a ``.grad`` view with the parameter's OWN strides (channels_last convolution weights
+    included): the fused AdamW refuses params / grads of different layouts, which is how the first GPU run of the flat path failed."""
+    from revisiting_at_amd.train_step import FlatGradSync
+    m = _CutNet().to(memory_format=torch.channels_last)
+    assert any(not p.is_contiguous() for p in m.parameters())
+    fs = FlatGradSync(m, "cpu")
+    n = 0
+    for group, views, buf in zip((fs.late, fs.early), fs.views, fs.flat):
+        for p, v in zip(group, views):
+            assert p.grad is v and v.shape == p.shape and v.stride() == p.stride()
+            assert buf.data_ptr() <= v.data_ptr() < buf.data_ptr() + 4 * buf.numel()
+            n += p.numel()
+    assert n == sum(b.numel() for b in fs.flat) == sum(p.numel() for p in m.parameters())
+    # the views tile the buffers without overlap: writing one parameter's gradient leaves the others alone
+    for v in fs.views[0] + fs.views[1]:
+        v.zero_()
+    fs.views[0][0].fill_(1.0)
+    assert float(sum(b.sum() for b in fs.flat)) == fs.views[0][0].numel()
+    assert fs.bytes_per_step == 4 * n and len(fs.late) == len(list(m.b.parameters()))
+
+
 def test_optimizer_groups_follow_reference_rules():
     m = R.get_new_model('convnext_tiny', pretrained=False, not_original=True)
     opt = R.create_optimizer(m, 'convnext_tiny', 0.05)
