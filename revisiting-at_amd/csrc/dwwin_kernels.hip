@@ -496,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_win_kernel(const WinWg
   }
 }
 
+
 int& win_policy() {
   static int p = getenv("APGD_DW_WIN") ? atoi(getenv("APGD_DW_WIN")) : 1;
   return p;
@@ -573,7 +574,10 @@ int dw_win_wgrad_launch(const void* x, int x_dtype, const void* dy, float* ws, i
   a.n_sg = (a.n_strips + (64 / ch) - 1) / (64 / ch);
   a.n_cg = C / ch;
   a.items_per_cg = static_cast<long>(N) * a.n_sg;
-  // three wavefronts per SIMD = 768 workgroups of four on the chip; one partial sum per workgroup
+  // three wavefronts per SIMD would be 768 workgroups of four on the chip (the kernel takes two); one partial sum per workgroup.
+  // (Measured and dropped: the 7 filter rows split over three launches - 21 / 14 / 14 sums and 3- / 2-row windows per lane, 83 - 128
+  //  registers, four to five wavefronts per SIMD - re-reads dy and repeats the per-row overheads three times: 281 / 125 / 74 / 52 us
+  //  against 159 / 74 / 47 / 32, profiles/r04_dwwin.md.)
   long parts = (768 + a.n_cg - 1) / a.n_cg;
   if (parts > max_parts) parts = max_parts;
   if (parts * 4 > a.items_per_cg) parts = (a.items_per_cg + 3) / 4;
