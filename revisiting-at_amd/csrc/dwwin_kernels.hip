@@ -519,13 +519,15 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   const int on = win_policy();
   if (!on || C % 32 != 0 || H < 1 || W < 7) return -1;
   if (on == 1) {
-    // Measured on MI355X (profiles/r04_dwwin.md; us, window kernel vs LDS-ring kernels): ahead at every 64-channel-group shape -
-    // 28x28x192: 72 vs 113 (fwd), 96 vs 136 (dgrad + add);  14x14x384: 44 vs 49, 48 vs 63;  7x7x768: 24 vs 35, 26 vs 45 - and at
-    // 56x56x96 (32-channel groups: half-wave runs of 128 / 64 bytes, masks in VGPRs) for the batch-128 chunks of the two-stream
-    // attack (72 vs 83, 95 vs 101) and the plain bf16 calls (154 vs 159); at batch 256 its fp32 -> bf16 forward (166 - 172 vs 156)
-    // and input gradient + add (189 vs 187) stay with the LDS-ring kernel.
+    // Measured on MI355X (profiles/r04_dwwin.md; us, window kernel vs LDS-ring kernels): ahead at every map up to 40 x 40 -
+    // 28x28x192: 72 vs 113 (fwd), 96 vs 136 (dgrad + add);  14x14x384: 44 vs 49, 48 vs 63;  7x7x768: 24 vs 35, 26 vs 45;  ConvNeXt-B / -L
+    // shapes alike (28x28x256 108 vs 148, 40x40x384 168 vs 245, 10x10x1536 52 vs 71) - and at 56 x 56 for the batch-128 chunks of the
+    // two-stream attack (72 vs 83, 95 vs 101).  NOT ahead: 56 x 56 at batch 256 (x96: 166 vs 156, 189 vs 187; x128: 218 vs 208) and
+    // the ragged-width input gradient + add above 10 x 10 (its ~180 registers leave two wavefronts per SIMD: 80x80x192 514 vs 465,
+    // 20x20x768 170 vs 119).
     const long px = static_cast<long>(H) * W;
-    if ((C % 64 != 0) && px >= 2000 && N > 128 && !(x_dtype == APGD_BF16 && out_dtype == APGD_BF16 && !add)) return -1;
+    if (px >= 2000 && px < 4000 && N > 128) return -1;
+    if (add && W % kT != 0 && px >= 150) return -1;
   }
   if (x_dtype == APGD_F32 && out_dtype == APGD_F32) return -1;             // the exact-fp32 path is not a bf16 kernel's business
   if (add && x_dtype == APGD_F32) return -1;                                // (no caller: forward calls carry no add operand)
