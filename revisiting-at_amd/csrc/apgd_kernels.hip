@@ -808,16 +808,9 @@ int apgd_linf_step_f32_ex(const float* x, const float* x_adv, const float* x_adv
 int apgd_linf_step_f32(const float* x, const float* x_adv, const float* x_adv_old, const void* grad, int grad_dtype,
                        const float* step_size, float* out, uint16_t* out_bf16, int64_t B, int64_t E, float eps,
                        float a, void* stream) {
-  // launch shape of the general form: tuning experiments only (APGD_K1_SHAPE="bps,unroll,nontemporal"); default 0,0,0
-  static int shape[3] = {0, 0, 0};
-  static bool parsed = false;
-  if (!parsed) {
-    if (const char* e = getenv("APGD_K1_SHAPE")) sscanf(e, "%d,%d,%d", &shape[0], &shape[1], &shape[2]);
-    parsed = true;
-  }
-  const bool first = x_adv_old == x_adv && a == 1.0f;
+  // (launch-shape experiments go through apgd_linf_step_f32_ex: tools/k1_sweep.py; the defaults 0, 0, 0 are the measured best)
   return apgd_linf_step_f32_ex(x, x_adv, x_adv_old, grad, grad_dtype, step_size, out, out_bf16, B, E, eps, a,
-                               first ? 0 : shape[0], first ? 0 : shape[1], first ? 0 : shape[2], stream);
+                               0, 0, 0, stream);
 }
 
 int apgd_l2_parts(void) { return kL2Parts; }

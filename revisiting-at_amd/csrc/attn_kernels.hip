@@ -464,7 +464,7 @@ int launch_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, i
 template <int NKB, bool ROWS_LDS>
 int launch_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, uint16_t* dqkv, float* dvec,
                     int64_t B, int32_t N, int32_t H, float scale, hipStream_t s) {
-  static const bool vg_on = !(getenv("APGD_ATTN_VG") && atoi(getenv("APGD_ATTN_VG")) == 0);
+  constexpr bool vg_on = true;
   constexpr bool VG = NKB <= 7;
   const bool vg = VG && vg_on;
   const size_t lds_q = static_cast<size_t>(NKB) * ((vg ? 1 : 2) * kKS + 2 * kDB) * 1024;
@@ -528,7 +528,7 @@ int cnx_attention_bwd(const void* qkv, const void* out, const void* dout, const 
   auto* g = static_cast<uint16_t*>(dqkv);
   // N <= 224: row operands from memory too (56 KB of LDS and 246 registers: two workgroups per CU; with the row images in LDS -
   // 112 KB, 303 registers - it is one); APGD_ATTN_DKV_ROWS=1 selects the LDS-row form
-  static const bool rows_lds = getenv("APGD_ATTN_DKV_ROWS") && atoi(getenv("APGD_ATTN_DKV_ROWS")) == 1;
+  constexpr bool rows_lds = false;
   if (N <= 224) return rows_lds ? launch_attn_bwd<7, true>(q, o, d, lse, g, dvec, B, N, H, scale, s)
                                 : launch_attn_bwd<7, false>(q, o, d, lse, g, dvec, B, N, H, scale, s);
   return launch_attn_bwd<13, false>(q, o, d, lse, g, dvec, B, N, H, scale, s);

@@ -72,7 +72,6 @@ struct WinArgs {
   int N, H, W, C, flip;
   int n_strips, n_sg, n_cg, band, n_bands;   // strips per image row, strip groups (of 64 / CH strips), channel groups, rows per band, bands
   long items_per_cg, items_per_cg_real;      // wavefront work items of one channel group: N * n_bands * n_sg, padded to a multiple of 4
-  int per_wave_cg;                           // 1: a workgroup = the n_cg channel groups of ONE (image, band, strip group), one wavefront each
 };
 
 // One wavefront = one item: (image, band, channel group, strip group), strip group fastest.
@@ -94,18 +93,13 @@ void dwconv7x7_win_kernel(const WinArgs a) {
   }
   // (everything derived from the item is wave-uniform: say so, and the addresses below become SGPR base + one VGPR offset)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // Two workgroup shapes:
-  //  * per_wave_cg (narrow tensors, n_cg <= 4: C = 96): the workgroup's wavefronts are the CHANNEL GROUPS of one (image, band, strip
-  //    group).  A 32-channel group is 128 bytes (fp32) / 64 bytes (bf16) of every position: read on its own, at another time than its
-  //    neighbours, it uses half / a quarter of every DRAM burst the position's 384 / 192 bytes sit in (PMC, profiles/r04_dwwin.md:
-  //    2.7 TB/s with the groups apart).  Together the wavefronts walk whole contiguous rows.  Each fills its own filter slot.
-  //  * shared (everything else): four wavefronts = four items of ONE channel group, whose packed filter they share; item order
-  //    strip group fastest, then band, image, channel group slowest (the launcher pads a group's items to a multiple of four).
-  // In both an XCD's contiguous eighth of the workgroup list keeps the strips / bands of an image in one L2.
-  int cg;
-  long it;
-  if (a.per_wave_cg) { cg = wave; it = blk; }
-  else { const long item = blk * 4 + wave; cg = static_cast<int>(item / a.items_per_cg); it = item % a.items_per_cg; }
+  // four wavefronts = four items of ONE channel group, whose packed filter they share; item order strip group fastest, then band,
+  // image, channel group slowest (the launcher pads a group's items to a multiple of four).  An XCD's contiguous eighth of the
+  // workgroup list keeps the strips / bands of an image in one L2.  (Measured and dropped: a workgroup = the three channel groups
+  // of one strip group at C = 96, so that a position's 384 bytes are read together - 3 - 15 % slower, profiles/r04_dwwin.md.)
+  const long item = blk * 4 + wave;
+  const int cg = static_cast<int>(item / a.items_per_cg);
+  const long it = item % a.items_per_cg;
   const bool item_ok = it < a.items_per_cg_real;
   const int sg = static_cast<int>(it % a.n_sg);
   const int bd = static_cast<int>((it / a.n_sg) % a.n_bands);
@@ -138,7 +132,6 @@ void dwconv7x7_win_kernel(const WinArgs a) {
   //  per-load 64-bit address arithmetic; an ELEMENT index would be scaled after the extension and lose the form)
   const uint32_t vb_in = voff * static_cast<uint32_t>(sizeof(TI)), vb_out = voff * static_cast<uint32_t>(sizeof(TO)), vb_add = voff * 4u;
   const long goff = static_cast<long>(sg * UPW * kT - 3) * C + cg * CH;   // window column 0 of the group's first strip (may be < 0)
-  const TI* ximg = static_cast<const TI*>(a.x) + n * H * rs;
   const long last_row = static_cast<long>(a.N) * H - 1;
 
   // Buffer addressing (raw buffer resources over the whole tensors): address = resource base + one per-lane 32-bit byte offset
@@ -152,7 +145,6 @@ void dwconv7x7_win_kernel(const WinArgs a) {
   const uint32_t img_elem = static_cast<uint32_t>(n * H * rs);             // first element of this image
   auto load_row = [&](RawRow<TI>& r, int hrow) {                          // hrow: a row of this image, 0 <= hrow < H
     const long grow = n * H + hrow;
-    const TI* prow = ximg + hrow * rs;
     if (grow == 0 || grow == last_row) {                                  // (wave-uniform, rare) element index clamped into the row:
       asm volatile("; first / last row of the tensor" ::: "memory");      // nothing outside the tensor is read.  (The asm keeps this a
       const int row0 = static_cast<int>(img_elem) + hrow * static_cast<int>(rs);   // branch; 32-bit per-lane offsets, no 64-bit pointers:
@@ -180,9 +172,8 @@ void dwconv7x7_win_kernel(const WinArgs a) {
   // ---- packed filter of the workgroup's channel group in LDS: wl[kh][parity][channel] = 4 dwords (16 bytes, one ds_read_b128 per
   //      lane, conflict-free; the two units of a CH = 32 wavefront read the same addresses).  56 dwords per channel would be a
   //      third of the register budget of three wavefronts per SIMD; here a filter row lives in registers only while it is used.
-  extern __shared__ uint4 wl_all[];                                       // [per_wave_cg ? n_cg : 1][7 * 2 * CH]
-  uint4* wl = wl_all + (a.per_wave_cg ? wave * (7 * 2 * CH) : 0);
-  for (int q = a.per_wave_cg ? lane : static_cast<int>(threadIdx.x); q < 7 * CH; q += a.per_wave_cg ? 64 : 256) {
+  __shared__ uint4 wl[7 * 2 * CH];
+  for (int q = threadIdx.x; q < 7 * CH; q += 256) {
     const int kh = q / CH, cc = q % CH;
     float f[7];
 #pragma unroll
@@ -301,10 +292,9 @@ void dwconv7x7_win_kernel(const WinArgs a) {
 
 template <typename TI, typename TO, int CH, bool ADD>
 int launch_win(const WinArgs& a, int rows_per_step, hipStream_t s) {
-  const long blocks = a.per_wave_cg ? a.items_per_cg : a.items_per_cg / 4 * a.n_cg;
-  const dim3 grid(static_cast<unsigned>(blocks)), block(a.per_wave_cg ? 64 * a.n_cg : 256);
-  const size_t lds = static_cast<size_t>(a.per_wave_cg ? a.n_cg : 1) * 7 * 2 * CH * sizeof(uint4);
-#define WIN_K(RG, RR) hipLaunchKernelGGL((dwconv7x7_win_kernel<TI, TO, CH, ADD, RG, RR>), grid, block, lds, s, a)
+  const long blocks = a.items_per_cg / 4 * a.n_cg;
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+#define WIN_K(RG, RR) hipLaunchKernelGGL((dwconv7x7_win_kernel<TI, TO, CH, ADD, RG, RR>), grid, block, 0, s, a)
   // (R = 2 - two output rows per step, two rows of loads in flight per wavefront - measured on MI355X: needs ~180 registers, i.e.
   //  two wavefronts per SIMD, and is 10 - 40 % SLOWER than R = 1 at three (profiles/r04_dwwin.md): only R = 1 is instantiated)
   (void)rows_per_step;
@@ -364,7 +354,6 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_win_kernel(const WinWg
     const long n = it / a.n_sg;
     const bool unit_ok = sg * UPW + ul < a.n_strips;
     const int ulc = unit_ok ? ul : a.n_strips - 1 - sg * UPW;
-    const int w0 = (sg * UPW + ulc) * kT;
     // pair masks (what lies outside the image is zero in the window): wave-uniform per unit, so they live in SGPRs and a CH = 32
     // wavefront selects its unit's with one v_cndmask per use - seven VGPRs less than the forward kernel's per-lane array
     uint32_t mu[UPW][kPairs];
@@ -541,7 +530,7 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   a.n_cg = C / ch;
   // rows per band: whole image for the small maps; for the large ones as few bands as give >= ~3 rounds of 12 wavefronts per CU
   // (every band re-reads 6 halo rows)
-  static const int band_env = getenv("APGD_DW_WIN_BAND") ? atoi(getenv("APGD_DW_WIN_BAND")) : 0;
+  constexpr int band_env = 0;
   const long per_band_items = static_cast<long>(N) * a.n_cg * a.n_sg;
   int n_bands = 1;
   while (n_bands < 8 && per_band_items * n_bands < 3L * 256 * 12 && (H + n_bands) / (n_bands + 1) >= 7) ++n_bands;
@@ -550,9 +539,7 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   a.band = band_env > 0 ? band_env : ((H + n_bands - 1) / n_bands + ns - 1) / ns * ns;   // whole groups of NS rows (the kernel's unrolled window rotation)
   a.n_bands = (H + a.band - 1) / a.band;
   a.items_per_cg_real = static_cast<long>(N) * a.n_sg * a.n_bands;
-  static const int pw_env = getenv("APGD_DW_WIN_PWCG") ? atoi(getenv("APGD_DW_WIN_PWCG")) : 0;   // measured: 3 - 15 % slower (profiles/r04_dwwin.md)
-  a.per_wave_cg = (pw_env && ch == 32 && a.n_cg >= 2 && a.n_cg <= 4) ? 1 : 0;
-  a.items_per_cg = a.per_wave_cg ? a.items_per_cg_real : (a.items_per_cg_real + 3) / 4 * 4;
+  a.items_per_cg = (a.items_per_cg_real + 3) / 4 * 4;
 #define WIN_GO(TI, TO, ADDV) return (ch == 64) ? launch_win<TI, TO, 64, ADDV>(a, rps, s) : launch_win<TI, TO, 32, ADDV>(a, rps, s);
   if (x_dtype == APGD_F32) WIN_GO(float, uint16_t, false)
   if (out_dtype == APGD_F32) { if (add) WIN_GO(uint16_t, float, true) else WIN_GO(uint16_t, float, false) }

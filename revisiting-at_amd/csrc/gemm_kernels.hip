@@ -394,9 +394,9 @@ int cnx_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* D,
   a.M = M; a.N = N; a.K = K;
   // tile: 256 x 256 (128 FLOP per staged byte) where N is a multiple of 256 and the grid still has >= ~2 rounds of workgroups;
   // else 256 x 192 (every N of the models is a multiple of 192) when that gives >= ~3 rounds; else 128 x 192
-  static const int bm_env = getenv("APGD_GEMM_BM") ? atoi(getenv("APGD_GEMM_BM")) : 0;      // tuning experiments only
-  static const int bn_env = getenv("APGD_GEMM_BN") ? atoi(getenv("APGD_GEMM_BN")) : 0;
-  static const int pw_env = getenv("APGD_GEMM_PW") ? atoi(getenv("APGD_GEMM_PW")) : 0;
+  constexpr int bm_env = 0;      // tuning experiments only
+  constexpr int bn_env = 0;
+  constexpr int pw_env = 0;
   const long rows256 = (M + 255) / 256;
   int bn = (N % 256 == 0 && rows256 * (N / 256) >= 512) ? 256 : 192;
   if (bn_env == 192 || bn_env == 256) bn = bn_env;

@@ -677,14 +677,14 @@ __global__ __launch_bounds__(MAXT) void dwconv7x7_roll_kernel(const TI* __restri
 
 struct DwRoll { int threads, units, rs, n_seg; size_t lds; };
 inline bool dw_roll_plan(int H, int W, int C, int in_bytes, int out_bytes, DwRoll* t) {
-  static const int off = getenv("APGD_DW_ROLL") ? atoi(getenv("APGD_DW_ROLL")) : 1;          // 0: tile kernel everywhere
+  constexpr int off = 1;          // 0: tile kernel everywhere
   // smallest map (pixels).  28x28 and up always; 20x20 ... 27x27 (ConvNeXt-L @320 stage 2, 768 channels, batch 128; too many
   // strips for the multi-image kernel) measured 123 -> 107 us forward and 235 -> 125 us input gradient + add against the
   // whole-image tile kernel; at 10x10 the tile / multi-image kernels stay ahead for fp32 inputs.
-  static const int roll_min = getenv("APGD_DW_ROLL_MIN") ? atoi(getenv("APGD_DW_ROLL_MIN")) : 400;
+  constexpr int roll_min = 400;
   if (!off || C % kDC != 0 || H * W < roll_min) return false;
   const int n_sc = (W + kDT - 1) / kDT, P2 = n_sc * (kDT / 2) + 3;
-  static const int max_sc = getenv("APGD_DW_ROLL_SC") ? atoi(getenv("APGD_DW_ROLL_SC")) : kRollMaxThreads / kDC;
+  constexpr int max_sc = kRollMaxThreads / kDC;
   if (n_sc > max_sc || n_sc * kDC > kRollMaxThreads) return false;
   // 65 ... 80 pixels wide (ConvNeXt-L @320 stage 0, 80x80x192, batch 128): five wavefronts and up to 96 KB of LDS leave one
   // workgroup per CU - still ahead of the tile kernels for bf16 inputs (697 -> 441 us all-bf16, 897 -> 792 us input gradient
@@ -696,7 +696,7 @@ inline bool dw_roll_plan(int H, int W, int C, int in_bytes, int out_bytes, DwRol
   if (t->units > 2 || (t->threads > 256 && t->units != 1)) return false;
   const int chunks = kDR * W * (kDC * out_bytes / 16);
   if ((chunks + t->threads - 1) / t->threads > 8) return false;                                // AC in the kernel
-  static const int rs_env = getenv("APGD_DW_RS") ? atoi(getenv("APGD_DW_RS")) : 0;            // tuning experiments only
+  constexpr int rs_env = 0;            // tuning experiments only
   // band height, measured (tools/dw_bench.py): 28 rows at 56x56 (two bands per image) and for fp32 tensors at 28x28, 16 for all-bf16 28x28
   int rs = rs_env > 0 ? rs_env : ((H >= 56 || in_bytes == 4 || out_bytes == 4) ? 28 : 16);
   rs = ((rs + kDR - 1) / kDR) * kDR;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_multi_kernel(const TI* __restri
 
 struct DwMulti { int threads, n_sr, ut, ipw; size_t lds; };
 inline bool dw_multi_plan(int N, int H, int W, int C, int in_bytes, int out_bytes, DwMulti* t) {
-  static const int on = getenv("APGD_DW_MULTI") ? atoi(getenv("APGD_DW_MULTI")) : 1;          // 0: tile kernel
+  constexpr int on = 1;          // 0: tile kernel
   // measured (tools/dw_bench.py, 14x14x384 / 7x7x768): bf16 inputs 74 -> 50 us / 42 -> 31 us, fp32 inputs no better than the
   // tile kernel (40 prefetch registers per thread at the 256-VGPR limit) - those stay there
   if (!on || C % kDC != 0 || H * W >= 784 || in_bytes == 4) return false;
@@ -892,7 +892,7 @@ inline bool dw_multi_plan(int N, int H, int W, int C, int in_bytes, int out_byte
   t->ut = ut <= 5 ? 5 : (ut <= 7 ? 7 : 0);
   if (!t->ut) return false;
   if ((H * W * (kDC * out_bytes / 16) + t->threads - 1) / t->threads > 8) return false;        // AC in the kernel
-  static const int ipw_env = getenv("APGD_DW_IPW") ? atoi(getenv("APGD_DW_IPW")) : 0;         // tuning experiments only
+  constexpr int ipw_env = 0;         // tuning experiments only
   t->ipw = ipw_env > 0 ? ipw_env : (H * W <= 64 ? 2 : 4);
   t->lds = static_cast<size_t>(n_sr * kDR + 6) * P2 * kDC * 4 + static_cast<size_t>(H) * W * kDC * out_bytes;
   return t->lds <= 150 * 1024;
@@ -912,7 +912,7 @@ inline bool dw_dot2_plan(int H, int W, int C, DwDot* t) {
   while (th > kDR && static_cast<size_t>(th + 6) * P2 * kDC * 4 > 64 * 1024) th -= kDR;
   const int n_sr = (th + kDR - 1) / kDR;
   t->th = th; t->threads = ((n_sr * n_sc * kDC + 63) / 64) * 64;
-  static const int th_override = getenv("APGD_DW_TH") ? atoi(getenv("APGD_DW_TH")) : 0;     // tuning experiments only
+  constexpr int th_override = 0;     // tuning experiments only
   if (th_override > 0 && th_override <= th) {
     t->th = th_override;
     t->threads = ((((th_override + kDR - 1) / kDR) * n_sc * kDC + 63) / 64) * 64;
@@ -1797,7 +1797,7 @@ int launch_ln_fwd(const TX* x, const float* w, const float* b, float eps, TY* y,
                        b, eps, y, mean, rstd, M, C, gelu);                                                     \
     return launch_status();                                                                                    \
   }
-  static const int wide_on = getenv("APGD_LN_WIDE") ? atoi(getenv("APGD_LN_WIDE")) : 1;     // 0: 4-channel kernels everywhere
+  constexpr int wide_on = 1;     // 0: 4-channel kernels everywhere
   if (const int g = wide_on ? ln_wide_group(C) : 0) {
 #define LN_FWD_W(G)                                                                                            \
   {                                                                                                            \
@@ -1838,7 +1838,7 @@ int launch_ln_bwd(const TD* dy, const TX* x, const float* w, const float* b, con
                        x, w, b, mean, rstd, dx, ws, M, C, gelu, add);                                          \
     return launch_status();                                                                                    \
   }
-  static const int wide_on = getenv("APGD_LN_WIDE") ? atoi(getenv("APGD_LN_WIDE")) : 1;
+  constexpr int wide_on = 1;
   if (const int g = wide_on ? ln_wide_group(C) : 0) {
 #define LN_BWD_W(G)                                                                                            \
   {                                                                                                            \
@@ -1887,7 +1887,11 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     const int rc = dw_win_launch(x, x_dtype, w49c, bias, add, out, out_dtype, N, H, W, C, flip, s);
     if (rc != -1) return rc;
   }
-  static const int dw_dbg = getenv("APGD_DW_DBG") ? atoi(getenv("APGD_DW_DBG")) : 0;   // timing experiments only
+#if DW_ABLATE
+  static const int dw_dbg = getenv("APGD_DW_DBG") ? atoi(getenv("APGD_DW_DBG")) : 0;   // timing experiments: ablation builds only
+#else
+  constexpr int dw_dbg = 0;
+#endif
   // The packed-dot kernels fuse "+ add" only into an fp32 result.  A bf16 result with an add operand (the residual gradient
   // of a block whose input is bf16) goes to the strip kernel below, which honours it for every output type - never silently
   // dropped.
@@ -1989,7 +1993,7 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
     DwDot dp;
     if (dw_dot2_plan(H, W, C, &dp)) {
       const int tiles_h = (H + dp.th - 1) / dp.th;
-      static const int ipw_env = getenv("APGD_DW_TIPW") ? atoi(getenv("APGD_DW_TIPW")) : 0;     // tuning experiments only
+      constexpr int ipw_env = 0;     // tuning experiments only
       const int ipw = tiles_h == 1 ? (ipw_env > 0 ? ipw_env : (H * W <= 64 ? 2 : 1)) : 1;     // measured: 7x7 40 -> 36 us, 14x14 no gain
       const dim3 grid(static_cast<unsigned>(((N + ipw - 1) / ipw) * tiles_h * (C / kDC))), block(dp.threads);
 #define DWD_LAUNCH(TI, TO)                                                                                            \
@@ -2075,10 +2079,10 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
         return launch_status();
       }
     }
-    static const int wroll = getenv("APGD_DW_WROLL") ? atoi(getenv("APGD_DW_WROLL")) : 1;        // 0: tile kernel
+    constexpr int wroll = 1;        // 0: tile kernel
     if (wroll && P2 * (kDC / 4) <= 256) {
-      static const int rs_env = getenv("APGD_DW_WRS") ? atoi(getenv("APGD_DW_WRS")) : 0;         // tuning experiments only
-      static const int im_env = getenv("APGD_DW_WIMGS") ? atoi(getenv("APGD_DW_WIMGS")) : 0;
+      constexpr int rs_env = 0;         // tuning experiments only
+      constexpr int im_env = 0;
       int rs = rs_env > 0 ? rs_env : (H >= 56 ? 28 : H);
       rs = ((rs + 3) / 4) * 4;
       const int n_seg = (H + rs - 1) / rs;

@@ -125,8 +125,8 @@ class grad_sign_sink:
 
 # Measured (tools/k1_ab.py, B = 256 x 3 x 224 x 224, alternating launches): the blocked order is 2.5 % SLOWER than element order (119.6 vs
 # 116.6 us warm, 129.6 vs 127.4 us behind a 512 MB copy) - the int8 stream's request count was not what holds the update kernel at
-# 0.64 - 0.70 of 8 TB/s of moved bytes - so it is off by default (APGD_SIGN_BLOCKED=1 enables it; kernels and tests stay).
-SIGN_BLOCKED = os.environ.get("APGD_SIGN_BLOCKED", "0") != "0"
+# 0.64 - 0.70 of 8 TB/s of moved bytes - so it is off (a module constant since round 4; the kernels stay, the tests switch it on by attribute).
+SIGN_BLOCKED = False
 
 
 def signs_to_linear(t):
@@ -296,7 +296,7 @@ class _LayerNormRowsSkip(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-_LN_SKIP = os.environ.get("APGD_LN_SKIP", "1") != "0"
+_LN_SKIP = True
 
 
 def layer_norm_skip(x, weight, bias, eps):
@@ -578,8 +578,8 @@ class _StemConvLnGelu(torch.autograd.Function):
 def stem_fused_ln():
     """Measured on MI355X (batch 256, 224x224): the one-kernel stem (162 + 147 us as two kernels) is not faster - the GELU of
     154 M activations makes the convolution kernel VALU-bound - so the two-kernel composition stays the default;
-    ``APGD_STEM_FUSED_LN=1`` selects the fused kernel (it writes 308 MB less per gradient-free forward)."""
-    return os.environ.get("APGD_STEM_FUSED_LN", "0") != "0"
+    the fused kernel stays in the library (it writes 308 MB less per gradient-free forward) behind this constant."""
+    return False
 
 
 def stem_conv_ln_gelu(x, weight, bias, ln_w, ln_b, eps):
@@ -620,8 +620,8 @@ def _pack_conv2(w):
     return pk
 
 
-# 2 (default): forward and input gradient through cnx_conv3x3s2_fwd / _dgrad; 1: forward only; 0: library (APGD_CONV2 overrides)
-_CONV2_MODE = int(os.environ.get("APGD_CONV2", "2"))
+# 2: forward and input gradient through cnx_conv3x3s2_fwd / _dgrad (1: forward only; 0: library - measured behind, kept for A/B by attribute)
+_CONV2_MODE = 2
 
 
 def conv3x3s2_supported(x, conv):
@@ -1002,8 +1002,8 @@ def _wgrad_t(xt, y):
     return _sum_parts(part)
 
 
-# d(b1) of the fused blocks as an extra column of the dW1 GEMM (APGD_DB1_IN_GEMM=0: a separate reduction over [4C, M])
-_DB1_IN_GEMM = os.environ.get("APGD_DB1_IN_GEMM", "1") != "0"
+# d(b1) of the fused blocks as an extra column of the dW1 GEMM (False: a separate reduction over [4C, M])
+_DB1_IN_GEMM = True
 _ONES_COL = {}
 
 
@@ -1173,7 +1173,7 @@ class _LinearLib(torch.autograd.Function):
         return dx, dw, db
 
 
-_LINEAR_LIB = os.environ.get("APGD_LINEAR_LIB", "1") != "0"
+_LINEAR_LIB = True
 
 
 def linear_lib(x, w, b):
@@ -1184,7 +1184,7 @@ def linear_lib(x, w, b):
     return _LinearLib.apply(x, w, b)
 
 
-_MLP_RESIDUAL = os.environ.get("APGD_MLP_RESIDUAL", "1") != "0"
+_MLP_RESIDUAL = True
 
 
 def mlp_residual(xs, h, w1, b1, w2, b2, gamma=None):
