@@ -34,6 +34,10 @@ __all__ = ["apgd_train", "checkpoint_schedule", "criterion_names", "ApgdWorkspac
 # the stream the kernel runs on: entries are (name, iteration, start_event, end_event, gradient element bytes).
 PROFILE_EVENTS = None
 
+# launch shape of the general Linf update (blocks per sample, unroll, non-temporal loads) handed to apgd_linf_step_f32_ex; None = the
+# library's default (tools/k1_instep.py sweeps it inside the AT step, where the kernel's operands come from HBM, not from the cache)
+K1_SHAPE = None
+
 # Linf only reads sign(grad) (:221): let our own stem kernel hand the attack int8 signs instead of the fp32 gradient
 # (ops.grad_sign_sink).  Same decisions bit for bit; 17 instead of 20 bytes per element in the update kernel.
 USE_SIGN_SINK = True
@@ -397,9 +401,14 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
                     ev0 = torch.cuda.Event(enable_timing=True)
                     ev0.record()
                 g_code = _lib.I8_BLK if getattr(grad, "apgd_blocked", False) else _lib.dtype_code(grad.dtype)
-                _lib.check(lib.apgd_linf_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
-                                                  step_size.data_ptr(), out.data_ptr(), None, B, E, eps, a, _stream_ptr()),
-                           "apgd_linf_step_f32")                             # :214-226
+                if K1_SHAPE is not None and g_code != _lib.I8_BLK:
+                    _lib.check(lib.apgd_linf_step_f32_ex(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
+                                                         step_size.data_ptr(), out.data_ptr(), None, B, E, eps, a, int(K1_SHAPE[0]),
+                                                         int(K1_SHAPE[1]), int(K1_SHAPE[2]), _stream_ptr()), "apgd_linf_step_f32_ex")
+                else:
+                    _lib.check(lib.apgd_linf_step_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
+                                                      step_size.data_ptr(), out.data_ptr(), None, B, E, eps, a, _stream_ptr()),
+                               "apgd_linf_step_f32")                         # :214-226
                 if PROFILE_EVENTS is not None:
                     ev1 = torch.cuda.Event(enable_timing=True)
                     ev1.record()

@@ -322,7 +322,8 @@ struct WinWgArgs {
   long items_per_cg;                         // N * n_sg
 };
 
-template <typename TX, int CH>
+// RAGGED: W is not a multiple of 7 - the last strip's dy columns beyond the row are loaded from a clamped column and zeroed.
+template <typename TX, int CH, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_win_kernel(const WinWgArgs a) {
   constexpr int UPW = 64 / CH;
   const int lane = threadIdx.x & 63;
@@ -401,13 +402,21 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_win_kernel(const WinWg
         }
       }
     };
+    const int w0r = (sg * UPW + ulc) * kT;                                // (ragged strips) first column of this lane's strip
     auto load_dy = [&](uint16_t (&d)[kT], int hrow) {
       const uint32_t base = dy_base + static_cast<uint32_t>(hrow * rs);
       uint32_t Cs = static_cast<uint32_t>(C);
       asm volatile("" : "+s"(Cs));
 #pragma unroll
-      for (int t = 0; t < kT; ++t)
-        d[t] = __builtin_amdgcn_raw_buffer_load_b16(rs_d, vb_d, (base + static_cast<uint32_t>(t) * Cs) * 2u, 0);
+      for (int t = 0; t < kT; ++t) {
+        if constexpr (RAGGED) {
+          const uint32_t vo = vb_d + static_cast<uint32_t>(min(t, W - 1 - w0r)) * Cs * 2u;    // per-lane clamped column
+          const uint16_t v = __builtin_amdgcn_raw_buffer_load_b16(rs_d, vo, base * 2u, 0);
+          d[t] = w0r + t < W ? v : static_cast<uint16_t>(0);
+        } else {
+          d[t] = __builtin_amdgcn_raw_buffer_load_b16(rs_d, vb_d, (base + static_cast<uint32_t>(t) * Cs) * 2u, 0);
+        }
+      }
     };
 
     uint32_t win[7][kPairs];
@@ -553,13 +562,13 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
 // shape is not for the window kernel.
 int dw_win_wgrad_launch(const void* x, int x_dtype, const void* dy, float* ws, int max_parts, int64_t N, int32_t H, int32_t W, int32_t C,
                         hipStream_t s) {
-  if (win_policy() == 0 || C % 32 != 0 || W % kT != 0 || H < 1) return 0;
+  if (win_policy() == 0 || C % 32 != 0 || W < kT || H < 1) return 0;
   if (static_cast<long>(N) * H * W * C >= (1L << 30)) return 0;
   WinWgArgs a;
   a.x = x; a.dy = static_cast<const uint16_t*>(dy); a.ws = ws;
   a.N = static_cast<int>(N); a.H = H; a.W = W; a.C = C;
   const int ch = (C % 64 == 0) ? 64 : 32;
-  a.n_strips = W / kT;
+  a.n_strips = (W + kT - 1) / kT;
   a.n_sg = (a.n_strips + (64 / ch) - 1) / (64 / ch);
   a.n_cg = C / ch;
   a.items_per_cg = static_cast<long>(N) * a.n_sg;
@@ -572,13 +581,11 @@ int dw_win_wgrad_launch(const void* x, int x_dtype, const void* dy, float* ws, i
   if (parts * 4 > a.items_per_cg) parts = (a.items_per_cg + 3) / 4;
   a.parts = static_cast<int>(parts < 1 ? 1 : parts);
   const dim3 grid(static_cast<unsigned>(a.parts) * a.n_cg), block(256);
-  if (x_dtype == APGD_F32) {
-    if (ch == 64) hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<float, 64>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<float, 32>), grid, block, 0, s, a);
-  } else {
-    if (ch == 64) hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<uint16_t, 64>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<uint16_t, 32>), grid, block, 0, s, a);
-  }
+#define WGK(TXX, CHH) { if (W % kT == 0) hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<TXX, CHH, false>), grid, block, 0, s, a); \
+                        else hipLaunchKernelGGL((dwconv7x7_wgrad_win_kernel<TXX, CHH, true>), grid, block, 0, s, a); }
+  if (x_dtype == APGD_F32) { if (ch == 64) WGK(float, 64) else WGK(float, 32) }
+  else { if (ch == 64) WGK(uint16_t, 64) else WGK(uint16_t, 32) }
+#undef WGK
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? a.parts : -(1 + static_cast<int>(e));
 }

@@ -2070,7 +2070,7 @@ int cnx_dwconv7x7_wgrad_nhwc(const void* x, int x_dtype, const void* dy, int dy_
     // autocast path: bf16 output gradient; an fp32 x is rounded to bf16 (as the convolution itself did); packed dot products
     const int D2 = (W + 1) / 2, P2 = D2 + 3;
     {
-      // register-window form (dwwin_kernels.hip, round 4): maps whose width is a multiple of 7
+      // register-window form (dwwin_kernels.hip, round 4): every map at least 7 columns wide
       const int parts = dw_win_wgrad_launch(x, x_dtype, dy, ws, kWgradBlocks, N, H, W, C, s);
       if (parts < 0) return -(parts + 1);
       if (parts > 0) {
