@@ -15,6 +15,7 @@ ap.add_argument("--n-iter", type=int, default=2)
 ap.add_argument("--top", type=int, default=40)
 ap.add_argument("--md", default=None)
 ap.add_argument("--title", default="")
+ap.add_argument("--seq", default=None, help="also write the window's launches in order (start offset us, duration us, name)")
 a = ap.parse_args()
 
 rows = []
@@ -86,6 +87,10 @@ lines += ["", f"idle inside the window: {sum(g for g, _ in gaps) / 1e3:.1f} us i
           + ", ".join(f"{g / 1e3:.1f} us before `{short(n_)[:40]}`" for g, n_ in sorted(gaps, reverse=True)[:6])]
 out = "\n".join(lines)
 print(out)
+if a.seq:
+    with open(a.seq, "w") as f:
+        for s_, e_, n_ in win:
+            f.write(f"{(s_ - t0) / 1e3:9.1f} {(e_ - s_) / 1e3:7.1f} {short(n_)[:110]}\n")
 if a.md:
     with open(a.md, "w") as f:
         f.write(f"# {a.title}\n\n{out}\n")
