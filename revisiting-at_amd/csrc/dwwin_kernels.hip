@@ -306,6 +306,328 @@ int launch_win(const WinArgs& a, int rows_per_step, hipStream_t s) {
 
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The same window kernel with every global access going THROUGH LDS: rows in by DMA (`buffer_load_dwordx4 ... lds`), rows out
+// as 16-byte stores.  The default form for every width that is a multiple of 7 (dw_win_launch).
+//
+// Why.  Counters on the register form (profiles/r04_dwwin.md): 53 % of the wavefront cycles parked in s_waitcnt at 56 x 56 x 96 with
+// the VALU 50 % busy - and 4.35 M VMEM instructions per launch, ~24 cycles of kernel time each per CU: 13 loads + 7 stores per output
+// row, every one of them moving 4 (or 2) bytes per lane.  The texture path takes an instruction's 64 addresses at a fixed rate
+// whatever their width, so a lane = (strip, channel) kernel that loads one element per lane and instruction is bound by the NUMBER
+// of its memory instructions.  Two steps, both measured:
+//   1. the row that enters the window comes in by LDS-DMA, two steps ahead of its use (K = 2 row slots per wavefront; an LDS-DMA load
+//      has no destination register, so the depth of the prefetch costs LDS, not VGPRs: 13 in-flight registers per row had capped
+//      the register form at one row ahead).  With one dword per lane and instruction: 170 -> 144 us (fp32 forward, 56 x 56 x 96).
+//   2. one instruction moves 16 bytes per lane: a row of a strip group is 13 column runs of 256 (fp32) / 128 (bf16) contiguous
+//      bytes; lane l of a load fetches chunk l % LPC of column l / LPC, and because LDS-DMA writes lane l at dst + 16 l the slot comes
+//      out as [column][(unit, channel)] - the lane = (unit, channel) layout the window reads with ds_read_b32 / _u16.  4 (fp32) or
+//      2 (bf16) loads per row instead of 13, 2 for the add operand's row instead of 7; the finished row goes the other way: 7
+//      ds_write into [column][(unit, channel)], one ds_read_b128 and ONE (bf16) or TWO (fp32) buffer_store_dwordx4 instead of 7
+//      stores.  5 - 6 VMEM instructions per output row instead of 20 - 27.
+// With loads and stores out of the register file the kernel needs ~75 VGPRs; the packed filter (56 dwords per lane) moves from LDS
+// into registers (no 14 KiB of LDS reads per wavefront and row), ~130 VGPRs, three wavefronts per SIMD.
+// A band of an image pays three full memory latencies for its first six rows (nothing to overlap them with), so the launcher cuts
+// the images into as few bands as fill the chip ONCE (3072 wavefronts = every ConvNeXt-T stage at batch 256 in one band).
+// Measured, batch 256, us (this form / register form / LDS-ring kernels): 56 x 56 x 96 forward 128 / 171 / 156, input gradient + add
+// 172 / 196 / 197;  28 x 28 x 192 61 / 71 / 113, 85 / 94 / 137;  14 x 14 x 384 37 / 42 / 49, 40 / 47 / 63;  7 x 7 x 768 25 / 26 / 35; the step
+// 49.5 - 50.0 ms against 51.0 - 51.7 (profiles/r04_dwwin.md).
+//
+// Counting.  The DMA loads are inline asm (the builtin form makes the compiler's wait-count pass wait for ZERO outstanding
+// loads in front of every LDS read it cannot tell apart from the ring: block_kernels.hip, glds16); the compiler sees no VMEM load
+// at all in the row loop - only its stores, which need no wait - so every vmcnt wait below is ours, and the number of VMEM
+// instructions per step is a compile-time constant: [NA add-row DMA] NR row DMA ... NSO stores - a step that has no row to store (the
+// surplus steps of a band's last group) issues NSO sink loads instead; a half-idle wavefront (odd strip count at 32-channel groups)
+// stores under EXEC.  (Loads and stores retire vmcnt in issue order on this family: the compiler's own counted waits rely on it.)
+// The ring is wave-private: a row is ordered for its reader by the issuing wavefront's own counted vmcnt, a slot is re-issued
+// behind the lgkmcnt(0) that retired its reads.
+typedef __attribute__((ext_vector_type(4))) uint32_t rsrc4_t;
+
+template <int BYTES>
+__device__ __forceinline__ void dma_lds(uint32_t lds_dst, uint32_t voff, rsrc4_t rs, uint32_t soff) {
+  // lds_dst: wave-uniform LDS byte address (M0); lane l's dword lands at lds_dst + 4 l (zero-extended for the 16-bit form)
+  if constexpr (BYTES == 4)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ushort %1, %2, %3 offen lds" : : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+// 16 bytes per lane: one instruction moves 1 KiB (four 256-byte or eight 128-byte column runs of a row); lane l lands at lds_dst + 16 l
+__device__ __forceinline__ void dma_lds16(uint32_t lds_dst, uint32_t voff, rsrc4_t rs, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ rsrc4_t make_rsrc4(const void* p, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  rsrc4_t r;
+  r.x = static_cast<uint32_t>(a);
+  r.y = static_cast<uint32_t>(a >> 32) & 0xffffu;          // stride 0: raw buffer
+  r.z = bytes;
+  r.w = 0x00020000u;                                       // as __builtin_amdgcn_make_buffer_rsrc(..., 0x00020000) above
+  return r;
+}
+
+__device__ __forceinline__ void pack_row_lds(uint32_t (&d)[kPairs], const uint32_t (&r)[kCols], const uint32_t (&m)[kPairs], float) {
+#pragma unroll
+  for (int i = 0; i < kPairs; ++i)
+    d[i] = pack2_bf16(__uint_as_float(r[2 * i]), 2 * i + 1 < kCols ? __uint_as_float(r[2 * i + 1 < kCols ? 2 * i + 1 : 0]) : 0.f) & m[i];
+}
+__device__ __forceinline__ void pack_row_lds(uint32_t (&d)[kPairs], const uint32_t (&r)[kCols], const uint32_t (&m)[kPairs], uint16_t) {
+#pragma unroll
+  for (int i = 0; i < kPairs; ++i) {
+    const uint32_t hi = 2 * i + 1 < kCols ? r[2 * i + 1 < kCols ? 2 * i + 1 : 0] : 0u;
+    d[i] = ((r[2 * i] & 0xffffu) | (hi << 16)) & m[i];
+  }
+}
+
+template <typename TI, typename TO, int CH, bool ADD>
+__global__ __launch_bounds__(256, 3)
+void dwconv7x7_dma_kernel(const WinArgs a) {
+  constexpr int UPW = 64 / CH, K = 2, NS = 7;
+  // a row slot: 16 columns (13 used) x 64 lanes x sizeof(TI), written by NR wide loads of CPI columns each
+  constexpr int COLB = 64 * sizeof(TI);                                    // bytes of one column in a slot
+  constexpr int CPI = 1024 / COLB;                                         // columns per 1 KiB instruction: 4 (fp32) / 8 (bf16)
+  constexpr int NR = 16 / CPI;                                             // row loads per step: 4 (fp32) / 2 (bf16)
+  constexpr int NA = 2;                                                    // add-row loads per step (8 columns x 256 bytes, 7 used)
+  constexpr uint32_t SLOT = 16u * COLB;
+  static_assert((sizeof(TI) == 4 && NR == 4) || (sizeof(TI) == 2 && NR == 2), "row loads");
+  // vmcnt of the row wait: VMEM instructions issued after the DMA group of the row a step needs (issued two steps before it, behind
+  // that step's add-row DMA): NSO stores, [NA add DMA,] NR row DMA, NSO stores
+  // output row: staged through LDS (the lane's 7 values -> [column][(unit, channel)]) and stored as NSO instructions of 16 bytes per lane
+  constexpr int COLBO = 64 * sizeof(TO), CPIO = 1024 / COLBO, LPCO = COLBO / 16, LPUO = LPCO / UPW, EPLO = 16 / sizeof(TO);
+  constexpr int NSO = (kT + CPIO - 1) / CPIO;                              // 1 (bf16) / 2 (fp32)
+  constexpr int WAIT_ROW = 2 * NSO + NR + (ADD ? NA : 0);
+  const int lane = threadIdx.x & 63;
+  long blk;
+  {
+    const long L = blockIdx.x, B = gridDim.x;
+    const long q = B / 8, r = B % 8, xcd = L % 8, k = L / 8;
+    blk = xcd * q + (xcd < r ? xcd : r) + k;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long item = blk * 4 + wave;
+  const int cg = static_cast<int>(item / a.items_per_cg);
+  const long it = item % a.items_per_cg;
+  const bool item_ok = it < a.items_per_cg_real;
+  const int sg = static_cast<int>(it % a.n_sg);
+  const int bd = static_cast<int>((it / a.n_sg) % a.n_bands);
+  const long n = item_ok ? it / (static_cast<long>(a.n_sg) * a.n_bands) : 0;
+  const int H = a.H, W = a.W, C = a.C;
+  const int ul = lane / CH;
+  const bool unit_ok = sg * UPW + ul < a.n_strips;
+  const int ulc = unit_ok ? ul : a.n_strips - 1 - sg * UPW;
+  const int w0 = (sg * UPW + ulc) * kT;
+  const int c = cg * CH + (lane % CH);
+  const int r_begin = bd * a.band, r_end = min(H, r_begin + a.band);
+  const int n_rows = r_end - r_begin;
+  const long rs = static_cast<long>(W) * C;
+
+  uint32_t m[kPairs];
+#pragma unroll
+  for (int i = 0; i < kPairs; ++i) {
+    const int wl_ = w0 - 3 + 2 * i, wh = wl_ + 1;
+    m[i] = ((wl_ >= 0 && wl_ < W) ? 0x0000ffffu : 0u) | ((2 * i + 1 < kCols && wh >= 0 && wh < W) ? 0xffff0000u : 0u);
+  }
+  const uint32_t zero_m[kPairs] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+
+  const uint32_t voff = static_cast<uint32_t>(ulc * kT * C + (lane % CH));
+  const uint32_t vb_in = voff * static_cast<uint32_t>(sizeof(TI)), vb_out = voff * static_cast<uint32_t>(sizeof(TO)), vb_add = voff * 4u;
+  const long goff = static_cast<long>(sg * UPW * kT - 3) * C + cg * CH;
+  const long last_row = static_cast<long>(a.N) * H - 1;
+  const uint32_t tensor_elems = static_cast<uint32_t>(static_cast<long>(a.N) * H * rs);
+  const rsrc4_t rx = make_rsrc4(a.x, tensor_elems * static_cast<uint32_t>(sizeof(TI)));
+  const rsrc4_t ra = make_rsrc4(a.add, ADD ? tensor_elems * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, tensor_elems * static_cast<uint32_t>(sizeof(TO)), 0x00020000);
+  const uint32_t img_elem = static_cast<uint32_t>(n * H * rs);
+
+  __shared__ __attribute__((aligned(16))) unsigned char ring[4][K][SLOT];
+  __shared__ __attribute__((aligned(16))) uint32_t aring[ADD ? 4 : 1][ADD ? 8 : 1][64];   // add row of the step (8 columns, 7 used)
+  __shared__ uint32_t sink[4][64];                                        // target of the loads that only keep the count
+  __shared__ __attribute__((aligned(16))) unsigned char stg[4][8 * COLBO]; // output row of the step on its way to 16-byte stores
+  if (!item_ok) return;
+  // ---- the lane's packed filter in 56 registers (the register form above keeps it in LDS: with 13 load destinations and 7 store
+  //      operands per row there was no room; here loads and stores go through LDS and the per-step filter reads - 14 KiB of LDS
+  //      traffic per wavefront and row - are gone):  we[kh] . pairs (q .. q+3) for even t = 2q, wo[kh] for odd t
+  uint32_t we[7][4], wo[7][4];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+    float f[7];
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int tap = kh * 7 + kw;
+      f[kw] = a.w49c[(a.flip ? 48 - tap : tap) * C + c];
+    }
+    we[kh][0] = pack2_bf16(f[0], f[1]); we[kh][1] = pack2_bf16(f[2], f[3]); we[kh][2] = pack2_bf16(f[4], f[5]); we[kh][3] = pack2_bf16(f[6], 0.f);
+    wo[kh][0] = pack2_bf16(0.f, f[0]); wo[kh][1] = pack2_bf16(f[1], f[2]); wo[kh][2] = pack2_bf16(f[3], f[4]); wo[kh][3] = pack2_bf16(f[5], f[6]);
+  }
+  typedef const volatile __attribute__((address_space(3))) uint32_t* lds_u32_t;
+  typedef const volatile __attribute__((address_space(3))) uint16_t* lds_u16_t;
+  typedef volatile __attribute__((address_space(3))) uint32_t* lds_w32_t;
+  typedef volatile __attribute__((address_space(3))) uint16_t* lds_w16_t;
+  typedef const volatile __attribute__((address_space(3))) u32x4_t* lds_v4_t;
+  const uint32_t ring_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&ring[wave][0][0]));
+  const uint32_t aring_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&aring[ADD ? wave : 0][0][0]));
+  const uint32_t sink_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&sink[wave][0]));
+  // ---- per-lane source offsets of the wide loads.  A 1 KiB load covers CPI columns; inside a column the 64 (unit, channel) values
+  //      are 256 / 128 contiguous bytes of LDS but UPW separate runs of memory (a unit's strip starts 7 columns after its
+  //      neighbour's): lane l -> column l / LPC, unit (l % LPC) / LPU, 16-byte chunk l % LPU of the unit's CH-channel run.
+  constexpr int LPC = COLB / 16, LPU = LPC / UPW, EPL = 16 / sizeof(TI);   // lanes per column, per unit run; elements per lane
+  const int wcol = lane / LPC, wun = (lane % LPC) / LPU, wch = lane % LPU;
+  const int wun_c = (sg * UPW + wun < a.n_strips) ? wun : a.n_strips - 1 - sg * UPW;        // an idle unit shadows the last strip
+  const uint32_t vw_in = static_cast<uint32_t>((wun_c * kT + wcol) * C + wch * EPL) * static_cast<uint32_t>(sizeof(TI));
+  // the last load of a row starts at column (NR - 1) CPI: its lanes beyond column 12 re-read column 12 (valid memory, unused slot columns)
+  const int wcol_l = min(wcol, 12 - (NR - 1) * CPI);
+  const uint32_t vw_in_l = static_cast<uint32_t>((wun_c * kT + wcol_l) * C + wch * EPL) * static_cast<uint32_t>(sizeof(TI));
+  // output row: lane l of store k -> column k CPIO + l / LPCO (columns > 6: no store), unit, 16-byte chunk
+  const uint32_t stg_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&stg[wave][0]));
+  const int ocol = lane / LPCO, oun = (lane % LPCO) / LPUO, och = lane % LPUO;
+  const bool oun_ok = sg * UPW + oun < a.n_strips;
+  const uint32_t vw_o = static_cast<uint32_t>((oun * kT + ocol) * C + och * EPLO) * static_cast<uint32_t>(sizeof(TO));
+  // add row (fp32): 4 columns per load, two loads, the second one's fourth column re-reads column 6
+  const int acol = lane / 16, aun = (lane % 16) / (16 / UPW), ach = lane % (16 / UPW);
+  const int aun_c = (sg * UPW + aun < a.n_strips) ? aun : a.n_strips - 1 - sg * UPW;
+  const uint32_t vw_a = static_cast<uint32_t>((aun_c * kT + acol) * C + ach * 4) * 4u;
+  const uint32_t vw_a_l = static_cast<uint32_t>((aun_c * kT + min(acol, 2)) * C + ach * 4) * 4u;
+  const float b0 = a.bias ? a.bias[c] : 0.f;
+
+  // NR wide DMA loads of input row `hrow` of this image (0 <= hrow < H) into ring slot `slot` - always NR instructions
+  auto dma_row = [&](int slot, int hrow) {
+    const uint32_t dst = ring_w + static_cast<uint32_t>(slot) * SLOT;
+    const long grow = n * H + hrow;
+    if (grow == 0 || grow == last_row) {                                  // (wave-uniform, rare) per-lane offsets clamped into the row:
+      const int row0 = static_cast<int>(img_elem) + hrow * static_cast<int>(rs);   // what a clamped lane fetches belongs to a column outside
+      const int g0 = static_cast<int>(goff);                                        // the image, which the pair masks zero anyway
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int colk = (k == NR - 1) ? wcol_l + k * CPI : wcol + k * CPI;
+        const int rel = min(max(g0 + (wun_c * kT + colk) * C + wch * EPL, 0), static_cast<int>(rs) - EPL);
+        dma_lds16(dst + k * 1024u, static_cast<uint32_t>(row0 + rel) * static_cast<uint32_t>(sizeof(TI)), rx, 0u);
+      }
+    } else {
+      const uint32_t base = static_cast<uint32_t>(static_cast<long>(img_elem) + hrow * rs + goff);
+      uint32_t Cs = static_cast<uint32_t>(C);
+      asm volatile("" : "+s"(Cs));
+#pragma unroll
+      for (int k = 0; k < NR; ++k)
+        dma_lds16(dst + k * 1024u, k == NR - 1 ? vw_in_l : vw_in, rx, (base + static_cast<uint32_t>(k * CPI) * Cs) * static_cast<uint32_t>(sizeof(TI)));
+    }
+  };
+  // the row a slot holds -> registers (the caller has waited for its DMA)
+  auto read_row = [&](uint32_t (&r)[kCols], int slot) {
+    uint32_t ad = ring_w + static_cast<uint32_t>(slot) * SLOT + static_cast<uint32_t>(lane) * static_cast<uint32_t>(sizeof(TI));
+    asm volatile("" : "+v"(ad));
+    if constexpr (sizeof(TI) == 4) {
+      lds_u32_t p = reinterpret_cast<lds_u32_t>(static_cast<uintptr_t>(ad));
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) r[j] = p[j * 64];
+    } else {
+      lds_u16_t p = reinterpret_cast<lds_u16_t>(static_cast<uintptr_t>(ad));
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) r[j] = p[j * 64];
+    }
+  };
+
+  uint32_t win[NS][kPairs];
+  // prologue: input rows r_begin - 3 .. r_begin + 2 through the ring, two at a time (full waits: six rows per band.  Measured and
+  // dropped: filling the window through six compute-less steps of the pipeline below - with nothing to overlap a fill step waits
+  // for its row just the same, and pays the step's bookkeeping: 143 / 165 / 203 / 150 us against 138 / 135 / 180 / 134 at 56 x 56 x 96)
+#pragma unroll
+  for (int j0 = 0; j0 < 6; j0 += 2) {
+    dma_row(0, min(max(r_begin - 3 + j0, 0), H - 1));
+    dma_row(1, min(max(r_begin - 3 + j0 + 1, 0), H - 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      uint32_t raw[kCols];
+      read_row(raw, jj);
+      const int hr = r_begin - 3 + j0 + jj;
+      if (hr >= 0 && hr < H) pack_row_lds(win[j0 + jj], raw, m, TI());
+      else pack_row_lds(win[j0 + jj], raw, zero_m, TI());
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the slots are read before they are re-issued
+  }
+  // rows of steps 0 and 1 (input rows r_begin + 3, r_begin + 4) -> slots 0, 1
+  dma_row(0, min(r_begin + 3, H - 1));
+  dma_row(1, min(r_begin + 4, H - 1));
+
+  const long gout = static_cast<long>(sg * UPW * kT) * C + cg * CH;
+  const uint32_t out_base = img_elem + static_cast<uint32_t>(gout);
+
+#define DWDMA_STEP(P)                                                                                              \
+  {                                                                                                                \
+    const int st = i + (P);                                               /* step number inside the band */        \
+    const int h0 = r_begin + st;                                                                                   \
+    const int slot = st & 1;                                                                                       \
+    const int h = min(h0, H - 1);                                                                                  \
+    const bool row_ok = st < n_rows;                                      /* wave-uniform */                       \
+    /* the row issued two steps ago (the first two steps: in the prologue, nothing else behind it that we may count on) */ \
+    if (st < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_ROW) : "memory");                                           \
+    if (ADD) {                                                             /* this step's add row: one slot, one step ahead of its use */ \
+      dma_lds16(aring_w, vw_a, ra, (out_base + static_cast<uint32_t>(h * rs)) * 4u);                                \
+      dma_lds16(aring_w + 1024u, vw_a_l, ra, (out_base + static_cast<uint32_t>(h * rs) + 4u * static_cast<uint32_t>(C)) * 4u); \
+    }                                                                                                              \
+    {                                                                                                              \
+      uint32_t raw[kCols];                                                                                         \
+      read_row(raw, slot);                                                                                         \
+      if (h0 + 3 < H) pack_row_lds(win[((P) + 6) % NS], raw, m, TI());                                             \
+      else pack_row_lds(win[((P) + 6) % NS], raw, zero_m, TI());                                                   \
+    }                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     /* slot read: free for the row of step st + 2 */ \
+    dma_row(slot, min(h0 + 3 + K, H - 1));                                                                         \
+    float acc[kT];                                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[t] = b0;                                                    \
+    _Pragma("unroll") for (int kh = 0; kh < 7; ++kh) {                                                             \
+      const uint32_t(&d)[kPairs] = win[((P) + kh) % NS];                                                           \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                              \
+          acc[t] = dot2(d[t / 2 + e], (t & 1) ? wo[kh][e] : we[kh][e], acc[t]);                                    \
+      }                                                                                                            \
+    }                                                                                                              \
+    if (ADD) {                                                                                                     \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NR) : "memory");           /* behind the add row: this step's row loads */ \
+      uint32_t ad = aring_w + static_cast<uint32_t>(lane) * 4u;                                                    \
+      asm volatile("" : "+v"(ad));                                                                                 \
+      lds_u32_t ap = reinterpret_cast<lds_u32_t>(static_cast<uintptr_t>(ad));                                      \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[t] += __uint_as_float(ap[t * 64]);                        \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   /* read before the next step re-issues the slot */ \
+    }                                                                                                              \
+    {                                                                     /* the lane's 7 values -> stg[column][(unit, channel)] */ \
+      uint32_t sa = stg_w + static_cast<uint32_t>(lane) * static_cast<uint32_t>(sizeof(TO));                       \
+      asm volatile("" : "+v"(sa));                                                                                 \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
+        if constexpr (sizeof(TO) == 4) reinterpret_cast<lds_w32_t>(static_cast<uintptr_t>(sa))[t * 64] = __float_as_uint(acc[t]);   \
+        else reinterpret_cast<lds_w16_t>(static_cast<uintptr_t>(sa))[t * 64] = static_cast<uint16_t>(pack2_bf16(acc[t], 0.f));      \
+      }                                                                                                            \
+    }                                                                                                              \
+    if (row_ok) {                                                                                                  \
+      uint32_t la = stg_w + static_cast<uint32_t>(lane) * 16u;                                                     \
+      asm volatile("" : "+v"(la));                                                                                 \
+      _Pragma("unroll") for (int k = 0; k < NSO; ++k) {                                                            \
+        const u32x4_t v = *reinterpret_cast<lds_v4_t>(static_cast<uintptr_t>(la + k * 1024u));                     \
+        if (oun_ok && k * CPIO + ocol < kT)                                                                        \
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, vw_o,                                                    \
+              (out_base + static_cast<uint32_t>(h * rs) + static_cast<uint32_t>(k * CPIO) * static_cast<uint32_t>(C)) * static_cast<uint32_t>(sizeof(TO)), 0); \
+      }                                                                                                            \
+    } else {                                                               /* nothing to store: keep the count (loads nobody reads) */ \
+      _Pragma("unroll") for (int k = 0; k < NSO; ++k) dma_lds<4>(sink_w, 0u, rx, 0u);                              \
+    }                                                                                                              \
+  }
+
+  for (int i = 0; i < n_rows; i += NS) {
+    DWDMA_STEP(0) DWDMA_STEP(1) DWDMA_STEP(2) DWDMA_STEP(3) DWDMA_STEP(4) DWDMA_STEP(5) DWDMA_STEP(6)
+  }
+#undef DWDMA_STEP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // no DMA may land in LDS that is no longer ours
+}
+
+template <typename TI, typename TO, int CH, bool ADD>
+int launch_dma(const WinArgs& a, hipStream_t s) {
+  const long blocks = a.items_per_cg / 4 * a.n_cg;
+  hipLaunchKernelGGL((dwconv7x7_dma_kernel<TI, TO, CH, ADD>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Filter / bias gradient in the same form:  dw[kh][kw][c] = sum_{n,h,w} dy[n,h,w,c] x[n,h+kh-3,w+kw-3,c],  db[c] = sum dy.
 // lane = (strip of 7 columns, channel) keeps its 49 + 1 partial sums in registers next to the 7-row x window and walks down whole
 // images (one item = (image, strip group); a wavefront takes every (4 x parts)-th item of its channel group).  Per dy row: the 7
@@ -505,18 +827,20 @@ int& win_policy() {
 extern "C" int cnx_dwconv7x7_win_policy(int policy) {
   int& p = win_policy();
   const int prev = p;
-  if (policy >= 0) p = policy > 2 ? 2 : policy;
+  if (policy >= 0) p = policy > 3 ? 3 : policy;
   return prev;
 }
 
 // -> APGD_OK / an error of the launch; -1 when this shape is not for the window kernel (the caller goes on to the LDS kernels)
 int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bias, const float* add, void* out, int out_dtype,
                   int64_t N, int32_t H, int32_t W, int32_t C, int32_t flip, hipStream_t s) {
-  // policy (cnx_dwconv7x7_win_policy / APGD_DW_WIN): 0 = never, 1 = where it measured ahead of the LDS-ring kernels (default), 2 = every
-  // shape it supports
+  // policy (cnx_dwconv7x7_win_policy / APGD_DW_WIN): 0 = never (the LDS-ring kernels of model_kernels.hip);  1 (default) = the LDS-DMA
+  // form for every width that is a multiple of 7 (every ConvNeXt map at 224: ahead of both other families at every shape and batch,
+  // profiles/r04_dwwin.md), the register form for the ragged widths where it measured ahead of the LDS-ring kernels;  2 = the
+  // register form for every shape it supports;  3 = as 1 (the DMA form wherever it applies), the register form for every other shape
   const int on = win_policy();
   if (!on || C % 32 != 0 || H < 1 || W < 7) return -1;
-  if (on == 1) {
+  if (on == 1 && W % kT != 0) {
     // Measured on MI355X (profiles/r04_dwwin.md; us, window kernel vs LDS-ring kernels): ahead at every map up to 40 x 40 -
     // 28x28x192: 72 vs 113 (fwd), 96 vs 136 (dgrad + add);  14x14x384: 44 vs 49, 48 vs 63;  7x7x768: 24 vs 35, 26 vs 45;  ConvNeXt-B / -L
     // shapes alike (28x28x256 108 vs 148, 40x40x384 168 vs 245, 10x10x1536 52 vs 71) - and at 56 x 56 for the batch-128 chunks of the
@@ -530,6 +854,7 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   if (x_dtype == APGD_F32 && out_dtype == APGD_F32) return -1;             // the exact-fp32 path is not a bf16 kernel's business
   if (add && x_dtype == APGD_F32) return -1;                                // (no caller: forward calls carry no add operand)
   if (static_cast<long>(N) * H * W * C >= (1L << 30)) return -1;           // 32-bit BYTE offsets into the fp32 tensors (buffer addressing)
+  const bool dma = W % kT == 0 && (on == 1 || on == 3);                    // strips without a ragged end: the LDS-DMA form
   WinArgs a;
   a.x = x; a.w49c = w49c; a.bias = bias; a.add = add; a.out = out;
   a.N = static_cast<int>(N); a.H = H; a.W = W; a.C = C; a.flip = flip;
@@ -539,17 +864,23 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   a.n_cg = C / ch;
   // rows per band: whole image for the small maps; for the large ones as few bands as give >= ~3 rounds of 12 wavefronts per CU
   // (every band re-reads 6 halo rows)
-  constexpr int band_env = 0;
   const long per_band_items = static_cast<long>(N) * a.n_cg * a.n_sg;
   int n_bands = 1;
-  while (n_bands < 8 && per_band_items * n_bands < 3L * 256 * 12 && (H + n_bands) / (n_bands + 1) >= 7) ++n_bands;
+  // (the DMA form: ONE round - every band pays three full memory latencies for its first six rows, and a lone round has no tail;
+  //  56 x 56 x 96, batch 256: 1 / 2 / 3 bands = 128 / 133 / 143 us, batch 128: 1 band 86, 2 bands 72)
+  const long want_items = (dma ? 1L : 3L) * 256 * 12;
+  while (n_bands < 8 && per_band_items * n_bands < want_items && (H + n_bands) / (n_bands + 1) >= 7) ++n_bands;
   const int rps = 1;                                                       // output rows per step
   const int ns = 6 + rps;
-  a.band = band_env > 0 ? band_env : ((H + n_bands - 1) / n_bands + ns - 1) / ns * ns;   // whole groups of NS rows (the kernel's unrolled window rotation)
+  a.band = ((H + n_bands - 1) / n_bands + ns - 1) / ns * ns;   // whole groups of NS rows (the kernel's unrolled window rotation)
   a.n_bands = (H + a.band - 1) / a.band;
   a.items_per_cg_real = static_cast<long>(N) * a.n_sg * a.n_bands;
   a.items_per_cg = (a.items_per_cg_real + 3) / 4 * 4;
-#define WIN_GO(TI, TO, ADDV) return (ch == 64) ? launch_win<TI, TO, 64, ADDV>(a, rps, s) : launch_win<TI, TO, 32, ADDV>(a, rps, s);
+#define WIN_GO(TI, TO, ADDV)                                                                                        \
+  {                                                                                                                 \
+    if (dma) return (ch == 64) ? launch_dma<TI, TO, 64, ADDV>(a, s) : launch_dma<TI, TO, 32, ADDV>(a, s);          \
+    return (ch == 64) ? launch_win<TI, TO, 64, ADDV>(a, rps, s) : launch_win<TI, TO, 32, ADDV>(a, rps, s);         \
+  }
   if (x_dtype == APGD_F32) WIN_GO(float, uint16_t, false)
   if (out_dtype == APGD_F32) { if (add) WIN_GO(uint16_t, float, true) else WIN_GO(uint16_t, float, false) }
   if (add) WIN_GO(uint16_t, uint16_t, true)

@@ -31,15 +31,17 @@ def close(a, b, rtol, atol):
                                      (2, 200, 6, 8), (1, 96, 56, 56), (6, 64, 14, 14), (5, 32, 7, 7), (3, 64, 28, 28),
                                      (2, 32, 30, 27), (1, 192, 80, 80), (1, 384, 40, 40), (2, 384, 4, 4), (2, 64, 20, 20), (1, 32, 24, 24),
                                      (2, 32, 10, 10), (2, 192, 28, 28), (3, 384, 14, 14), (2, 768, 7, 7), (3, 96, 28, 28), (2, 96, 35, 21),
-                                     (9, 96, 56, 56)])   # cfg#4 / cfg#1 maps; 20x20: output tile > input tile; 35x21x96: an odd strip count (idle half-wave)
+                                     (9, 96, 56, 56), (2, 64, 10, 14), (1, 96, 9, 7), (4, 128, 33, 28)])
+# cfg#4 / cfg#1 maps; 20x20: output tile > input tile; 35x21x96: an odd strip count (idle half-wave); 10x14, 9x7, 33x28: widths the LDS-DMA
+# form takes with heights that are no multiple of its 7-row groups (surplus steps store nothing) and several bands per image
 @pytest.mark.parametrize("xdt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
-@pytest.mark.parametrize("win", [0, 2], ids=["lds-ring", "reg-window"])
+@pytest.mark.parametrize("win", [0, 2, 3], ids=["lds-ring", "reg-window", "dma-window"])
 def test_dwconv7x7_fwd_bwd_data_wgrad(R, N, C, H, W, xdt, odt, win):
     """All-fp32 calls are exact fp32 stencils.  Any call with a bf16 operand is the autocast convolution: input AND
     filter rounded to bf16, fp32 accumulation (packed bf16 dot products) - the references below round the same way.
-    ``win``: both kernel families on every shape (cnx_dwconv7x7_win_policy 0 / 2; the default policy picks per shape)."""
-    lib = R._lib.load()
+    ``win``: all three kernel families on every shape (cnx_dwconv7x7_win_policy 0 / 2 / 3: LDS ring, register window, LDS-DMA window
+    - the last one for widths that are multiples of 7, the register form otherwise; the default policy picks per shape)."""
     prev = lib.cnx_dwconv7x7_win_policy(win)
     try:
         _dwconv_case(R, lib, N, C, H, W, xdt, odt)
