@@ -565,21 +565,28 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
       dma_lds16(aring_w, vw_a, ra, (out_base + static_cast<uint32_t>(h * rs)) * 4u);                                \
       dma_lds16(aring_w + 1024u, vw_a_l, ra, (out_base + static_cast<uint32_t>(h * rs) + 4u * static_cast<uint32_t>(C)) * 4u); \
     }                                                                                                              \
-    {                                                                                                              \
-      uint32_t raw[kCols];                                                                                         \
-      read_row(raw, slot);                                                                                         \
-      if (h0 + 3 < H) pack_row_lds(win[((P) + 6) % NS], raw, m, TI());                                             \
-      else pack_row_lds(win[((P) + 6) % NS], raw, zero_m, TI());                                                   \
-    }                                                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     /* slot read: free for the row of step st + 2 */ \
-    dma_row(slot, min(h0 + 3 + K, H - 1));                                                                         \
+    /* the 13 LDS reads of the entering row are issued here and consumed behind six of the seven filter rows (the row is the \
+       window's LAST: only kh = 6 needs it) - their latency runs under 168 dot products instead of in front of them */          \
+    uint32_t raw[kCols];                                                                                           \
+    read_row(raw, slot);                                                                                           \
     float acc[kT];                                                                                                 \
     _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[t] = b0;                                                    \
-    _Pragma("unroll") for (int kh = 0; kh < 7; ++kh) {                                                             \
+    _Pragma("unroll") for (int kh = 0; kh < 6; ++kh) {                                                             \
       const uint32_t(&d)[kPairs] = win[((P) + kh) % NS];                                                           \
       _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                              \
           acc[t] = dot2(d[t / 2 + e], (t & 1) ? wo[kh][e] : we[kh][e], acc[t]);                                    \
+      }                                                                                                            \
+    }                                                                                                              \
+    if (h0 + 3 < H) pack_row_lds(win[((P) + 6) % NS], raw, m, TI());                                               \
+    else pack_row_lds(win[((P) + 6) % NS], raw, zero_m, TI());                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     /* slot read: free for the row of step st + 2 */ \
+    dma_row(slot, min(h0 + 3 + K, H - 1));                                                                         \
+    {                                                                                                              \
+      const uint32_t(&d)[kPairs] = win[((P) + 6) % NS];                                                            \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                              \
+          acc[t] = dot2(d[t / 2 + e], (t & 1) ? wo[6][e] : we[6][e], acc[t]);                                      \
       }                                                                                                            \
     }                                                                                                              \
     if (ADD) {                                                                                                     \

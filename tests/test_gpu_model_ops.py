@@ -42,6 +42,7 @@ def test_dwconv7x7_fwd_bwd_data_wgrad(R, N, C, H, W, xdt, odt, win):
     filter rounded to bf16, fp32 accumulation (packed bf16 dot products) - the references below round the same way.
     ``win``: all three kernel families on every shape (cnx_dwconv7x7_win_policy 0 / 2 / 3: LDS ring, register window, LDS-DMA window
     - the last one for widths that are multiples of 7, the register form otherwise; the default policy picks per shape)."""
+    lib = R._lib.load()
     prev = lib.cnx_dwconv7x7_win_policy(win)
     try:
         _dwconv_case(R, lib, N, C, H, W, xdt, odt)
