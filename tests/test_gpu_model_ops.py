@@ -31,9 +31,10 @@ def close(a, b, rtol, atol):
                                      (2, 200, 6, 8), (1, 96, 56, 56), (6, 64, 14, 14), (5, 32, 7, 7), (3, 64, 28, 28),
                                      (2, 32, 30, 27), (1, 192, 80, 80), (1, 384, 40, 40), (2, 384, 4, 4), (2, 64, 20, 20), (1, 32, 24, 24),
                                      (2, 32, 10, 10), (2, 192, 28, 28), (3, 384, 14, 14), (2, 768, 7, 7), (3, 96, 28, 28), (2, 96, 35, 21),
-                                     (9, 96, 56, 56), (2, 64, 10, 14), (1, 96, 9, 7), (4, 128, 33, 28)])
+                                     (9, 96, 56, 56), (2, 64, 10, 14), (1, 96, 9, 7), (4, 128, 33, 28), (1, 64, 3, 7), (2, 32, 1, 14)])
 # cfg#4 / cfg#1 maps; 20x20: output tile > input tile; 35x21x96: an odd strip count (idle half-wave); 10x14, 9x7, 33x28: widths the LDS-DMA
-# form takes with heights that are no multiple of its 7-row groups (surplus steps store nothing) and several bands per image
+# form takes with heights that are no multiple of its 7-row groups (surplus steps store nothing) and several bands per image; 3x7, 1x14:
+# maps lower than the window
 @pytest.mark.parametrize("xdt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
 @pytest.mark.parametrize("win", [0, 2, 3], ids=["lds-ring", "reg-window", "dma-window"])
