@@ -31,11 +31,9 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
                        const float* add, void* out, int out_dtype,
                        int64_t N, int32_t H, int32_t W, int32_t C, int32_t flip, void* stream);
 
-/* Which calls with a bf16 operand and C % 32 == 0 take a sliding-window kernel (csrc/dwwin_kernels.hip) instead of the LDS-ring
- * kernels: 0 = none; 1 (default; APGD_DW_WIN overrides the default at start-up) = the LDS-DMA form for every width that is a
- * multiple of 7, the register form for the other widths where it measured ahead on MI355X; 2 = the register form for every shape
- * it supports; 3 = the LDS-DMA form wherever it applies, the register form elsewhere.  Same arithmetic in every form (bf16
- * operands, fp32 accumulation; the summation order differs between the window kernels and the LDS-ring kernels).
+/* Whether calls with a bf16 operand, C % 32 == 0 and W >= 7 take the sliding-window kernels (csrc/dwwin_kernels.hip: forward / input
+ * gradient through LDS-DMA, filter gradient) instead of the LDS-ring kernels: 0 = no, anything else = yes (default; APGD_DW_WIN
+ * overrides the default at start-up).  Same arithmetic either way (bf16 operands, fp32 accumulation; the summation order differs).
  * Returns the previous setting; a negative `policy` only queries.  Process-wide, not synchronised: set it before launching. */
 int cnx_dwconv7x7_win_policy(int policy);
 
