@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Workload for rocprofv3 passes over the depthwise 7x7 kernels: forward fp32 -> bf16 and input gradient bf16 -> fp32 + add at the
-ConvNeXt-T stage shapes, batch 256 (APGD_DW_WIN=0 / 1 selects the LDS-ring / register-window kernels), plus a device copy of known
+ConvNeXt-T stage shapes, batch 256 (APGD_DW_WIN=0 / 1 selects the LDS-ring / sliding-window kernels), plus a device copy of known
 size as the byte-count calibration of FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
