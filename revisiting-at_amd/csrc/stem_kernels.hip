@@ -47,15 +47,20 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // Both directions are tiny GEMMs per group of 32 positions, on MFMA 32x32x16 (the fp32-FMA form of these kernels was
 // VALU-bound at 420 / 780 us; 1296 MACs per position against 27 loads):
-//   forward  D[pos][co]  = patch[pos][k] W[k][co],  k = (ci, kh, kw) padded 27 -> 32:      2 k-steps x ceil(P/32) blocks
+//   forward  D[pos][co]  = patch[pos][k] W[k][co],  k = 4 (ci * 3 + kh) + kw, kw = 3 a zero column: 36 padded to 48 = 3 k-steps x
+//            ceil(P/32) blocks.  The padding buys 16-byte loads: the three taps of a (ci, kh) are consecutive fp32 of one image row,
+//            a lane fetches them (and the float behind them, which meets a zero weight) with ONE instruction - 6 loads per lane and
+//            32 positions instead of 16 scalar ones with their per-element address arithmetic (the first form of this kernel:
+//            166 us; the instruction count of its loads and their integer divisions were the bound, not the 462 MB it moves)
 //   dgrad    D[o][patch] = Wp[o][k] dY[k][patch],   k = (q, co): the 2x2 output positions q around a 2x2 input patch times the
 //            P channels; o = ci*4 + i*2 + j: the 12 values of the patch.  Wp[o][(q, co)] = w[co][ci][kh][kw] with the (kh, kw)
 //            that connects pixel (i, j) to position q (stride 2: at most one), else 0.                  4P/16 k-steps
-// Packed filter (cnx_stem_conv_pack): [NB][2][64][8] bf16 forward B fragments, then [4P/16][64][8] bf16 dgrad A fragments.
+// Packed filter (cnx_stem_conv_pack): [NB][3][64][8] bf16 forward B fragments, then [4P/16][64][8] bf16 dgrad A fragments.
 template <int P> struct StemGeo {
   static constexpr int NB = (P + 31) / 32;            // 32-wide blocks of output channels
   static constexpr int KD = 4 * P / 16;               // k-steps of the dgrad GEMM
-  static constexpr int FWD_BYTES = NB * 2 * 1024;
+  static constexpr int KF = 3;                        // k-steps of the forward GEMM: 9 (ci, kh) quads of 4 (kw 0..2 + a zero) = 36 -> 48
+  static constexpr int FWD_BYTES = NB * KF * 1024;
   static constexpr int BYTES = FWD_BYTES + KD * 1024;
 };
 
@@ -63,13 +68,14 @@ template <typename TW>
 __global__ void stem_pack_kernel(const TW* __restrict__ w, uint16_t* __restrict__ wq, int P) {
   const int NB = (P + 31) / 32, KD = 4 * P / 16;
   const int i = blockIdx.x * 256 + threadIdx.x;                      // one bf16 element each
-  const int n_fwd = NB * 2 * 512, n_all = n_fwd + KD * 512;
+  const int n_fwd = NB * 3 * 512, n_all = n_fwd + KD * 512;
   if (i >= n_all) return;
   float v = 0.f;
   if (i < n_fwd) {
-    const int e = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) & 1, nb = i >> 10;
+    const int e = i & 7, lane = (i >> 3) & 63, piece = i >> 9, ks = piece % 3, nb = piece / 3;
     const int co = nb * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + e;
-    if (co < P && k < 27) v = static_cast<float>(w[co * 27 + k]);
+    const int quad = k >> 2, kw = k & 3;                              // quad = ci * 3 + kh
+    if (co < P && quad < 9 && kw < 3) v = static_cast<float>(w[co * 27 + quad * 3 + kw]);
   } else {
     const int t = i - n_fwd;
     const int e = t & 7, lane = (t >> 3) & 63, ks = t >> 9;
@@ -105,11 +111,27 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
     for (int i = 0; i < NCH * 8; ++i) { lw[i] = ln_w[h2 * (P / 2) + i]; lb[i] = ln_b[h2 * (P / 2) + i]; }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
-  bf16x8 bw[G::NB][2];
+  bf16x8 bw[G::NB][G::KF];
 #pragma unroll
   for (int nb = 0; nb < G::NB; ++nb)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) bw[nb][ks] = *reinterpret_cast<const bf16x8*>(wq + ((nb * 2 + ks) * 64 + lane) * 8);
+    for (int ks = 0; ks < G::KF; ++ks) bw[nb][ks] = *reinterpret_cast<const bf16x8*>(wq + ((nb * G::KF + ks) * 64 + lane) * 8);
+  // the lane's quads: k-step s, slot t -> quad q = 4 s + 2 half + t (q >= 9: none); element offset of its image row relative to
+  // row 2 oh - 1 of channel 0, and whether it is the filter's first row (kh = 0: outside the image for oh = 0)
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0,
+      static_cast<uint32_t>((total / (static_cast<long>(OH) * OW)) * 3 * H * W * 4), 0x00020000);
+  int qoff[G::KF][2];
+  bool qtop[G::KF][2], qhas[G::KF][2];
+#pragma unroll
+  for (int sk = 0; sk < G::KF; ++sk)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int q = 4 * sk + 2 * half + t;
+      const int ci = q / 3, kh = q - 3 * ci;
+      qoff[sk][t] = (ci * H + kh) * W;
+      qtop[sk][t] = kh == 0;
+      qhas[sk][t] = q < 9;
+    }
   float bv[G::NB];
 #pragma unroll
   for (int nb = 0; nb < G::NB; ++nb) bv[nb] = (bias && nb * 32 + l32 < P) ? bias[nb * 32 + l32] : 0.f;
@@ -122,18 +144,27 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
     const long r = pos / OW;
     const int oh = static_cast<int>(r % OH);
     const float* xn = x + (r / OH) * 3 * static_cast<long>(H) * W;
-    bf16x8 pa[2];
+    // element index of (channel 0, row 2 oh - 1, column 2 ow - 1) of this image: may be negative (first row / column); a quad outside
+    // the image or absent is fetched from offset 0xffffffff - beyond the buffer's range, the hardware returns zeros
+    const long e0 = (r / OH) * 3 * static_cast<long>(H) * W + static_cast<long>(2 * oh - 1) * W + (2 * ow - 1);
+    bf16x8 pa[G::KF];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      float v[8];
+    for (int sk = 0; sk < G::KF; ++sk) {
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4s;
+      u32x4s qv[2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = ks * 16 + half * 8 + e;
-        const int ci = k / 9, rem = k - ci * 9, kh = rem / 3, kw = rem - kh * 3;
-        const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
-        v[e] = (k < 27 && ih >= 0 && ih < H && iw >= 0 && iw < W) ? xn[(static_cast<long>(ci) * H + ih) * W + iw] : 0.f;
+      for (int t = 0; t < 2; ++t) {
+        const bool in = qhas[sk][t] && !(qtop[sk][t] && oh == 0);
+        // (ow = 0: the quad would start at column -1 - for the tensor's very first row at element -1; it is fetched from column 0
+        //  and shifted instead)
+        const uint32_t off = in ? static_cast<uint32_t>(e0 + qoff[sk][t] + (ow == 0 ? 1 : 0)) * 4u : 0xffffffffu;
+        qv[t] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+        if (ow == 0) { qv[t].w = qv[t].z; qv[t].z = qv[t].y; qv[t].y = qv[t].x; qv[t].x = 0u; }
       }
-      pa[ks] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])));
+      pa[sk] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(__uint_as_float(qv[0].x), __uint_as_float(qv[0].y)),
+                                                     pack_bf16(__uint_as_float(qv[0].z), __uint_as_float(qv[0].w)),
+                                                     pack_bf16(__uint_as_float(qv[1].x), __uint_as_float(qv[1].y)),
+                                                     pack_bf16(__uint_as_float(qv[1].z), __uint_as_float(qv[1].w))));
     }
     uint16_t* st = stage[wave];
 #pragma unroll
@@ -141,8 +172,8 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
       f32x16 acc;
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) acc[rr] = bv[nb];
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], bw[nb][0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], bw[nb][1], acc, 0, 0, 0);
+#pragma unroll
+      for (int sk = 0; sk < G::KF; ++sk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[sk], bw[nb][sk], acc, 0, 0, 0);
       const int co = nb * 32 + l32;
       if (co < P) {
 #pragma unroll
@@ -270,7 +301,7 @@ extern "C" {
 
 int cnx_stem_conv_supported(int32_t P) { return (P == 48 || P == 64 || P == 96) ? 1 : 0; }
 
-int64_t cnx_stem_conv_packed_bytes(int32_t P) { return (static_cast<int64_t>((P + 31) / 32) * 2 + 4 * P / 16) * 1024; }
+int64_t cnx_stem_conv_packed_bytes(int32_t P) { return (static_cast<int64_t>((P + 31) / 32) * 3 + 4 * P / 16) * 1024; }   // StemGeo<P>::BYTES
 
 int cnx_stem_conv_pack(const void* w, int w_dtype, void* wq, int32_t P, void* stream) {
   if (!w || !wq) return APGD_ERR_NULL;
@@ -291,6 +322,7 @@ int cnx_stem_conv_fwd(const float* x, const void* wq, const float* bias, void* o
   if (N == 0) return APGD_OK;
   if (!x || !wq || !out) return APGD_ERR_NULL;
   if (!cnx_stem_conv_supported(P)) return APGD_ERR_ARG;
+  if ((H & 1) || (W & 1) || static_cast<long>(N) * 3 * H * W >= (1L << 30)) return APGD_ERR_ARG;   // even maps; 32-bit byte offsets (buffer loads)
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const long total = N * OH * OW;
   long nb = (total + 127) / 128;
@@ -316,6 +348,7 @@ int cnx_stem_conv_ln_gelu_fwd(const float* x, const void* wq, const float* bias,
   if (!x || !wq || !ln_w || !ln_b || !act) return APGD_ERR_NULL;
   if ((mean == nullptr) != (rstd == nullptr)) return APGD_ERR_ARG;
   if (!cnx_stem_conv_supported(P)) return APGD_ERR_ARG;
+  if ((H & 1) || (W & 1) || static_cast<long>(N) * 3 * H * W >= (1L << 30)) return APGD_ERR_ARG;
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const long total = N * OH * OW;
   long nb = (total + 127) / 128;

@@ -576,9 +576,12 @@ class _StemConvLnGelu(torch.autograd.Function):
 
 
 def stem_fused_ln():
-    """Measured on MI355X (batch 256, 224x224): the one-kernel stem (162 + 147 us as two kernels) is not faster - the GELU of
-    154 M activations makes the convolution kernel VALU-bound - so the two-kernel composition stays the default;
-    the fused kernel stays in the library (it writes 308 MB less per gradient-free forward) behind this constant."""
+    """The one-kernel stem (convolution + LayerNorm + GELU on the tile in LDS) or convolution + LayerNorm-GELU kernel.  Measured on
+    MI355X (``tools/stem_bench.py``, batch 256 / 128, 224 x 224, after the convolution's move to 16-byte quad loads - 112 us alone,
+    162 before): one kernel 214 / 111 us for a gradient-free forward and 234 / 139 us with the saved convolution output, two kernels
+    282 / 147 and 278 / 141 us.  In the step (three interleaved pairs, ``gpurun_out/r4sf``) the two compositions are inside each
+    other's noise (49.16 / 49.49 / 49.32 vs 49.78 / 49.22 / 49.28 ms): the two-kernel composition stays the default, the fused kernel
+    stays in the library behind this constant."""
     return False
 
 

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""First stem convolution (3->48, 3x3 s2) at batch 256, 224x224: hand-written image kernels vs the library path."""
+"""First ConvStem convolution (3 -> 48, 3x3 / 2) at batch 256, 224 x 224: the convolution alone, followed by the LayerNorm + GELU kernel,
+and the one-kernel form (cnx_stem_conv_ln_gelu_fwd); gradient-free calls, HIP events, median of 10."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, torch.nn.functional as F
+import torch
 import revisiting_at_amd as R
-from revisiting_at_amd import ops
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+x = torch.rand(B, 3, 224, 224, device="cuda")
+w = torch.randn(48, 3, 3, 3, device="cuda") * 0.3
+b = torch.randn(48, device="cuda") * 0.1
+lw = torch.ones(48, device="cuda"); lb = torch.zeros(48, device="cuda")
 
 
 def timeit(fn, iters=10, warm=3):
@@ -17,24 +22,12 @@ def timeit(fn, iters=10, warm=3):
     ts.sort(); return ts[len(ts) // 2] * 1e3
 
 
-B = 256
-x = torch.rand(B, 3, 224, 224, device="cuda").requires_grad_()
-conv = torch.nn.Conv2d(3, 48, 3, 2, 1).cuda().to(memory_format=torch.channels_last)
+with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+    t_conv = timeit(lambda: R.ops.stem_conv(x, w, b))
+    t_two = timeit(lambda: R.ops.layer_norm_cf_gelu(R.ops.stem_conv(x, w, b), lw, lb, 1e-6))
+    t_one = timeit(lambda: R.ops.stem_conv_ln_gelu(x, w, b, lw, lb, 1e-6))
+xg = x.clone().requires_grad_()
 with torch.autocast("cuda", dtype=torch.bfloat16):
-    def ours_f():
-        with torch.no_grad():
-            return ops.stem_conv(x, conv.weight, conv.bias)
-    def lib_f():
-        torch.clear_autocast_cache()
-        with torch.no_grad():
-            return conv(x)
-    def ours_b():
-        with ops.input_grad_only():
-            o = ops.stem_conv(x, conv.weight, conv.bias)
-            torch.autograd.grad(o, x, torch.ones_like(o))
-    def lib_b():
-        torch.clear_autocast_cache()
-        o = conv(x)
-        torch.autograd.grad(o, x, torch.ones_like(o))
-    print(f"forward: ours {timeit(ours_f):.1f} us   library {timeit(lib_f):.1f} us")
-    print(f"forward + input gradient: ours {timeit(ours_b):.1f} us   library {timeit(lib_b):.1f} us")
+    t_one_g = timeit(lambda: R.ops.stem_conv_ln_gelu(xg, w, b, lw, lb, 1e-6))
+    t_two_g = timeit(lambda: R.ops.layer_norm_cf_gelu(R.ops.stem_conv(xg, w, b), lw, lb, 1e-6))
+print(f"B={B}: conv {t_conv:.1f} us | conv + LN/GELU kernel {t_two:.1f} us | one kernel {t_one:.1f} us | with saved tensors: two {t_two_g:.1f}, one {t_one_g:.1f}")
