@@ -385,9 +385,17 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
       asm volatile("" : "+v"(la));                                                                                 \
       _Pragma("unroll") for (int k = 0; k < NSO; ++k) {                                                            \
         const u32x4_t v = *reinterpret_cast<lds_v4_t>(static_cast<uintptr_t>(la + k * 1024u));                     \
-        if (oun_ok && k * CPIO + ocol < kT && ow0 + k * CPIO + ocol < W)   /* (ragged widths: the last strip's columns inside the image) */ \
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, vw_o,                                                    \
-              (out_base + static_cast<uint32_t>(h * rs) + static_cast<uint32_t>(k * CPIO) * static_cast<uint32_t>(C)) * static_cast<uint32_t>(sizeof(TO)), 0); \
+        const bool st_ok = oun_ok && k * CPIO + ocol < kT && ow0 + k * CPIO + ocol < W;   /* (ragged widths: the last strip's columns inside the image) */ \
+        /* the compiler guards a store under EXEC with s_cbranch_execz: a store NO lane of the wavefront takes (the ragged last  \
+           strip, second 16-byte group) would not be issued and the counted vmcnt waits would run two instructions short - the   \
+           wave-uniform test keeps the number of VMEM instructions per step independent of EXEC */                               \
+        if (__builtin_amdgcn_ballot_w64(st_ok) != 0ull) {                                                          \
+          if (st_ok)                                                                                               \
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, vw_o,                                                  \
+                (out_base + static_cast<uint32_t>(h * rs) + static_cast<uint32_t>(k * CPIO) * static_cast<uint32_t>(C)) * static_cast<uint32_t>(sizeof(TO)), 0); \
+        } else {                                                                                                   \
+          dma_lds<4>(sink_w, 0u, rx, 0u);                                                                          \
+        }                                                                                                          \
       }                                                                                                            \
     } else {                                                               /* nothing to store: keep the count (loads nobody reads) */ \
       _Pragma("unroll") for (int k = 0; k < NSO; ++k) dma_lds<4>(sink_w, 0u, rx, 0u);                              \

@@ -108,6 +108,31 @@ def _dwconv_case(R, lib, N, C, H, W, xdt, odt):
     close(db, gb, 1e-4, 1e-4 * float(gb.abs().max()) + 1e-5)
 
 
+@pytest.mark.parametrize("N,C,H,W", [(128, 128, 80, 80), (128, 768, 10, 10), (64, 64, 24, 64), (96, 192, 32, 32)])
+def test_dwconv_dma_ragged_fp32_stores_under_load(R, N, C, H, W):
+    """bf16 in, fp32 out, no add operand, widths with W % 7 in 1..4, the whole chip busy: the second 16-byte store group of the
+    ragged last strip has no active lane in some wavefronts; the kernel must still issue a constant number of VMEM instructions
+    per step (a sink load stands in), or its counted vmcnt waits let a row be read before its LDS-DMA has landed (round-4 advice).
+    Checked against the fp32 convolution of the same bf16-rounded operands on the GPU (library path, different kernel), twice."""
+    lib = R._lib.load()
+    prev = lib.cnx_dwconv7x7_win_policy(1)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(C + W)
+        dy = torch.randn(N, H, W, C, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(C, 1, 7, 7, device="cuda", generator=g) * 0.2)
+        w49c = w.reshape(C, 49).t().contiguous()
+        code = R._lib.dtype_code
+        ref = F.conv2d(dy.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float().flip(-1, -2), None, padding=3, groups=C)
+        for _ in range(2):
+            dx = torch.full((N, H, W, C), float("nan"), device="cuda")
+            assert lib.cnx_dwconv7x7_nhwc(dy.data_ptr(), code(torch.bfloat16), w49c.data_ptr(), None, None, dx.data_ptr(), 0,
+                                          N, H, W, C, 1, S()) == 0
+            err = (dx.permute(0, 3, 1, 2) - ref).abs().max().item()
+            assert err <= 1e-3, err                               # fp32 accumulation of 49 bf16 products, |values| ~ 1
+    finally:
+        lib.cnx_dwconv7x7_win_policy(prev)
+
+
 @pytest.mark.parametrize("M_,C", [(5, 48), (37, 96), (64, 64), (10, 144), (33, 192), (21, 384), (9, 768), (4, 1536), (3, 8),
                                   (1000, 48), (3000, 96), (700, 384), (300, 768)])
 @pytest.mark.parametrize("gelu", [0, 1])
