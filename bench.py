@@ -380,6 +380,20 @@ def spawn_ranks(args, child_argv=None, ndev=None) -> int:
     return 0
 
 
+def mark_graph_fallbacks(extra, graph, graph_train):
+    """``{"error": ...}`` entries for a step that ran on an eager fallback although replay was asked for: a failed (or missing)
+    capture of the attack (``extra["attack_graph"]`` = graphed.STATS) or of the training pass (``extra["train_graph"]``).  Such an
+    entry lands in ``extra.errors`` and makes ``--strict`` exit non-zero: under a process group a failed three-segment capture must
+    not pass for a measurement of the replayed N > 1 step."""
+    tg, ag = extra.get("train_graph") or {}, extra.get("attack_graph") or {}
+    if graph_train and (tg.get("failed") or not tg.get("captured")):
+        tg["error"] = ("the training pass was NOT replayed from hipGraphs (capture failed or never happened): this line measured "
+                       "the eager training pass")
+    if graph and (ag.get("failed") or not ag.get("captures")):
+        ag["error"] = "the attack was NOT replayed from hipGraphs (capture failed or never happened): this line measured the eager attack"
+    return extra
+
+
 class PowerSampler:
     """Package power and shader clock of this rank's GPU from sysfs hwmon (power1_input in uW, freq1_input in Hz), sampled by a
     host thread during the timed steps.  The fused LN+MLP kernels run AT the package power cap (profiles/r02_power_and_overlap.md),
@@ -476,9 +490,24 @@ def main():
     # the attack's hipGraphs are captured on its third call (graphed.WARMUP_CALLS eager calls first): never inside the timed region
     # ... and the training pass on the step after TRAIN_GRAPH_WARMUP eager ones
     n_warm = max(args.warmup, R.graphed.WARMUP_CALLS + 1, R.train_step.TRAIN_GRAPH_WARMUP + 1) if args.graph else args.warmup
+    if world > 1:
+        # Library find / autotune (MIOpen's per-shape search, hipBLASLt's heuristics) is per process: eight ranks would each spend
+        # the same seconds on it, at once, on one host.  Rank 0 meets every shape first - one local training forward / backward,
+        # no optimizer step, no collective - and leaves its results in the user find-db; the others follow behind a barrier.
+        t_lib = time.perf_counter()
+        if rank == 0:
+            trainer.warm_libraries(x, y)
+            torch.cuda.synchronize()
+        dist.barrier()
+        if rank != 0:
+            trainer.warm_libraries(x, y)
+            torch.cuda.synchronize()
+        dist.barrier()
+        t_lib = time.perf_counter() - t_lib
     for _ in range(n_warm):
         trainer.step(x, y)
     sync()
+    reduces0 = trainer.sync.reduces if trainer.sync else 0
     apgd_mod.PROFILE_EVENTS = []                                # K1 launches get bracketed by HIP events
     power = PowerSampler(dev.index or 0) if rank == 0 else None
     if power:
@@ -492,6 +521,7 @@ def main():
     dt_enqueue = time.perf_counter() - t0                      # host time inside the K step() calls (no synchronisation in a step)
     sync()
     dt = time.perf_counter() - t0
+    reduces_per_step = ((trainer.sync.reduces - reduces0) / args.steps) if trainer.sync else None
     power_stats = power.stop() if power else None
     events = apgd_mod.PROFILE_EVENTS
     apgd_mod.PROFILE_EVENTS = None
@@ -503,6 +533,9 @@ def main():
     # roofline of the dominant hand-written kernel (APGD Linf update), its two forms reported separately:
     #   general (i >= 1): 20 algorithmic B/elem - the `roofline` object;
     #   first   (i == 0): x_adv_old aliases x_adv, 16 algorithmic B/elem - `roofline.first_iter`.
+    # Since round 5 the launch also performs the row moves of the iteration before it (K3; at i = 0 the prologue's clones): its
+    # algorithmic bytes are the SUM of the step's and the row moves' (SURVEY.md §8d gives both rules; the latter from the flag bytes
+    # each timed launch read); `frac_step_only` keeps the step's 20 (16) B/element over the same time for comparison with rounds 1-4.
     # `achieved` = algorithmic bytes / HIP-event time measured here; `traffic` = HBM bytes per launch of the same kernel
     # form from the PMC passes (profiles/k1_traffic.json).  With int8 gradient signs the kernel moves 17 / 13 B/elem, i.e.
     # LESS than the algorithmic figure: `bytes_moved` and `moved_GBs` state that side by side.
@@ -513,30 +546,78 @@ def main():
     except Exception:
         pass
 
+    E_row = 3 * args.res * args.res
+
+    def track_bytes(flags, gbytes, first):
+        """(algorithmic, moved) bytes of the row moves a fused update launch performs (per flagged sample 8 B/elem
+        read + 4 B/elem per destination written - x_best, grad_best, x_best_adv; a restore counts 8 + 8) from the flag bytes the
+        launch read.  Iteration 0 writes the prologue's three clones (4 B/elem each; their source is the step's own operand)."""
+        if first:
+            return 12.0 * n_elem, (8.0 + gbytes) * n_elem, (B, B, 0)
+        if flags is None:
+            return 0.0, 0.0, (0, 0, 0)
+        f = flags.to(torch.int64)
+        nb, mc, hv = (f & 1) != 0, (f & 2) != 0, (f & 4) != 0
+        rs = hv & ~nb
+        anyf = nb | mc                                        # (a restore-only sample: its 8 + 8 are counted below, no more)
+        alg = (8.0 * anyf.sum() + 8.0 * nb.sum() + 4.0 * mc.sum() + 16.0 * rs.sum()).item() * E_row
+        # moved: the step reads x_adv / grad anyway; NEW_BEST writes 4 + g, MISCLS 4, a restore reads 4 + g and writes 4
+        mov = ((4.0 + gbytes) * nb.sum() + 4.0 * mc.sum() + (8.0 + gbytes) * rs.sum()).item() * E_row
+        return alg, mov, (int(nb.sum()), int(mc.sum()), int(rs.sum()))
+
     def k1_entry(sel, alg_bpe, form):
-        ev = [(a.elapsed_time(b), gb) for (name, i, a, b, gb) in events if name == "apgd_linf_step_f32" and sel(i)]
+        ev = [(a.elapsed_time(b), gb, name, fl) for (name, i, a, b, gb, fl) in events if name.startswith("apgd_linf_step") and sel(i)]
         if not ev:
             return None
-        avg_ms = sum(t for t, _ in ev) / len(ev)
+        avg_ms = sum(e[0] for e in ev) / len(ev)
         gbytes = ev[0][1]
-        blk = gbytes == 1 and R.ops.SIGN_BLOCKED and (3 * args.res * args.res) % 1024 == 0    # the stem's blocked sign order
-        moved_bpe = alg_bpe - 4 + gbytes
-        ach = alg_bpe * n_elem / (avg_ms * 1e-3) / 1e9
-        tr = traffic_tab.get(f"{form}_{('i8blk' if blk else 'i8') if gbytes == 1 else 'f32'}", {})
-        traffic = tr.get("hbm_bytes_per_launch") if n_elem * alg_bpe == tr.get("algorithmic_bytes_per_launch") else None
+        fused = ev[0][2] == "apgd_linf_step_track_f32"
+        blk = gbytes == 1 and R.ops.SIGN_BLOCKED and E_row % 1024 == 0 and not fused          # the stem's blocked sign order
+        step_alg, step_mov = alg_bpe * n_elem, (alg_bpe - 4 + gbytes) * n_elem
+        tb = [track_bytes(e[3], gbytes, form == "first") if fused else (0.0, 0.0, (0, 0, 0)) for e in ev]
+        alg_launch = step_alg + sum(t[0] for t in tb) / len(tb)                              # average per launch
+        mov_launch = step_mov + sum(t[1] for t in tb) / len(tb)
+        ach = alg_launch / (avg_ms * 1e-3) / 1e9
+        gname = ('i8blk' if blk else 'i8') if gbytes == 1 else 'f32'
+        traffic, tr, traffic_src = None, {}, None
+        for key in ([f"track_{form}_{gname}_f3", f"track_{form}_{gname}_f1", f"track_{form}_{gname}"] if fused else [f"{form}_{gname}"]):
+            tr = traffic_tab.get(key, {})
+            if tr and abs(alg_launch - tr.get("algorithmic_bytes_per_launch", -1)) < 1.0:
+                traffic, traffic_src = tr.get("hbm_bytes_per_launch"), f"PMC pass of this kernel form ({key})"
+                break
+        if traffic is None and fused and form == "general" and n_elem == 256 * 3 * 224 * 224:
+            # a launch's flag bytes are a MIX (most samples NEW_BEST | MISCLS, some NEW_BEST only, ...): the PMC passes cover the
+            # uniform mixes (every sample 3, every sample 1) and the plain step; the kernel's traffic is linear in the per-flag sample
+            # counts (PMC / designed bytes = 1.0000 in every pass), so the launch's traffic is assembled from the passes' per-sample costs
+            t0, t1, t3 = (traffic_tab.get(k, {}).get("hbm_bytes_per_launch") for k in
+                          (f"general_{gname}", f"track_general_{gname}_f1", f"track_general_{gname}_f3"))
+            if t0 and t1 and t3:
+                nbr, mcr, rsr = (sum(t[2][k] for t in tb) / len(tb) for k in range(3))
+                traffic = t0 + nbr * (t1 - t0) / B + mcr * (t3 - t1) / B + rsr * (8.0 + gbytes) * E_row
+                traffic_src = ("PMC passes of the plain step and of the uniform flag mixes 1 / 3, combined by this run's average per-flag "
+                               f"sample counts per launch (NEW_BEST {nbr:.1f}, MISCLS {mcr:.1f}, restore {rsr:.1f} of {B})")
         if traffic is None and rank == 0:
             print(f"bench.py: roofline.traffic is null for the {form} K1 form - profiles/k1_traffic.json holds PMC passes of the headline "
-                  f"shape only ({tr.get('algorithmic_bytes_per_launch')} algorithmic bytes per launch; this run: {int(n_elem * alg_bpe)}); "
+                  f"shape and of uniform flag bytes only (this run: {alg_launch:.0f} algorithmic bytes per launch); "
                   "re-run tools/k1_traffic.py for this shape", file=sys.stderr)
+        if fused:
+            kern = f"linf_step_track_vec4_kernel<{'true' if form == 'first' else 'false'}> (apgd_linf_step_track_f32: the Linf step + "
+            kern += ("the prologue's clones" if form == "first" else "the row moves of the iteration before it")
+            kern += f", {'int8 sign' if gbytes == 1 else 'fp32'} gradient)"
+        else:
+            kern = ((("linf_step_i8blk_kernel<false>" if form == "general" else "linf_step_i8blk_kernel<true>") if blk else
+                     ("linf_step_vec4_kernel" if form == "general" else "linf_step_first_vec4_kernel"))
+                    + f" (apgd_linf_step_f32, {('blocked int8 sign' if blk else 'int8 sign') if gbytes == 1 else 'fp32'} gradient)")
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": (("linf_step_i8blk_kernel<false>" if form == "general" else "linf_step_i8blk_kernel<true>") if blk else
-                           ("linf_step_vec4_kernel" if form == "general" else "linf_step_first_vec4_kernel"))
-                          + f" (apgd_linf_step_f32, {('blocked int8 sign' if blk else 'int8 sign') if gbytes == 1 else 'fp32'} gradient)",
-                "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": alg_bpe * n_elem,
-                "bytes_moved": moved_bpe * n_elem, "moved_GBs": round(moved_bpe * n_elem / (avg_ms * 1e-3) / 1e9, 1),
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic and round(traffic), "traffic_source": traffic_src, "kernel": kern,
+                "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": round(alg_launch),
+                # SURVEY 8d: the step's 20 (16) B/element + the row moves' bytes from the flag bytes each launch read
+                "algorithmic_bytes_step": step_alg, "algorithmic_bytes_row_moves": round(alg_launch - step_alg),
+                "bytes_moved": round(mov_launch), "moved_GBs": round(mov_launch / (avg_ms * 1e-3) / 1e9, 1),
                 # the PHYSICAL reading: bytes the kernel is designed to move (= the PMC traffic) / time / 8 TB/s
-                "frac_moved": round(moved_bpe * n_elem / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                "frac_moved": round(mov_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # the step alone at its 20 (16) B/element over the same time (what rounds 1-4 reported for the unfused kernel)
+                "frac_step_only": round(step_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     roof = k1_entry(lambda i: i > 0, K1_BYTES_PER_ELEM, "general")
     first = k1_entry(lambda i: i == 0, K1_BYTES_PER_ELEM_IT0, "first")
@@ -598,10 +679,17 @@ def main():
                                                          if world > 1 else 0),
                                          "copies": 3} if args.graph else None),
              "train_graph": {"enabled": bool(trainer.graph_train),
-                             "captured": sum(v is not None for v in trainer._tg.values()), "failed": sum(v is None for v in trainer._tg.values())},
+                             "captured": sum(v is not None for v in trainer._tg.values()), "failed": sum(v is None for v in trainer._tg.values()),
+                             # graph segments of the captured training pass: 1 on one GPU, 3 with the two all-reduces between them
+                             "segments": [v.n_graphs for v in trainer._tg.values() if v is not None]},
              # how the ranks' gradients meet: "flat" = train_step.FlatGradSync (same replayed step at every N), "ddp" = torch DDP
              "grad_sync": {"path": grad_sync, "allreduce_bytes_per_step": trainer.sync.bytes_per_step if trainer.sync else None,
-                           "groups_MB": [round(4e-6 * b.numel(), 1) for b in trainer.sync.flat] if trainer.sync else None}}
+                           "groups_MB": [round(4e-6 * b.numel(), 1) for b in trainer.sync.flat] if trainer.sync else None,
+                           "reduces_per_step": reduces_per_step, "cut": bool(trainer.sync and trainer.sync.cut is not None),
+                           "library_warmup_s": round(t_lib, 2) if world > 1 else None}}
+    # A capture that failed leaves the step on its eager fallback (correct, but 30 - 40 ms of host per step): that must not pass for a
+    # measurement of the replayed step - an {"error": ...} entry puts it into extra.errors, and --strict fails the run.
+    mark_graph_fallbacks(extra, bool(args.graph), bool(trainer.graph_train))
     if True:
         # attack-only throughput (same tensors, eval mode), a few repetitions
         base = trainer.inner.base_model

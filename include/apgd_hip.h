@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define APGD_HIP_VERSION 10500 /* major*10000 + minor*100 + patch */
+#define APGD_HIP_VERSION 10600 /* major*10000 + minor*100 + patch */
 
 #define APGD_OK 0
 #define APGD_ERR_NULL (-1)    /* required pointer is NULL */
@@ -84,6 +84,23 @@ int apgd_linf_step_f32_ex(const float* x, const float* x_adv, const float* x_adv
                           float* out, uint16_t* out_bf16, int64_t B, int64_t E, float eps, float a,
                           int32_t blocks_per_sample, int32_t unroll, int32_t nontemporal,
                           void* stream);
+
+/* a2 + a4-a6 in one pass (round 5): the Linf step of iteration i+1 together with the row moves iteration i decided on —
+ * autopgd_train_clean.py:213-226, 260 and :304, 322-323, 345-346.  Per sample, by flags[b] (apgd_state_update of iteration i):
+ *   MISCLS   : x_best_adv <- x_adv
+ *   NEW_BEST : x_best <- x_adv, grad_best <- grad
+ *   HALVE (without NEW_BEST): the step runs from x_best / grad_best, and x_adv <- x_best (the buffer becomes x_adv_old by the
+ *              host's rotation); grad itself is not rewritten - the next backward replaces it (:277-283)
+ * then out = the step of apgd_linf_step_f32 on those operands, same arithmetic bit for bit.
+ * flags == NULL selects the iteration-0 form (requires x_adv_old == x_adv, a == 1): the prologue's clones x_best = x_best_adv =
+ * x_adv (:142-143) and grad_best = grad (:189) are written here, so apgd_init_f32 only has to produce x_adv.
+ * grad / grad_best: fp32, bf16 or APGD_I8 (not the blocked order).  Algorithmic bytes per element: 20 (16 at i = 0)
+ * for the step + for a flagged sample 8 + 4 per destination written (the restore counts 8 + 8).  The LAST iteration's row moves
+ * have no following step and stay with apgd_track_rows(final = 1). */
+int apgd_linf_step_track_f32(const float* x, float* x_adv, const float* x_adv_old,
+                             const void* grad, int grad_dtype, const float* step_size, float* out,
+                             const uint8_t* flags, float* x_best, void* grad_best, float* x_best_adv,
+                             int64_t B, int64_t E, float eps, float a, void* stream);
 
 /* a8 L2 step — autopgd_train_clean.py:228-237 with L2_norm (:14-18).  Four passes
  * (three per-sample sum-of-squares reductions, wavefront __shfl + LDS, deterministic order)

@@ -91,6 +91,17 @@ int64_t cnx_stem_conv_packed_bytes(int32_t P);
 int cnx_stem_conv_pack(const void* w, int w_dtype, void* wq, int32_t P, void* stream);
 int cnx_stem_conv_fwd(const float* x, const void* wq, const float* bias, void* out,
                       int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
+/* Filter / bias gradient of the same convolution (utils_architecture.py:205-211 backward; replaces the library's
+ * convolution_backward = MIOpen, whose per-process solver search ran seconds inside every rank's warm-up):
+ *   dw[p][ci][kh][kw] = sum_{n,oh,ow} dy[n,oh,ow,p] * bf16(x[n,ci,2oh-1+kh,2ow-1+kw]);  dbias[p] = sum dy      (fp32 results)
+ * x: the fp32 NCHW image batch, dy: bf16 [N, H/2, W/2, P] rows; bf16 operands, fp32 accumulation on the matrix pipe (the
+ * contraction runs over the positions: dy rows reach the MFMA through LDS transpose reads, see csrc/wgrad_kernels.hip).
+ * Deterministic: per-workgroup partial results in ws (cnx_stem_conv_wgrad_ws_floats(P) floats) summed in a fixed order.
+ * dbias may be NULL.  Same size limits as cnx_stem_conv_fwd. */
+int64_t cnx_stem_conv_wgrad_ws_floats(int32_t P);
+int cnx_stem_conv_wgrad(const float* x, const void* dy, float* dw, float* dbias, float* ws,
+                        int64_t N, int32_t H, int32_t W, int32_t P, void* stream);
+
 /* The same convolution with the ConvStem's LayerNorm(channels_first) + GELU (utils_architecture.py:76-81, 128-129) applied to
  * the output tile while it is still on chip: act [N, H/2, W/2, P] bf16 = GELU(LN(conv(x) rounded to bf16)); y (nullable: a
  * gradient-free forward does not need it) = the convolution output, mean / rstd (nullable pair) [N*H/2*W/2] the LayerNorm

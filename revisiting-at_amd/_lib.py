@@ -27,6 +27,7 @@ PROTOTYPES = {
     "apgd_linf_step_f32": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _f, _f, _p]),
     "apgd_linf_step_f32_ex": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _f, _f,
                                         _i32, _i32, _i32, _p]),
+    "apgd_linf_step_track_f32": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _p]),
     "apgd_l2_parts": (C.c_int, []),
     "apgd_l2_step_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _p]),
     "apgd_loss_pred": (C.c_int, [_p, C.c_int, _i64, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _p]),
@@ -67,6 +68,8 @@ PROTOTYPES = {
     "cnx_stem_conv_pack": (C.c_int, [_p, C.c_int, _p, _i32, _p]),
     "cnx_stem_conv_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_ln_gelu_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_stem_conv_wgrad_ws_floats": (C.c_int64, [_i32]),
+    "cnx_stem_conv_wgrad": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_dgrad": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_dgrad_sign": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_stem_conv_dgrad_sign_blk": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),

@@ -42,6 +42,10 @@ K1_SHAPE = None
 # (ops.grad_sign_sink).  Same decisions bit for bit; 17 instead of 20 bytes per element in the update kernel.
 USE_SIGN_SINK = True
 
+# the Linf update kernel also performs the row moves of the iteration before it (apgd_linf_step_track_f32): one element-wise
+# pass per iteration instead of two.  False = the separate apgd_track_rows pass of rounds 1-4 (kept for A/B and the tests)
+FUSED_TRACKING = os.environ.get("APGD_FUSED_TRACKING", "1") not in ("0", "")
+
 # default of apgd_train(graph=None): hipGraph replay of the attack (graphed.py)
 GRAPH_DEFAULT = os.environ.get("APGD_GRAPH", "0") not in ("0", "")
 
@@ -146,7 +150,9 @@ class ApgdWorkspace:
         self.loss_steps = torch.zeros(max(n_iter, 1), B, **f32)     # :144
         self.pred = torch.empty(B, device=dev, dtype=torch.uint8)
         self.acc = torch.empty(B, device=dev, dtype=torch.uint8)
-        self.flags = torch.empty(B, device=dev, dtype=torch.uint8)
+        # flag bytes of every iteration (apgd_state_update): row i drives the row moves of iteration i, which the Linf step of
+        # iteration i + 1 performs (apgd_linf_step_track_f32); bench.py reads them back for the algorithmic-byte count
+        self.flags = torch.zeros(max(n_iter, 1), B, device=dev, dtype=torch.uint8)
 
 
 def _model_fwd_bwd_inner(model, x_in: torch.Tensor, y_hard, y_soft, ws: ApgdWorkspace, loss_out, pred_out,
@@ -372,8 +378,11 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
             start = torch.empty_like(x).copy_(x_init)
     if y_target is not None:
         y_target = y_target.detach().to(torch.int64).contiguous()
-    _lib.check(lib.apgd_init_f32(start.data_ptr(), cur.data_ptr(), ws.x_best.data_ptr(), ws.x_best_adv.data_ptr(),
-                                 x.numel(), stream), "apgd_init_f32")       # :135, 141-143
+    # Linf: the update kernel also makes the row moves of the iteration before it (and, at i = 0, the prologue's clones), see
+    # apgd_linf_step_track_f32; the blocked sign order and L2 keep the separate tracking pass
+    fused = norm == 'Linf' and n_iter > 0 and FUSED_TRACKING
+    _lib.check(lib.apgd_init_f32(start.data_ptr(), cur.data_ptr(), None if fused else ws.x_best.data_ptr(),
+                                 None if fused else ws.x_best_adv.data_ptr(), x.numel(), stream), "apgd_init_f32")  # :135, 141-143
     alpha = 2.0                                                              # :159
     step_size = torch.full((B,), alpha * eps, device=x.device, dtype=torch.float32)   # :169-170
     sched = dict(checkpoint_schedule(n_iter))
@@ -386,7 +395,13 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
     grad = _model_fwd_bwd_split(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok, sign_ok, splits,
                                 attack_gemm)
     grad_best = torch.empty_like(grad)                                       # :189
-    grad_best.copy_(grad)
+    if fused and getattr(grad, "apgd_blocked", False):
+        # (blocked signs, APGD_SIGN_BLOCKED=1: an experiment of round 3, slower) the prologue's clones after all
+        fused = False
+        ws.x_best.copy_(cur)
+        ws.x_best_adv.copy_(cur)
+    if not fused:
+        grad_best.copy_(grad)
     ws.loss_best_last.copy_(ws.loss_best)                                    # :200
     old = cur                                                                # :205 (x_adv_old == x_adv)
     free = [ws.rot[1]] + ([ws.rot[2]] if n_iter > 1 else [])
@@ -395,13 +410,21 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
         a = 0.75 if i > 0 else 1.0                                           # :218
         out = free.pop()
         if norm == 'Linf':
-            def k1(i=i, a=a, cur=cur, old=old, grad=grad, out=out):
+            fl_prev = ws.flags[i - 1] if (fused and i > 0) else None         # the flag bytes iteration i - 1 wrote
+            def k1(i=i, a=a, cur=cur, old=old, grad=grad, out=out, fl_prev=fl_prev):
                 # (the stream is looked up when the closure RUNS: under graph replay that is not the capture stream)
                 if PROFILE_EVENTS is not None:
+                    fl = fl_prev.clone() if fl_prev is not None else None            # what this launch will read (outside the bracket)
                     ev0 = torch.cuda.Event(enable_timing=True)
                     ev0.record()
                 g_code = _lib.I8_BLK if getattr(grad, "apgd_blocked", False) else _lib.dtype_code(grad.dtype)
-                if K1_SHAPE is not None and g_code != _lib.I8_BLK:
+                if fused:
+                    _lib.check(lib.apgd_linf_step_track_f32(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
+                                                            step_size.data_ptr(), out.data_ptr(),
+                                                            _lib.ptr(fl_prev), ws.x_best.data_ptr(),
+                                                            grad_best.data_ptr(), ws.x_best_adv.data_ptr(), B, E, eps, a,
+                                                            _stream_ptr()), "apgd_linf_step_track_f32")   # :214-226 + :304, 322-323, 345-346
+                elif K1_SHAPE is not None and g_code != _lib.I8_BLK:
                     _lib.check(lib.apgd_linf_step_f32_ex(x.data_ptr(), cur.data_ptr(), old.data_ptr(), grad.data_ptr(), g_code,
                                                          step_size.data_ptr(), out.data_ptr(), None, B, E, eps, a, int(K1_SHAPE[0]),
                                                          int(K1_SHAPE[1]), int(K1_SHAPE[2]), _stream_ptr()), "apgd_linf_step_f32_ex")
@@ -412,7 +435,8 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
                 if PROFILE_EVENTS is not None:
                     ev1 = torch.cuda.Event(enable_timing=True)
                     ev1.record()
-                    PROFILE_EVENTS.append(("apgd_linf_step_f32", i, ev0, ev1, grad.element_size()))
+                    PROFILE_EVENTS.append(("apgd_linf_step_track_f32" if fused else "apgd_linf_step_f32", i, ev0, ev1,
+                                           grad.element_size(), fl))
             if rec is not None:
                 rec.eager(k1)
             else:
@@ -440,11 +464,12 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
         _lib.check(lib.apgd_state_update(ws.loss.data_ptr(), ws.pred.data_ptr(), ws.acc.data_ptr(),
                                          ws.loss_best.data_ptr(), ws.loss_best_last.data_ptr(),
                                          ws.reduced_last.data_ptr(), step_size.data_ptr(), ws.loss_steps.data_ptr(),
-                                         ws.flags.data_ptr(), B, n_iter, i, int(do_check), k, float(k * 0.75), stream),
+                                         ws.flags[i].data_ptr(), B, n_iter, i, int(do_check), k, float(k * 0.75), stream),
                    "apgd_state_update")                                      # :296, 319-343
-        _lib.check(lib.apgd_track_rows(ws.flags.data_ptr(), cur.data_ptr(), grad.data_ptr(), ws.x_best.data_ptr(),
-                                       grad_best.data_ptr(), ws.x_best_adv.data_ptr(), grad.element_size(), B, E,
-                                       int(last), stream), "apgd_track_rows")  # :304, 322-323, 345-346
+        if last or not fused:                                # (fused: iteration i's row moves ride on the step of iteration i + 1)
+            _lib.check(lib.apgd_track_rows(ws.flags[i].data_ptr(), cur.data_ptr(), grad.data_ptr(), ws.x_best.data_ptr(),
+                                           grad_best.data_ptr(), ws.x_best_adv.data_ptr(), grad.element_size(), B, E,
+                                           int(last), stream), "apgd_track_rows")  # :304, 322-323, 345-346
         if verbose:                                                          # :306-311 (host sync, debug only)
             print('iteration: {} - best loss: {:.6f} curr loss {:.6f} - robust accuracy: {:.2%} - step size: {:.5f}'.format(
                 i, ws.loss_best.sum().item(), ws.loss.mean().item(), ws.acc.float().mean().item(),

@@ -44,14 +44,16 @@ def load_weights(model: torch.nn.Module, ckpt) -> str:
             return 'loaded'                                                           # :868-871
 
 
-def save_weights(model: torch.nn.Module, folder, epoch: int, ema_state: Dict[str, torch.Tensor] = None):
+def save_weights(model, folder, epoch: int, ema_state: Dict[str, torch.Tensor] = None):
+    """``model``: anything with ``state_dict()`` - pass the ``ATTrainStep`` itself under N > 1 ranks: its ``state_dict()`` carries the
+    ``module.`` prefix of the reference's DDP-wrapped model also on the flat gradient path (no DDP object there)."""
     os.makedirs(folder, exist_ok=True)
     torch.save(model.state_dict(), os.path.join(folder, f'weights_{epoch}.pt'))       # main.py:738
     if ema_state is not None:
         torch.save(ema_state, os.path.join(folder, f'weights_ema_{epoch}.pt'))        # :740
 
 
-def save_full(model: torch.nn.Module, optimizer, folder, epoch: int, ema_state=None):
+def save_full(model, optimizer, folder, epoch: int, ema_state=None):
     os.makedirs(folder, exist_ok=True)
     d = {'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict(), 'epoch': epoch}
     if ema_state is not None:

@@ -45,6 +45,9 @@ template <> struct Elt<uint16_t> {  // bf16
   static __device__ __forceinline__ float load(const uint16_t* p, int64_t i) { return bf16_to_f32(p[i]); }
   static __device__ __forceinline__ void store(uint16_t* p, int64_t i, float v) { p[i] = f32_to_bf16_rne(v); }
 };
+template <> struct Elt<int8_t> {    // gradient signs
+  static __device__ __forceinline__ float load(const int8_t* p, int64_t i) { return static_cast<float>(p[i]); }
+};
 template <> struct Elt<_Float16> {
   static __device__ __forceinline__ float load(const _Float16* p, int64_t i) { return static_cast<float>(p[i]); }
   static __device__ __forceinline__ void store(_Float16* p, int64_t i, float v) { p[i] = static_cast<_Float16>(v); }
@@ -673,6 +676,124 @@ inline int blocks_for(int64_t work_items, int64_t per_block, int64_t cap) {
   return static_cast<int>(n);
 }
 
+// ---------------------------------------------------------------- a2 + a4-a6 in one pass
+// The Linf step of iteration i + 1 reads x_adv(i) and grad(i) anyway: it also performs the row moves iteration i decided on
+// (apgd_state_update's flag byte; :304, 322-323, 345-346) instead of leaving them to a pass of their own:
+//   NEW_BEST : x_best <- x_adv, grad_best <- grad                               (4 + sizeof(GT) more bytes written per element)
+//   MISCLS   : x_best_adv <- x_adv                                              (4 more)
+//   HALVE (and not NEW_BEST - then the restore is a no-op): the step runs from x_best / grad_best instead of x_adv / grad,
+//              and x_adv <- x_best so that the buffer is the restored iterate when the rotation makes it x_adv_old (:215, 345);
+//              grad is not rewritten: the next backward replaces it (:277-283) and nothing else reads it.
+// The flags are per sample = per blockIdx.y: wave-uniform branches, the element math is linf_elem / linf_elem_first unchanged.
+// FIRST (iteration 0; flags == NULL): x_adv_old is x_adv, a == 1, and the prologue's clones are made here - x_best = x_best_adv =
+// x_adv (:142-143), grad_best = grad (:189) - so that apgd_init_f32 writes x_adv only.
+template <typename GT> struct Raw4;
+template <> struct Raw4<float> {
+  typedef f32x4 T;
+  static __device__ __forceinline__ G4 cvt(T t) { return {t.x, t.y, t.z, t.w}; }
+};
+template <> struct Raw4<uint16_t> {
+  typedef u32x2 T;
+  static __device__ __forceinline__ G4 cvt(T t) {
+    return {__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+  }
+};
+template <> struct Raw4<int8_t> {
+  typedef uint32_t T;
+  static __device__ __forceinline__ G4 cvt(T t) {
+    return {static_cast<float>(static_cast<int8_t>(t & 0xffu)), static_cast<float>(static_cast<int8_t>((t >> 8) & 0xffu)),
+            static_cast<float>(static_cast<int8_t>((t >> 16) & 0xffu)), static_cast<float>(static_cast<int8_t>(t >> 24))};
+  }
+};
+
+template <typename GT, bool FIRST>
+__global__ __launch_bounds__(kBlock) void linf_step_track_vec4_kernel(
+    const float* __restrict__ x, float* xa, const float* xo, const GT* g, const float* __restrict__ step,
+    float* __restrict__ out, const uint8_t* __restrict__ flags, float* xb, GT* gb, float* xba,
+    int64_t E, float eps, float a, float oma) {
+  typedef typename Raw4<GT>::T RT;
+  const int64_t b = blockIdx.y;
+  const float st = step[b];
+  const uint32_t f = FIRST ? (APGD_FLAG_NEW_BEST | APGD_FLAG_MISCLS) : flags[b];
+  const bool nb = f & APGD_FLAG_NEW_BEST, mc = f & APGD_FLAG_MISCLS;
+  const bool rs = (f & APGD_FLAG_HALVE) && !nb;
+  const int64_t row = b * E;
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;      // one float4 per stream per thread
+  if (v >= (E >> 2)) return;
+  const f32x4 X = reinterpret_cast<const f32x4*>(x + row)[v];
+  f32x4 A = reinterpret_cast<const f32x4*>(xa + row)[v];
+  f32x4 O;
+  if (!FIRST) O = reinterpret_cast<const f32x4*>(xo + row)[v];
+  RT Gr = reinterpret_cast<const RT*>(g + row)[v];
+  if (mc) reinterpret_cast<f32x4*>(xba + row)[v] = A;                             // :304 (the iterate as the model saw it)
+  if (nb) {                                                                       // :322-323
+    reinterpret_cast<f32x4*>(xb + row)[v] = A;
+    reinterpret_cast<RT*>(gb + row)[v] = Gr;
+  } else if (rs) {                                                                // :345-346
+    A = reinterpret_cast<const f32x4*>(xb + row)[v];
+    Gr = reinterpret_cast<const RT*>(gb + row)[v];
+    reinterpret_cast<f32x4*>(xa + row)[v] = A;
+  }
+  const G4 Gd = Raw4<GT>::cvt(Gr);
+  f32x4 r;
+  if (FIRST) {
+    r.x = linf_elem_first(X.x, A.x, Gd.x, st, eps); r.y = linf_elem_first(X.y, A.y, Gd.y, st, eps);
+    r.z = linf_elem_first(X.z, A.z, Gd.z, st, eps); r.w = linf_elem_first(X.w, A.w, Gd.w, st, eps);
+  } else {
+    r.x = linf_elem(X.x, A.x, O.x, Gd.x, st, eps, a, oma); r.y = linf_elem(X.y, A.y, O.y, Gd.y, st, eps, a, oma);
+    r.z = linf_elem(X.z, A.z, O.z, Gd.z, st, eps, a, oma); r.w = linf_elem(X.w, A.w, O.w, Gd.w, st, eps, a, oma);
+  }
+  reinterpret_cast<f32x4*>(out + row)[v] = r;
+}
+
+// any E / alignment: one element per thread
+template <typename GT, bool FIRST>
+__global__ __launch_bounds__(kBlock) void linf_step_track_scalar_kernel(
+    const float* __restrict__ x, float* xa, const float* xo, const GT* g, const float* __restrict__ step,
+    float* __restrict__ out, const uint8_t* __restrict__ flags, float* xb, GT* gb, float* xba,
+    int64_t E, float eps, float a, float oma) {
+  const int64_t b = blockIdx.y;
+  const float st = step[b];
+  const uint32_t f = FIRST ? (APGD_FLAG_NEW_BEST | APGD_FLAG_MISCLS) : flags[b];
+  const bool nb = f & APGD_FLAG_NEW_BEST, mc = f & APGD_FLAG_MISCLS;
+  const bool rs = (f & APGD_FLAG_HALVE) && !nb;
+  const int64_t row = b * E;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < E; e += stride) {
+    const float X = x[row + e];
+    float A = xa[row + e];
+    GT Gr = g[row + e];
+    if (mc) xba[row + e] = A;
+    if (nb) { xb[row + e] = A; gb[row + e] = Gr; }
+    else if (rs) { A = xb[row + e]; Gr = gb[row + e]; xa[row + e] = A; }
+    const float G = Elt<GT>::load(&Gr, 0);
+    out[row + e] = FIRST ? linf_elem_first(X, A, G, st, eps) : linf_elem(X, A, xo[row + e], G, st, eps, a, oma);
+  }
+}
+
+template <typename GT>
+int linf_track_dispatch(const float* x, float* xa, const float* xo, const GT* g, const float* step, float* out,
+                        const uint8_t* flags, float* xb, GT* gb, float* xba, int64_t B, int64_t E, float eps, float a,
+                        bool vec, hipStream_t s) {
+  const float oma = static_cast<float>(1.0 - static_cast<double>(a));   // python: (1 - a) in double, then fp32
+  const bool first = flags == nullptr;
+  if (vec) {
+    const dim3 grid(blocks_for(E / 4, kBlock, 65535), static_cast<unsigned>(B));
+    if (static_cast<int64_t>(grid.x) * kBlock < E / 4) return APGD_ERR_SIZE;
+    if (first)
+      hipLaunchKernelGGL((linf_step_track_vec4_kernel<GT, true>), grid, dim3(kBlock), 0, s, x, xa, xo, g, step, out, flags, xb, gb, xba, E, eps, a, oma);
+    else
+      hipLaunchKernelGGL((linf_step_track_vec4_kernel<GT, false>), grid, dim3(kBlock), 0, s, x, xa, xo, g, step, out, flags, xb, gb, xba, E, eps, a, oma);
+  } else {
+    const dim3 grid(blocks_for(E, kBlock * 4, 64), static_cast<unsigned>(B));
+    if (first)
+      hipLaunchKernelGGL((linf_step_track_scalar_kernel<GT, true>), grid, dim3(kBlock), 0, s, x, xa, xo, g, step, out, flags, xb, gb, xba, E, eps, a, oma);
+    else
+      hipLaunchKernelGGL((linf_step_track_scalar_kernel<GT, false>), grid, dim3(kBlock), 0, s, x, xa, xo, g, step, out, flags, xb, gb, xba, E, eps, a, oma);
+  }
+  return launch_status();
+}
+
 template <typename GT, int U, bool NT>
 int launch_linf_vec4(const float* x, const float* xa, const float* xo, const GT* g, const float* step, float* out,
                      uint16_t* ob, int64_t B, int64_t E, float eps, float a, int bps, hipStream_t s) {
@@ -719,9 +840,6 @@ int apgd_init_f32(const float* x, float* x_adv, float* x_best, float* x_best_adv
 }  // extern "C"
 
 namespace {
-template <> struct Elt<int8_t> {    // gradient signs
-  static __device__ __forceinline__ float load(const int8_t* p, int64_t i) { return static_cast<float>(p[i]); }
-};
 
 template <typename GT>
 int linf_dispatch(const float* x, const float* x_adv, const float* x_adv_old, const GT* g, const float* step_size,
@@ -811,6 +929,33 @@ int apgd_linf_step_f32(const float* x, const float* x_adv, const float* x_adv_ol
   // (launch-shape experiments go through apgd_linf_step_f32_ex: tools/k1_sweep.py; the defaults 0, 0, 0 are the measured best)
   return apgd_linf_step_f32_ex(x, x_adv, x_adv_old, grad, grad_dtype, step_size, out, out_bf16, B, E, eps, a,
                                0, 0, 0, stream);
+}
+
+int apgd_linf_step_track_f32(const float* x, float* x_adv, const float* x_adv_old, const void* grad, int grad_dtype,
+                             const float* step_size, float* out, const uint8_t* flags, float* x_best, void* grad_best,
+                             float* x_best_adv, int64_t B, int64_t E, float eps, float a, void* stream) {
+  if (B < 0 || E < 0) return APGD_ERR_SIZE;
+  if (B == 0 || E == 0) return APGD_OK;
+  if (!x || !x_adv || !x_adv_old || !grad || !step_size || !out || !x_best || !grad_best || !x_best_adv) return APGD_ERR_NULL;
+  if (grad_dtype != APGD_F32 && grad_dtype != APGD_BF16 && grad_dtype != APGD_I8) return APGD_ERR_DTYPE;
+  if (B > 65535) return APGD_ERR_SIZE;
+  if (!flags && (x_adv_old != x_adv || a != 1.0f)) return APGD_ERR_ARG;      // the first-iteration form is iteration 0's
+  if (out == x || out == x_adv || out == x_adv_old || out == grad || out == x_best || out == x_best_adv || out == grad_best ||
+      x_best == x_best_adv || x_best == x_adv || x_best_adv == x_adv || grad_best == grad || (flags && x_adv_old == x_adv))
+    return APGD_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  const int galign = grad_dtype == APGD_F32 ? 16 : (grad_dtype == APGD_BF16 ? 8 : 4);
+  const bool vec = (E % 4 == 0) && aligned16(x) && aligned16(x_adv) && aligned16(x_adv_old) && aligned16(out) &&
+                   aligned16(x_best) && aligned16(x_best_adv) && (reinterpret_cast<uintptr_t>(grad) % galign == 0) &&
+                   (reinterpret_cast<uintptr_t>(grad_best) % galign == 0);
+  if (grad_dtype == APGD_F32)
+    return linf_track_dispatch(x, x_adv, x_adv_old, static_cast<const float*>(grad), step_size, out, flags, x_best,
+                               static_cast<float*>(grad_best), x_best_adv, B, E, eps, a, vec, s);
+  if (grad_dtype == APGD_BF16)
+    return linf_track_dispatch(x, x_adv, x_adv_old, static_cast<const uint16_t*>(grad), step_size, out, flags, x_best,
+                               static_cast<uint16_t*>(grad_best), x_best_adv, B, E, eps, a, vec, s);
+  return linf_track_dispatch(x, x_adv, x_adv_old, static_cast<const int8_t*>(grad), step_size, out, flags, x_best,
+                             static_cast<int8_t*>(grad_best), x_best_adv, B, E, eps, a, vec, s);
 }
 
 int apgd_l2_parts(void) { return kL2Parts; }

@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
         //  and shifted instead)
         const uint32_t off = in ? static_cast<uint32_t>(e0 + qoff[sk][t] + (ow == 0 ? 1 : 0)) * 4u : 0xffffffffu;
         qv[t] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
-        if (ow == 0) { qv[t].w = qv[t].z; qv[t].z = qv[t].y; qv[t].y = qv[t].x; qv[t].x = 0u; }
+        if (ow == 0) { qv[t].z = qv[t].y; qv[t].y = qv[t].x; qv[t].x = 0u; }
+        qv[t].w = 0u;                                                  // the quad's 4th value is a NEIGHBOUR (next column / row / image) under
+                                                                       // a zero weight: 0 * Inf would be NaN in this position's output
       }
       pa[sk] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(__uint_as_float(qv[0].x), __uint_as_float(qv[0].y)),
                                                      pack_bf16(__uint_as_float(qv[0].z), __uint_as_float(qv[0].w)),

@@ -1,0 +1,264 @@
+// wgrad_kernels.hip — contractions over the ROW index m of row-major operands, for gfx950 (round 5):
+//
+//     D[i][j] = sum_m A[m][i] * B[m][j]            A: [M, NA], B: [M, NB] bf16, both row-major; D fp32
+//
+// This is the shape of every weight gradient of the path (models/convnext.py:42-46 backward, utils_architecture.py:205-211 backward):
+// the pointwise convolutions' dW1 = dHpre^T a and dW2 = dO^T H, the head, and - with im2col rows gathered on the fly - the ConvStem
+// convolutions' filter gradients, which were the last MIOpen kernels of the step.  Both MFMA operands want, per lane, 8 consecutive
+// values of the contraction index for ONE row / column of D - i.e. a column of the row-major operand.  gfx950's LDS transpose read
+// does exactly that on the way out of LDS: `ds_read_b64_tr_b16` takes, per group of 16 lanes, sixteen 8-byte pieces (lane i of the
+// group: 4 consecutive bf16 of row i / 4 at column chunk i % 4 of a 4 x 16 block - each lane hands over its own 8-byte-aligned
+// address, so the row stride is free) and returns to lane i COLUMN i of the block: four consecutive m for one column.  Two reads
+// make one operand fragment of `mfma_f32_32x32x16_bf16` (lane l: row / column l % 32, k = 8 (l / 32) .. + 7): the operand tiles
+// go from HBM to LDS as they lie in memory (16-byte pieces), no transposing pass over either operand exists anywhere.
+// (/opt/skills/guides/cdna_hip_programming.md T10; tools/probe/tr_probe.cpp prints the lane map this file relies on.)
+//
+// Kernels:
+//   stem_conv_wgrad_kernel<P>   filter / bias gradient of Conv2d(3, P, 3, stride 2, padding 1) on the fp32 NCHW image (the attack's
+//                               iterate): D[(ci,kh,kw) | 1][p] = sum_pos patch[pos][.] dy[pos][p]; the patch values are gathered
+//                               straight from the image (rounded to bf16 as the autocast convolution does), dy rows through LDS
+//   wgrad_reduce_kernel         fixed-order sum of the workgroups' partial results (deterministic)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "apgd_hip.h"
+#include "convnext_hip.h"
+
+namespace {
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// LDS byte address of a __shared__ object (the DS instructions take 32-bit LDS addresses)
+template <typename T>
+__device__ __forceinline__ uint32_t lds_addr(const T* p) {
+  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p));
+}
+
+// One transpose read: 4 consecutive contraction indices (rows of the LDS image) for this lane's column.  `addr` is THIS lane's
+// piece: 8-byte aligned (an address off by 2 / 4 / 6 silently returns the aligned piece: guide, guideline 17).
+__device__ __forceinline__ u32x2 tr_read(uint32_t addr) {
+  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      reinterpret_cast<s16x4 __attribute__((address_space(3)))*>(static_cast<uintptr_t>(addr)));
+  return __builtin_bit_cast(u32x2, r);
+}
+// Operand fragment of mfma_f32_32x32x16_bf16 from a row-major LDS image: lane l = (k-block kb = l / 32, column c = l % 32) gets
+// rows 8 kb .. 8 kb + 7 of column c.  piece = the lane's own 8-byte piece of read 0 (row 8 kb + (l % 16) / 4, columns
+// 16 ((l / 16) % 2) + 4 (l % 4) ..); read 1 is four rows further down (row_bytes = the image's row stride in bytes).
+__device__ __forceinline__ bf16x8 tr_fragment(uint32_t piece, uint32_t row_bytes) {
+  const u32x2 lo = tr_read(piece), hi = tr_read(piece + 4u * row_bytes);
+  const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// byte offset of a lane's piece inside a [rows][row_bytes] image for the fragment of columns c0 .. c0 + 31, rows r0 .. r0 + 15
+__device__ __forceinline__ uint32_t tr_piece(int lane, int r0, int c0, uint32_t row_bytes) {
+  const int g = lane >> 4, i = lane & 15;
+  return static_cast<uint32_t>(r0 + 8 * (g >> 1) + (i >> 2)) * row_bytes + static_cast<uint32_t>(c0 + 16 * (g & 1) + 4 * (i & 3)) * 2u;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Stem convolution filter gradient.  A wavefront takes chunks of 16 consecutive output positions (flattened (n, oh, ow)):
+//   A fragment [32 x 16]: row i = (ci*3 + kh)*3 + kw for i < 27, row 27 = ones (its products are the bias gradient), rest zero;
+//                         lane (i, kb) gathers its 8 positions' image values with scalar fp32 loads (out of the image: zero)
+//   B fragments [16 x 32] per 32-channel block of dy: the chunk's dy rows are 16 P contiguous bf16 - copied to LDS in 16-byte
+//                         pieces and read back transposed
+//   acc[nb] += A x B[nb]                                 (27 x P products per position on the matrix pipe)
+// ROW16: OW is a multiple of 16 - a chunk lies inside one output row, (n, oh) are wave-uniform and ow needs no wrap; otherwise
+// every element derives its own (n, oh, ow) (widths the ConvStem meets only at odd evaluation resolutions).
+// The workgroup's four partial results are added through LDS and written to ws[blockIdx.x][28][P].
+template <int P, bool ROW16>
+__global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                              float* __restrict__ ws, long total, int N, int H, int W, int OH, int OW) {
+  constexpr int NB = (P + 31) / 32;
+  constexpr uint32_t ROWB = P * 2;                                   // dy row in bytes
+  constexpr int PIECES = 16 * P * 2 / 16;                            // 16-byte pieces of a chunk's dy rows (P = 48: 96)
+  constexpr int NLD = (PIECES + 63) / 64;
+  __shared__ __attribute__((aligned(16))) uint16_t img[4][2][16 * P + 32 * 8];   // per wave, two chunks; tail: columns P .. 32 NB of the last block read zeros / finite junk
+  __shared__ float red[4][28][NB * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kb = lane >> 5;
+  const int ci = i / 9, kh = (i - ci * 9) / 3, kw = i - ci * 9 - kh * 3;
+  const bool tap = i < 27, one = i == 27;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0,
+      static_cast<uint32_t>(static_cast<long>(N) * 3 * H * W * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dy), 0,
+      static_cast<uint32_t>(total * P * 2), 0x00020000);
+  // zero the image tails once (columns beyond P of the last block are multiplied into rows of D nobody reads, but must be finite)
+  {
+    uint16_t* flat = &img[wave][0][0];
+    for (int e = lane; e < 2 * (16 * P + 32 * 8); e += 64) flat[e] = 0;
+  }
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  const long nchunks = (total + 15) / 16;
+  const long wstride = static_cast<long>(gridDim.x) * 4;
+  float xv[8];
+  u32x4 dv[NLD];
+  auto fetch = [&](long c) {                                          // global -> registers: chunk c's patch values and dy pieces
+    const long p0 = c * 16;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int piece = k * 64 + lane;
+      const uint32_t off = piece < PIECES ? static_cast<uint32_t>(p0 * ROWB) + static_cast<uint32_t>(piece) * 16u : 0xffffffffu;
+      dv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0);  // beyond the tensor (tail chunk): zeros
+    }
+    if (ROW16) {
+      const long r = p0 / OW;                                         // wave-uniform
+      const int ow0 = static_cast<int>(p0 - r * OW) + 8 * kb;
+      const int oh = static_cast<int>(r % OH);
+      const long n = r / OH;
+      const int ih = 2 * oh - 1 + kh;
+      const bool rok = tap && ih >= 0 && p0 < total;
+      const long base = (n * 3 + ci) * static_cast<long>(H) * W + static_cast<long>(ih) * W + (2 * ow0 - 1 + kw);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const bool ok = rok && (2 * (ow0 + t) - 1 + kw) >= 0;
+        const uint32_t off = ok ? static_cast<uint32_t>(base + 2 * t) * 4u : 0xffffffffu;
+        xv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsx, off, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const long p = p0 + 8 * kb + t;
+        const long r = p / OW;
+        const int ow = static_cast<int>(p - r * OW), oh = static_cast<int>(r % OH);
+        const long n = r / OH;
+        const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+        const bool ok = tap && p < total && ih >= 0 && iw >= 0;
+        const uint32_t off = ok ? static_cast<uint32_t>((n * 3 + ci) * static_cast<long>(H) * W + static_cast<long>(ih) * W + iw) * 4u : 0xffffffffu;
+        xv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsx, off, 0, 0));
+      }
+    }
+  };
+
+  long c = static_cast<long>(blockIdx.x) * 4 + wave;
+  int buf = 0;
+  if (c < nchunks) fetch(c);
+  for (; c < nchunks; c += wstride) {
+    // this chunk: registers -> A fragment / LDS image
+    const long p0 = c * 16;
+    u32x4 av;
+    {
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = one ? ((p0 + 8 * kb + t) < total ? 1.0f : 0.0f) : xv[t];
+      av = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+    }
+    uint16_t* im = img[wave][buf];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int piece = k * 64 + lane;
+      if (piece < PIECES) *reinterpret_cast<u32x4*>(im + piece * 8) = dv[k];
+    }
+    const long cn = c + wstride;
+    if (cn < nchunks) fetch(cn);                                      // the next chunk's loads fly under this chunk's LDS round trip + MFMAs
+    const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+    const uint32_t im_a = lds_addr(im);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const bf16x8 b = tr_fragment(im_a + tr_piece(lane, 0, nb * 32, ROWB), ROWB);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+    }
+    buf ^= 1;                                                        // (the wave's own DS operations execute in order: no barrier)
+  }
+
+  // workgroup partial: rows 0 .. 27 of D
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+      if (row < 28) red[wave][row][nb * 32 + i] = acc[nb][r];
+    }
+  __syncthreads();
+  float* out = ws + static_cast<long>(blockIdx.x) * 28 * P;
+  for (int e = threadIdx.x; e < 28 * P; e += 256) {
+    const int row = e / P, col = e - row * P;
+    out[e] = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+  }
+}
+
+// out[j] = sum over parts (fixed order: 8 interleaved running sums, then a tree) of ws[part * len + j]; one thread per j and
+// part-lane, 32 part-lanes per output.  map: j -> destination index (the caller's layouts differ from the partials'), or identity.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
+                                                           int len, int split, int nparts, int tr_rows, int tr_cols) {
+  __shared__ float part[32][9];
+  const int jl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int j = blockIdx.x * 8 + jl;
+  float s = 0.f;
+  if (j < len)
+    for (int p = pl; p < nparts; p += 32) s += ws[static_cast<long>(p) * len + j];
+  part[pl][jl] = s;
+  __syncthreads();
+  if (pl == 0 && j < len) {
+    float t[32];
+#pragma unroll
+    for (int g = 0; g < 32; ++g) t[g] = part[g][jl];
+#pragma unroll
+    for (int w = 16; w > 0; w >>= 1)
+#pragma unroll
+      for (int g = 0; g < w; ++g) t[g] += t[g + w];
+    if (j < split) {
+      // the first `split` values are a [tr_rows][tr_cols] matrix that the caller wants transposed
+      const int r = j / tr_cols, cc = j - r * tr_cols;
+      out0[tr_rows > 0 ? cc * tr_rows + r : j] = t[0];
+    } else if (out1) {
+      out1[j - split] = t[0];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t cnx_stem_conv_wgrad_ws_floats(int32_t P) { return 1024L * 28 * P; }
+
+int cnx_stem_conv_wgrad(const float* x, const void* dy, float* dw, float* dbias, float* ws, int64_t N, int32_t H, int32_t W, int32_t P,
+                        void* stream) {
+  if (N < 0 || H <= 0 || W <= 0) return APGD_ERR_SIZE;
+  if (!(P == 48 || P == 64 || P == 96)) return APGD_ERR_ARG;
+  if ((H & 1) || (W & 1) || static_cast<long>(N) * 3 * H * W >= (1L << 30)) return APGD_ERR_ARG;
+  if (!dw || !ws || (N > 0 && (!x || !dy))) return APGD_ERR_NULL;
+  const int OH = H / 2, OW = W / 2;
+  const long total = N * OH * OW;
+  if (total * P * 2 >= (1L << 32)) return APGD_ERR_ARG;                // 32-bit byte offsets into dy
+  hipStream_t s = as_stream(stream);
+  long nchunks = (total + 15) / 16;
+  long nwg = (nchunks + 4 * 6 - 1) / (4 * 6);                          // ~6 chunks per wavefront, at most 1024 partial results
+  if (nwg > 1024) nwg = 1024;
+  if (nwg < 1) nwg = 1;
+  const dim3 grid(static_cast<unsigned>(nwg)), block(256);
+  const auto* d = static_cast<const uint16_t*>(dy);
+  const bool row16 = OW % 16 == 0;
+#define STEM_WG(PP)                                                                                                          \
+  if (row16) hipLaunchKernelGGL((stem_conv_wgrad_kernel<PP, true>), grid, block, 0, s, x, d, ws, total, static_cast<int>(N), H, W, OH, OW);  \
+  else hipLaunchKernelGGL((stem_conv_wgrad_kernel<PP, false>), grid, block, 0, s, x, d, ws, total, static_cast<int>(N), H, W, OH, OW);
+  if (P == 48) { STEM_WG(48) } else if (P == 64) { STEM_WG(64) } else { STEM_WG(96) }
+#undef STEM_WG
+  int rc = launch_status();
+  if (rc) return rc;
+  // partial layout [28][P]: rows 0..26 = (ci, kh, kw) x P  ->  dw[p][27] ([P, 3, 3, 3]); row 27 -> dbias[P]
+  const int len = 28 * P;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((len + 7) / 8), dim3(256), 0, s, ws, dw, dbias, len, 27 * P, static_cast<int>(nwg), 27, P);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -56,7 +56,12 @@ class _LibGemmWatch(torch.utils._python_dispatch.TorchDispatchMode):
     would-be two-stream signature under it, on one stream: if anything in the attack's model calls still reaches the library
     although ``ops.attack_pass`` is on (a layer that fails cnx_gemm_nt's guards, a foreign submodule), the signature is
     captured and run on ONE stream - overlapping chunks never contain a library GEMM."""
-    NAMES = ("mm", "addmm", "bmm", "baddbmm", "linear", "matmul", "_scaled_mm", "addmv", "mv")
+    # GEMMs, and the library convolutions: MIOpen lowers 1x1, patchify and 2x2-stride-2 convolutions to rocBLAS / hipBLASLt GEMMs
+    # (a foreign stem, a downsample layer that fails ops.downsample_supported) - two of those in flight are the same hazard
+    NAMES = ("mm", "addmm", "bmm", "baddbmm", "linear", "matmul", "_scaled_mm", "addmv", "mv",
+             "convolution", "convolution_backward", "_convolution", "cudnn_convolution", "miopen_convolution",
+             "miopen_convolution_transpose", "miopen_depthwise_convolution", "convolution_overrideable",
+             "convolution_backward_overrideable", "_convolution_double_backward")
 
     def __init__(self):
         super().__init__()

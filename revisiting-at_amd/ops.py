@@ -467,6 +467,30 @@ def downsample_ln_conv(x, ln_w, ln_b, eps, weight, bias):
 
 
 # ------------------------------------------------------------------------------ first ConvStem convolution
+# True: the ConvStem convolutions' filter / bias gradients on csrc/wgrad_kernels.hip (round 5); False: the library's
+# convolution_backward (MIOpen) - kept for the A/B and the parity tests
+STEM_WGRAD_HIP = os.environ.get("APGD_STEM_WGRAD", "hip") != "lib"
+
+
+def _stem_wgrad(lib, x, gr, weight, has_bias):
+    """Filter / bias gradient of the first ConvStem convolution from the fp32 NCHW image ``x`` and the bf16 NHWC rows ``gr`` of the
+    output gradient (``utils_architecture.py:205-211`` backward)."""
+    N, _, H, W = x.shape
+    P = weight.shape[0]
+    if STEM_WGRAD_HIP:
+        dw = torch.empty(weight.shape, device=x.device, dtype=torch.float32)
+        db = torch.empty(P, device=x.device, dtype=torch.float32) if has_bias else None
+        ws = torch.empty(lib.cnx_stem_conv_wgrad_ws_floats(P), device=x.device, dtype=torch.float32)
+        _lib.check(lib.cnx_stem_conv_wgrad(x.data_ptr(), gr.data_ptr(), dw.data_ptr(), _lib.ptr(db), ws.data_ptr(), N, H, W, P,
+                                           _stream()), "cnx_stem_conv_wgrad")
+        return dw.to(weight.dtype), db
+    xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gb = gr.permute(0, 3, 1, 2)                                    # NCHW view of channels-last memory
+    _, dw, db = torch.ops.aten.convolution_backward(gb, xb, weight.to(torch.bfloat16), [P], [2, 2], [1, 1], [1, 1],
+                                                    False, [0, 0], 1, [False, True, has_bias])
+    return dw.to(weight.dtype), (db.float() if has_bias else None)
+
+
 class _StemConv(torch.autograd.Function):
     """``Conv2d(3, P, 3, stride 2, padding 1)`` on the fp32 NCHW image batch -> NCHW-shaped view of NHWC bf16 rows.
 
@@ -502,12 +526,7 @@ class _StemConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _stem_dgrad(lib, x, gr, wq, N, H, W, P)
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY:
-            xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            gb = gr.permute(0, 3, 1, 2)                                    # NCHW view of channels-last memory
-            _, dw, db = torch.ops.aten.convolution_backward(gb, xb, weight.to(torch.bfloat16), [P], [2, 2], [1, 1], [1, 1],
-                                                            False, [0, 0], 1, [False, True, ctx.has_bias])
-            dw = dw.to(weight.dtype)
-            db = db.float() if ctx.has_bias else None
+            dw, db = _stem_wgrad(lib, x, gr, weight, ctx.has_bias)
         return dx, dw, db
 
 
@@ -566,12 +585,7 @@ class _StemConvLnGelu(torch.autograd.Function):
         if nig[0]:
             dx = _stem_dgrad(lib, x, dy, wq, N, H, W, P)
         if (nig[1] or nig[2]) and not _INPUT_GRAD_ONLY:
-            xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            gb = dy.permute(0, 3, 1, 2)                                    # NCHW view of channels-last memory
-            _, dw, db = torch.ops.aten.convolution_backward(gb, xb, weight.to(torch.bfloat16), [P], [2, 2], [1, 1], [1, 1],
-                                                            False, [0, 0], 1, [False, True, ctx.has_bias])
-            dw = dw.to(weight.dtype)
-            db = db.float() if ctx.has_bias else None
+            dw, db = _stem_wgrad(lib, x, dy, weight, ctx.has_bias)
         return dx, dw, db, dlw, dlb, None
 
 
@@ -603,6 +617,7 @@ def _pack_stem(w):
 def stem_conv_supported(x, weight, stride, padding):
     return (MODE != "eager" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
             and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and tuple(weight.shape[1:]) == (3, 3, 3)
+            and x.numel() < 2 ** 30                               # 32-bit buffer offsets in the kernel (it returns APGD_ERR_ARG beyond)
             and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and torch.is_autocast_enabled()
             and torch.get_autocast_dtype('cuda') == torch.bfloat16 and bool(_lib.load().cnx_stem_conv_supported(weight.shape[0])))
 

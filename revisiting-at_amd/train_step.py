@@ -170,6 +170,7 @@ class FlatGradSync:
                     raise TypeError("FlatGradSync keeps fp32 gradients (the path's parameters are fp32, main.py:797)")
                 p.grad = v                                                 # for the optimizer; never set to None again
         self._works = []
+        self.verified = self.cut is None                                   # split backward checked against the whole one (check_split)
         self.reduces = 0                                                   # collectives issued (tests, bench)
         self.bytes_per_step = 4 * sum(b.numel() for b in self.flat)
 
@@ -191,6 +192,27 @@ class FlatGradSync:
         for v, g in zip(vs, grads):
             if g is None:
                 v.zero_()
+
+    def check_split(self, loss, h):
+        """First eager pass with a cut point: the two-call backward must reach every parameter the whole backward reaches.  A
+        trainable parameter that lies downstream of the cut but is not listed in the model's late modules (or is shared across the
+        cut) gets ``None`` from ``autograd.grad([h], early)`` and ``store`` would zero-fill it on every step without a sound - so the
+        used-sets are compared once (one extra backward, graph retained); on a mismatch the cut is dropped with a warning and the
+        exchange runs behind ONE whole backward (same gradients as ``loss.backward()``, no overlap of the first all-reduce)."""
+        full = torch.autograd.grad([loss], self.late + self.early, allow_unused=True, retain_graph=True)
+        g1 = torch.autograd.grad([loss], self.late + [h], allow_unused=True, retain_graph=True)
+        g2 = torch.autograd.grad([h], self.early, grad_outputs=[g1[-1]], allow_unused=True, retain_graph=True)
+        split = list(g1[:-1]) + list(g2)
+        lost = [i for i, (a, b) in enumerate(zip(full, split)) if a is not None and b is None]
+        short = [i for i, (a, b) in enumerate(zip(full, split))
+                 if a is not None and b is not None       # (5 % in norm: far above the run-to-run noise of the library's
+                 and float((a.float() - b.float()).norm()) > 0.05 * float(a.float().norm()) + 1e-12]    # split-K filter gradients)
+        self.verified = True
+        if lost or short:
+            import warnings
+            warnings.warn(f"FlatGradSync: the model's ddp_cut() does not partition its parameters ({len(lost)} parameters would lose "
+                          f"their gradient, {len(short)} would get a part of it): cut point dropped, one whole backward per step")
+            self.cut = None
 
     def start_reduce(self, which: int):
         if self.world > 1 and self.flat[which].numel():
@@ -279,6 +301,7 @@ class ATTrainStep:
                  soft_targets: bool = False, perturb=None, gemm_table: bool = False, ema_decay: float = 0.9999,
                  graph_train: Optional[bool] = None, grad_sync: Optional[str] = None):
         self.device = torch.device(device)
+        self.distributed = bool(distributed)
         if grad_sync not in (None, "flat", "ddp"):
             raise ValueError(f"grad_sync={grad_sync!r}")
         if grad_sync is None and distributed:
@@ -323,6 +346,17 @@ class ATTrainStep:
             self.inner.set_perturb(True)                                   # main.py:950-954
         self.model.train()
 
+    def state_dict(self):
+        """The model's state dict with the keys the reference's ``self.model.state_dict()`` has (``main.py:738-754``): under N > 1
+        ranks that is ``DDP(WrappedModel(model))`` = ``module.base_model.*``.  On the flat gradient path ``self.model`` is the bare
+        ``WrappedModel`` (no DDP object: ``.module`` / ``register_comm_hook`` do not exist there), so the ``module.`` prefix is added
+        here and ``weights_{epoch}.pt`` / ``full_model_{epoch}.pth`` keep the reference's on-disk layout byte for byte; the loaders
+        (``checkpoint.load_weights``, ``main.py:858``) strip it either way."""
+        sd = self.model.state_dict()
+        if self.distributed and not isinstance(self.model, nn.parallel.DistributedDataParallel):
+            sd = {f"module.{k}": v for k, v in sd.items()}
+        return sd
+
     def _set_lr(self, lr):
         for g in self.optimizer.param_groups:                              # main.py:973-974
             if isinstance(g['lr'], torch.Tensor):
@@ -354,7 +388,9 @@ class ATTrainStep:
                 else:
                     fn()
             h = stash.get("h")
-            if isinstance(h, torch.Tensor) and h.requires_grad and sync.late and sync.early:
+            if (rec is None and not sync.verified and isinstance(h, torch.Tensor) and h.requires_grad and sync.late and sync.early):
+                sync.check_split(loss, h)                                  # once, on the first eager pass (never inside a capture)
+            if sync.cut is not None and isinstance(h, torch.Tensor) and h.requires_grad and sync.late and sync.early:
                 g1 = torch.autograd.grad([loss], sync.late + [h], allow_unused=True)
                 sync.store(0, g1[:-1])
                 between(lambda: sync.start_reduce(0))                      # ... runs under the backward of the early stages
@@ -376,6 +412,20 @@ class ATTrainStep:
         if self.ema is not None:
             self.ema.update()                                              # main.py:996-997
         return loss.detach()
+
+    def warm_libraries(self, images, target):
+        """One LOCAL training forward / backward of the model on this batch shape - no attack, no optimizer step, no collective,
+        ``.grad`` untouched - so that the libraries under the path (MIOpen's find for the convolutions it still serves, hipBLASLt's
+        heuristics) meet every shape of the training pass.  ``bench.py`` runs it on rank 0 first and on the other ranks behind a
+        barrier: the per-process search of eight ranks is serialised into one search + seven find-db hits."""
+        was = self.inner.base_model.training
+        self.inner.base_model.train()
+        params = [p for p in self.inner.base_model.parameters() if p.requires_grad]
+        with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            out = self.inner.base_model(images)
+            loss = self.loss(out, target)
+        torch.autograd.grad([loss], params, allow_unused=True)
+        self.inner.base_model.train(was)
 
     def _perturbed(self, images, target, borrow=False):
         """The first half of ``WrappedModel.forward`` (``main.py:276-292``): the attack in eval mode, under the step's autocast as

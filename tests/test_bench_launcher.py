@@ -60,3 +60,20 @@ def test_a_dead_rank_ends_the_job_instead_of_hanging_it(tmp_path, capsys):
 def test_fewer_devices_than_ranks_is_refused(tmp_path, capsys):
     import bench
     assert bench.spawn_ranks(argparse.Namespace(gpus=4), child_argv=[sys.executable, "-c", "pass"], ndev=1) == 2
+
+
+def test_a_failed_graph_capture_is_an_error_entry_not_a_silent_eager_measurement():
+    """bench.py --strict fails on extra.errors; a training pass (or attack) that fell back to its eager form although replay was
+    asked for must show up there (round-4 review: under RCCL a failed three-segment capture silently benchmarked the eager pass)."""
+    import bench
+    ok = {"train_graph": {"enabled": True, "captured": 1, "failed": 0, "segments": [3]}, "attack_graph": {"captures": 1, "failed": 0}}
+    assert "error" not in bench.mark_graph_fallbacks(ok, True, True)["train_graph"] and "error" not in ok["attack_graph"]
+    bad = {"train_graph": {"enabled": True, "captured": 0, "failed": 1, "segments": []}, "attack_graph": {"captures": 1, "failed": 0}}
+    bench.mark_graph_fallbacks(bad, True, True)
+    assert "error" in bad["train_graph"] and "error" not in bad["attack_graph"]
+    never = {"train_graph": {"enabled": True, "captured": 0, "failed": 0}, "attack_graph": {"captures": 0, "failed": 0}}
+    bench.mark_graph_fallbacks(never, True, True)
+    assert "error" in never["train_graph"] and "error" in never["attack_graph"]
+    eager = {"train_graph": {"enabled": False, "captured": 0, "failed": 0}, "attack_graph": {"captures": 0, "failed": 0}}
+    bench.mark_graph_fallbacks(eager, False, False)                      # --graph 0: nothing was asked for, nothing is wrong
+    assert "error" not in eager["train_graph"] and "error" not in eager["attack_graph"]

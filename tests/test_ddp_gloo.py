@@ -114,7 +114,8 @@ def _worker(rank, world, port, q, grad_sync="ddp", kind="seq"):
     if rank == 0:
         q.put(dict(params=flat, same=bool(all(torch.equal(gathered[0], t) for t in gathered)), losses=losses,
                    ema_moved=bool(not torch.equal(ema0, tr.inner.state_dict()[list(tr.inner.state_dict())[0]])),
-                   training=tr.model.training, keys=list(tr.model.state_dict())[:2], coll=dict(st)))
+                   training=tr.model.training, keys=list(tr.model.state_dict())[:2], ckpt_keys=list(tr.state_dict())[:2],
+                   coll=dict(st)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -137,6 +138,8 @@ def test_ddp_world2_matches_single_process(grad_sync, kind):
     assert res["same"], "ranks diverged: gradients were not all-reduced"
     assert res["training"]
     assert res["keys"][0].startswith("module.base_model." if grad_sync == "ddp" else "base_model.")   # DDP(WrappedModel(model)) / WrappedModel(model)
+    # what a checkpoint writer gets (ATTrainStep.state_dict): the reference's on-disk keys, module.base_model.*, on both paths
+    assert all(k.startswith("module.base_model.") for k in res["ckpt_keys"]), res["ckpt_keys"]
     assert res["ema_moved"]
     # no inter-rank traffic inside the attack; the only exchange is the gradient all-reduce of the
     # outer backward (>= 1 bucket per step, 3 steps)
@@ -167,6 +170,50 @@ def test_flat_gradient_path_on_one_rank_equals_the_plain_backward(kind):
         out.append((losses, torch.cat([p.detach().flatten() for p in tr.inner.parameters()]), tr.ema.ema[0].clone()))
         assert (tr.sync is not None) == (gs == "flat")
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
+class _BadCutNet(_CutNet):
+    """``ddp_cut`` forgets a module that lies behind the cut (a later edit adding e.g. an ``fc_norm``), and shares one parameter
+    across the cut: the split backward would silently zero the first and halve the second."""
+
+    def __init__(self):
+        super().__init__()
+        self.extra = nn.Linear(5, 5)
+        self.shared = nn.Parameter(torch.ones(1))
+
+    def forward(self, x):
+        return self.extra(self.b(self.a(x) * self.shared)) * self.shared
+
+    def ddp_cut(self):
+        return self.a, [self.b]                              # `extra` is downstream of the cut but not listed
+
+
+def test_flat_gradient_path_checks_the_models_cut_point():
+    """Round-4 advice: FlatGradSync trusted ``ddp_cut()``.  The first eager pass now compares the two-call backward with the
+    whole one; a partition that would drop (or split) a parameter's gradient loses its cut point with a warning and the step
+    equals ``loss.backward()`` again."""
+    torch.set_num_threads(1)
+    x, y = _data(8)
+    out = []
+    for gs in (None, "flat"):
+        torch.manual_seed(0)
+        tr = R.ATTrainStep(_BadCutNet(), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=False, channels_last=False,
+                           amp_dtype=None, ema=False, perturb=_sign_attack, grad_sync=gs)
+        if gs == "flat":
+            assert tr.sync.cut is not None and not tr.sync.verified
+            with pytest.warns(UserWarning, match="does not partition"):
+                losses = [float(tr.step(x, y))]
+            assert tr.sync.cut is None and tr.sync.verified
+        else:
+            losses = [float(tr.step(x, y))]
+        losses += [float(tr.step(x, y)) for _ in range(2)]
+        out.append((losses, torch.cat([p.detach().flatten() for p in tr.inner.parameters()])))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+    # a sound partition passes the check and keeps its cut
+    tr = R.ATTrainStep(_model("cut"), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=False, channels_last=False,
+                       amp_dtype=None, ema=False, perturb=_sign_attack, grad_sync="flat")
+    tr.step(x, y)
+    assert tr.sync.verified and tr.sync.cut is not None
 
 
 def test_flat_gradient_views_keep_the_parameters_layout():

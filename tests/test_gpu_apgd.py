@@ -214,6 +214,73 @@ def test_track_rows_moves_int8_sign_rows_of_odd_length(lib):
         assert torch.equal(gr[b], gb0[b] if rs else gr0[b]), b
 
 
+@pytest.mark.parametrize("B,E", [(8, 3 * 16 * 16), (8, 3 * 5 * 5), (16, 1021), (9, 3 * 64 * 64), (256, 3 * 32 * 32)])
+@pytest.mark.parametrize("gdt", [torch.float32, torch.bfloat16, torch.int8])
+def test_linf_step_track_equals_track_rows_then_step(lib, B, E, gdt):
+    """apgd_linf_step_track_f32 (round 5: the Linf step of iteration i + 1 also performs the row moves of iteration i) against the
+    two-pass sequence it replaces - apgd_track_rows, then apgd_linf_step_f32 - for every flag byte, bit for bit on EVERY buffer:
+    the new iterate, x_best, grad_best, x_best_adv and the restored x_adv; the gradient buffer is the one deliberate difference
+    (a restored row is not written back: nothing reads it before the next backward replaces it)."""
+    eps, a = 4 / 255, 0.75
+    x, xa, xo, g, step = _step_inputs(B, E, B * 13 + E, eps)
+    gen = torch.Generator(device="cuda").manual_seed(E)
+    flags = (torch.arange(B, device="cuda") % 8).to(torch.uint8)
+    xd, xad, xod, sd = map(dev, (x, xa, xo, step))
+    if gdt == torch.int8:
+        gr = torch.randint(-1, 2, (B, E), device="cuda", generator=gen, dtype=torch.int8)
+        gb = torch.randint(-1, 2, (B, E), device="cuda", generator=gen, dtype=torch.int8)
+    else:
+        gr = dev(g).to(gdt)
+        gb = (torch.randn(B, E, device="cuda", generator=gen) * 1e-3).to(gdt)
+    code = {torch.float32: 0, torch.bfloat16: 1, torch.int8: 3}[gdt]
+    xb, xba = torch.rand(B, E, device="cuda", generator=gen), torch.rand(B, E, device="cuda", generator=gen)
+    # reference: the two passes of rounds 1 - 4
+    xa1, gr1, xb1, gb1, xba1 = xad.clone(), gr.clone(), xb.clone(), gb.clone(), xba.clone()
+    out1 = torch.zeros_like(xd)
+    assert lib.apgd_track_rows(flags.data_ptr(), xa1.data_ptr(), gr1.data_ptr(), xb1.data_ptr(), gb1.data_ptr(), xba1.data_ptr(),
+                               gr.element_size(), B, E, 0, S()) == 0
+    assert lib.apgd_linf_step_f32(xd.data_ptr(), xa1.data_ptr(), xod.data_ptr(), gr1.data_ptr(), code, sd.data_ptr(),
+                                  out1.data_ptr(), None, B, E, eps, a, S()) == 0
+    xa2, gr2, xb2, gb2, xba2 = xad.clone(), gr.clone(), xb.clone(), gb.clone(), xba.clone()
+    out2 = torch.zeros_like(xd)
+    assert lib.apgd_linf_step_track_f32(xd.data_ptr(), xa2.data_ptr(), xod.data_ptr(), gr2.data_ptr(), code, sd.data_ptr(),
+                                        out2.data_ptr(), flags.data_ptr(), xb2.data_ptr(), gb2.data_ptr(), xba2.data_ptr(),
+                                        B, E, eps, a, S()) == 0
+    for name, u, v in (("out", out1, out2), ("x_adv", xa1, xa2), ("x_best", xb1, xb2), ("x_best_adv", xba1, xba2)):
+        assert bits_equal(u.cpu().numpy(), v.cpu().numpy()), name
+    assert torch.equal(gb1.view(torch.uint8), gb2.view(torch.uint8))
+    assert torch.equal(gr2.view(torch.uint8), gr.view(torch.uint8))          # the fused pass never writes the gradient
+
+
+@pytest.mark.parametrize("B,E", [(4, 3 * 16 * 16), (3, 75), (2, 3 * 224 * 224)])
+@pytest.mark.parametrize("gdt", [torch.float32, torch.int8])
+def test_linf_step_track_first_iteration_makes_the_prologue_clones(lib, B, E, gdt):
+    """flags == NULL: iteration 0 (x_adv_old is x_adv, a == 1) - the new iterate equals apgd_linf_step_f32's, and x_best =
+    x_best_adv = x_adv (:142-143), grad_best = grad (:189) are written by the same launch."""
+    eps = 4 / 255
+    x, xa, _, g, step = _step_inputs(B, E, B * 5 + E, eps)
+    xd, xad, sd = map(dev, (x, xa, step))
+    gr = torch.sign(dev(g)).to(torch.int8) if gdt == torch.int8 else dev(g)
+    code = 3 if gdt == torch.int8 else 0
+    want = torch.zeros_like(xd)
+    assert lib.apgd_linf_step_f32(xd.data_ptr(), xad.data_ptr(), xad.data_ptr(), gr.data_ptr(), code, sd.data_ptr(), want.data_ptr(),
+                                  None, B, E, eps, 1.0, S()) == 0
+    out, xb, xba, gb = torch.zeros_like(xd), torch.full_like(xd, -1), torch.full_like(xd, -1), torch.zeros_like(gr)
+    xa0 = xad.clone()
+    assert lib.apgd_linf_step_track_f32(xd.data_ptr(), xad.data_ptr(), xad.data_ptr(), gr.data_ptr(), code, sd.data_ptr(),
+                                        out.data_ptr(), None, xb.data_ptr(), gb.data_ptr(), xba.data_ptr(), B, E, eps, 1.0, S()) == 0
+    assert bits_equal(out.cpu().numpy(), want.cpu().numpy())
+    assert torch.equal(xb, xa0) and torch.equal(xba, xa0) and torch.equal(xad, xa0)
+    assert torch.equal(gb.view(torch.uint8), gr.view(torch.uint8))
+    # argument checks: the first form needs x_adv_old == x_adv and a == 1; aliasing outputs are refused
+    assert lib.apgd_linf_step_track_f32(xd.data_ptr(), xad.data_ptr(), xd.data_ptr(), gr.data_ptr(), code, sd.data_ptr(),
+                                        out.data_ptr(), None, xb.data_ptr(), gb.data_ptr(), xba.data_ptr(), B, E, eps, 1.0, S()) == -4
+    assert lib.apgd_linf_step_track_f32(xd.data_ptr(), xad.data_ptr(), xad.data_ptr(), gr.data_ptr(), code, sd.data_ptr(),
+                                        out.data_ptr(), None, xb.data_ptr(), gb.data_ptr(), xb.data_ptr(), B, E, eps, 1.0, S()) == -4
+    assert lib.apgd_linf_step_track_f32(xd.data_ptr(), xad.data_ptr(), xad.data_ptr(), gr.data_ptr(), 4, sd.data_ptr(),
+                                        out.data_ptr(), None, xb.data_ptr(), gb.data_ptr(), xba.data_ptr(), B, E, eps, 1.0, S()) == -3
+
+
 def test_linf_step_unaligned_rows(lib):
     eps, B, E = 8 / 255, 3, 64
     x, xa, xo, g, step = _step_inputs(B, E + 1, 5, eps)
@@ -501,8 +568,12 @@ def _run_replay(R, g, norm):
     return x, m, out
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-track", "two-pass"])
 @pytest.mark.parametrize("case", LINF)
-def test_apgd_linf_golden_bit_exact_with_reference_losses(R, monkeypatch, case):
+def test_apgd_linf_golden_bit_exact_with_reference_losses(R, monkeypatch, case, fused):
+    """``fused``: the row moves inside the next iteration's update kernel (apgd_linf_step_track_f32, the default since round 5)
+    or as the separate apgd_track_rows pass - the same trajectories bit for bit either way."""
+    monkeypatch.setattr(R.apgd, "FUSED_TRACKING", fused)
     g = load_golden(case)
     _inject_losses(monkeypatch, R, g["losses"])
     x, m, (xb, acc, lb, xba) = _run_replay(R, g, "Linf")
@@ -552,8 +623,10 @@ def test_l2_step_vs_oracle(lib, B, E):
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-track", "two-pass"])
 @pytest.mark.parametrize("K", [2, 7, 40])
-def test_apgd_fuzz_against_oracle(R, monkeypatch, K):
+def test_apgd_fuzz_against_oracle(R, monkeypatch, K, fused):
+    monkeypatch.setattr(R.apgd, "FUSED_TRACKING", fused)
     """Random scripted trajectories (many ties, halvings, mis-classifications): the oracle is the
     yardstick, driven by the same logits/grads/losses."""
     rng = np.random.default_rng(K)

@@ -33,6 +33,6 @@ for rep in range(2):
         torch.cuda.synchronize()
         ev = A.PROFILE_EVENTS
         A.PROFILE_EVENTS = None
-        gen = sorted(a.elapsed_time(b) * 1e3 for (n, i, a, b, gb) in ev if i > 0)
-        first = sorted(a.elapsed_time(b) * 1e3 for (n, i, a, b, gb) in ev if i == 0)
+        gen = sorted(a.elapsed_time(b) * 1e3 for (n, i, a, b, gb, fl) in ev if i > 0)
+        first = sorted(a.elapsed_time(b) * 1e3 for (n, i, a, b, gb, fl) in ev if i == 0)
         print(f"rep {rep} shape {sh}: general median {gen[len(gen) // 2]:.1f} us (min {gen[0]:.1f}), first-iteration {first[len(first) // 2]:.1f} us", flush=True)

@@ -30,5 +30,20 @@ for grad, code in ((gr, 0), (sg, 3), (sb, 4)):
     for _ in range(10):       # iteration-0 form: x_adv_old aliases x_adv (a = 1.0)
         assert lib.apgd_linf_step_f32(x.data_ptr(), xa.data_ptr(), xa.data_ptr(), grad.data_ptr(), code, step.data_ptr(),
                                       out.data_ptr(), None, B, E, eps, 1.0, S) == 0
+# round 5: the fused form (apgd_linf_step_track_f32: the step + the row moves of the iteration before it).  Per gradient type, in this
+# order (tools/k1_traffic.py slices the dispatches of a kernel name by it): 10 launches with every sample NEW_BEST | MISCLS (what a
+# random-init model's APGD-2 step looks like), 10 with every sample NEW_BEST only, then 10 of the iteration-0 form (flags == NULL)
+xb, xba = torch.empty_like(x), torch.empty_like(x)
+for grad, code in ((gr, 0), (sg, 3)):
+    gb = torch.empty_like(grad)
+    for fv in (3, 1):
+        flags = torch.full((B,), fv, device="cuda", dtype=torch.uint8)
+        for _ in range(10):
+            assert lib.apgd_linf_step_track_f32(x.data_ptr(), xa.data_ptr(), xo.data_ptr(), grad.data_ptr(), code, step.data_ptr(),
+                                                out.data_ptr(), flags.data_ptr(), xb.data_ptr(), gb.data_ptr(), xba.data_ptr(), B, E,
+                                                eps, 0.75, S) == 0
+    for _ in range(10):
+        assert lib.apgd_linf_step_track_f32(x.data_ptr(), xa.data_ptr(), xa.data_ptr(), grad.data_ptr(), code, step.data_ptr(),
+                                            out.data_ptr(), None, xb.data_ptr(), gb.data_ptr(), xba.data_ptr(), B, E, eps, 1.0, S) == 0
 torch.cuda.synchronize()
 print("done", B * E * 4)
