@@ -221,6 +221,17 @@ int cnx_conv3x3s2_fwd(const void* x, const void* packed, const float* bias, void
 int cnx_conv3x3s2_dgrad(const void* dy, const void* packed, void* dx, int64_t N, int32_t H, int32_t W, int32_t CI, int32_t CO,
                         void* stream);
 
+/* Filter / bias gradient of the same convolution (utils_architecture.py:205-211 backward; the library's convolution_backward = MIOpen
+ * before round 5):  dw[co][kh][kw][ci] = sum_{n,oh,ow} dy[n,oh,ow,co] * x[n,2oh-1+kh,2ow-1+kw,ci]   (fp32, the weight's
+ * channels-last order: a [CO, CI, 3, 3] tensor with strides (9 CI, 1, 3 CI, CI));  dbias[co] = sum dy  (dbias may be NULL).
+ * x: bf16 [N, H, W, CI] rows, dy: bf16 [N, H/2, W/2, CO] rows.  Implicit GEMM over the positions with both operands read out of LDS
+ * by transpose reads (csrc/wgrad_kernels.hip); deterministic (per-workgroup partials in ws, cnx_conv3x3s2_wgrad_ws_floats floats,
+ * summed in a fixed order).  Shapes: cnx_conv3x3s2_wgrad_supported (CO = 96, CI in {48, 64}, even H, W up to the LDS budget). */
+int cnx_conv3x3s2_wgrad_supported(int32_t CI, int32_t CO, int32_t H, int32_t W);
+int64_t cnx_conv3x3s2_wgrad_ws_floats(int32_t CI, int32_t CO);
+int cnx_conv3x3s2_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws,
+                        int64_t N, int32_t H, int32_t W, int32_t CI, int32_t CO, void* stream);
+
 /* Fused multi-head softmax attention of the ViT family (timm 0.8 `Attention.forward`, reached through the models of
  * /root/reference/utils_architecture.py:272-301):
  *     q, k, v = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4);   out = softmax(q k^T * scale) v

@@ -58,6 +58,9 @@ PROTOTYPES = {
     "cnx_conv3x3s2_pack": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _p]),
     "cnx_conv3x3s2_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cnx_conv3x3s2_dgrad": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "cnx_conv3x3s2_wgrad_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "cnx_conv3x3s2_wgrad_ws_floats": (C.c_int64, [_i32, _i32]),
+    "cnx_conv3x3s2_wgrad": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cnx_block_mlp_hpre_supported": (C.c_int, [_i32]),
     "cnx_block_mlp_hpre_elems": (C.c_int64, [_i64, _i32]),
     "cnx_block_mlp_fwd_hpre": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _i64, _i32, _p]),

@@ -195,6 +195,154 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
   }
 }
 
+// LDS-DMA: 16 bytes per lane from a raw buffer straight into LDS; lds_dst is wave-uniform (M0), lane l lands at lds_dst + 16 l.
+// Honours EXEC; the compiler sees neither the load nor its LDS write: completion is the caller's s_waitcnt vmcnt.
+__device__ __forceinline__ void dma_lds16(uint32_t lds_dst, uint32_t voff, u32x4 rs, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 make_rsrc4(const void* p, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  return u32x4{static_cast<uint32_t>(a), static_cast<uint32_t>(a >> 32) & 0xffffu, bytes, 0x00020000u};   // stride 0: raw buffer
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Filter / bias gradient of the second ConvStem convolution, Conv2d(CI, CO, 3, stride 2, padding 1) on channels-last bf16 rows
+// (utils_architecture.py:205-211: 48 -> 96; ConvBlock3(64): 64 -> 96):
+//     dW[co][(kh, kw, ci)] = sum_{n, oh, ow} dy[n, oh, ow, co] * x[n, 2 oh - 1 + kh, 2 ow - 1 + kw, ci]       (66.6 GFLOP at batch 256)
+// An implicit-GEMM contraction over the positions with BOTH operands coming out of LDS through transpose reads.  A workgroup (four
+// wavefronts) takes one output row (n, oh) at a time: the three input rows it touches go to LDS as they lie in memory
+// ([3][WP][CI] bf16; image column iw sits at slot iw + 1, slot 0 and the slots behind the row stay zero: padding and the k-step
+// tail), the dy row likewise ([16 KS][CO], rows >= OW stay zero).  D is [CO = 3 blocks of 32] x [9 CI columns, flat index
+// c = (kh*3 + kw)*CI + ci - the weight's own channels-last order - in blocks of 32]; a 16-column group of a block lies inside one tap
+// because CI % 16 == 0, so a lane's piece address is  position part (2 ow * CI * 2 bytes) + column part (tap offset + ci), the k-step
+// and the second read are immediates.  Column blocks are dealt over the workgroup's eight wavefronts (block cb -> wavefront cb % 8,
+// two wavefronts per SIMD sharing the row images); the first wavefront with one block fewer also owns the bias gradient: one more
+// "column block" whose B fragment is a constant (column 0 = ones).  Per k-step and wavefront: 6 + 2 NCB transpose reads for 3 NCB
+// MFMAs.  One partial result per workgroup, summed in fixed order.
+constexpr int kW2 = 8;                                                 // wavefronts per workgroup
+template <int CI, int CO, int NCB>
+__global__ __launch_bounds__(kW2 * 64, 2) void conv2_wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                                             float* __restrict__ ws, int N, int H, int W) {
+  static_assert(CO == 96 && CI % 16 == 0, "shapes");
+  constexpr int KT = 9 * CI;                                           // columns of D
+  constexpr int NCOLB = (KT + 31) / 32;                                // 32-column blocks (the last may be half empty)
+  constexpr int BIAS_WAVE = NCOLB % kW2;                               // the first wavefront with one block fewer (NCOLB % kW2 != 0 here)
+  static_assert(NCOLB % kW2 != 0 && (NCOLB + kW2 - 1) / kW2 == NCB, "column-block deal");
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  const int OH = H / 2, OW = W / 2, KS = (OW + 15) / 16, WP = 32 * KS + 3;
+  uint16_t* ximg = lds;                                                // [3][WP][CI]      (two buffers of both images: a row is
+  uint16_t* dimg = lds + 3 * WP * CI;                                  // [16 KS][CO]       loaded while the one before is multiplied)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i16 = lane & 15;
+  for (int e = tid; e < 2 * (3 * WP * CI + 16 * KS * CO) / 8; e += kW2 * 64) reinterpret_cast<u32x4*>(lds)[e] = u32x4{0u, 0u, 0u, 0u};
+
+  // the lane's piece offsets: A (dy image, row stride 2 CO bytes) and the position part of B (a position = 2 image columns)
+  const uint32_t a_piece = lds_addr(dimg) + static_cast<uint32_t>(8 * (g >> 1) + (i16 >> 2)) * (CO * 2) + static_cast<uint32_t>(16 * (g & 1) + 4 * (i16 & 3)) * 2u;
+  const uint32_t b_pos = lds_addr(ximg) + static_cast<uint32_t>(8 * (g >> 1) + (i16 >> 2)) * (4 * CI);
+  uint32_t b_piece[NCB];
+#pragma unroll
+  for (int j = 0; j < NCB; ++j) {
+    int c = 32 * (wave + kW2 * j) + 16 * (g & 1) + 4 * (i16 & 3);
+    if (c >= KT) c = 0;                                                // (columns behind the filter: any finite data, never stored)
+    const int tap = c / CI, ci = c - tap * CI, kh = tap / 3, kw = tap - 3 * kh;
+    b_piece[j] = b_pos + static_cast<uint32_t>((kh * WP + kw) * CI + ci) * 2u;
+  }
+  const int ncb = (NCOLB - wave + kW2 - 1) / kW2;                      // this wavefront's blocks: wave, wave + 8, ...
+  const bool bias_wave = wave == BIAS_WAVE;
+  bf16x8 ones;                                                         // B fragment of the bias "block": column 0 = 1
+  {
+    const uint32_t v = (lane & 31) == 0 ? 0x3f803f80u : 0u;
+    const u32x4 t = {v, v, v, v};
+    ones = __builtin_bit_cast(bf16x8, t);
+  }
+  f32x16 acc[3][NCB];
+#pragma unroll
+  for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+    for (int j = 0; j < NCB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][j][r] = 0.f;
+
+  const u32x4 rsx = make_rsrc4(x, static_cast<uint32_t>(static_cast<long>(N) * H * W * CI * 2));
+  const u32x4 rsd = make_rsrc4(dy, static_cast<uint32_t>(static_cast<long>(N) * OH * OW * CO * 2));
+  const int xrow_pieces = W * CI / 8, drow_pieces = OW * CO / 8;       // 16-byte pieces per input / dy row
+  const long rows = static_cast<long>(N) * OH;
+  const uint32_t buf_elems = static_cast<uint32_t>(3 * WP * CI + 16 * KS * CO);
+  // A row's images arrive by LDS-DMA (buffer_load_dwordx4 ... lds: 64 consecutive 16-byte pieces per instruction land at M0 + 16 l,
+  // no staging registers): units of 64 pieces - 3 x NXU for the input rows, NDU for the dy row - dealt over the eight wavefronts.
+  // Lanes behind a row's last piece are switched off (EXEC): the slots / rows behind the data keep their zeros.  The filter row
+  // above the image (oh = 0, kh = 0) is written as zeros by hand.  Completion: s_waitcnt vmcnt(0) in front of the barrier that
+  // hands the buffer over (the compiler does not see these loads).
+  const int NXU = (xrow_pieces + 63) / 64, NDU = (drow_pieces + 63) / 64;
+  const uint32_t lds0 = lds_addr(lds);
+  auto dma_row = [&](long row, int buf) {
+    const long n = row / OH;
+    const int oh = static_cast<int>(row - n * OH);
+    const uint32_t xb = lds0 + static_cast<uint32_t>(buf) * buf_elems * 2u, db = xb + static_cast<uint32_t>(3 * WP * CI) * 2u;
+    for (int u = wave; u < 3 * NXU + NDU; u += kW2) {                  // wave-uniform
+      if (u < 3 * NXU) {
+        const int kh = u / NXU, blk = u - kh * NXU, pc = blk * 64 + lane;
+        const int ih = 2 * oh - 1 + kh;
+        const uint32_t dst = xb + static_cast<uint32_t>((kh * WP + 1) * CI) * 2u + static_cast<uint32_t>(blk) * 1024u;
+        if (ih >= 0) {
+          if (pc < xrow_pieces) dma_lds16(dst, static_cast<uint32_t>(pc) * 16u, rsx, static_cast<uint32_t>(((n * H + ih) * W) * CI * 2));
+        } else if (pc < xrow_pieces) {
+          *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>(static_cast<uintptr_t>(dst + static_cast<uint32_t>(lane) * 16u)) = u32x4{0u, 0u, 0u, 0u};
+        }
+      } else {
+        const int blk = u - 3 * NXU, pc = blk * 64 + lane;
+        if (pc < drow_pieces) dma_lds16(db + static_cast<uint32_t>(blk) * 1024u, static_cast<uint32_t>(pc) * 16u, rsd, static_cast<uint32_t>(row * OW * CO * 2));
+      }
+    }
+  };
+  long row = blockIdx.x;
+  int buf = 0;
+  __syncthreads();                                                     // zero fill done
+  if (row < rows) dma_row(row, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (; row < rows; row += gridDim.x) {
+    const long next = row + gridDim.x;
+    if (next < rows) dma_row(next, buf ^ 1);                           // (that buffer: last read one row ago, behind a barrier)
+    const uint32_t boff = static_cast<uint32_t>(buf) * buf_elems * 2u;
+    const uint32_t a_cur = a_piece + boff;
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int cb = 0; cb < 3; ++cb) a[cb] = tr_fragment(a_cur + static_cast<uint32_t>(ks * 16 * CO * 2 + cb * 64), CO * 2);
+#pragma unroll
+      for (int j = 0; j < NCB; ++j) {
+        if (j < ncb) {
+          const bf16x8 b = tr_fragment(b_piece[j] + boff + static_cast<uint32_t>(ks * 16 * 4 * CI), 4 * CI);
+#pragma unroll
+          for (int cb = 0; cb < 3; ++cb) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b, acc[cb][j], 0, 0, 0);
+        } else if (j == NCB - 1 && bias_wave) {
+#pragma unroll
+          for (int cb = 0; cb < 3; ++cb) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], ones, acc[cb][j], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial result: ws[blockIdx.x][CO][KT] then [CO] bias sums
+  float* out = ws + static_cast<long>(blockIdx.x) * (CO * KT + CO);
+  const int col = lane & 31, kb = lane >> 5;
+#pragma unroll
+  for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+      const int c = 32 * (wave + kW2 * j) + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        if (j < ncb) { if (c < KT) out[co * KT + c] = acc[cb][j][r]; }
+        else if (j == NCB - 1 && bias_wave && col == 0) out[CO * KT + co] = acc[cb][j][r];
+      }
+    }
+}
+
 // out[j] = sum over parts (fixed order: 8 interleaved running sums, then a tree) of ws[part * len + j]; one thread per j and
 // part-lane, 32 part-lanes per output.  map: j -> destination index (the caller's layouts differ from the partials'), or identity.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
@@ -258,6 +406,46 @@ int cnx_stem_conv_wgrad(const float* x, const void* dy, float* dw, float* dbias,
   // partial layout [28][P]: rows 0..26 = (ci, kh, kw) x P  ->  dw[p][27] ([P, 3, 3, 3]); row 27 -> dbias[P]
   const int len = 28 * P;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((len + 7) / 8), dim3(256), 0, s, ws, dw, dbias, len, 27 * P, static_cast<int>(nwg), 27, P);
+  return launch_status();
+}
+
+int cnx_conv3x3s2_wgrad_supported(int32_t CI, int32_t CO, int32_t H, int32_t W) {
+  if (!(CO == 96 && (CI == 48 || CI == 64)) || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
+  const int KS = (W / 2 + 15) / 16, WP = 32 * KS + 3;
+  return ((3L * WP * CI + 16L * KS * CO) * 4 <= 150 * 1024 && (W * CI) % 8 == 0) ? 1 : 0;   // two buffers of both row images in LDS
+}
+
+int64_t cnx_conv3x3s2_wgrad_ws_floats(int32_t CI, int32_t CO) { return 512L * (9L * CI * CO + CO); }
+
+int cnx_conv3x3s2_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws, int64_t N, int32_t H, int32_t W, int32_t CI,
+                        int32_t CO, void* stream) {
+  if (N < 0) return APGD_ERR_SIZE;
+  if (!cnx_conv3x3s2_wgrad_supported(CI, CO, H, W)) return APGD_ERR_ARG;
+  if (!dw || !ws || (N > 0 && (!x || !dy))) return APGD_ERR_NULL;
+  if (static_cast<long>(N) * H * W * CI * 2 >= (1L << 32)) return APGD_ERR_ARG;     // 32-bit byte offsets
+  hipStream_t s = as_stream(stream);
+  const int KS = (W / 2 + 15) / 16, WP = 32 * KS + 3;
+  const size_t lds_bytes = (3L * WP * CI + 16L * KS * CO) * 4;
+  const long rows = N * (H / 2);
+  long nwg = rows < 256 ? rows : 256;                                  // one resident workgroup (eight wavefronts) per CU
+  if (nwg < 1) nwg = 1;
+  const auto* xp = static_cast<const uint16_t*>(x);
+  const auto* dp = static_cast<const uint16_t*>(dy);
+  static const bool lds_attr = [] {                                    // dynamic LDS beyond 64 KB needs the attribute (once per process)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_kernel<48, 96, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_kernel<64, 96, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)lds_attr;
+  if (CI == 48)
+    hipLaunchKernelGGL((conv2_wgrad_kernel<48, 96, 2>), dim3(static_cast<unsigned>(nwg)), dim3(kW2 * 64), lds_bytes, s, xp, dp, ws, static_cast<int>(N), H, W);
+  else
+    hipLaunchKernelGGL((conv2_wgrad_kernel<64, 96, 3>), dim3(static_cast<unsigned>(nwg)), dim3(kW2 * 64), lds_bytes, s, xp, dp, ws, static_cast<int>(N), H, W);
+  int rc = launch_status();
+  if (rc) return rc;
+  // partials [CO][9 CI] (+ [CO]) -> dw in the weight's channels-last order [CO][kh][kw][CI], dbias[CO]
+  const int len = CO * 9 * CI + CO;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((len + 7) / 8), dim3(256), 0, s, ws, dw, dbias, len, CO * 9 * CI, static_cast<int>(nwg), 0, 1);
   return launch_status();
 }
 

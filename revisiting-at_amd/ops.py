@@ -691,6 +691,17 @@ class _Conv3x3s2(torch.autograd.Function):
                                                _stream()), "cnx_conv3x3s2_dgrad")
             dx = dxr.permute(0, 3, 1, 2)
         need_lib_dx = ctx.needs_input_grad[0] and dx is None
+        if want_w and STEM_WGRAD_HIP and lib.cnx_conv3x3s2_wgrad_supported(CI, CO, H, W):
+            # filter / bias gradient on csrc/wgrad_kernels.hip, in the weight's channels-last order
+            dwf = torch.empty(CO, 3, 3, CI, device=x.device, dtype=torch.float32)
+            db = torch.empty(CO, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            ws = torch.empty(lib.cnx_conv3x3s2_wgrad_ws_floats(CI, CO), device=x.device, dtype=torch.float32)
+            _lib.check(lib.cnx_conv3x3s2_wgrad(x.permute(0, 2, 3, 1).data_ptr(), g.permute(0, 2, 3, 1).data_ptr(), dwf.data_ptr(),
+                                               _lib.ptr(db), ws.data_ptr(), N, H, W, CI, CO, _stream()), "cnx_conv3x3s2_wgrad")
+            dw = dwf.permute(0, 3, 1, 2).to(weight.dtype)
+            if db is not None:
+                db = db.to(weight.dtype)
+            want_w = False
         if need_lib_dx or want_w:
             wl = _cached((weight,), "bf16_cl", lambda w: w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
             r = torch.ops.aten.convolution_backward(g, x, wl, [CO] if ctx.has_bias else None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,

@@ -487,6 +487,38 @@ def test_second_stem_convolution_vs_library(R, CI, N, H, W, bias):
     assert lib.cnx_conv3x3s2_dgrad(dys.data_ptr(), pk.data_ptr(), dx1.data_ptr(), N, H + 2, W, CI, CO, S()) < 0
 
 
+@pytest.mark.parametrize("CI,N,H,W", [(48, 2, 32, 32), (48, 3, 8, 16), (48, 2, 112, 112), (64, 2, 32, 48), (64, 1, 16, 16), (48, 1, 2, 2),
+                                      (48, 5, 6, 10), (64, 3, 112, 112), (48, 700, 4, 4)])
+def test_second_stem_convolution_filter_gradient_vs_fp32_reference(R, CI, N, H, W):
+    """cnx_conv3x3s2_wgrad (csrc/wgrad_kernels.hip: implicit GEMM over the positions, both operands through LDS transpose reads,
+    row images by LDS-DMA) against the fp32 filter / bias gradient of F.conv2d on the same bf16 operands.  Covers widths whose
+    output rows are no multiple of the 16-position k-step (tails), the first image row (zero filter row), more rows than
+    workgroups, both channel counts; the result is in the weight's channels-last order and deterministic."""
+    lib = R._lib.load()
+    CO = 96
+    assert lib.cnx_conv3x3s2_wgrad_supported(CI, CO, H, W) == 1
+    g = torch.Generator().manual_seed(CI + H + N)
+    x = (torch.randn(N, CI, H, W, generator=g) * torch.linspace(0.5, 1.5, CI).view(1, CI, 1, 1)).to(torch.bfloat16)
+    dy = (torch.randn(N, CO, H // 2, W // 2, generator=g) * torch.linspace(0.3, 2.0, CO).view(1, CO, 1, 1)).to(torch.bfloat16)
+    w = torch.zeros(CO, CI, 3, 3, requires_grad=True)
+    b = torch.zeros(CO, requires_grad=True)
+    gw, gb = torch.autograd.grad(F.conv2d(x.float(), w, b, stride=2, padding=1), (w, b), dy.float())
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dw = torch.full((CO, 3, 3, CI), float("nan"), device="cuda")
+    db = torch.full((CO,), float("nan"), device="cuda")
+    ws = torch.empty(lib.cnx_conv3x3s2_wgrad_ws_floats(CI, CO), device="cuda")
+    assert lib.cnx_conv3x3s2_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), N, H, W, CI, CO, S()) == 0
+    scale = float(gw.abs().max()) + 1e-6
+    close(dw.permute(0, 3, 1, 2), gw, 1e-4, 3e-5 * scale)          # fp32 sums of exact bf16 products, another order
+    close(db, gb, 1e-4, 3e-5 * float(gb.abs().max()) + 1e-6)
+    dw2 = torch.empty_like(dw)
+    assert lib.cnx_conv3x3s2_wgrad(xd.data_ptr(), dyd.data_ptr(), dw2.data_ptr(), None, ws.data_ptr(), N, H, W, CI, CO, S()) == 0
+    assert torch.equal(dw, dw2)
+    assert lib.cnx_conv3x3s2_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), N, H, W, 32, CO, S()) == -4
+    assert lib.cnx_conv3x3s2_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), N, H + 1, W, CI, CO, S()) == -4
+
+
 def test_full_model_matches_reference_model_fp32(R):
     torch.manual_seed(0)
     ref = M.ConvNeXtTimm(depths=(1, 1, 2, 1), dims=(32, 64, 96, 128), num_classes=10)
@@ -814,6 +846,40 @@ def test_stem_image_conv_forward_and_input_gradient(R, P, N, H, W):
             out2 = R.ops.stem_conv(xd, wd, bd)
         (dx2,) = torch.autograd.grad(out2, xd, cot.cuda().to(torch.bfloat16))
     assert torch.equal(dx2, dx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,N,H,W", [(48, 2, 32, 32), (64, 1, 16, 24), (96, 3, 8, 8), (48, 3, 224, 224), (64, 5, 64, 96), (48, 1, 2, 2),
+                                     (96, 2, 32, 64)])
+def test_stem_conv_filter_gradient_vs_fp32_reference(R, P, N, H, W):
+    """cnx_stem_conv_wgrad (csrc/wgrad_kernels.hip: contraction over the positions, dy rows through LDS transpose reads) against the
+    fp32 filter / bias gradient of F.conv2d on the operands the autocast convolution multiplies (x and dy rounded to bf16).  Widths
+    whose output rows are multiples of 16 take the row-chunk form, the others the general one; sizes below one 16-position chunk
+    and tails are covered.  Asymmetric random data: a transposed or permuted operand cannot pass."""
+    lib = R._lib.load()
+    g = torch.Generator().manual_seed(P + H)
+    x = torch.rand(N, 3, H, W, generator=g)
+    dy = torch.randn(N, P, H // 2, W // 2, generator=g) * torch.linspace(0.5, 2.0, P).view(1, P, 1, 1)
+    xb, dyb = x.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
+    w = torch.zeros(P, 3, 3, 3, requires_grad=True)
+    b = torch.zeros(P, requires_grad=True)
+    gw, gb = torch.autograd.grad(F.conv2d(xb, w, b, stride=2, padding=1), (w, b), dyb)
+    xd = x.cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    dw = torch.full((P, 3, 3, 3), float("nan"), device="cuda")
+    db = torch.full((P,), float("nan"), device="cuda")
+    ws = torch.empty(lib.cnx_stem_conv_wgrad_ws_floats(P), device="cuda")
+    for dbp in (db, None):
+        assert lib.cnx_stem_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None if dbp is None else dbp.data_ptr(),
+                                       ws.data_ptr(), N, H, W, P, S()) == 0
+        scale = float(gw.abs().max()) + 1e-6
+        close(dw, gw, 1e-4, 2e-5 * scale)                       # fp32 accumulation of exact bf16 products, another order
+        close(db, gb, 1e-4, 2e-5 * float(gb.abs().max()) + 1e-6)
+    dw2 = torch.empty_like(dw)
+    assert lib.cnx_stem_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw2.data_ptr(), None, ws.data_ptr(), N, H, W, P, S()) == 0
+    assert torch.equal(dw, dw2)                                  # deterministic (fixed-order partial sums)
+    assert lib.cnx_stem_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), N, H + 1, W, P, S()) == -4
+    assert lib.cnx_stem_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), N, H, W, 40, S()) == -4
 
 
 @pytest.mark.gpu

@@ -31,3 +31,21 @@ with torch.autocast("cuda", dtype=torch.bfloat16):
     t_one_g = timeit(lambda: R.ops.stem_conv_ln_gelu(xg, w, b, lw, lb, 1e-6))
     t_two_g = timeit(lambda: R.ops.layer_norm_cf_gelu(R.ops.stem_conv(xg, w, b), lw, lb, 1e-6))
 print(f"B={B}: conv {t_conv:.1f} us | conv + LN/GELU kernel {t_two:.1f} us | one kernel {t_one:.1f} us | with saved tensors: two {t_two_g:.1f}, one {t_one_g:.1f}")
+
+# filter / bias gradient: cnx_stem_conv_wgrad (round 5) against the library's convolution_backward on the same operands
+lib = R._lib.load()
+dy = torch.randn(B, 112, 112, 48, device="cuda").to(torch.bfloat16)
+dw = torch.empty(48, 3, 3, 3, device="cuda"); db = torch.empty(48, device="cuda")
+ws = torch.empty(lib.cnx_stem_conv_wgrad_ws_floats(48), device="cuda")
+S = torch.cuda.current_stream().cuda_stream
+t_wg = timeit(lambda: lib.cnx_stem_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, 224, 224, 48, S))
+
+
+def lib_wgrad():
+    xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), xb, w.to(torch.bfloat16), [48], [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                               [False, True, True])
+
+
+t_lib = timeit(lib_wgrad)
+print(f"B={B}: filter gradient: cnx_stem_conv_wgrad {t_wg:.1f} us (462 MB: {0.462e3 * B / 256 / t_wg:.2f} TB/s) | library (cast + layout copy + MIOpen) {t_lib:.1f} us")
