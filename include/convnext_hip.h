@@ -207,6 +207,27 @@ int cnx_block_mlp_bwd_input_hpre(const void* u, const float* ln_w, const float* 
                                  const void* g, int g_dtype, const float* gamma, const void* Wb, const void* hpre_ws,
                                  void* du, int64_t M, int32_t C, void* stream);
 
+/* The TRAINING pass on the same kernel pair (round 5; C = 128 ... 384): forward and backward hand the weight-gradient contractions
+ * their operands in the layouts cnx_gemm_tn_ex reads, so that no GEMM of the block is a library call and nothing is transposed:
+ *   cnx_block_mlp_fwd_train      = cnx_block_mlp_fwd_hpre + H = GELU(Hpre) into a second workspace of the same size and tiles
+ *                                  (CNX_TN_ACC), the LN(u) rows a_rows [M, C] bf16, and (optionally) y2_out like cnx_block_mlp_fwd;
+ *   cnx_block_mlp_bwd_train_hpre   from g, gamma, the packed backward weights and the Hpre workspace: da [M, C] bf16 = gradient w.r.t.
+ *                                  LN(u) (the LayerNorm backward with its parameter gradients is cnx_layernorm_bwd), do_rows [M, C]
+ *                                  bf16 = g * gamma, dhpre_ws = dHpre as CNX_TN_ACC tiles (cnx_block_mlp_hpre_elems elements).
+ * Then dW2, db2 = cnx_gemm_tn_ex(A = do_rows ROWS, B = h_ws ACC), dW1, db1 = cnx_gemm_tn_ex(A = dhpre_ws ACC, B = a_rows ROWS).
+ *   cnx_block_mlp_bwd_acc        the recomputing training backward (cnx_block_mlp_bwd; C = 96 ... 256) with H and dHpre written as
+ *                                  CNX_TN_ACC tiles instead of transposed [4C, M] matrices (M a multiple of 32; workspaces of
+ *                                  M * 4C elements each). */
+int cnx_block_mlp_fwd_train(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
+                            const void* Wf, const float* b1, const float* b2, const float* gamma, const void* resid,
+                            int resid_dtype, void* out, int out_dtype, void* y2_out, void* hpre_ws, void* h_ws, void* a_rows,
+                            int64_t M, int32_t C, void* stream);
+int cnx_block_mlp_bwd_train_hpre(const void* g, int g_dtype, const float* gamma, const void* Wb, const void* hpre_ws, void* da,
+                                 void* do_rows, void* dhpre_ws, int64_t M, int32_t C, void* stream);
+int cnx_block_mlp_bwd_acc(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                          const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
+                          void* a_rows, void* do_rows, void* h_ws, void* dhpre_ws, int64_t M, int32_t C, void* stream);
+
 /* Second ConvStem convolution (utils_architecture.py:207-209 `ConvBlock1`: 48 -> 96; `ConvBlock3`: 64 -> 96): 3x3, stride 2, padding 1
  * on channels-last bf16 activations, forward and input gradient as implicit GEMMs on MFMA (filter resident in LDS, activations as
  * 16-byte loads straight from the NHWC tensor).  x [N, H, W, CI] bf16 -> out [N, H/2, W/2, CO] bf16 (+ bias [CO] fp32, nullable);
@@ -250,6 +271,31 @@ int cnx_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int32_t
 int cnx_attention_bwd_supported(int32_t N, int32_t head_dim);
 int cnx_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dvec,
                       int64_t B, int32_t N, int32_t H, int32_t head_dim, float scale, void* stream);
+
+/* Contraction over the ROW index of two row-major operands (round 5; csrc/wgrad_kernels.hip):
+ *     D[N1][N2] = A^T B,   A: bf16 [M, N1] (row stride lda elements), B: bf16 [M, N2] (ldb), D: fp32 [N1, N2] contiguous
+ * - the weight gradients of the pointwise convolutions and linears (models/convnext.py:42-46 backward: dW1 = dHpre^T LN(u),
+ * dW2 = dO^T H), which were split-K batched library GEMMs (hipBLASLt) plus a partial-sum pass.  Both operands go HBM -> LDS as
+ * they lie in memory (LDS-DMA) and reach the MFMA through transpose reads (ds_read_b64_tr_b16); M is split over workgroups, the
+ * fp32 partial results (ws: cnx_gemm_tn_ws_floats(M, N1, N2) floats) are added in a fixed order: deterministic.
+ * Shapes: M % 64 == 0; (N1, N2) multiples of one of the tiles 384x192, 192x384, 256x128, 128x256, 384x96, 96x384, 256x64, 64x256
+ * (cnx_gemm_tn_supported); lda, ldb multiples of 8; 16-byte aligned pointers; operands below 4 GB. */
+int cnx_gemm_tn_supported(int64_t M, int32_t N1, int32_t N2);
+int64_t cnx_gemm_tn_ws_floats(int64_t M, int32_t N1, int32_t N2);
+int cnx_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* D, float* ws,
+                int64_t M, int32_t N1, int32_t N2, void* stream);
+/* The same contraction with a per-operand layout:
+ *   CNX_TN_ROWS  row-major [M][N] with a leading dimension;
+ *   CNX_TN_ACC   tiles [M / 32][N / 32] of 2 KiB in the accumulator order of the fused block kernels (element (m, n) of a tile at byte
+ *                64 m + 32 ((n / 4) % 2) + 8 (n / 8) + 2 (n % 4)): what cnx_block_mlp_fwd_hpre / the emitting backward kernels write for
+ *                the hidden activation H, its pre-activation and dHpre - two 16-byte stores per lane straight from the accumulators,
+ *                no transposition pass; the leading dimension is ignored (M a multiple of 32, N = the operand's width).
+ * At most one operand is CNX_TN_ACC.  With an ACC operand the call also returns colsum_a[N1] = sum_m A[m][.] (required then): the bias
+ * gradient that belongs to the weight gradient (db1 = sum dHpre with dW1 = dHpre^T a; db2 = sum dO with dW2 = dO^T H). */
+#define CNX_TN_ROWS 0
+#define CNX_TN_ACC 1
+int cnx_gemm_tn_ex(const void* A, int64_t lda, int32_t a_layout, const void* B, int64_t ldb, int32_t b_layout,
+                   float* D, float* colsum_a, float* ws, int64_t M, int32_t N1, int32_t N2, void* stream);
 
 /* bf16 GEMM with a fused epilogue (csrc/gemm_kernels.hip) for the pointwise convolutions / linears without a fused-block kernel:
  * models/convnext.py:42-46 (pwconv1 / act / pwconv2 / gamma / residual) at the widths and passes the fused kernels do not cover,

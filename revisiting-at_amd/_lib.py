@@ -65,6 +65,9 @@ PROTOTYPES = {
     "cnx_block_mlp_hpre_elems": (C.c_int64, [_i64, _i32]),
     "cnx_block_mlp_fwd_hpre": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _i64, _i32, _p]),
     "cnx_block_mlp_bwd_input_hpre": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _i64, _i32, _p]),
+    "cnx_block_mlp_fwd_train": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _i64, _i32, _p]),
+    "cnx_block_mlp_bwd_train_hpre": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "cnx_block_mlp_bwd_acc": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "cnx_attention_supported": (C.c_int, [_i32, _i32]),
     "cnx_stem_conv_supported": (C.c_int, [_i32]),
     "cnx_stem_conv_packed_bytes": (C.c_int64, [_i32]),
@@ -90,6 +93,10 @@ PROTOTYPES = {
     "cnx_layernorm_bwd_add": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32,
                                         _i32, _p]),
     "cnx_layernorm_fwd_patch2": (C.c_int, [_p, C.c_int, _p, _p, C.c_float, _p, C.c_int, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "cnx_gemm_tn_supported": (C.c_int, [_i64, _i32, _i32]),
+    "cnx_gemm_tn_ws_floats": (C.c_int64, [_i64, _i32, _i32]),
+    "cnx_gemm_tn": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p]),
+    "cnx_gemm_tn_ex": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _i64, _i32, _i32, _p]),
     "cnx_gemm_nt_supported": (C.c_int, [_i64, _i32, _i32]),
     "cnx_gemm_nt": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, C.c_int, _i64, _i32, _i32, _i32, _p, _p, _p, _i64, C.c_int, _p, _p, _i64, _p]),
     "cnx_layernorm_bwd_patch2": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32,

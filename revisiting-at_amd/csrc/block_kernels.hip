@@ -312,7 +312,11 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const TW* __restrict__ W1
 // branch inside the hidden loop makes the compiler's wait-count pass merge its scoreboards at the join and wait lgkmcnt(0) - for
 // the fragment read issued one MFMA ago - instead of the counted wait (a dozen ~80-cycle stalls per C = 384 slice in round 2's
 // loop, which tested p.hpre and the "is there a slice left to prefetch" conditions at run time).
-template <int C, typename TX, typename TO, bool WS = false>
+// WS == 2 (the training forward on this kernel pair, round 5): also H = GELU(Hpre) into a second workspace of the same tiles and the
+// LN(u) rows - the operands of the weight-gradient contractions (cnx_gemm_tn_ex).  Workspace tile (32 rows x 32 hidden units, 2 KiB,
+// tile index = (row tile, hidden block)): the lane (row m = lane % 32, half = lane / 32) stores its 16 accumulator values as bf16 at
+// byte 64 m + 32 half: rows of 64 bytes = the CNX_TN_ACC layout of include/convnext_hip.h (opaque to every other caller).
+template <int C, typename TX, typename TO, int WS = 0>
 __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(const BlkFwdArgs p) {
   using G = Geo<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -426,6 +430,9 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
           pk[j] = pack_bf16(a, b);
         }
         af[ks] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        if constexpr (WS == 2) {
+          if (row_ok) reinterpret_cast<uint4*>(p.a_out + row * C + half * (C / 2))[ks] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
       }
     } else {
 #pragma unroll
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       SLICE_SYNC(T, ST)                                                                                        \
       if constexpr (WS) {   /* Hpre of block T-1 for the input-gradient kernel: 16 bf16 per lane, accumulator order */ \
         uint4* dst = reinterpret_cast<uint4*>(p.hpre) +                                                        \
-                     ((static_cast<long>(blockIdx.x) * 4 + wave) * G::NHB + ((T) - 1)) * 128 + lane * 2;       \
+                     ((static_cast<long>(blockIdx.x) * 4 + wave) * G::NHB + ((T) - 1)) * 128 + l32 * 4 + half * 2; \
         dst[0] = make_uint4(cvt_pk_bf16(ZIN[0], ZIN[1]), cvt_pk_bf16(ZIN[2], ZIN[3]), cvt_pk_bf16(ZIN[4], ZIN[5]),   \
                             cvt_pk_bf16(ZIN[6], ZIN[7]));                                                      \
         dst[1] = make_uint4(cvt_pk_bf16(ZIN[8], ZIN[9]), cvt_pk_bf16(ZIN[10], ZIN[11]), cvt_pk_bf16(ZIN[12], ZIN[13]), \
@@ -552,6 +559,12 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
         __builtin_amdgcn_sched_barrier(0);                                                                     \
       }                                                                                                        \
       hf1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));                                \
+      if constexpr (WS == 2) {   /* H of block T-1 (the GEMM2 operand pairs just formed), same tile as its Hpre */ \
+        uint4* hdst = reinterpret_cast<uint4*>(p.hact) +                                                       \
+                      ((static_cast<long>(blockIdx.x) * 4 + wave) * G::NHB + ((T) - 1)) * 128 + l32 * 4 + half * 2; \
+        hdst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);                                                      \
+        hdst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);                                                      \
+      }                                                                                                        \
       _Pragma("unroll") for (int j = G::CB; j < 2 * G::CB; ++j) {                                              \
         const int i = G::KS + j;                                                                               \
         if (PABL(4)) { asm volatile("" ::"v"(fr[i % PF]), "v"(hf1)); }                                        \
@@ -721,7 +734,7 @@ template <int C>
 int launch_blk_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
   using G = Geo<C>;
   const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(256);
-#define BLK_LAUNCH(TX, TO) { if (a.hpre) { if constexpr (G::PIPE) BLK_LAUNCH_WS(TX, TO, true) else return APGD_ERR_ARG; } else BLK_LAUNCH_WS(TX, TO, false) }
+#define BLK_LAUNCH(TX, TO) { if (a.hpre) { if constexpr (G::PIPE) { if (a.hact) BLK_LAUNCH_WS(TX, TO, 2) else BLK_LAUNCH_WS(TX, TO, 1) } else return APGD_ERR_ARG; } else BLK_LAUNCH_WS(TX, TO, 0) }
 #define BLK_LAUNCH_WS(TX, TO, WSV)                                                                               \
   {                                                                                                              \
     auto kfn = blk_mlp_fwd_kernel<C, TX, TO, WSV>;                                                               \
@@ -807,6 +820,7 @@ struct BlkBwdArgs {
   const uint16_t* hpre;    // HPRE kernels: the forward's Hpre workspace (cnx_block_mlp_fwd_hpre), else unused
   long M;
   long a_stride;           // row stride of a_out in elements (>= C; lets the caller append a ones column for d(b1))
+  int emit_acc;            // emit mode 2: ht_out / dhpt_out are CNX_TN_ACC tiles of H / dHpre ([M/32][4C/32] x 2 KiB), not [4C, M]
 };
 
 #ifndef BLK_BWD_PIPE
@@ -833,10 +847,14 @@ struct GeoB {
 // HPRE: Hpre comes from the workspace the pipelined forward wrote (cnx_block_mlp_fwd_hpre) instead of being recomputed - no
 // LN(u) operand fragments (C/4 registers less per lane: what makes C = 384 fit one wavefront per SIMD), a third fewer MFMAs,
 // and only the W2^T and GEMM3 pieces of a packed slice go through LDS (KS + 2 CB KiB: three ring slots fit at C = 384).
-template <int C, typename TG, bool EMIT, bool LNB, bool HPRE = false>
+// EMIT: 0 = input gradient only; 1 = also the operands of the weight-gradient GEMMs as rounds 1 - 4 wrote them (a, dO rows; H^T, dHpre^T
+// as [4C, M] through an LDS transposition; recomputing kernels only); 2 = a (recomputing kernels) and dO rows, and H (recomputing
+// kernels) and dHpre as CNX_TN_ACC tiles - the lane's accumulator-order pairs leave with two 16-byte stores, nothing is transposed:
+// cnx_gemm_tn_ex reads that layout (round 5).  With HPRE the forward (WS == 2) has already written H and the LN(u) rows.
+template <int C, typename TG, int EMIT, bool LNB, bool HPRE = false>
 __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192)) ? 2 : 1)) void blk_mlp_bwd_kernel(const BlkBwdArgs p) {
   using G = GeoB<C>;
-  static_assert(!(HPRE && EMIT), "the emit mode recomputes LN(u) anyway");
+  static_assert(!(HPRE && EMIT == 1) && !(EMIT && LNB), "emit modes: see above");
   // PIPE_R: the recomputing input-gradient kernel at one wavefront per SIMD (C >= 128) runs the software-pipelined loop too
   // (GEMM1 / dH of block t+1 interleaved with the unpacked GELU' of block t); C = 96 (two wavefronts per SIMD, power cap) and the
   // emit mode keep the straight loop.
@@ -952,7 +970,7 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
     }
 #define H_LOAD_HPRE(DST, T)                                                                                    \
     {                                                                                                          \
-      const uint4* hp_ = reinterpret_cast<const uint4*>(p.hpre) + (tile * G::NHB + ((T) < G::NHB ? (T) : G::NHB - 1)) * 128 + lane * 2; \
+      const uint4* hp_ = reinterpret_cast<const uint4*>(p.hpre) + (tile * G::NHB + ((T) < G::NHB ? (T) : G::NHB - 1)) * 128 + l32 * 4 + half * 2; \
       DST[0] = hp_[0]; DST[1] = hp_[1];                                                                        \
     }
 #pragma unroll
@@ -1016,6 +1034,11 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
         __builtin_amdgcn_sched_barrier(0);                                                                     \
       }                                                                                                        \
       dhf1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));                               \
+      if constexpr (EMIT == 2) {   /* dHpre of block t = L - 1 in its Hpre's tile (accumulator order: CNX_TN_ACC) */ \
+        uint4* dd_ = reinterpret_cast<uint4*>(p.dhpt_out) + (tile * G::NHB + ((L) - 1)) * 128 + l32 * 4 + half * 2; \
+        dd_[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);                                                       \
+        dd_[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);                                                       \
+      }                                                                                                        \
       _Pragma("unroll") for (int j = G::CB; j < 2 * G::CB; ++j) {                                              \
         const int i = G::KS + j;                                                                               \
         acc3[j - G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dhf1, fr[i % PF], acc3[j - G::CB], 0, 0, 0); \
@@ -1195,7 +1218,15 @@ __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192
       }
       dhf[0] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       dhf[1] = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
-      if constexpr (EMIT) {
+      if constexpr (EMIT == 2) {
+        if (m0 < p.M) {                                   // (wave-uniform; M is a multiple of 32 on this path: whole tiles)
+          const long tq = ((m0 >> 5) * G::NHB + s) * 128 + l32 * 4 + half * 2;
+          uint4* hd = reinterpret_cast<uint4*>(p.ht_out) + tq;
+          uint4* dd = reinterpret_cast<uint4*>(p.dhpt_out) + tq;
+          hd[0] = make_uint4(hk[0], hk[1], hk[2], hk[3]); hd[1] = make_uint4(hk[4], hk[5], hk[6], hk[7]);
+          dd[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]); dd[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        }
+      } else if constexpr (EMIT == 1) {
         if ((p.M & 7) == 0) {
           // [4C, M] operands of the weight-gradient GEMMs: a lane holds 16 hidden units of ONE row, the tensors are
           // contiguous along rows.  2x2 exchange with the neighbouring lane (row m^1) turns the (h, h+1) pairs into
@@ -1352,22 +1383,22 @@ template <int C>
 int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, bool ln_bwd, hipStream_t s) {
   using G = GeoB<C>;
   const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(G::WAVES * 64);
-  const bool emit = a.a_out != nullptr;
+  const int emit = a.a_out != nullptr ? (a.emit_acc ? 2 : 1) : 0;
 #define BLK_LAUNCH(TG, EM, LN)                                                                                   \
   {                                                                                                              \
     auto kfn = blk_mlp_bwd_kernel<C, TG, EM, LN>;                                                                \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (EM) ? G::LDS_EMIT : G::LDS);                                                    \
+                                (EM) == 1 ? G::LDS_EMIT : G::LDS);                                                    \
       attr_done = true;                                                                                          \
     }                                                                                                            \
-    hipLaunchKernelGGL(kfn, grid, block, (EM) ? G::LDS_EMIT : G::LDS, s, a);                                     \
+    hipLaunchKernelGGL(kfn, grid, block, (EM) == 1 ? G::LDS_EMIT : G::LDS, s, a);                                     \
   }
   if (g_dtype == APGD_F32) {
-    if (emit) BLK_LAUNCH(float, true, false) else if (ln_bwd) BLK_LAUNCH(float, false, true) else BLK_LAUNCH(float, false, false)
+    if (emit == 2) BLK_LAUNCH(float, 2, false) else if (emit) BLK_LAUNCH(float, 1, false) else if (ln_bwd) BLK_LAUNCH(float, 0, true) else BLK_LAUNCH(float, 0, false)
   } else {
-    if (emit) BLK_LAUNCH(uint16_t, true, false) else if (ln_bwd) BLK_LAUNCH(uint16_t, false, true) else BLK_LAUNCH(uint16_t, false, false)
+    if (emit == 2) BLK_LAUNCH(uint16_t, 2, false) else if (emit) BLK_LAUNCH(uint16_t, 1, false) else if (ln_bwd) BLK_LAUNCH(uint16_t, 0, true) else BLK_LAUNCH(uint16_t, 0, false)
   }
 #undef BLK_LAUNCH
   return launch_status();
@@ -1379,8 +1410,16 @@ int launch_blk_bwd_hpre(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
   constexpr int LDS_BYTES = G::DEPTH * (G::KS + 2 * G::CB) * 1024 + 16 * C;
   const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(G::WAVES * 64);
 #define BLK_LAUNCH(TG)                                                                                           \
-  {                                                                                                              \
-    auto kfn = blk_mlp_bwd_kernel<C, TG, false, true, true>;                                                     \
+  if (a.dhpt_out) {                                                                                              \
+    auto kfn = blk_mlp_bwd_kernel<C, TG, 2, false, true>;                                                        \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, LDS_BYTES, s, a);                                                       \
+  } else {                                                                                                       \
+    auto kfn = blk_mlp_bwd_kernel<C, TG, 0, true, true>;                                                         \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
@@ -1420,7 +1459,7 @@ int cnx_mlp_pack_weights(const void* W1, const void* W2, int w_dtype, void* Wf, 
 static int block_mlp_fwd_impl(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
                               const void* Wf, const float* b1, const float* b2, const float* gamma, const void* resid,
                               int resid_dtype, void* out, int out_dtype, void* y2_out, void* hpre_ws, int64_t M, int32_t C,
-                              void* stream) {
+                              void* stream, void* h_ws = nullptr, void* a_rows = nullptr) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
   if (M == 0) return APGD_OK;
   if (!u || !Wf || !b1 || !b2 || !out) return APGD_ERR_NULL;
@@ -1433,6 +1472,8 @@ static int block_mlp_fwd_impl(const void* u, const float* ln_w, const float* ln_
   a.Wf = static_cast<const uint16_t*>(Wf); a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.resid = resid; a.out = out;
   a.y2 = static_cast<uint16_t*>(y2_out); a.M = M;
   a.hpre = static_cast<uint16_t*>(hpre_ws);
+  a.hact = static_cast<uint16_t*>(h_ws); a.a_out = static_cast<uint16_t*>(a_rows);
+  if ((h_ws != nullptr) != (a_rows != nullptr) || (h_ws && !hpre_ws)) return APGD_ERR_NULL;
   if (hpre_ws && !blk_fwd_pipe(C)) return APGD_ERR_ARG;          // only the pipelined loop writes the workspace
 #if MLP_ABLATE
   static const int dbg = getenv("APGD_BLK_DBG") ? atoi(getenv("APGD_BLK_DBG")) : 0;   // timing experiments: ablation builds only
@@ -1481,7 +1522,37 @@ int cnx_block_mlp_bwd_input_hpre(const void* u, const float* ln_w, const float* 
   BlkBwdArgs a;
   a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = nullptr; a.mean = mean; a.rstd = rstd; a.g = g; a.gamma = gamma;
   a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = nullptr; a.da = static_cast<uint16_t*>(du);
-  a.a_out = a.do_out = a.ht_out = a.dhpt_out = nullptr; a.hpre = static_cast<const uint16_t*>(hpre_ws); a.M = M; a.a_stride = C;
+  a.a_out = a.do_out = a.ht_out = a.dhpt_out = nullptr; a.hpre = static_cast<const uint16_t*>(hpre_ws); a.M = M; a.a_stride = C; a.emit_acc = 0;
+  switch (C) {
+    case 128: return launch_blk_bwd_hpre<128>(a, g_dtype, as_stream(stream));
+    case 192: return launch_blk_bwd_hpre<192>(a, g_dtype, as_stream(stream));
+    case 256: return launch_blk_bwd_hpre<256>(a, g_dtype, as_stream(stream));
+    case 384: return launch_blk_bwd_hpre<384>(a, g_dtype, as_stream(stream));
+    default: return APGD_ERR_ARG;
+  }
+}
+
+int cnx_block_mlp_fwd_train(const void* u, const float* ln_w, const float* ln_b, float eps, float* mean, float* rstd,
+                            const void* Wf, const float* b1, const float* b2, const float* gamma, const void* resid,
+                            int resid_dtype, void* out, int out_dtype, void* y2_out, void* hpre_ws, void* h_ws, void* a_rows,
+                            int64_t M, int32_t C, void* stream) {
+  if (!hpre_ws || !h_ws || !a_rows || !ln_w) return APGD_ERR_NULL;
+  if (!cnx_block_mlp_hpre_supported(C)) return APGD_ERR_ARG;
+  return block_mlp_fwd_impl(u, ln_w, ln_b, eps, mean, rstd, Wf, b1, b2, gamma, resid, resid_dtype, out, out_dtype, y2_out, hpre_ws,
+                            M, C, stream, h_ws, a_rows);
+}
+
+int cnx_block_mlp_bwd_train_hpre(const void* g, int g_dtype, const float* gamma, const void* Wb, const void* hpre_ws, void* da,
+                                 void* do_rows, void* dhpre_ws, int64_t M, int32_t C, void* stream) {
+  if (M < 0 || C <= 0) return APGD_ERR_SIZE;
+  if (M == 0) return APGD_OK;
+  if (!g || !Wb || !hpre_ws || !da || !do_rows || !dhpre_ws) return APGD_ERR_NULL;
+  if (g_dtype != APGD_F32 && g_dtype != APGD_BF16) return APGD_ERR_DTYPE;
+  BlkBwdArgs a;
+  a.u = nullptr; a.ln_w = nullptr; a.ln_b = nullptr; a.mean = nullptr; a.rstd = nullptr; a.g = g; a.gamma = gamma;
+  a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = nullptr; a.da = static_cast<uint16_t*>(da);
+  a.a_out = nullptr; a.do_out = static_cast<uint16_t*>(do_rows); a.ht_out = nullptr; a.dhpt_out = static_cast<uint16_t*>(dhpre_ws);
+  a.hpre = static_cast<const uint16_t*>(hpre_ws); a.M = M; a.a_stride = C; a.emit_acc = 1;
   switch (C) {
     case 128: return launch_blk_bwd_hpre<128>(a, g_dtype, as_stream(stream));
     case 192: return launch_blk_bwd_hpre<192>(a, g_dtype, as_stream(stream));
@@ -1512,8 +1583,9 @@ int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* 
 static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
                               const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
                               void* a_out, int64_t a_stride, void* do_out, void* ht_out, void* dhpt_out, bool ln_bwd,
-                              int64_t M, int32_t C, void* stream) {
+                              int64_t M, int32_t C, void* stream, int emit_acc = 0) {
   if (M < 0 || C <= 0) return APGD_ERR_SIZE;
+  if (emit_acc && M % 32 != 0) return APGD_ERR_ARG;                  // whole tiles
   if (M == 0) return APGD_OK;
   if (!u || !ln_w || !ln_b || !mean || !rstd || !g || !Wb || !b1 || !da) return APGD_ERR_NULL;
   const int n_emit = (a_out != nullptr) + (do_out != nullptr) + (ht_out != nullptr) + (dhpt_out != nullptr);
@@ -1523,7 +1595,7 @@ static int block_mlp_bwd_impl(const void* u, const float* ln_w, const float* ln_
   a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = ln_b; a.mean = mean; a.rstd = rstd; a.g = g; a.gamma = gamma;
   a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = b1; a.da = static_cast<uint16_t*>(da);
   a.a_out = static_cast<uint16_t*>(a_out); a.do_out = static_cast<uint16_t*>(do_out);
-  a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.hpre = nullptr; a.M = M;
+  a.ht_out = static_cast<uint16_t*>(ht_out); a.dhpt_out = static_cast<uint16_t*>(dhpt_out); a.hpre = nullptr; a.M = M; a.emit_acc = emit_acc;
   if (a_stride != 0 && (a_stride < C || a_stride % 8 != 0)) return APGD_ERR_ARG;
   a.a_stride = a_stride ? a_stride : C;
   hipStream_t s = as_stream(stream);
@@ -1549,6 +1621,14 @@ int cnx_block_mlp_bwd_input(const void* u, const float* ln_w, const float* ln_b,
                             int64_t M, int32_t C, void* stream) {
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, du, nullptr, 0, nullptr, nullptr, nullptr,
                             true, M, C, stream);
+}
+
+int cnx_block_mlp_bwd_acc(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                          const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* da,
+                          void* a_rows, void* do_rows, void* h_ws, void* dhpre_ws, int64_t M, int32_t C, void* stream) {
+  if (!a_rows || !do_rows || !h_ws || !dhpre_ws) return APGD_ERR_NULL;
+  return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_rows, 0, do_rows, h_ws, dhpre_ws, false, M, C,
+                            stream, 1);
 }
 
 int cnx_block_mlp_bwd_supported(int32_t C) { return (C == 96 || C == 128 || C == 192 || C == 256) ? 1 : 0; }

@@ -1,5 +1,4 @@
 // mlp_internal.h — argument block and layout switches of the fused LN + MLP kernels (block_kernels.hip).  Not part of the C ABI.
-// (tools/probe/mlp_kernels.hip - the round-2 study of LDS-resident-weight variants, not built into the library - includes it too.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,6 +28,8 @@ struct BlkFwdArgs {
   void* out;               // [M, C] TO
   uint16_t* y2;            // [M, C] bf16 pre-gamma fc2 output, or NULL
   uint16_t* hpre;          // pipelined kernels only: workspace for Hpre = LN(u) W1^T + b1 in accumulator order (see cnx_block_mlp_fwd_hpre), or NULL
+  uint16_t* hact;          // training forward (WS == 2): H = GELU(Hpre) in the same tiles, for the weight-gradient contraction dW2 = dO^T H
+  uint16_t* a_out;         // training forward (WS == 2): LN(u) rows [M, C] bf16, for dW1 = dHpre^T LN(u)
   long M;
   int dbg;                 // timing experiments only (APGD_BLK_DBG)
 };

@@ -20,6 +20,7 @@
 //   wgrad_reduce_kernel         fixed-order sum of the workgroups' partial results (deterministic)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "apgd_hip.h"
 #include "convnext_hip.h"
@@ -343,6 +344,233 @@ __global__ __launch_bounds__(kW2 * 64, 2) void conv2_wgrad_kernel(const uint16_t
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// cnx_gemm_tn:  D[N1][N2] = A^T B,  A [M, N1], B [M, N2] bf16, D fp32 - the weight gradients of the pointwise convolutions / linears
+// (dW1 = dHpre^T a, dW2 = dO^T H: models/convnext.py:42-46 backward).
+//
+// Operand layouts (per operand):
+//   ROWS  row-major [M][N] with a leading dimension (activations as every other kernel writes them);
+//   ACC   tiles [M / 32][N / 32] of 2 KiB in the order the fused block kernels hold a 32 x 32 tile of the hidden activation in their
+//         MFMA accumulators: element (m, n) of a tile at byte 64 m + 32 ((n / 4) % 2) + 8 (n / 8) + 2 (n % 4) - a lane of those kernels
+//         (row m = lane % 32, half = lane / 32) owns the 32 bytes at 64 m + 32 half = its 16 accumulator values as bf16, and stores
+//         them with two 16-byte instructions, no transposition anywhere (cnx_block_mlp_*: Hpre workspace, emitted H / dHpre).
+// Either way 4 consecutive n of one row m are 8 contiguous, 8-byte-aligned bytes: a transpose-read piece.
+//
+// LDS image of an operand tile: per 32 columns a sub-image of 64 rows (one stage) x 64 bytes.  ROWS: row m at 64 m, the 32 columns
+// in order; ACC: the two 2 KiB tiles of the stage verbatim.  A fragment of mfma_f32_32x32x16_bf16 (32 columns x 16 rows) is ONE
+// contiguous KiB in both; a transpose read's two 16-lane groups of a half-wave take rows r .. r + 3 x 64 bytes = 256 contiguous
+// bytes: every LDS bank once (no padding, no swizzle).  The LDS-DMA instruction that fills such a KiB reads 16 rows x 64 bytes
+// (ROWS: lane l = row l / 4, 16-byte piece l % 4) or one contiguous KiB (ACC) and writes lane-linear.
+// Workgroup = WI x WJ wavefronts, wavefront tile (32 F) x (32 F): BM = 32 F WI rows of D (columns of A), BN = 32 F WJ columns.
+// K runs over M in stages of 64 rows, two stages in LDS: the DMA of stage t + 1 is issued before the 4 k-steps of stage t
+// (per k-step and wavefront: 2 F + 2 F transpose reads for F x F MFMAs), s_waitcnt vmcnt(0) + one barrier per stage.  M is split
+// over workgroups (rows_per_split, a multiple of 64): every workgroup writes its fp32 partial tile, gemm_tn_reduce_kernel adds the
+// splits in a fixed order.  Workgroups of one split are neighbours on an XCD (they re-read each other's operand columns from L2).
+// CS: also the column sums of A (= the bias gradient that belongs to this weight gradient: db1 = sum_m dHpre, db2 = sum_m dO) -
+// the wavefronts of the first tile column multiply their A fragments with a constant B fragment (column 0 = ones): F more MFMAs
+// per k-step there, no pass over A of its own.
+constexpr int kRows = 0, kAcc = 1;
+template <int LAYOUT>
+__device__ __forceinline__ uint32_t tn_lane_off(int lane) {            // the lane's piece inside a fragment's KiB (k-step 0 of a stage, read 0)
+  const int g = lane >> 4, i = lane & 15;
+  const int row = 8 * (g >> 1) + (i >> 2), hq = 4 * (g & 1) + (i & 3);       // hq: the 4-column chunk of the fragment's 32 columns
+  if (LAYOUT == kRows) return static_cast<uint32_t>(row * 64 + hq * 8);
+  return static_cast<uint32_t>(row * 64 + (hq & 1) * 32 + (hq >> 1) * 8);
+}
+template <int F, int WI, int WJ, int LA, int LB, bool CS>
+__global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_kernel(
+    const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, float* __restrict__ ws, int M, int N1, int N2,
+    int rows_per_split, int n_split, int dbg) {
+  constexpr int NW = WI * WJ, BM = 32 * F * WI, BN = 32 * F * WJ, KT = 64;
+  constexpr int SUBA = BM / 32, SUBB = BN / 32;
+  constexpr uint32_t A_BYTES = SUBA * KT * 64, B_BYTES = SUBB * KT * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int NBLK = STAGE / 1024;
+  static_assert(NBLK % NW == 0, "DMA blocks per wavefront");
+  constexpr int NDMA = NBLK / NW;
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave / WJ, wj = wave - wi * WJ;
+  const int TI = N1 / BM, TJ = N2 / BN;
+  long lid;                                                            // logical workgroup id: consecutive ids share an XCD
+  {
+    const long L = blockIdx.x, G = gridDim.x;
+    const long q = G / 8, r = G % 8, xcd = L % 8, k = L / 8;
+    lid = xcd * q + (xcd < r ? xcd : r) + k;
+  }
+  const int split = static_cast<int>(lid / (TI * TJ)), tile = static_cast<int>(lid - static_cast<long>(split) * (TI * TJ));
+  const int ti = tile / TJ, tj = tile - ti * TJ;
+  const int i0 = ti * BM, j0 = tj * BN;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+  const int n_stage = (m_end - m_begin) / KT;
+
+  const u32x4 rsa = make_rsrc4(A, static_cast<uint32_t>(LA == kRows ? static_cast<long>(M) * lda * 2 : static_cast<long>(M) * N1 * 2));
+  const u32x4 rsb = make_rsrc4(B, static_cast<uint32_t>(LB == kRows ? static_cast<long>(M) * ldb * 2 : static_cast<long>(M) * N2 * 2));
+  const uint32_t lds0 = lds_addr(lds);
+  // lane part of a DMA source address.  ROWS: row lane / 4 of the block's 16, 16-byte piece lane % 4 of the sub-image's 64-byte row
+  const uint32_t va = LA == kRows ? static_cast<uint32_t>((lane >> 2) * lda * 2 + (lane & 3) * 16) : static_cast<uint32_t>(lane * 16);
+  const uint32_t vb = LB == kRows ? static_cast<uint32_t>((lane >> 2) * ldb * 2 + (lane & 3) * 16) : static_cast<uint32_t>(lane * 16);
+  auto dma_stage = [&](int t, int buf) {
+    const uint32_t sb = lds0 + static_cast<uint32_t>(buf) * STAGE;
+    const long m0 = m_begin + static_cast<long>(t) * KT;
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+      const int b = wave + NW * k;                                     // wave-uniform block: (operand, sub-image, 16-row block)
+      if (b < SUBA * 4) {
+        const int sub = b >> 2, rb = b & 3;
+        const long src = LA == kRows ? ((m0 + rb * 16) * lda + i0 + 32 * sub) * 2
+                                     : (((m0 >> 5) + (rb >> 1)) * (N1 >> 5) + (i0 >> 5) + sub) * 2048 + (rb & 1) * 1024;
+        dma_lds16(sb + static_cast<uint32_t>(sub * 4096 + rb * 1024), va, rsa, static_cast<uint32_t>(src));
+      } else {
+        const int bb = b - SUBA * 4, sub = bb >> 2, rb = bb & 3;
+        const long src = LB == kRows ? ((m0 + rb * 16) * ldb + j0 + 32 * sub) * 2
+                                     : (((m0 >> 5) + (rb >> 1)) * (N2 >> 5) + (j0 >> 5) + sub) * 2048 + (rb & 1) * 1024;
+        dma_lds16(sb + A_BYTES + static_cast<uint32_t>(sub * 4096 + rb * 1024), vb, rsb, static_cast<uint32_t>(src));
+      }
+    }
+  };
+  const uint32_t a_lane = lds0 + tn_lane_off<LA>(lane) + static_cast<uint32_t>(wi * F) * 4096u;
+  const uint32_t b_lane = lds0 + A_BYTES + tn_lane_off<LB>(lane) + static_cast<uint32_t>(wj * F) * 4096u;
+
+  f32x16 acc[F][F];
+#pragma unroll
+  for (int fi = 0; fi < F; ++fi)
+#pragma unroll
+    for (int fj = 0; fj < F; ++fj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fi][fj][r] = 0.f;
+  f32x16 accs[CS ? F : 1];
+  bf16x8 ones;
+  const bool cs_wave = CS && tj == 0 && wj == 0;
+  if constexpr (CS) {
+#pragma unroll
+    for (int fi = 0; fi < F; ++fi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accs[fi][r] = 0.f;
+    const uint32_t v = (lane & 31) == 0 ? 0x3f803f80u : 0u;
+    const u32x4 t = {v, v, v, v};
+    ones = __builtin_bit_cast(bf16x8, t);
+  }
+
+  if (n_stage > 0) dma_stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < n_stage; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < n_stage && !(dbg & 1)) dma_stage(t + 1, buf ^ 1);      // (that buffer's readers passed the barrier below)
+    const uint32_t ab = a_lane + static_cast<uint32_t>(buf) * STAGE, bb = b_lane + static_cast<uint32_t>(buf) * STAGE;
+    if (!(dbg & 2))
+#pragma unroll
+    for (int ks = 0; ks < KT / 16; ++ks) {
+      bf16x8 af[F], bfr[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        af[f] = tr_fragment(ab + static_cast<uint32_t>(f * 4096 + ks * 1024), 64u);
+        bfr[f] = tr_fragment(bb + static_cast<uint32_t>(f * 4096 + ks * 1024), 64u);
+      }
+#pragma unroll
+      for (int fi = 0; fi < F; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < F; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fi], bfr[fj], acc[fi][fj], 0, 0, 0);
+      if constexpr (CS) {
+        if (cs_wave) {
+#pragma unroll
+          for (int fi = 0; fi < F; ++fi) accs[fi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fi], ones, accs[fi], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // partial tile -> ws[split][N1][N2] (then [N1] column sums of A)
+  float* out = ws + static_cast<long>(split) * (static_cast<long>(N1) * N2 + (CS ? N1 : 0));
+  const int col = lane & 31, kb = lane >> 5;
+#pragma unroll
+  for (int fi = 0; fi < F; ++fi)
+#pragma unroll
+    for (int fj = 0; fj < F; ++fj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + 32 * (wi * F + fi) + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        const int j = j0 + 32 * (wj * F + fj) + col;
+        out[static_cast<long>(i) * N2 + j] = acc[fi][fj][r];
+      }
+  if constexpr (CS) {
+    if (cs_wave && col == 0) {
+#pragma unroll
+      for (int fi = 0; fi < F; ++fi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[static_cast<long>(N1) * N2 + i0 + 32 * (wi * F + fi) + (r & 3) + 8 * (r >> 2) + 4 * kb] = accs[fi][r];
+    }
+  }
+}
+
+// D (then the optional column-sum vector) = sum of the n_split partial results, in split order (deterministic); four consecutive
+// outputs per thread.  part_len = floats per split = len_d + len_cs.
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ D, float* __restrict__ cs,
+                                                             long len_d, long part_len, int n_split) {
+  const long v = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (v * 4 >= part_len) return;
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  const f32x4* p = reinterpret_cast<const f32x4*>(ws) + v;
+  const long stride = part_len / 4;
+  f32x4 s = p[0];
+  int k = 1;
+  for (; k + 3 < n_split; k += 4) {
+    const f32x4 a = p[static_cast<long>(k) * stride], b = p[static_cast<long>(k + 1) * stride], c = p[static_cast<long>(k + 2) * stride],
+                d = p[static_cast<long>(k + 3) * stride];
+    s += a; s += b; s += c; s += d;
+  }
+  for (; k < n_split; ++k) s += p[static_cast<long>(k) * stride];
+  if (v * 4 < len_d) reinterpret_cast<f32x4*>(D)[v] = s;
+  else reinterpret_cast<f32x4*>(cs)[v - len_d / 4] = s;
+}
+
+template <int F, int WI, int WJ, int LA, int LB, bool CS>
+int launch_gemm_tn(const uint16_t* A, long lda, const uint16_t* B, long ldb, float* D, float* cs, float* ws, int M, int N1, int N2,
+                   int rows_per_split, int n_split, hipStream_t s) {
+  constexpr int BM = 32 * F * WI, BN = 32 * F * WJ;
+  constexpr size_t lds_bytes = 2 * (BM / 32 + BN / 32) * 64 * 64;
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<F, WI, WJ, LA, LB, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    return true;
+  }();
+  (void)attr;
+  const long grid = static_cast<long>(N1 / BM) * (N2 / BN) * n_split;
+  static const int dbg = getenv("APGD_TN_DBG") ? atoi(getenv("APGD_TN_DBG")) : 0;     // experiments: 1 = no DMA after stage 0, 2 = no MFMAs, 4 = no reduce
+  // (a single split with no column sums writes D directly; everything else goes through the workspace and the fixed-order sum)
+  const bool direct = n_split == 1 && !CS;
+  hipLaunchKernelGGL((gemm_tn_kernel<F, WI, WJ, LA, LB, CS>), dim3(static_cast<unsigned>(grid)), dim3(64 * WI * WJ), lds_bytes, s, A, lda, B,
+                     ldb, direct ? D : ws, M, N1, N2, rows_per_split, n_split, dbg);
+  int rc = launch_status();
+  if (rc || direct || (dbg & 4)) return rc;
+  const long len_d = static_cast<long>(N1) * N2, part = len_d + (CS ? N1 : 0);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(static_cast<unsigned>((part / 4 + 255) / 256)), dim3(256), 0, s, ws, D, cs, len_d, part, n_split);
+  return launch_status();
+}
+
+// tile shape for (N1, N2): 0 = none.  code = F * 100 + WI * 10 + WJ
+inline int gemm_tn_shape(int N1, int N2) {
+  const int cand[8][3] = {{3, 4, 2}, {3, 2, 4}, {2, 4, 2}, {2, 2, 4}, {3, 4, 1}, {3, 1, 4}, {2, 4, 1}, {2, 1, 4}};
+  for (const auto& c : cand)
+    if (N1 % (32 * c[0] * c[1]) == 0 && N2 % (32 * c[0] * c[2]) == 0) return c[0] * 100 + c[1] * 10 + c[2];
+  return 0;
+}
+// split of M over workgroups: about one workgroup per CU (a workgroup fills a CU's LDS), whole stages of 64 rows, at least 4 stages
+// per split.  Measured (tools/gemm_tn_bench.py): 512 workgroups double the partial results' traffic and run 20 - 30 % longer.
+inline void gemm_tn_split(int M, int tiles, int* rows_per_split, int* n_split) {
+  const int stages = M / 64;
+  static const int wgs = getenv("APGD_TN_WGS") ? atoi(getenv("APGD_TN_WGS")) : 256;
+  int want = (wgs + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  int per = (stages + want - 1) / want;
+  if (per < 4) per = stages < 4 ? stages : 4;
+  *rows_per_split = per * 64;
+  *n_split = (stages + per - 1) / per;
+}
+
 // out[j] = sum over parts (fixed order: 8 interleaved running sums, then a tree) of ws[part * len + j]; one thread per j and
 // part-lane, 32 part-lanes per output.  map: j -> destination index (the caller's layouts differ from the partials'), or identity.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
@@ -447,6 +675,58 @@ int cnx_conv3x3s2_wgrad(const void* x, const void* dy, float* dw, float* dbias, 
   const int len = CO * 9 * CI + CO;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((len + 7) / 8), dim3(256), 0, s, ws, dw, dbias, len, CO * 9 * CI, static_cast<int>(nwg), 0, 1);
   return launch_status();
+}
+
+int cnx_gemm_tn_supported(int64_t M, int32_t N1, int32_t N2) {
+  return (M > 0 && M % 64 == 0 && M < (1L << 31) && gemm_tn_shape(N1, N2) != 0) ? 1 : 0;
+}
+
+int64_t cnx_gemm_tn_ws_floats(int64_t M, int32_t N1, int32_t N2) {
+  const int code = gemm_tn_shape(N1, N2);
+  if (!code || M <= 0 || M % 64 != 0) return 0;
+  const int F = code / 100, WI = (code / 10) % 10, WJ = code % 10;
+  int rows, ns;
+  gemm_tn_split(static_cast<int>(M), (N1 / (32 * F * WI)) * (N2 / (32 * F * WJ)), &rows, &ns);
+  return static_cast<int64_t>(ns) * (static_cast<int64_t>(N1) * N2 + N1);
+}
+
+int cnx_gemm_tn_ex(const void* A, int64_t lda, int32_t a_layout, const void* B, int64_t ldb, int32_t b_layout, float* D, float* colsum_a,
+                   float* ws, int64_t M, int32_t N1, int32_t N2, void* stream) {
+  if (M < 0 || N1 <= 0 || N2 <= 0) return APGD_ERR_SIZE;
+  if (!A || !B || !D || !ws) return APGD_ERR_NULL;
+  if (!cnx_gemm_tn_supported(M, N1, N2)) return APGD_ERR_ARG;
+  if ((a_layout != CNX_TN_ROWS && a_layout != CNX_TN_ACC) || (b_layout != CNX_TN_ROWS && b_layout != CNX_TN_ACC)) return APGD_ERR_ARG;
+  if (a_layout == CNX_TN_ACC && b_layout == CNX_TN_ACC) return APGD_ERR_ARG;            // (no caller: not instantiated)
+  if (a_layout == CNX_TN_ROWS && (lda < N1 || lda % 8 != 0)) return APGD_ERR_ARG;
+  if (b_layout == CNX_TN_ROWS && (ldb < N2 || ldb % 8 != 0)) return APGD_ERR_ARG;
+  if (colsum_a && a_layout == CNX_TN_ROWS && b_layout == CNX_TN_ROWS) return APGD_ERR_ARG;   // column sums come with an ACC operand pair
+  if (!colsum_a && (a_layout == CNX_TN_ACC || b_layout == CNX_TN_ACC)) return APGD_ERR_NULL;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(ws) |
+       reinterpret_cast<uintptr_t>(colsum_a)) % 16 != 0)
+    return APGD_ERR_ARG;
+  const int64_t la = a_layout == CNX_TN_ROWS ? lda : N1, lb = b_layout == CNX_TN_ROWS ? ldb : N2;
+  if (M * la * 2 >= (1L << 32) || M * lb * 2 >= (1L << 32)) return APGD_ERR_ARG;        // 32-bit byte offsets
+  const int code = gemm_tn_shape(N1, N2);
+  const int F = code / 100, WI = (code / 10) % 10, WJ = code % 10;
+  int rows, ns;
+  gemm_tn_split(static_cast<int>(M), (N1 / (32 * F * WI)) * (N2 / (32 * F * WJ)), &rows, &ns);
+  hipStream_t s = as_stream(stream);
+  const auto* a = static_cast<const uint16_t*>(A);
+  const auto* b = static_cast<const uint16_t*>(B);
+  const int m = static_cast<int>(M);
+#define TN_CASE(FF, II, JJ)                                                                                                        \
+  if (code == FF * 100 + II * 10 + JJ) {                                                                                           \
+    if (a_layout == CNX_TN_ACC) return launch_gemm_tn<FF, II, JJ, kAcc, kRows, true>(a, lda, b, ldb, D, colsum_a, ws, m, N1, N2, rows, ns, s); \
+    if (b_layout == CNX_TN_ACC) return launch_gemm_tn<FF, II, JJ, kRows, kAcc, true>(a, lda, b, ldb, D, colsum_a, ws, m, N1, N2, rows, ns, s); \
+    return launch_gemm_tn<FF, II, JJ, kRows, kRows, false>(a, lda, b, ldb, D, nullptr, ws, m, N1, N2, rows, ns, s);                 \
+  }
+  TN_CASE(3, 4, 2) TN_CASE(3, 2, 4) TN_CASE(2, 4, 2) TN_CASE(2, 2, 4) TN_CASE(3, 4, 1) TN_CASE(3, 1, 4) TN_CASE(2, 4, 1) TN_CASE(2, 1, 4)
+#undef TN_CASE
+  return APGD_ERR_ARG;
+}
+
+int cnx_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* D, float* ws, int64_t M, int32_t N1, int32_t N2, void* stream) {
+  return cnx_gemm_tn_ex(A, lda, CNX_TN_ROWS, B, ldb, CNX_TN_ROWS, D, nullptr, ws, M, N1, N2, stream);
 }
 
 }  // extern "C"

@@ -1007,7 +1007,46 @@ def _split_k(M, N1, N2):
     return S
 
 
+# "hip": the weight gradients (contractions over the rows of two row-major operands) on cnx_gemm_tn (csrc/wgrad_kernels.hip, round 5)
+# wherever its shape guards hold; "lib": the split-K batched library GEMM + partial sums of rounds 1 - 4 (A/B, parity tests)
+_WGRAD_MODE = os.environ.get("APGD_WGRAD", "hip")
+
+
 def _wgrad(x, y):
+    """``x^T y`` for tall operands (``x`` [M, N1], ``y`` [M, N2], M >> N) -> fp32 [N1, N2]: ``cnx_gemm_tn`` (both operands as
+    they lie in memory, transposed on their way out of LDS), or the library composition ``_wgrad_lib``."""
+    M, N1 = x.shape
+    N2 = y.shape[1]
+    if (_WGRAD_MODE == "hip" and MODE != "eager" and x.is_cuda and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16
+            and x.stride(1) == 1 and y.stride(1) == 1 and x.stride(0) % 8 == 0 and y.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and M * max(x.stride(0), y.stride(0)) * 2 < 2 ** 32):
+        lib = _lib.load()
+        if lib.cnx_gemm_tn_supported(M, N1, N2):
+            d = torch.empty(N1, N2, device=x.device, dtype=torch.float32)
+            ws = torch.empty(max(4, lib.cnx_gemm_tn_ws_floats(M, N1, N2)), device=x.device, dtype=torch.float32)
+            _lib.check(lib.cnx_gemm_tn(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), d.data_ptr(), ws.data_ptr(), M, N1, N2,
+                                       _stream()), "cnx_gemm_tn")
+            return d
+    return _wgrad_lib(x, y)
+
+
+def _tn_ok(M, N1, N2):
+    return _WGRAD_MODE == "hip" and MODE != "eager" and M * 4 * max(N1, N2) < 2 ** 32 and bool(_lib.load().cnx_gemm_tn_supported(M, N1, N2))
+
+
+def _wgrad_acc(a_t, a_acc, b_t, b_acc, M, N1, N2):
+    """``A^T B`` -> (fp32 [N1, N2], fp32 [N1] column sums of A) through ``cnx_gemm_tn_ex`` with ONE operand in the accumulator-order
+    tiles the fused block kernels write (``CNX_TN_ACC``: ``a_acc`` / ``b_acc``), the other a contiguous [M, N] bf16 row matrix."""
+    lib = _lib.load()
+    d = torch.empty(N1, N2, device=a_t.device, dtype=torch.float32)
+    cs = torch.empty(N1, device=a_t.device, dtype=torch.float32)
+    ws = torch.empty(lib.cnx_gemm_tn_ws_floats(M, N1, N2), device=a_t.device, dtype=torch.float32)
+    _lib.check(lib.cnx_gemm_tn_ex(a_t.data_ptr(), N1, 1 if a_acc else 0, b_t.data_ptr(), N2, 1 if b_acc else 0, d.data_ptr(),
+                                  cs.data_ptr(), ws.data_ptr(), M, N1, N2, _stream()), "cnx_gemm_tn_ex")
+    return d, cs
+
+
+def _wgrad_lib(x, y):
     """``x^T y`` for tall operands (``x`` [M, N1], ``y`` [M, N2], M >> N) -> fp32 [N1, N2].
 
     The weight gradients contract over M = N*H*W (802 816 rows at 56x56, batch 256) into a small result: as one GEMM that
@@ -1277,6 +1316,26 @@ class _BlockFused(torch.autograd.Function):
         # that need no backward at all)
         via_hpre = _use_hpre_block(C) and ((need_grad and _ATTACK_FWD) or ((not need_grad) and not fused))
         mean = rstd = y2 = a = hpre = h = None
+        if need_p and not _ATTACK_FWD and not _INPUT_GRAD_ONLY and _use_train_hpre(C, M):
+            # ---- training pass on the Hpre pair: the forward also leaves H (same tiles as Hpre) and the LN(u) rows for the weight gradients
+            wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
+            mean = torch.empty(M, device=x.device, dtype=torch.float32)
+            rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+            n_ws = lib.cnx_block_mlp_hpre_elems(M, C)
+            hpre = torch.empty(n_ws, device=x.device, dtype=torch.bfloat16)
+            h = torch.empty(n_ws, device=x.device, dtype=torch.bfloat16)
+            a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+            if gamma is not None:
+                y2 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.cnx_block_mlp_fwd_train(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, mean.data_ptr(), rstd.data_ptr(),
+                                                   wf.data_ptr(), b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), _code(x),
+                                                   out.data_ptr(), _code(out), _lib.ptr(y2), hpre.data_ptr(), h.data_ptr(), a.data_ptr(),
+                                                   M, C, _stream()), "cnx_block_mlp_fwd_train")
+            wa = _cached((w1, w2), "mlp_packed_bwd", _pack_mlp_bwd)
+            ctx.fused = "train_hpre"
+            ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, None, b1f, gf, y2, a, hpre, h)
+            ctx.has_dw_bias, ctx.eps = dw_b is not None, eps
+            return out
         if via_hpre:
             wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
             if need_grad:
@@ -1362,6 +1421,27 @@ class _BlockFused(torch.autograd.Function):
             _lib.check(lib.cnx_block_mlp_bwd_input_hpre(u.data_ptr(), lw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g2.data_ptr(),
                                                         _code(g2), _lib.ptr(gf), w1b.data_ptr(), hpre.data_ptr(), d_u.data_ptr(),
                                                         M, C, _stream()), "cnx_block_mlp_bwd_input_hpre")
+        elif ctx.fused == "train_hpre":
+            # ---- training backward from the Hpre workspace: dH, GELU', da in one kernel that also leaves dO rows and dHpre tiles;
+            #      both weight gradients (with their bias gradients as column sums) on cnx_gemm_tn_ex; d(gamma) in one pass over g, y2
+            if g2.dtype not in (torch.float32, torch.bfloat16):
+                g2 = g2.float()
+            dos = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+            dhp = torch.empty(hpre.numel(), device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.cnx_block_mlp_bwd_train_hpre(g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), hpre.data_ptr(),
+                                                        da.data_ptr(), dos.data_ptr(), dhp.data_ptr(), M, C, _stream()),
+                       "cnx_block_mlp_bwd_train_hpre")
+            if want_p:
+                dw2, db2 = _wgrad_acc(dos, False, h, True, M, C, 4 * C)              # dO^T H        [C, 4C]
+                dw1, db1 = _wgrad_acc(dhp, True, a_s, False, M, 4 * C, C)            # dHpre^T LN(u) [4C, C]
+                if gf is not None:
+                    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+                    db2_ = torch.empty(C, device=x.device, dtype=torch.float32)
+                    ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=x.device, dtype=torch.float32)
+                    _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2.reshape(M, C).data_ptr(), gf.data_ptr(), None,
+                                                          dgamma.data_ptr(), db2_.data_ptr(), ws.data_ptr(), M, C, _stream()),
+                               "cnx_scale_residual_bwd")
+            del dos, dhp
         elif ctx.fused and not want_p:
             # ---- attack backward: ONE kernel down to the depthwise-conv output (LayerNorm backward in its epilogue)
             if g2.dtype not in (torch.float32, torch.bfloat16):
@@ -1374,7 +1454,34 @@ class _BlockFused(torch.autograd.Function):
             # ---- one kernel: LN recompute, dO = g*gamma, Hpre / dH / dHpre per hidden slice on-chip, da
             a = dos = ht = dhpt = None
             a_cols = C + 8 if _DB1_IN_GEMM else C
-            if want_p:
+            acc_emit = want_p and _tn_ok(M, 4 * C, C) and _tn_ok(M, C, 4 * C)
+            if acc_emit:
+                # H and dHpre leave the kernel as accumulator-order tiles (two 16-byte stores per lane, no LDS transposition) and
+                # the weight gradients - with d(b1), d(b2) as column sums - are cnx_gemm_tn_ex contractions over those tiles
+                a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+                dos = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
+                ht = torch.empty(M * 4 * C, device=x.device, dtype=torch.bfloat16)
+                dhpt = torch.empty(M * 4 * C, device=x.device, dtype=torch.bfloat16)
+                if g2.dtype not in (torch.float32, torch.bfloat16):
+                    g2 = g2.float()
+                _lib.check(lib.cnx_block_mlp_bwd_acc(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                     g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
+                                                     da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
+                                                     M, C, _stream()), "cnx_block_mlp_bwd_acc")
+                dw2, db2 = _wgrad_acc(dos, False, ht, True, M, C, 4 * C)
+                dw1, db1 = _wgrad_acc(dhpt, True, a, False, M, 4 * C, C)
+                if gf is not None:
+                    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+                    db2_ = torch.empty(C, device=x.device, dtype=torch.float32)
+                    ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=x.device, dtype=torch.float32)
+                    _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2.reshape(M, C).data_ptr(), gf.data_ptr(), None,
+                                                          dgamma.data_ptr(), db2_.data_ptr(), ws.data_ptr(), M, C, _stream()),
+                               "cnx_scale_residual_bwd")
+                del a, dos, ht, dhpt
+                want_emit = False
+            else:
+                want_emit = want_p
+            if want_emit:
                 # with 8 extra columns (1, 0, ..., 0) behind LN(u), the d(b1) sum is column C of the dW1 GEMM's result
                 a = torch.empty(M, a_cols, device=x.device, dtype=torch.bfloat16)
                 if a_cols != C:
@@ -1384,11 +1491,12 @@ class _BlockFused(torch.autograd.Function):
                 dhpt = torch.empty(4 * C, M, device=x.device, dtype=torch.bfloat16)
             if g2.dtype not in (torch.float32, torch.bfloat16):
                 g2 = g2.float()
-            _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                             g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
-                                             da.data_ptr(), _lib.ptr(a), (a_cols if want_p else 0), _lib.ptr(dos), _lib.ptr(ht),
-                                             _lib.ptr(dhpt), M, C, _stream()), "cnx_block_mlp_bwd")
-            if want_p:
+            if not acc_emit:
+                _lib.check(lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                 g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
+                                                 da.data_ptr(), _lib.ptr(a), (a_cols if want_p else 0), _lib.ptr(dos), _lib.ptr(ht),
+                                                 _lib.ptr(dhpt), M, C, _stream()), "cnx_block_mlp_bwd")
+            if want_emit:
                 dw1 = _wgrad_t(dhpt, a)                                          # [4C, C (+8)]
                 if a_cols != C:
                     dw1, db1 = dw1[:, :C], dw1[:, C].contiguous()
@@ -1479,6 +1587,18 @@ _FUSED_WIDTHS = {int(v) for v in _FUSED_WIDTHS.split(",") if v.strip()}
 # Hpre workspace while the training pass stays on the library GEMMs (cnx_block_mlp_fwd_hpre).  APGD_BLOCK_HPRE overrides ("" = none).
 _HPRE_WIDTHS = os.environ.get("APGD_BLOCK_HPRE", "128,192,256,384")
 _HPRE_WIDTHS = {int(v) for v in _HPRE_WIDTHS.split(",") if v.strip().isdigit()}
+
+
+# Widths whose TRAINING pass runs on the Hpre kernel pair as well (round 5: cnx_block_mlp_fwd_train / cnx_block_mlp_bwd_train_hpre, weight
+# gradients through cnx_gemm_tn_ex on the kernels' own tile layout) whenever the row count suits the contraction kernel (M % 64 == 0);
+# otherwise - and with APGD_TRAIN_HPRE="" - the training pass of rounds 1 - 4 (recomputing fused kernels / library GEMMs).
+_TRAIN_HPRE_WIDTHS = os.environ.get("APGD_TRAIN_HPRE", "128,192,256,384")
+_TRAIN_HPRE_WIDTHS = {int(v) for v in _TRAIN_HPRE_WIDTHS.split(",") if v.strip().isdigit()}
+
+
+def _use_train_hpre(C, M):
+    return (C in _TRAIN_HPRE_WIDTHS and MODE != "eager" and bool(_lib.load().cnx_block_mlp_hpre_supported(C))
+            and _tn_ok(M, 4 * C, C) and _tn_ok(M, C, 4 * C))
 
 
 def _use_hpre_block(C):

@@ -169,3 +169,32 @@ def test_library_path_block_on_the_gemm_kernels_matches_hipblaslt(R, monkeypatch
     assert rel(res["hip"][0], res["lib"][0]) <= 2e-3
     for i, (a, b) in enumerate(zip(res["hip"][1], res["lib"][1])):
         assert rel(a, b) <= 2e-2, (i, rel(a, b))
+
+
+@pytest.mark.parametrize("M,N1,N2", [(64, 384, 192), (640, 192, 384), (1024, 256, 128), (320, 128, 256), (4096, 384, 96), (1984, 96, 384),
+                                     (256, 256, 64), (192, 64, 256), (12544, 768, 192), (6272, 1536, 384), (3136, 768, 3072),
+                                     (50176, 384, 96), (2048, 512, 128), (128, 2304, 768)])
+def test_gemm_tn_vs_fp32_reference_through_the_c_abi(M, N1, N2):
+    """cnx_gemm_tn: D = A^T B (contraction over the rows of two row-major bf16 operands; LDS transpose reads) against the fp32
+    product of the same bf16 values.  All eight tile shapes, one and many splits of M, strided operands (views into wider
+    tensors), determinism.  The operands are random with per-column scales: a transposed / permuted fragment cannot pass."""
+    import revisiting_at_amd as R
+    lib = R._lib.load()
+    assert lib.cnx_gemm_tn_supported(M, N1, N2) == 1
+    g = torch.Generator(device="cuda").manual_seed(M + N1)
+    pa, pb = 8 * (M % 3), 16                                        # leading dimensions wider than the operands
+    Aw = (torch.randn(M, N1 + pa, device="cuda", generator=g) * torch.linspace(0.5, 2.0, N1 + pa, device="cuda")).to(torch.bfloat16)
+    Bw = (torch.randn(M, N2 + pb, device="cuda", generator=g) * torch.linspace(2.0, 0.5, N2 + pb, device="cuda")).to(torch.bfloat16)
+    A, B = Aw[:, :N1], Bw[:, :N2]
+    ref = A.float().t() @ B.float()
+    D = torch.full((N1, N2), float("nan"), device="cuda")
+    ws = torch.empty(max(4, lib.cnx_gemm_tn_ws_floats(M, N1, N2)), device="cuda")
+    S = torch.cuda.current_stream().cuda_stream
+    assert lib.cnx_gemm_tn(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), D.data_ptr(), ws.data_ptr(), M, N1, N2, S) == 0
+    err = float((D - ref).norm() / ref.norm())
+    assert err < 2e-6, err                                          # exact bf16 products, fp32 sums in another order
+    D2 = torch.empty_like(D)
+    assert lib.cnx_gemm_tn(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), D2.data_ptr(), ws.data_ptr(), M, N1, N2, S) == 0
+    assert torch.equal(D, D2)
+    assert lib.cnx_gemm_tn(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), D.data_ptr(), ws.data_ptr(), M + 8, N1, N2, S) == -4
+    assert lib.cnx_gemm_tn_supported(M, N1 + 32, N2) in (0, 1) and lib.cnx_gemm_tn_supported(M, 1000, 768) == 0

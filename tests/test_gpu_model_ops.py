@@ -710,6 +710,125 @@ def test_fused_block_tail_backward_vs_fp32_reference(R, C, M_, gamma, emit, gdt)
     assert lib.cnx_block_mlp_bwd_supported(384) == 0
 
 
+def _acc_to_rows(ws, M_, N_):
+    """CNX_TN_ACC tiles ([M/32][N/32] x 2 KiB; element (m, n) of a tile at byte 64 m + 32 ((n/4) % 2) + 8 (n/8) + 2 (n % 4)) -> [M, N]."""
+    t = ws[:M_ * N_].view(M_ // 32, N_ // 32, 32, 2, 4, 4)              # (row tile, column tile, m, half, q, e): n = 8 q + 4 half + e
+    return t.permute(0, 2, 1, 4, 3, 5).reshape(M_, N_)
+
+
+@pytest.mark.parametrize("C,M_", [(128, 64), (128, 1024), (192, 448), (256, 256), (384, 128), (384, 2048), (192, 12544)])
+@pytest.mark.parametrize("gamma", [True, False])
+def test_training_pass_on_the_hpre_kernel_pair_vs_fp32_reference(R, C, M_, gamma):
+    """Round 5: the training pass of a block on cnx_block_mlp_fwd_train / cnx_block_mlp_bwd_train_hpre with both weight gradients
+    (and their bias gradients) as cnx_gemm_tn_ex contractions over the kernels' own accumulator-order tiles - against fp32 autograd
+    of the same chain on the same bf16-quantised operands: block output, saved tiles (decoded), da, dO, dHpre, dW1, db1, dW2, db2."""
+    lib = R._lib.load()
+    gen = torch.Generator().manual_seed(C + M_)
+    u = (torch.randn(M_, C, generator=gen) * 1.5 + 0.3).to(torch.bfloat16)
+    xres = torch.randn(M_, C, generator=gen)
+    w1 = (torch.randn(4 * C, C, generator=gen) * C ** -0.5).to(torch.bfloat16).float()
+    w2 = (torch.randn(C, 4 * C, generator=gen) * (4 * C) ** -0.5).to(torch.bfloat16).float()
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen)
+    b1, b2 = torch.randn(4 * C, generator=gen) * 0.3, torch.randn(C, generator=gen) * 0.3
+    gm = torch.randn(C, generator=gen) if gamma else None
+    g = torch.randn(M_, C, generator=gen)
+    # fp32 reference with the roundings the kernels make (LN output, H, dO, dHpre are bf16 operands)
+    a = F.layer_norm(u.float(), (C,), lw, lb, 1e-6).to(torch.bfloat16).float()
+    hpre = a @ w1.t() + b1
+    h = F.gelu(hpre).to(torch.bfloat16).float()
+    y2 = h @ w2.t() + b2
+    out_ref = xres + (y2 * gm if gamma else y2)
+    dO = (g * gm if gamma else g).to(torch.bfloat16).float()
+    dh = dO @ w2
+    hp2 = hpre.clone().requires_grad_()
+    (dhpre,) = torch.autograd.grad(F.gelu(hp2), hp2, dh)
+    dhpre_b = dhpre.to(torch.bfloat16).float()
+    da_ref = dhpre_b @ w1
+    dev_ = lambda t: t.detach().cuda().contiguous()
+    P = R._lib.ptr
+    wf = R.ops._pack_mlp(w1.cuda(), w2.cuda())
+    wb = R.ops._pack_mlp_bwd(w1.cuda(), w2.cuda())
+    ud, xd, lwd, lbd, b1d, b2d, gd = map(dev_, (u, xres, lw, lb, b1, b2, g))
+    gmd = dev_(gm) if gamma else None
+    n_ws = lib.cnx_block_mlp_hpre_elems(M_, C)
+    mean, rstd = torch.empty(M_, device="cuda"), torch.empty(M_, device="cuda")
+    hpre_ws = torch.zeros(n_ws, device="cuda", dtype=torch.bfloat16)
+    h_ws = torch.zeros(n_ws, device="cuda", dtype=torch.bfloat16)
+    a_rows = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+    y2d = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(M_, C, device="cuda")
+    assert lib.cnx_block_mlp_fwd_train(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), 1e-6, mean.data_ptr(), rstd.data_ptr(), wf.data_ptr(),
+                                       b1d.data_ptr(), b2d.data_ptr(), P(gmd), xd.data_ptr(), 0, out.data_ptr(), 0, y2d.data_ptr(),
+                                       hpre_ws.data_ptr(), h_ws.data_ptr(), a_rows.data_ptr(), M_, C, S()) == 0
+    rel = lambda t, r: float((t.float().cpu() - r).norm() / r.norm())
+    assert rel(out, out_ref) < 5e-3 and rel(y2d, y2) < 6e-3
+    assert rel(a_rows, a) < 4e-3                                   # one bf16 ulp here and there (fma order before the rounding)
+    assert rel(_acc_to_rows(hpre_ws, M_, 4 * C), hpre) < 5e-3 and rel(_acc_to_rows(h_ws, M_, 4 * C), h) < 6e-3
+    da = torch.full((M_, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dos = torch.empty(M_, C, device="cuda", dtype=torch.bfloat16)
+    dhp_ws = torch.zeros(n_ws, device="cuda", dtype=torch.bfloat16)
+    assert lib.cnx_block_mlp_bwd_train_hpre(gd.data_ptr(), 0, P(gmd), wb.data_ptr(), hpre_ws.data_ptr(), da.data_ptr(), dos.data_ptr(),
+                                            dhp_ws.data_ptr(), M_, C, S()) == 0
+    assert rel(da, da_ref) < 1e-2 and rel(dos, dO) < 4e-3 and rel(_acc_to_rows(dhp_ws, M_, 4 * C), dhpre) < 8e-3
+    # weight / bias gradients from the tiles: exact contractions of what the kernels stored ...
+    N1, N2 = C, 4 * C
+    dw2 = torch.empty(N1, N2, device="cuda"); db2 = torch.empty(N1, device="cuda")
+    ws = torch.empty(lib.cnx_gemm_tn_ws_floats(M_, N1, N2), device="cuda")
+    assert lib.cnx_gemm_tn_ex(dos.data_ptr(), C, 0, h_ws.data_ptr(), 0, 1, dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M_, N1, N2, S()) == 0
+    dw1 = torch.empty(N2, N1, device="cuda"); db1 = torch.empty(N2, device="cuda")
+    assert lib.cnx_gemm_tn_ex(dhp_ws.data_ptr(), 0, 1, a_rows.data_ptr(), C, 0, dw1.data_ptr(), db1.data_ptr(), ws.data_ptr(), M_, N2, N1, S()) == 0
+    Hs, Ds = _acc_to_rows(h_ws, M_, 4 * C).float(), _acc_to_rows(dhp_ws, M_, 4 * C).float()
+    assert float((dw2 - dos.float().t() @ Hs).norm() / dw2.norm()) < 3e-6 and float((db2 - dos.float().sum(0)).norm() / db2.norm()) < 3e-6
+    assert float((dw1 - Ds.t() @ a_rows.float()).norm() / dw1.norm()) < 3e-6 and float((db1 - Ds.sum(0)).norm() / db1.norm()) < 3e-6
+    # ... and against the fp32 chain
+    assert rel(dw2, dO.t() @ h) < 6e-3 and rel(dw1, dhpre_b.t() @ a) < 8e-3
+    assert rel(db2, dO.sum(0)) < 6e-3 and rel(db1, dhpre_b.sum(0)) < 1e-2
+    # argument checks
+    assert lib.cnx_gemm_tn_ex(dos.data_ptr(), C, 0, h_ws.data_ptr(), 0, 1, dw2.data_ptr(), None, ws.data_ptr(), M_, N1, N2, S()) == -1
+    assert lib.cnx_gemm_tn_ex(dhp_ws.data_ptr(), 0, 1, h_ws.data_ptr(), 0, 1, dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M_, N2, N2, S()) == -4
+    assert lib.cnx_block_mlp_fwd_train(ud.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), 1e-6, mean.data_ptr(), rstd.data_ptr(), wf.data_ptr(),
+                                       b1d.data_ptr(), b2d.data_ptr(), P(gmd), xd.data_ptr(), 0, out.data_ptr(), 0, None,
+                                       hpre_ws.data_ptr(), None, a_rows.data_ptr(), M_, C, S()) == -1
+
+
+@pytest.mark.parametrize("C,M_", [(96, 64), (96, 3136), (192, 256), (128, 128), (256, 64)])
+def test_recomputing_training_backward_with_accumulator_order_tiles(R, C, M_):
+    """cnx_block_mlp_bwd_acc: the recomputing training backward with H / dHpre written as CNX_TN_ACC tiles equals cnx_block_mlp_bwd
+    (transposed [4C, M] matrices) value for value, and its tiles feed cnx_gemm_tn_ex."""
+    lib = R._lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(C + M_)
+    u = (torch.randn(M_, C, device="cuda", generator=gen) * 1.5 + 0.3).to(torch.bfloat16)
+    w1 = torch.randn(4 * C, C, device="cuda", generator=gen) * C ** -0.5
+    w2 = torch.randn(C, 4 * C, device="cuda", generator=gen) * (4 * C) ** -0.5
+    lw, lb = 1 + 0.2 * torch.randn(C, device="cuda", generator=gen), 0.2 * torch.randn(C, device="cuda", generator=gen)
+    b1 = torch.randn(4 * C, device="cuda", generator=gen) * 0.3
+    gm = torch.randn(C, device="cuda", generator=gen)
+    g = torch.randn(M_, C, device="cuda", generator=gen)
+    mu = u.float().mean(1)
+    rstd = (u.float().var(1, unbiased=False) + 1e-6).rsqrt()
+    wb = R.ops._pack_mlp_bwd(w1, w2)
+    mk = lambda *sh: torch.full(sh, float("nan"), device="cuda", dtype=torch.bfloat16)
+    da0, a0, do0, ht, dhpt = mk(M_, C), mk(M_, C), mk(M_, C), mk(4 * C, M_), mk(4 * C, M_)
+    assert lib.cnx_block_mlp_bwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mu.data_ptr(), rstd.data_ptr(), g.data_ptr(), 0, gm.data_ptr(),
+                                 wb.data_ptr(), b1.data_ptr(), da0.data_ptr(), a0.data_ptr(), 0, do0.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
+                                 M_, C, S()) == 0
+    da1, a1, do1, hw, dw = mk(M_, C), mk(M_, C), mk(M_, C), mk(M_ * 4 * C), mk(M_ * 4 * C)
+    assert lib.cnx_block_mlp_bwd_acc(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mu.data_ptr(), rstd.data_ptr(), g.data_ptr(), 0, gm.data_ptr(),
+                                     wb.data_ptr(), b1.data_ptr(), da1.data_ptr(), a1.data_ptr(), do1.data_ptr(), hw.data_ptr(), dw.data_ptr(),
+                                     M_, C, S()) == 0
+    assert torch.equal(da0, da1) and torch.equal(a0, a1) and torch.equal(do0, do1)
+    assert torch.equal(_acc_to_rows(hw, M_, 4 * C), ht.t()) and torch.equal(_acc_to_rows(dw, M_, 4 * C), dhpt.t())
+    if lib.cnx_gemm_tn_supported(M_, 4 * C, C):
+        d = torch.empty(4 * C, C, device="cuda"); cs = torch.empty(4 * C, device="cuda")
+        ws = torch.empty(lib.cnx_gemm_tn_ws_floats(M_, 4 * C, C), device="cuda")
+        assert lib.cnx_gemm_tn_ex(dw.data_ptr(), 0, 1, a1.data_ptr(), C, 0, d.data_ptr(), cs.data_ptr(), ws.data_ptr(), M_, 4 * C, C, S()) == 0
+        ref = dhpt.float() @ a1.float()
+        assert float((d - ref).norm() / ref.norm()) < 3e-6 and float((cs - dhpt.float().sum(1)).norm() / cs.norm()) < 3e-6
+    assert lib.cnx_block_mlp_bwd_acc(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mu.data_ptr(), rstd.data_ptr(), g.data_ptr(), 0, gm.data_ptr(),
+                                     wb.data_ptr(), b1.data_ptr(), da1.data_ptr(), a1.data_ptr(), do1.data_ptr(), hw.data_ptr(), dw.data_ptr(),
+                                     M_ - 16, C, S()) == -4
+
+
 @pytest.mark.parametrize("N", [1, 5, 32, 33, 197, 224, 225, 257, 401, 416])
 @pytest.mark.parametrize("B,H", [(2, 3), (1, 12)])
 def test_fused_attention_forward_and_backward_vs_fp32_reference(R, N, B, H):
@@ -1091,7 +1210,10 @@ def test_stem_conv_ln_gelu_fused_equals_the_two_kernel_composition(R, P, N, H, W
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("arch,nb,res", [("convnext_tiny", 2, 224), ("convnext_tiny", 3, 160), ("convnext_tiny", 1, 96),
-                                         ("convnext_base", 2, 224), ("vit_s", 2, 224), ("deit_s", 2, 224), ("vit_b", 2, 224)])
+                                         ("convnext_base", 2, 224), ("vit_s", 2, 224), ("deit_s", 2, 224), ("vit_b", 2, 224),
+                                         # row counts that are multiples of 64 at every stage: the round-5 training pass (Hpre kernel
+                                         # pair at C = 192 / 384 resp. 128 / 256, accumulator-order emit at C = 96, cnx_gemm_tn weight gradients)
+                                         ("convnext_tiny", 64, 64), ("convnext_base", 64, 64), ("convnext_tiny", 16, 224)])
 def test_train_step_gradients_hip_vs_library_composition(R, monkeypatch, arch, nb, res):
     """End to end at the benchmark's shapes (ConvNeXt-T-CvSt, 224x224, bf16 autocast, batch 2): logits, input gradient and
     EVERY parameter gradient of the hand-written path (rolling / tile depthwise kernels, fused LN+MLP blocks and their emit
@@ -1105,7 +1227,7 @@ def test_train_step_gradients_hip_vs_library_composition(R, monkeypatch, arch, n
                 p.fill_(0.5)
     model.train()
     x = torch.rand(nb, 3, res, res, device="cuda")
-    y = torch.tensor([3, 7, 11][:nb], device="cuda")
+    y = (torch.arange(nb, device="cuda") * 37 + 3) % 1000
 
     def run(mode):
         monkeypatch.setattr(R.ops, "MODE", mode)
