@@ -534,8 +534,10 @@ def main():
     #   general (i >= 1): 20 algorithmic B/elem - the `roofline` object;
     #   first   (i == 0): x_adv_old aliases x_adv, 16 algorithmic B/elem - `roofline.first_iter`.
     # Since round 5 the launch also performs the row moves of the iteration before it (K3; at i = 0 the prologue's clones): its
-    # algorithmic bytes are the SUM of the step's and the row moves' (SURVEY.md §8d gives both rules; the latter from the flag bytes
-    # each timed launch read); `frac_step_only` keeps the step's 20 (16) B/element over the same time for comparison with rounds 1-4.
+    # algorithmic bytes are the step's 20 (16) B/element plus 4 B/element per row-move destination the launch writes (from the flag
+    # bytes each timed launch read; the moves' sources are the step's own operands) - at fp32, so with int8 gradient signs the kernel
+    # moves FEWER bytes than that and `frac` can pass 1 while `frac_moved`, the physical reading, is ~0.74; `frac_sum_8d` adds 8d's K3
+    # rule literally; `frac_step_only` keeps the step's 20 (16) B/element over the same time for comparison with rounds 1-4.
     # `achieved` = algorithmic bytes / HIP-event time measured here; `traffic` = HBM bytes per launch of the same kernel
     # form from the PMC passes (profiles/k1_traffic.json).  With int8 gradient signs the kernel moves 17 / 13 B/elem, i.e.
     # LESS than the algorithmic figure: `bytes_moved` and `moved_GBs` state that side by side.
@@ -549,21 +551,27 @@ def main():
     E_row = 3 * args.res * args.res
 
     def track_bytes(flags, gbytes, first):
-        """(algorithmic, moved) bytes of the row moves a fused update launch performs (per flagged sample 8 B/elem
-        read + 4 B/elem per destination written - x_best, grad_best, x_best_adv; a restore counts 8 + 8) from the flag bytes the
-        launch read.  Iteration 0 writes the prologue's three clones (4 B/elem each; their source is the step's own operand)."""
+        """Bytes of the row moves a fused update launch performs, from the flag bytes the launch read: (algorithmic, algorithmic by
+        the literal sum of SURVEY.md 8d's K1 and K3 rules, moved, per-flag sample counts).
+        algorithmic = what the FUSED operation has to move at fp32: the row moves' sources are the step's own operands (read once),
+        so a flagged sample adds 4 B/elem per destination written (x_best, grad_best, x_best_adv; a restore: x_adv and grad = 8).
+        8d's K3 rule prices the tracking as a pass of its own (8 B/elem read per flagged sample + 4 per destination; a restore
+        8 + 8): its sum with K1's 20 B/elem counts the shared reads twice - reported next to it as `frac_sum_8d`.
+        Iteration 0 writes the prologue's three clones (4 B/elem each; their source is the step's own operand)."""
         if first:
-            return 12.0 * n_elem, (8.0 + gbytes) * n_elem, (B, B, 0)
+            return 12.0 * n_elem, 12.0 * n_elem, (8.0 + gbytes) * n_elem, (B, B, 0)
         if flags is None:
-            return 0.0, 0.0, (0, 0, 0)
+            return 0.0, 0.0, 0.0, (0, 0, 0)
         f = flags.to(torch.int64)
         nb, mc, hv = (f & 1) != 0, (f & 2) != 0, (f & 4) != 0
         rs = hv & ~nb
         anyf = nb | mc                                        # (a restore-only sample: its 8 + 8 are counted below, no more)
-        alg = (8.0 * anyf.sum() + 8.0 * nb.sum() + 4.0 * mc.sum() + 16.0 * rs.sum()).item() * E_row
+        n_nb, n_mc, n_rs, n_any = int(nb.sum()), int(mc.sum()), int(rs.sum()), int(anyf.sum())
+        alg = (8.0 * n_nb + 4.0 * n_mc + 8.0 * n_rs) * E_row
+        alg8d = (8.0 * n_any + 8.0 * n_nb + 4.0 * n_mc + 16.0 * n_rs) * E_row
         # moved: the step reads x_adv / grad anyway; NEW_BEST writes 4 + g, MISCLS 4, a restore reads 4 + g and writes 4
-        mov = ((4.0 + gbytes) * nb.sum() + 4.0 * mc.sum() + (8.0 + gbytes) * rs.sum()).item() * E_row
-        return alg, mov, (int(nb.sum()), int(mc.sum()), int(rs.sum()))
+        mov = ((4.0 + gbytes) * n_nb + 4.0 * n_mc + (8.0 + gbytes) * n_rs) * E_row
+        return alg, alg8d, mov, (n_nb, n_mc, n_rs)
 
     def k1_entry(sel, alg_bpe, form):
         ev = [(a.elapsed_time(b), gb, name, fl) for (name, i, a, b, gb, fl) in events if name.startswith("apgd_linf_step") and sel(i)]
@@ -574,15 +582,16 @@ def main():
         fused = ev[0][2] == "apgd_linf_step_track_f32"
         blk = gbytes == 1 and R.ops.SIGN_BLOCKED and E_row % 1024 == 0 and not fused          # the stem's blocked sign order
         step_alg, step_mov = alg_bpe * n_elem, (alg_bpe - 4 + gbytes) * n_elem
-        tb = [track_bytes(e[3], gbytes, form == "first") if fused else (0.0, 0.0, (0, 0, 0)) for e in ev]
+        tb = [track_bytes(e[3], gbytes, form == "first") if fused else (0.0, 0.0, 0.0, (0, 0, 0)) for e in ev]
         alg_launch = step_alg + sum(t[0] for t in tb) / len(tb)                              # average per launch
-        mov_launch = step_mov + sum(t[1] for t in tb) / len(tb)
+        alg8d_launch = step_alg + sum(t[1] for t in tb) / len(tb)
+        mov_launch = step_mov + sum(t[2] for t in tb) / len(tb)
         ach = alg_launch / (avg_ms * 1e-3) / 1e9
         gname = ('i8blk' if blk else 'i8') if gbytes == 1 else 'f32'
         traffic, tr, traffic_src = None, {}, None
         for key in ([f"track_{form}_{gname}_f3", f"track_{form}_{gname}_f1", f"track_{form}_{gname}"] if fused else [f"{form}_{gname}"]):
             tr = traffic_tab.get(key, {})
-            if tr and abs(alg_launch - tr.get("algorithmic_bytes_per_launch", -1)) < 1.0:
+            if tr and abs(alg8d_launch - tr.get("algorithmic_bytes_per_launch", -1)) < 1.0:
                 traffic, traffic_src = tr.get("hbm_bytes_per_launch"), f"PMC pass of this kernel form ({key})"
                 break
         if traffic is None and fused and form == "general" and n_elem == 256 * 3 * 224 * 224:
@@ -592,7 +601,7 @@ def main():
             t0, t1, t3 = (traffic_tab.get(k, {}).get("hbm_bytes_per_launch") for k in
                           (f"general_{gname}", f"track_general_{gname}_f1", f"track_general_{gname}_f3"))
             if t0 and t1 and t3:
-                nbr, mcr, rsr = (sum(t[2][k] for t in tb) / len(tb) for k in range(3))
+                nbr, mcr, rsr = (sum(t[3][k] for t in tb) / len(tb) for k in range(3))
                 traffic = t0 + nbr * (t1 - t0) / B + mcr * (t3 - t1) / B + rsr * (8.0 + gbytes) * E_row
                 traffic_src = ("PMC passes of the plain step and of the uniform flag mixes 1 / 3, combined by this run's average per-flag "
                                f"sample counts per launch (NEW_BEST {nbr:.1f}, MISCLS {mcr:.1f}, restore {rsr:.1f} of {B})")
@@ -611,8 +620,10 @@ def main():
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic and round(traffic), "traffic_source": traffic_src, "kernel": kern,
                 "launches": len(ev), "avg_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": round(alg_launch),
-                # the step's 20 (16) B/element + the row moves' bytes from the flag bytes each launch read
+                # the step's 20 (16) B/element + 4 B/element per row-move destination written, from the flag bytes each
+                # launch read; `frac_sum_8d`: with 8d's K3 rule added literally (it re-counts the sources the step already reads)
                 "algorithmic_bytes_step": step_alg, "algorithmic_bytes_row_moves": round(alg_launch - step_alg),
+                "frac_sum_8d": round(alg8d_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "bytes_moved": round(mov_launch), "moved_GBs": round(mov_launch / (avg_ms * 1e-3) / 1e9, 1),
                 # the PHYSICAL reading: bytes the kernel is designed to move (= the PMC traffic) / time / 8 TB/s
                 "frac_moved": round(mov_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -410,11 +410,14 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
   // lane part of a DMA source address.  ROWS: row lane / 4 of the block's 16, 16-byte piece lane % 4 of the sub-image's 64-byte row
   const uint32_t va = LA == kRows ? static_cast<uint32_t>((lane >> 2) * lda * 2 + (lane & 3) * 16) : static_cast<uint32_t>(lane * 16);
   const uint32_t vb = LB == kRows ? static_cast<uint32_t>((lane >> 2) * ldb * 2 + (lane & 3) * 16) : static_cast<uint32_t>(lane * 16);
-  auto dma_stage = [&](int t, int buf) {
+  // part: the DMA instructions k with k % 4 == part (the loop below issues a quarter of a stage's DMA in front of each k-step's
+  // MFMAs: a burst of all NDMA at the top of the stage holds the in-order wavefront at issue while the texture path drains); -1: all
+  auto dma_stage = [&](int t, int buf, int part) {
     const uint32_t sb = lds0 + static_cast<uint32_t>(buf) * STAGE;
     const long m0 = m_begin + static_cast<long>(t) * KT;
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
+      if (part >= 0 && (k & 3) != part) continue;
       const int b = wave + NW * k;                                     // wave-uniform block: (operand, sub-image, 16-row block)
       if (b < SUBA * 4) {
         const int sub = b >> 2, rb = b & 3;
@@ -452,30 +455,42 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
     ones = __builtin_bit_cast(bf16x8, t);
   }
 
-  if (n_stage > 0) dma_stage(0, 0);
+  if (n_stage > 0) dma_stage(0, 0, -1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < n_stage; ++t) {
     const int buf = t & 1;
-    if (t + 1 < n_stage && !(dbg & 1)) dma_stage(t + 1, buf ^ 1);      // (that buffer's readers passed the barrier below)
+    const bool more = t + 1 < n_stage && !(dbg & 1);                   // (the other buffer's readers passed the barrier below)
     const uint32_t ab = a_lane + static_cast<uint32_t>(buf) * STAGE, bb = b_lane + static_cast<uint32_t>(buf) * STAGE;
-    if (!(dbg & 2))
-#pragma unroll
-    for (int ks = 0; ks < KT / 16; ++ks) {
-      bf16x8 af[F], bfr[F];
+    // the fragments of k-step ks + 1 are read while the MFMAs of k-step ks run (two register sets)
+    bf16x8 af[2][F], bfr[2][F];
+    if (!(dbg & 2)) {
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        af[f] = tr_fragment(ab + static_cast<uint32_t>(f * 4096 + ks * 1024), 64u);
-        bfr[f] = tr_fragment(bb + static_cast<uint32_t>(f * 4096 + ks * 1024), 64u);
+        af[0][f] = tr_fragment(ab + static_cast<uint32_t>(f * 4096), 64u);
+        bfr[0][f] = tr_fragment(bb + static_cast<uint32_t>(f * 4096), 64u);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KT / 16; ++ks) {
+      if (more) dma_stage(t + 1, buf ^ 1, ks);
+      if (dbg & 2) continue;
+      if (ks + 1 < KT / 16) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          af[(ks + 1) & 1][f] = tr_fragment(ab + static_cast<uint32_t>(f * 4096 + (ks + 1) * 1024), 64u);
+          bfr[(ks + 1) & 1][f] = tr_fragment(bb + static_cast<uint32_t>(f * 4096 + (ks + 1) * 1024), 64u);
+        }
       }
 #pragma unroll
       for (int fi = 0; fi < F; ++fi)
 #pragma unroll
-        for (int fj = 0; fj < F; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fi], bfr[fj], acc[fi][fj], 0, 0, 0);
+        for (int fj = 0; fj < F; ++fj)
+          acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][fi], bfr[ks & 1][fj], acc[fi][fj], 0, 0, 0);
       if constexpr (CS) {
         if (cs_wave) {
 #pragma unroll
-          for (int fi = 0; fi < F; ++fi) accs[fi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fi], ones, accs[fi], 0, 0, 0);
+          for (int fi = 0; fi < F; ++fi) accs[fi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][fi], ones, accs[fi], 0, 0, 0);
         }
       }
     }

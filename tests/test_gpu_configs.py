@@ -310,6 +310,19 @@ def _oracle_at_steps(ref, x, y, n_steps, lr, decay=0.9999):
 @pytest.mark.parametrize("mode", ["eager", "graph", "graph-flat"])
 @pytest.mark.parametrize("amp", [None, torch.bfloat16], ids=["fp32", "bf16"])
 def test_at_train_step_matches_oracle_step(R, amp, mode):
+    _at_step_case(R, amp, mode, 64, 4)
+
+
+@pytest.mark.parametrize("mode", ["graph", "graph-flat"])
+def test_at_train_step_full_size_captured_pass_matches_oracle_step(R, mode):
+    """The same comparison at the benchmark's resolution - ConvNeXt-T-CvSt at 224 x 224, batch 32, bf16 - for the two captured forms of
+    the step (round-4 review: the captured TRAINING pass had its oracle check at 64 x 64, batch 4 only).  At this size every stage but
+    the last has a row count the round-5 training pass takes (Hpre kernel pair at C = 192 / 384, accumulator-order emit at C = 96,
+    cnx_gemm_tn weight gradients), the attack replays on two streams, and steps 4 - 5 run from the captured training pass."""
+    _at_step_case(R, torch.bfloat16, mode, 224, 32)
+
+
+def _at_step_case(R, amp, mode, res, batch):
     """``mode``: "eager" - every kernel launched from Python (rounds 1 - 3 checked only this form against the oracle); "graph" - the
     step ``bench.py`` times: attack replayed from hipGraphs (two streams under bf16), training pass captured with the capturable
     AdamW, five steps so that the fourth is the capture's first replay and the fifth a plain replay; "graph-flat" - the same with
@@ -325,8 +338,8 @@ def test_at_train_step_matches_oracle_step(R, amp, mode):
     prod.load_state_dict(ref.state_dict(), strict=True)
     p0 = {k: v.detach().clone() for k, v in ref.state_dict().items()}
     g = torch.Generator().manual_seed(11)
-    x = torch.rand(4, 3, 64, 64, generator=g)
-    y = torch.randint(0, 1000, (4,), generator=g)
+    x = torch.rand(batch, 3, res, res, generator=g)
+    y = torch.randint(0, 1000, (batch,), generator=g)
     lr, n_steps = 1e-3, (3 if mode == "eager" else 5)
     R.graphed.reset()
 
@@ -363,7 +376,7 @@ def test_at_train_step_matches_oracle_step(R, amp, mode):
     ema_o = flat(o_ema, keys) - flat(p0, keys)
     ema_cos = float(F.cosine_similarity(ema_p.double(), ema_o.double(), dim=0))
     loss_rel = max(abs(a - b) / abs(b) for a, b in zip(losses, o_losses))
-    note("at_step", amp=str(amp), mode=mode, losses=losses, o_losses=o_losses, grad_rel=g_rel, update_cos=cos, ema_cos=ema_cos,
+    note("at_step", amp=str(amp), mode=mode, res=res, batch=batch, losses=losses, o_losses=o_losses, grad_rel=g_rel, update_cos=cos, ema_cos=ema_cos,
          upd_norm_ratio=float(upd_p.norm() / upd_o.norm()))
     # the product's EMA is exactly the ModelEmaV2 recursion over the product's own parameter trajectory
     d = 0.9999

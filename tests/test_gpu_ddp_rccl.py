@@ -55,7 +55,9 @@ def test_bench_line_carries_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "first_iter"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert 0.3 < rf["frac"] < 1.0 and 0.3 < rf["first_iter"]["frac"] < 1.05
+    # (algorithmic bytes are counted at fp32 - with int8 gradient signs the fused update + row-move kernel moves fewer: frac may pass 1;
+    #  the physical reading is frac_moved)
+    assert 0.3 < rf["frac"] < 1.3 and 0.3 < rf["first_iter"]["frac"] < 1.3 and 0.3 < rf["frac_moved"] < 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "img/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert d["extra"]["ops_mode"] == "hip"
