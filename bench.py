@@ -258,7 +258,8 @@ def other_configs(R, dev, graph=1, which=("cfg3", "cfg4", "cfg5")):
         # (A random-init model is broken by APGD-CE almost everywhere, so the targeted runs see few points, each with a batch
         # size the libraries have not met: `attack_runs` / `sample_iters` say what the evaluation amounted to.)
         _, st = R.run_standard_evaluation(model, x, y, bs=bs, norm="Linf", eps=4 / 255, attacks_to_run=("apgd-ce", "apgd-t"),
-                                          n_iter=100, n_target_classes=9, verbose=bool(os.environ.get("APGD_BENCH_VERBOSE")))
+                                          n_iter=100, n_target_classes=9, verbose=bool(os.environ.get("APGD_BENCH_VERBOSE")),
+                                          buckets=True, graph=bool(graph))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"] = {
@@ -274,7 +275,7 @@ def other_configs(R, dev, graph=1, which=("cfg3", "cfg4", "cfg5")):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             _, st2 = R.run_standard_evaluation(model, x, y, bs=bs, norm="Linf", eps=eps_t, attacks_to_run=("apgd-ce", "apgd-t"),
-                                               n_iter=100, n_target_classes=2)
+                                               n_iter=100, n_target_classes=2, buckets=True, graph=bool(graph))
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t0
             out["cfg5_convnext_base_cvst_standard_eval_ce_t_100step_224"]["with_targeted_leg"] = {

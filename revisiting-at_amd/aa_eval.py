@@ -41,7 +41,7 @@ def random_start(x: torch.Tensor, eps: float, norm: str = 'Linf', generator: Opt
 
 
 def apgd_attack(model, x, y, norm='Linf', eps=4. / 255., n_iter=100, loss='ce', y_target=None, use_rs=True,
-                generator: Optional[torch.Generator] = None):
+                generator: Optional[torch.Generator] = None, graph: bool = False, n_real: Optional[int] = None):
     """One APGD run (one restart) -> ``(x_best_adv, acc, loss_best, x_best)``.
 
     ``acc[b]`` is True iff sample ``b`` was classified correctly at the start point and at every iterate (it is still
@@ -56,10 +56,32 @@ def apgd_attack(model, x, y, norm='Linf', eps=4. / 255., n_iter=100, loss='ce', 
         raise ValueError("y_target goes with loss='dlr-targeted'")
     if norm not in ('Linf', 'L2'):
         raise NotImplementedError(f"norm={norm!r}")
-    x_init = random_start(x, eps, norm, generator) if use_rs else None
-    x_best, acc, loss_best, x_best_adv = _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False,
-                                                    y_target=y_target, x_init=x_init)
+    # ``n_real`` (run_standard_evaluation's padded batches): rows n_real .. are copies of row 0 that only fill the batch up to a
+    # size already met (and captured); the random start is drawn for the real rows only, so the random stream - and with it every
+    # real row's trajectory - is that of the unpadded call
+    x_init = None
+    if use_rs:
+        if n_real is not None and n_real < x.shape[0]:
+            x_init = torch.cat([random_start(x[:n_real], eps, norm, generator), x[n_real:]], 0)
+        else:
+            x_init = random_start(x, eps, norm, generator)
+    if graph:
+        from . import graphed
+        x_best, acc, loss_best, x_best_adv = graphed.run(model, x, y, norm, eps, n_iter, kind, False, y_target=y_target, x_init=x_init)
+    else:
+        x_best, acc, loss_best, x_best_adv = _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False,
+                                                        y_target=y_target, x_init=x_init)
     return x_best_adv, acc, loss_best, x_best
+
+
+def _bucket(n: int, bs: int) -> int:
+    """The padded size of an ``n``-row attack batch: the smallest of ``bs, ceil(bs/2), ceil(bs/4), ... >= 8`` that holds it."""
+    size = max(bs, n)
+    while True:
+        half = (size + 1) // 2
+        if half < n or half < 8:
+            return size
+        size = half
 
 
 @torch.no_grad()
@@ -72,13 +94,20 @@ def _predict(model, x, bs):
 
 def run_standard_evaluation(model, x, y, bs=200, norm='Linf', eps=4. / 255.,
                             attacks_to_run: Sequence[str] = ('apgd-ce', 'apgd-t'), n_iter=100, n_target_classes=9,
-                            seed=0, rank=0, world=1, device=None, amp_dtype=None, verbose=False) -> Tuple[torch.Tensor, dict]:
+                            seed=0, rank=0, world=1, device=None, amp_dtype=None, verbose=False, buckets: bool = False,
+                            graph: bool = False) -> Tuple[torch.Tensor, dict]:
     """``AutoAttack.run_standard_evaluation`` for ``attacks_to_run ⊆ {'apgd-ce', 'apgd-t'}`` (AA_eval.py:230-239).
 
     ``x`` [n,3,H,W] fp32 in [0,1] and ``y`` [n] may live on the host (as in AA_eval.py:116); this rank evaluates
     samples ``rank::world`` in batches of ``bs`` on ``device``.  Returns ``(x_adv_shard, stats)`` with
     ``stats = {'n', 'clean_correct', 'robust', 'attack_runs', 'sample_iters'}`` (counts on this rank; see ``robust_accuracy``;
     the last two say how much work the evaluation was: APGD runs started, and samples x iterations they covered).
+
+    ``buckets``: the still-robust subset an attack runs on has an arbitrary size - every one a batch shape the libraries (and a
+    captured program) have not met.  With ``buckets`` it is padded to the next of a few fixed sizes (``bs``, then halves down to
+    8) with copies of its first row; the padding rows are never read back (samples are independent: eval mode, LayerNorm models)
+    and draw no random numbers, so every real row's result is the unpadded evaluation's.  ``graph``: the attack runs replay
+    from hipGraphs (``graphed.run``: captured on the third call with a shape, which the buckets make recur).
     """
     assert not model.training
     for a in attacks_to_run:
@@ -111,16 +140,23 @@ def run_standard_evaluation(model, x, y, bs=200, norm='Linf', eps=4. / 255.,
                     idx = robust.nonzero().squeeze(1)                        # only still-robust points are attacked
                     if idx.numel() == 0:
                         break
-                    xi, yi = xb[idx].contiguous(), yb[idx]
+                    n_real = int(idx.numel())
                     attack_runs += 1
-                    sample_iters += int(idx.numel()) * n_iter
+                    sample_iters += n_real * n_iter
+                    if tc is not None and tc > logits.shape[1]:
+                        break
+                    idp = idx
+                    if buckets:
+                        nb = _bucket(n_real, bs)
+                        if nb > n_real:
+                            idp = torch.cat([idx, idx[:1].expand(nb - n_real)])
+                    xi, yi = xb[idp].contiguous(), yb[idp]
                     if tc is None:
-                        xa, acc, _, _ = apgd_attack(model, xi, yi, norm, eps, n_iter, 'ce', None, True, gen)
+                        xa, acc, _, _ = apgd_attack(model, xi, yi, norm, eps, n_iter, 'ce', None, True, gen, graph, n_real)
                     else:
-                        if tc > logits.shape[1]:
-                            break
-                        yt = order[idx, tc - 1]
-                        xa, acc, _, _ = apgd_attack(model, xi, yi, norm, eps, n_iter, 'dlr-targeted', yt, True, gen)
+                        yt = order[idp, tc - 1].contiguous()
+                        xa, acc, _, _ = apgd_attack(model, xi, yi, norm, eps, n_iter, 'dlr-targeted', yt, True, gen, graph, n_real)
+                    xa, acc = xa[:n_real], acc[:n_real]
                     broken = ~acc
                     if broken.any():
                         x_adv[idx[broken]] = xa[broken]

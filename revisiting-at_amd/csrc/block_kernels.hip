@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "apgd_hip.h"
 #include "convnext_hip.h"
@@ -43,6 +44,10 @@
 #define PIPE_ABL 0
 #endif
 #define PABL(bit) ((PIPE_ABL & (bit)) != 0)
+// compile-time ablations of blk2_fwd_kernel (-DBLK2_ABL=mask: 1 no GELU, 2 one MFMA of GEMM1 per block, 4 one MFMA of GEMM2 per block)
+#ifndef BLK2_ABL
+#define BLK2_ABL 0
+#endif
 #if MLP_ABLATE
 // per-workgroup phase stamps (100 MHz wall clock) of the forward kernel, read back with cnx_dbg_blk_trace (tools/blk_trace.py)
 #define BLK_TRACE_SLOTS 12
@@ -728,6 +733,382 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     }
   }
   TRACE(4)                                              // stores issued (not necessarily landed)
+}
+
+// =====================================================================================================================
+// The same forward with the two GEMMs of a row tile on TWO wavefronts of one SIMD (round 5).
+//
+// blk_mlp_fwd_kernel puts a row tile's whole chain - GEMM1, GELU, GEMM2 - on one wavefront: at C >= 256 its 32 x C fp32 output tile
+// plus the LN'd operand rows fill the register file, the SIMD hosts ONE wavefront, and a wavefront issues one instruction per four
+// cycles: 9 - 10 instructions per 32-cycle MFMA leave the matrix pipe 60 % busy inside the loop (profiles/r03_fused_mlp_issue.md).
+// Here a workgroup is eight wavefronts = four PAIRS sharing a SIMD:
+//   producer (wavefronts 0-3)  LN prologue; per hidden block s: Hpre^T = W1[s] x LN(u)^T (KS MFMAs, one accumulator), + b1, GELU in
+//                              unpacked VALU instructions, H(s) as bf16 operand pairs -> 2 KiB of LDS (the accumulator layout IS the
+//                              A-operand layout: the consumer lane reads back what the producer lane wrote, 32 bytes each);
+//   consumer (wavefronts 4-7)  O += H(s-1) x W2[s-1]^T (2 CB MFMAs into the 32 x C fp32 tile), epilogue (b2, gamma, residual, store).
+// Neither role needs more than 256 registers, so both live on the SIMD and their instruction streams issue side by side: the
+// producer's ~150 VALU instructions per block run under the consumer's MFMAs instead of between a single wavefront's.  One barrier
+// per hidden block hands H(s) over and recycles the weight rings.  Packed weights: the pipelined order of cnx_mlp_pack_weights
+// (slice t = [W1(t) | W2(t-1)]); LDS: W1 ring 3 x KS KiB (two blocks ahead), W2 ring 2 x 2 CB KiB (one block ahead), 16 KiB of H
+// hand-over buffers (two per pair), b1.  LayerNorm weights use the H buffers before the loop, b2 / gamma after it; the output tile
+// leaves through the dead rings as in blk_mlp_fwd_kernel.  WS as there (1: Hpre workspace, 2: + H workspace and LN(u) rows).
+template <int C>
+struct Geo2 {
+  static constexpr int KS = C / 16, CB = C / 32, NHB = C / 8;
+  static constexpr int PIECES = KS + 2 * CB, SLICE = PIECES * 1024;
+  static constexpr int R1 = KS / 8, R2 = 2 * CB / 8;            // DMA instructions per wavefront and block: W1 / W2 pieces
+  static_assert(KS % 8 == 0 && (2 * CB) % 8 == 0, "pieces deal evenly over eight wavefronts (C a multiple of 128)");
+  static constexpr int W1_RING = 3 * KS * 1024, W2_RING = 2 * 2 * CB * 1024, HBUF = 4 * 2 * 2048;
+  static constexpr int LDS = W1_RING + W2_RING + HBUF + 16 * C;
+  static_assert(LDS <= 160 * 1024 && 2 * C * 4 <= HBUF && 4 * 16 * C * 4 <= W1_RING + W2_RING, "LDS plan");
+};
+
+template <int C, typename TX, typename TO, int WS>
+__global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
+  using G = Geo2<C>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* hbuf = lds + G::W1_RING + G::W2_RING;
+  float* b1s = reinterpret_cast<float*>(hbuf + G::HBUF);
+  float* cst = reinterpret_cast<float*>(hbuf);                        // [2C] floats: ln_w | ln_b before the loop, b2 | gamma after it
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave & 3;
+  const int l32 = lane & 31, half = lane >> 5;
+  const long m0 = static_cast<long>(blockIdx.x) * 128 + pair * 32;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf);
+  const uint32_t lane16 = lane * 16, ring1 = __builtin_amdgcn_readfirstlane(lds_addr(lds)), ring2 = ring1 + G::W1_RING;
+  // W1(t): slice t, pieces [0, KS) -> ring slot t % 3;  W2(t): slice t + 1, pieces [KS, KS + 2 CB) -> ring slot t % 2
+  // (every wavefront moves an eighth of the pieces - wavefront w pieces w, w + 8, ... - one instruction per DMA_EVERY MFMAs: an
+  //  LDS-DMA instruction costs its issuer 60 - 185 cycles (MI355X_MICROARCH.md), twelve of them on one role were that role's block)
+#define DMA_W1_PIECE(T, I)                                                                                 \
+  {                                                                                                        \
+    const int q_ = (I) * 8 + wave;                                                                         \
+    glds16(wsrc + static_cast<long>(T) * G::SLICE + q_ * 1024, lane16, ring1 + ((T) % 3) * (G::KS * 1024) + q_ * 1024); \
+  }
+#define DMA_W2_PIECE(T, I)                                                                                 \
+  {                                                                                                        \
+    const int q_ = (I) * 8 + wave;                                                                         \
+    glds16(wsrc + static_cast<long>((T) + 1) * G::SLICE + (G::KS + q_) * 1024, lane16, ring2 + ((T) % 2) * (2 * G::CB * 1024) + q_ * 1024); \
+  }
+  // block B, DMA instruction K of this wavefront: first its W2(B - 1) pieces (read in block B + 1; the slot W2(B - 3) left), then its
+  // W1(B + 2) pieces (read in block B + 2; the slot W1(B - 1) left)
+  constexpr int R1W = G::KS / 8, R2W = 2 * G::CB / 8, NDMA = R1W + R2W;
+#define BLK_DMA(B, K, ST)                                                                                  \
+  if ((K) < R2W) { if (ST || ((B) >= 1 && (B) - 1 < G::NHB)) DMA_W2_PIECE((B) - 1, (K)) }                  \
+  else { if (ST || (B) + 2 < G::NHB) DMA_W1_PIECE((B) + 2, (K) - R2W) }
+  // ... and the end of a block: everything but this block's W1 pieces (and NST stores issued behind them) is in; barrier
+#define BLK_SYNC(B, ST, NST)                                                                               \
+  if (ST || (B) + 2 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R1W + (NST)) : "memory");           \
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+  __builtin_amdgcn_s_barrier();
+  for (int i = tid; i < C; i += 512) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  for (int i = tid; i < C; i += 512) { cst[i] = p.ln_w ? p.ln_w[i] : 1.0f; cst[C + i] = p.ln_w ? p.ln_b[i] : 0.0f; }
+  const long tile = static_cast<long>(blockIdx.x) * 4 + pair;
+  unsigned char* hb_lane = hbuf + pair * 4096 + lane * 32;
+
+  if (wave < 4) {
+    // ================================================================ producer: LN, GEMM1, GELU, H -> LDS
+    // (its own loop: the register allocation is per kernel, and a loop shared with the consumer would keep the producer's operand
+    //  rows AND the consumer's accumulators live through it - 96 + 192 registers at C = 384)
+    long row = m0 + l32;
+    const bool row_ok = row < p.M;
+    if (!row_ok) row = p.M - 1;
+    bf16x8 af[G::KS];
+    {
+      uint4 raw[G::KS];
+      const uint4* up = reinterpret_cast<const uint4*>(p.u + row * C + half * (C / 2));
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) raw[ks] = up[ks];
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+#pragma unroll
+      for (int i = 0; i < R1W; ++i) DMA_W1_PIECE(0, i)
+#pragma unroll
+      for (int i = 0; i < R1W; ++i) DMA_W1_PIECE(1, i)
+      __syncthreads();                                                // constants visible
+      if (p.ln_w) {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+          const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s += bf16_lo(w[j]) + bf16_hi(w[j]);
+        }
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / C);
+        // (the three passes each unpack the row again: kept across the passes the 8 KS fp32 values would sit next to the KS packed
+        //  quads and the operand fragments - more than the 256 registers of a wavefront that shares its SIMD)
+#define RAW_OPAQUE _Pragma("unroll") for (int ks_ = 0; ks_ < G::KS; ++ks_) asm volatile("" : "+v"(raw[ks_].x), "+v"(raw[ks_].y), "+v"(raw[ks_].z), "+v"(raw[ks_].w));
+        RAW_OPAQUE
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+          const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = bf16_lo(w[j]) - mean, b = bf16_hi(w[j]) - mean;
+            ss = fmaf(a, a, ss);
+            ss = fmaf(b, b, ss);
+          }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = rsqrtf(ss * (1.0f / C) + p.eps);
+        if (p.mean && half == 0 && row_ok) { p.mean[row] = mean; p.rstd[row] = rstd; }
+        RAW_OPAQUE
+#undef RAW_OPAQUE
+        const float4* lw = reinterpret_cast<const float4*>(cst + half * (C / 2));
+        const float4* lb = reinterpret_cast<const float4*>(cst + C + half * (C / 2));
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+          const uint32_t w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+          const float4 w0 = lw[2 * ks], w1 = lw[2 * ks + 1], c0 = lb[2 * ks], c1 = lb[2 * ks + 1];
+          const float g[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          const float o[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          uint32_t pk[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = fmaf((bf16_lo(w[j]) - mean) * rstd, g[2 * j], o[2 * j]);
+            const float b = fmaf((bf16_hi(w[j]) - mean) * rstd, g[2 * j + 1], o[2 * j + 1]);
+            pk[j] = pack_bf16(a, b);
+          }
+          af[ks] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+          if constexpr (WS == 2) {
+            if (row_ok) reinterpret_cast<uint4*>(p.a_out + row * C + half * (C / 2))[ks] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // W1(0), W1(1): this wavefront's pieces (and its LN(u) row stores)
+    __syncthreads();                                                  // ... everybody's; LN constants consumed
+    float c5v = -0.00041175442346105595f;
+    asm volatile("" : "+v"(c5v));
+    // Block b:  MFMA stream  Hpre(b) = W1[b] x LN(u)^T + b1 (KS MFMAs, b < NHB)
+    //           VALU stream  GELU of Hpre(b - 1) in unpacked instructions between those MFMAs (b >= 1); H(b - 1) -> hand-over buffer
+    // ST: compile-time promise 1 <= b < NHB (straight-line code, no branch inside the block)
+    constexpr int PF = 4, NUOP = 4 * 38;
+#define P_BLOCK(B, ZCUR, ZPREV, ST)                                                                        \
+    {                                                                                                      \
+      uint32_t pk[8];                                                                                      \
+      float gq[4], ghz[4];                                                                                 \
+      if (ST || (B) >= 1) {                                                                                \
+        if constexpr (WS >= 1) {                                                                           \
+          uint4* dst = reinterpret_cast<uint4*>(p.hpre) + (tile * G::NHB + ((B) - 1)) * 128 + l32 * 4 + half * 2; \
+          dst[0] = make_uint4(cvt_pk_bf16(ZPREV[0], ZPREV[1]), cvt_pk_bf16(ZPREV[2], ZPREV[3]), cvt_pk_bf16(ZPREV[4], ZPREV[5]), cvt_pk_bf16(ZPREV[6], ZPREV[7])); \
+          dst[1] = make_uint4(cvt_pk_bf16(ZPREV[8], ZPREV[9]), cvt_pk_bf16(ZPREV[10], ZPREV[11]), cvt_pk_bf16(ZPREV[12], ZPREV[13]), cvt_pk_bf16(ZPREV[14], ZPREV[15])); \
+        }                                                                                                  \
+      }                                                                                                    \
+      if (ST || (B) < G::NHB) {                                                                            \
+        const unsigned char* sl = lds + ((B) % 3) * (G::KS * 1024) + lane * 16;                            \
+        bf16x8 fr[PF];                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024); \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+          const float4 b4 = *reinterpret_cast<const float4*>(b1s + (B) * 32 + 8 * g + 4 * half);           \
+          ZCUR[4 * g + 0] = b4.x; ZCUR[4 * g + 1] = b4.y; ZCUR[4 * g + 2] = b4.z; ZCUR[4 * g + 3] = b4.w;  \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        _Pragma("unroll") for (int i = 0; i < G::KS; ++i) {                                                \
+          if constexpr ((BLK2_ABL & 2) == 0)                                                               \
+            ZCUR = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], ZCUR, 0, 0, 0);              \
+          else if (i == 0) ZCUR = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], af[i], ZCUR, 0, 0, 0); \
+          if (i + PF < G::KS) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);         \
+          if (i % P_DMA_EVERY == 0 && i / P_DMA_EVERY < NDMA) { BLK_DMA(B, i / P_DMA_EVERY, ST) }          \
+          __builtin_amdgcn_sched_barrier(0);                                                               \
+          if ((ST || (B) >= 1) && (BLK2_ABL & 1) == 0) {                                                   \
+            _Pragma("unroll") for (int uo = NUOP * i / G::KS; uo < NUOP * (i + 1) / G::KS; ++uo) {         \
+              const int qd = uo / 38;                                                                      \
+              gelu_uop(uo % 38, ZPREV[4 * qd], ZPREV[4 * qd + 1], ZPREV[4 * qd + 2], ZPREV[4 * qd + 3], gq, ghz, pk[2 * qd], pk[2 * qd + 1], c5v); \
+            }                                                                                              \
+          }                                                                                                \
+          __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                  \
+        /* the chain's result is read by inline-asm VALU instructions in the next block (cvt_pk_bf16, gelu_uop), whose operands the \
+           compiler's hazard recognizer does not take for VALU reads of a matrix result: the wait states by hand */ \
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(ZCUR));                                                  \
+      } else {                                                                                             \
+        _Pragma("unroll") for (int k_ = 0; k_ < NDMA; ++k_) { BLK_DMA(B, k_, false) }                      \
+      }                                                                                                    \
+      if (!(ST || (B) < G::NHB) && (B) >= 1 && (BLK2_ABL & 1) == 0) {                                      \
+        _Pragma("unroll") for (int qd = 0; qd < 4; ++qd) {                                                 \
+          _Pragma("unroll") for (int uo = 0; uo < 38; ++uo)                                                \
+            gelu_uop(uo, ZPREV[4 * qd], ZPREV[4 * qd + 1], ZPREV[4 * qd + 2], ZPREV[4 * qd + 3], gq, ghz, pk[2 * qd], pk[2 * qd + 1], c5v); \
+        }                                                                                                  \
+      }                                                                                                    \
+      if (ST || (B) >= 1) {                                                                                \
+        if constexpr ((BLK2_ABL & 1) != 0) { _Pragma("unroll") for (int e = 0; e < 8; ++e) pk[e] = cvt_pk_bf16(ZPREV[2 * e], ZPREV[2 * e + 1]); } \
+        uint4* hw = reinterpret_cast<uint4*>(hb_lane + (((B) - 1) & 1) * 2048);                            \
+        hw[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);                                                    \
+        hw[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);                                                    \
+        if constexpr (WS == 2) {                                                                           \
+          uint4* hdst = reinterpret_cast<uint4*>(p.hact) + (tile * G::NHB + ((B) - 1)) * 128 + l32 * 4 + half * 2; \
+          hdst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);                                                \
+          hdst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);                                                \
+        }                                                                                                  \
+      }                                                                                                    \
+      BLK_SYNC(B, ST, (WS == 2 ? 2 : 0))                                                                   \
+    }
+    static_assert(G::NHB % 2 == 0 && G::NHB >= 6, "two-block unroll, steady blocks 1 .. NHB - 3");
+    constexpr int P_DMA_EVERY = G::KS / NDMA;
+    static_assert(P_DMA_EVERY >= 1 && P_DMA_EVERY * NDMA <= G::KS, "one DMA instruction per P_DMA_EVERY MFMAs");
+    f32x16 za, zb;
+    P_BLOCK(0, za, zb, false)
+    for (int b = 1; b + 1 < G::NHB - 2; b += 2) {                     // blocks 1 .. NHB - 4 (pairs), all conditions true
+      P_BLOCK(b, zb, za, true)
+      P_BLOCK(b + 1, za, zb, true)
+    }
+    P_BLOCK(G::NHB - 3, zb, za, true)
+    P_BLOCK(G::NHB - 2, za, zb, false)
+    P_BLOCK(G::NHB - 1, zb, za, false)
+    P_BLOCK(G::NHB, za, zb, false)
+    __builtin_amdgcn_s_barrier();                                     // block NHB + 1: the consumers' last GEMM2
+#undef P_BLOCK
+    for (int i = tid; i < C; i += 256) { cst[i] = p.b2[i]; cst[C + i] = p.gamma ? p.gamma[i] : 1.0f; }   // for the consumers' epilogue
+    __syncthreads();
+    return;
+  }
+
+  // ================================================================== consumer: weight DMA, GEMM2, epilogue
+  f32x16 acc2[G::CB];
+#pragma unroll
+  for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[cb][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < R1W; ++i) DMA_W1_PIECE(0, i)
+#pragma unroll
+  for (int i = 0; i < R1W; ++i) DMA_W1_PIECE(1, i)
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // Block b:  O += H(b - 2) x W2[b - 2]^T (2 CB MFMAs, b >= 2); between them this wavefront's share of the weight DMA
+  constexpr int PFC = 4, DMA_EVERY = 2 * G::CB / NDMA;
+  static_assert(DMA_EVERY >= 1 && DMA_EVERY * NDMA <= 2 * G::CB, "one DMA instruction per DMA_EVERY MFMAs");
+#define C_BLOCK(B, ST)                                                                                     \
+  {                                                                                                        \
+    if (ST || ((B) >= 2 && (B) - 2 < G::NHB)) {                                                            \
+      const uint4* hr = reinterpret_cast<const uint4*>(hb_lane + (((B) - 2) & 1) * 2048);                  \
+      const bf16x8 hf0 = __builtin_bit_cast(bf16x8, hr[0]), hf1 = __builtin_bit_cast(bf16x8, hr[1]);       \
+      const unsigned char* sl = lds + G::W1_RING + (((B) - 2) % 2) * (2 * G::CB * 1024) + lane * 16;       \
+      bf16x8 fr[PFC];                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < PFC; ++j) fr[j] = *reinterpret_cast<const bf16x8*>(sl + j * 1024); \
+      _Pragma("unroll") for (int j = 0; j < 2 * G::CB; ++j) {                                              \
+        if ((BLK2_ABL & 4) == 0 || j == 0)                                                                 \
+          acc2[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(j < G::CB ? hf0 : hf1, fr[j % PFC], acc2[j % G::CB], 0, 0, 0); \
+        if (j + PFC < 2 * G::CB) fr[j % PFC] = *reinterpret_cast<const bf16x8*>(sl + (j + PFC) * 1024);    \
+        if (j % DMA_EVERY == 0 && j / DMA_EVERY < NDMA) { BLK_DMA(B, j / DMA_EVERY, ST) }                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+      }                                                                                                    \
+    } else {                                                                                               \
+      _Pragma("unroll") for (int k = 0; k < NDMA; ++k) { BLK_DMA(B, k, false) }                            \
+    }                                                                                                      \
+    BLK_SYNC(B, ST, 0)                                                                                     \
+  }
+  C_BLOCK(0, false)
+  C_BLOCK(1, false)
+  for (int b = 2; b + 2 < G::NHB; ++b) C_BLOCK(b, true)
+  C_BLOCK(G::NHB - 2, false)
+  C_BLOCK(G::NHB - 1, false)
+  C_BLOCK(G::NHB, false)
+  C_BLOCK(G::NHB + 1, false)
+#undef C_BLOCK
+#undef BLK_DMA
+#undef BLK_SYNC
+#undef DMA_W1_PIECE
+#undef DMA_W2_PIECE
+  // ---- epilogue: b2 / gamma through the H buffers (written by the producers), the tile through the dead rings, as blk_mlp_fwd_kernel
+  __syncthreads();
+  float* scr = reinterpret_cast<float*>(lds) + pair * (16 * C);
+  const float4* b2v = reinterpret_cast<const float4*>(cst);
+  const float4* gav = reinterpret_cast<const float4*>(cst + C);
+  const TX* resid = static_cast<const TX*>(p.resid);
+  TO* out = static_cast<TO*>(p.out);
+  constexpr int C4 = C / 4, NCH = 16 * C4 / 64;
+  constexpr int GRP = (NCH % 6 == 0 && C < 384) ? 6 : (NCH % 4 == 0 ? 4 : 3);       // residual chunks in flight per lane (256 registers)
+  static_assert(NCH % GRP == 0, "chunk groups");
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const long e0 = (m0 + 16 * pass) * C;
+    const long e_end = p.M * C;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc2[cb][8 * pass + r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g0 = 0; g0 < NCH; g0 += GRP) {
+      float4 xv[GRP];
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        const int idx = (g0 + j) * 64 + lane;
+        const long e = e0 + idx * 4;
+        xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (resid && e < e_end) {
+          if constexpr (sizeof(TX) == 4) {
+            xv[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resid) + e);
+          } else {
+            const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(resid) + e);
+            xv[j] = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        const int idx = (g0 + j) * 64 + lane;
+        const long e = e0 + idx * 4;
+        const int c4 = idx % C4;
+        const float4 o = reinterpret_cast<const float4*>(scr)[idx];
+        const float4 bb = b2v[c4], gg = gav[c4];
+        const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
+        if (e < e_end) {
+          if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
+          const float o0 = fmaf(y0, gg.x, xv[j].x), o1 = fmaf(y1, gg.y, xv[j].y);
+          const float o2 = fmaf(y2v, gg.z, xv[j].z), o3 = fmaf(y3, gg.w, xv[j].w);
+          if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + e) = make_float4(o0, o1, o2, o3);
+          else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + e) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+        }
+      }
+    }
+  }
+}
+
+// Which forward kernel serves width C?  Measured (tools/mlp_bench.py, batch 256, profiles/r05_fused_mlp.md): the wavefront-pair kernel is
+// ahead of the single-wavefront one at C = 384 without a workspace (170 vs 183 - 191 us) and at C = 256 with and without (100 / 106 vs
+// 106 / 111 us); with the Hpre workspace at C = 384 the producer's two extra 1 KiB stores per block sit on its critical path (213 vs
+// 199 us) and the single-wavefront kernel stays.  APGD_BLK2 overrides: a list of widths, "384w" = also the workspace forms at 384.
+inline bool use_blk2(int C, bool ws) {
+  static const char* env = getenv("APGD_BLK2");
+  static const bool w256 = env ? strstr(env, "256") != nullptr : true, w384 = env ? strstr(env, "384") != nullptr : true,
+                    w384w = env ? strstr(env, "384w") != nullptr : false;
+  return (C == 256 && w256) || (C == 384 && (ws ? w384w : w384));
+}
+
+template <int C>
+int launch_blk2_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
+  using G = Geo2<C>;
+  const dim3 grid(static_cast<unsigned>((a.M + 127) / 128)), block(512);
+#define BLK2_LAUNCH_WS(TX, TO, WSV)                                                                              \
+  {                                                                                                              \
+    auto kfn = blk2_fwd_kernel<C, TX, TO, WSV>;                                                                  \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, G::LDS, s, a);                                                          \
+  }
+#define BLK2_LAUNCH(TX, TO) { if (a.hpre) { if (a.hact) BLK2_LAUNCH_WS(TX, TO, 2) else BLK2_LAUNCH_WS(TX, TO, 1) } else BLK2_LAUNCH_WS(TX, TO, 0) }
+  if (resid_dtype == APGD_F32 && out_dtype == APGD_F32) BLK2_LAUNCH(float, float)
+  else if (resid_dtype == APGD_F32) BLK2_LAUNCH(float, uint16_t)
+  else if (out_dtype == APGD_F32) BLK2_LAUNCH(uint16_t, float)
+  else BLK2_LAUNCH(uint16_t, uint16_t)
+#undef BLK2_LAUNCH
+#undef BLK2_LAUNCH_WS
+  return launch_status();
 }
 
 template <int C>
@@ -1486,8 +1867,8 @@ static int block_mlp_fwd_impl(const void* u, const float* ln_w, const float* ln_
     case 96: return launch_blk_fwd<96>(a, resid_dtype, out_dtype, s);
     case 128: return launch_blk_fwd<128>(a, resid_dtype, out_dtype, s);
     case 192: return launch_blk_fwd<192>(a, resid_dtype, out_dtype, s);
-    case 256: return launch_blk_fwd<256>(a, resid_dtype, out_dtype, s);
-    case 384: return launch_blk_fwd<384>(a, resid_dtype, out_dtype, s);
+    case 256: return use_blk2(256, a.hpre != nullptr) ? launch_blk2_fwd<256>(a, resid_dtype, out_dtype, s) : launch_blk_fwd<256>(a, resid_dtype, out_dtype, s);
+    case 384: return use_blk2(384, a.hpre != nullptr) ? launch_blk2_fwd<384>(a, resid_dtype, out_dtype, s) : launch_blk_fwd<384>(a, resid_dtype, out_dtype, s);
     default: return APGD_ERR_ARG;
   }
 }

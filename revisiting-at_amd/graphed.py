@@ -150,12 +150,15 @@ class _Recorder:
 
 
 class _Program:
-    def __init__(self, model, x, y, norm, eps, n_iter, kind, soft, splits):
+    def __init__(self, model, x, y, norm, eps, n_iter, kind, soft, splits, y_target=None, x_init=None):
         self.model_ref = weakref.ref(model)
         self.x = torch.empty_like(x)
         self.y = torch.empty_like(y)
         self.x.copy_(x)
         self.y.copy_(y)
+        # evaluation attacks (aa_eval): target classes and the random start are inputs of the replay like x and y
+        self.yt = None if y_target is None else y_target.clone()
+        self.xi = None if x_init is None else torch.empty_like(x).copy_(x_init)
         self.derived = {}                                    # capture-local ops._cached entries (kept alive with the graphs)
         rec = _Recorder()
         if rec.mode != "global":
@@ -169,7 +172,7 @@ class _Program:
                 rec.begin()
                 try:
                     self.out = apgd._apgd_core(model, self.x, self.y, norm, eps, n_iter, kind, soft=soft, rec=rec, splits=splits,
-                                               attack_gemm=_attack_gemm(model))
+                                               attack_gemm=_attack_gemm(model), y_target=self.yt, x_init=self.xi)
                 except BaseException:
                     rec.abort()
                     raise
@@ -180,9 +183,13 @@ class _Program:
         self.steps = rec.steps
         self.n_graphs = sum(isinstance(s, torch.cuda.CUDAGraph) for s in self.steps)
 
-    def __call__(self, x, y):
+    def __call__(self, x, y, y_target=None, x_init=None):
         self.x.copy_(x)
         self.y.copy_(y)
+        if self.yt is not None:
+            self.yt.copy_(y_target)
+        if self.xi is not None:
+            self.xi.copy_(x_init)
         for s in self.steps:
             if isinstance(s, torch.cuda.CUDAGraph):
                 s.replay()
@@ -214,10 +221,10 @@ class borrow_outputs:
         return False
 
 
-def _signature(model, x, y, norm, eps, n_iter, kind, soft):
+def _signature(model, x, y, norm, eps, n_iter, kind, soft, y_target=None, x_init=None):
     ac = (torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
     return (id(model), tuple(x.shape), tuple(x.stride()), x.dtype, x.device.index, tuple(y.shape), y.dtype, norm, float(eps),
-            int(n_iter), int(kind), bool(soft), ac, ops.MODE, apgd.USE_SIGN_SINK, _streams(model))
+            int(n_iter), int(kind), bool(soft), ac, ops.MODE, apgd.USE_SIGN_SINK, _streams(model), y_target is not None, x_init is not None)
 
 
 def _attack_gemm(model):
@@ -231,15 +238,17 @@ def reset():
     _programs.clear()
 
 
-def run(model, x, y, norm, eps, n_iter, kind, soft):
-    """``_apgd_core`` with graph replay: eager for the first ``WARMUP_CALLS`` calls of a signature, captured on the next."""
+def run(model, x, y, norm, eps, n_iter, kind, soft, y_target=None, x_init=None):
+    """``_apgd_core`` with graph replay: eager for the first ``WARMUP_CALLS`` calls of a signature, captured on the next.
+    ``y_target`` / ``x_init`` (the evaluation attacks of ``aa_eval``: target classes, random start) are replay inputs like x and y."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and isinstance(y, torch.Tensor) and y.is_cuda):
-        return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft)     # raises the usual errors
+        return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, y_target=y_target, x_init=x_init)     # raises the usual errors
     x = x.detach()
     if not apgd._dense_rows(x):
         x = x.contiguous()
     y = y.detach()
-    key = _signature(model, x, y, norm, eps, n_iter, kind, soft)
+    ext = dict(y_target=y_target, x_init=x_init)
+    key = _signature(model, x, y, norm, eps, n_iter, kind, soft, y_target, x_init)
     ent = _programs.pop(key, None)
     if ent is None:
         ent = {"calls": 0, "prog": None, "failed": False, "one_stream": False}
@@ -258,7 +267,7 @@ def run(model, x, y, norm, eps, n_iter, kind, soft):
             if splits > 1 and ent["calls"] == 1:
                 # first warm-up call of a two-stream signature: one stream, library GEMMs counted
                 with _LibGemmWatch() as watch:
-                    out = apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=1, attack_gemm=ag)
+                    out = apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=1, attack_gemm=ag, **ext)
                 if watch.count:
                     ent["one_stream"] = True
                     STATS["lib_gemm_one_stream"] += 1
@@ -266,9 +275,9 @@ def run(model, x, y, norm, eps, n_iter, kind, soft):
                                   "one stream (overlapping chunks must not contain library GEMMs)")
                 return out
             # (same batch chunks as the capture will use: every kernel / library shape is initialised before it)
-            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=splits, attack_gemm=ag)
+            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, splits=splits, attack_gemm=ag, **ext)
         try:
-            prog = ent["prog"] = _Program(model, x, y, norm, eps, n_iter, kind, soft, splits)
+            prog = ent["prog"] = _Program(model, x, y, norm, eps, n_iter, kind, soft, splits, y_target, x_init)
             STATS["captures"] += 1
             _evict()
         except Exception as e:                               # noqa: BLE001 - any capture failure means "run eagerly"
@@ -276,6 +285,6 @@ def run(model, x, y, norm, eps, n_iter, kind, soft):
             STATS["failed"] += 1
             warnings.warn(f"APGD graph capture failed ({type(e).__name__}: {e}); this signature runs eagerly")
             torch.cuda.synchronize()
-            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, attack_gemm=ag)
+            return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, attack_gemm=ag, **ext)
     STATS["replays"] += 1
-    return prog(x, y)
+    return prog(x, y, y_target, x_init)

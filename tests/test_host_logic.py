@@ -135,3 +135,12 @@ def test_vit_block_operators_fall_back_to_the_plain_composition_off_the_device()
     out = blk(x)
     (gx,) = torch.autograd.grad(out.sum(), x)
     assert out.shape == x.shape and torch.isfinite(gx).all()
+
+
+def test_evaluation_batch_buckets():
+    """aa_eval._bucket: a handful of padded sizes per evaluation batch size (bs, then halves, not below 8), never below the subset."""
+    from revisiting_at_amd import aa_eval
+    for bs in (100, 200, 32, 7):
+        sizes = {aa_eval._bucket(k, bs) for k in range(1, bs + 1)}
+        assert len(sizes) <= 6 and max(sizes) == bs and all(aa_eval._bucket(k, bs) >= k for k in range(1, bs + 1))
+    assert aa_eval._bucket(150, 100) == 150                            # (a subset larger than bs cannot happen; it is not truncated)
