@@ -251,6 +251,18 @@ def other_configs(R, dev, graph=1, which=("cfg3", "cfg4", "cfg5")):
         # the first time it meets a convolution shape - ~10 s for this model's fp32 problems, which a warm-up at
         # another batch size leaves inside the timed run (round 2's first cfg5 figure, 2.4 img/s, was mostly that)
         R.aa_eval.apgd_attack(model, x, y, "Linf", 4 / 255, 2, "ce", None, True, g)
+        # ... and at the padded sizes the still-robust subsets are run at (run_standard_evaluation(buckets=True)): in an evaluation of
+        # 50 batches every bucket is met in the first batches; here each is met once, untimed, with both losses
+        yt = (y + 1) % 1000
+        nb = bs
+        while True:
+            nb2 = R.aa_eval._bucket(max(1, (nb + 1) // 2), bs)
+            if nb2 >= nb:
+                break
+            nb = nb2
+            R.aa_eval.apgd_attack(model, x[:nb].contiguous(), y[:nb], "Linf", 4 / 255, 2, "ce", None, True, g)
+            R.aa_eval.apgd_attack(model, x[:nb].contiguous(), y[:nb], "Linf", 4 / 255, 2, "dlr-targeted", yt[:nb], True, g)
+        R.aa_eval.apgd_attack(model, x, y, "Linf", 4 / 255, 2, "dlr-targeted", yt, True, g)
         torch.cuda.synchronize()
         note("cfg5 warm-up done")
         t0 = time.perf_counter()
