@@ -758,7 +758,7 @@ struct Geo2 {
   static constexpr int PIECES = KS + 2 * CB, SLICE = PIECES * 1024;
   static constexpr int R1 = KS / 8, R2 = 2 * CB / 8;            // DMA instructions per wavefront and block: W1 / W2 pieces
   static_assert(KS % 8 == 0 && (2 * CB) % 8 == 0, "pieces deal evenly over eight wavefronts (C a multiple of 128)");
-  static constexpr int W1_RING = 3 * KS * 1024, W2_RING = 2 * 2 * CB * 1024, HBUF = 4 * 2 * 2048;
+  static constexpr int W1_RING = 3 * KS * 1024, W2_RING = 2 * 2 * CB * 1024, HBUF = 4 * 2 * 4096;   // per pair, two buffers of [H | Hpre] tiles
   static constexpr int LDS = W1_RING + W2_RING + HBUF + 16 * C;
   static_assert(LDS <= 160 * 1024 && 2 * C * 4 <= HBUF && 4 * 16 * C * 4 <= W1_RING + W2_RING, "LDS plan");
 };
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
   for (int i = tid; i < C; i += 512) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
   for (int i = tid; i < C; i += 512) { cst[i] = p.ln_w ? p.ln_w[i] : 1.0f; cst[C + i] = p.ln_w ? p.ln_b[i] : 0.0f; }
   const long tile = static_cast<long>(blockIdx.x) * 4 + pair;
-  unsigned char* hb_lane = hbuf + pair * 4096 + lane * 32;
+  unsigned char* hb_lane = hbuf + pair * 8192 + lane * 32;           // buffer i at + 4096 i: H tile, then (+ 2048) the Hpre tile
 
   if (wave < 4) {
     // ================================================================ producer: LN, GEMM1, GELU, H -> LDS
@@ -894,8 +894,8 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
       uint32_t pk[8];                                                                                      \
       float gq[4], ghz[4];                                                                                 \
       if (ST || (B) >= 1) {                                                                                \
-        if constexpr (WS >= 1) {                                                                           \
-          uint4* dst = reinterpret_cast<uint4*>(p.hpre) + (tile * G::NHB + ((B) - 1)) * 128 + l32 * 4 + half * 2; \
+        if constexpr (WS >= 1) {   /* Hpre(B - 1) for the workspace: handed to the consumer next to H (it makes the global stores) */ \
+          uint4* dst = reinterpret_cast<uint4*>(hb_lane + (((B) - 1) & 1) * 4096 + 2048);                  \
           dst[0] = make_uint4(cvt_pk_bf16(ZPREV[0], ZPREV[1]), cvt_pk_bf16(ZPREV[2], ZPREV[3]), cvt_pk_bf16(ZPREV[4], ZPREV[5]), cvt_pk_bf16(ZPREV[6], ZPREV[7])); \
           dst[1] = make_uint4(cvt_pk_bf16(ZPREV[8], ZPREV[9]), cvt_pk_bf16(ZPREV[10], ZPREV[11]), cvt_pk_bf16(ZPREV[12], ZPREV[13]), cvt_pk_bf16(ZPREV[14], ZPREV[15])); \
         }                                                                                                  \
@@ -938,16 +938,11 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
       }                                                                                                    \
       if (ST || (B) >= 1) {                                                                                \
         if constexpr ((BLK2_ABL & 1) != 0) { _Pragma("unroll") for (int e = 0; e < 8; ++e) pk[e] = cvt_pk_bf16(ZPREV[2 * e], ZPREV[2 * e + 1]); } \
-        uint4* hw = reinterpret_cast<uint4*>(hb_lane + (((B) - 1) & 1) * 2048);                            \
+        uint4* hw = reinterpret_cast<uint4*>(hb_lane + (((B) - 1) & 1) * 4096);                            \
         hw[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);                                                    \
         hw[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);                                                    \
-        if constexpr (WS == 2) {                                                                           \
-          uint4* hdst = reinterpret_cast<uint4*>(p.hact) + (tile * G::NHB + ((B) - 1)) * 128 + l32 * 4 + half * 2; \
-          hdst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);                                                \
-          hdst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);                                                \
-        }                                                                                                  \
       }                                                                                                    \
-      BLK_SYNC(B, ST, (WS == 2 ? 2 : 0))                                                                   \
+      BLK_SYNC(B, ST, 0)                                                                                   \
     }
     static_assert(G::NHB % 2 == 0 && G::NHB >= 6, "two-block unroll, steady blocks 1 .. NHB - 3");
     constexpr int P_DMA_EVERY = G::KS / NDMA;
@@ -988,8 +983,19 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
 #define C_BLOCK(B, ST)                                                                                     \
   {                                                                                                        \
     if (ST || ((B) >= 2 && (B) - 2 < G::NHB)) {                                                            \
-      const uint4* hr = reinterpret_cast<const uint4*>(hb_lane + (((B) - 2) & 1) * 2048);                  \
-      const bf16x8 hf0 = __builtin_bit_cast(bf16x8, hr[0]), hf1 = __builtin_bit_cast(bf16x8, hr[1]);       \
+      const uint4* hr = reinterpret_cast<const uint4*>(hb_lane + (((B) - 2) & 1) * 4096);                  \
+      const uint4 hq0 = hr[0], hq1 = hr[1];                                                                \
+      const bf16x8 hf0 = __builtin_bit_cast(bf16x8, hq0), hf1 = __builtin_bit_cast(bf16x8, hq1);           \
+      if constexpr (WS >= 1) {   /* the workspace stores of block B - 2, in front of this block's DMA: the producer's stream stays \
+                                    free of global stores (an in-order wavefront pays ~100+ cycles of issue per KiB stored) */ \
+        const long tq = (tile * G::NHB + ((B) - 2)) * 128 + l32 * 4 + half * 2;                            \
+        uint4* dst = reinterpret_cast<uint4*>(p.hpre) + tq;                                                \
+        dst[0] = hr[128]; dst[1] = hr[129];                                                                \
+        if constexpr (WS == 2) {                                                                           \
+          uint4* hdst = reinterpret_cast<uint4*>(p.hact) + tq;                                             \
+          hdst[0] = hq0; hdst[1] = hq1;                                                                    \
+        }                                                                                                  \
+      }                                                                                                    \
       const unsigned char* sl = lds + G::W1_RING + (((B) - 2) % 2) * (2 * G::CB * 1024) + lane * 16;       \
       bf16x8 fr[PFC];                                                                                      \
       _Pragma("unroll") for (int j = 0; j < PFC; ++j) fr[j] = *reinterpret_cast<const bf16x8*>(sl + j * 1024); \
@@ -1077,14 +1083,13 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
 }
 
 // Which forward kernel serves width C?  Measured (tools/mlp_bench.py, batch 256, profiles/r05_fused_mlp.md): the wavefront-pair kernel is
-// ahead of the single-wavefront one at C = 384 without a workspace (170 vs 183 - 191 us) and at C = 256 with and without (100 / 106 vs
-// 106 / 111 us); with the Hpre workspace at C = 384 the producer's two extra 1 KiB stores per block sit on its critical path (213 vs
-// 199 us) and the single-wavefront kernel stays.  APGD_BLK2 overrides: a list of widths, "384w" = also the workspace forms at 384.
+// ahead of the single-wavefront one at C = 384 and C = 256 in all three forms (no workspace / Hpre / training outputs).  APGD_BLK2
+// overrides: a list of widths ("" = the single-wavefront kernel everywhere).
 inline bool use_blk2(int C, bool ws) {
   static const char* env = getenv("APGD_BLK2");
-  static const bool w256 = env ? strstr(env, "256") != nullptr : true, w384 = env ? strstr(env, "384") != nullptr : true,
-                    w384w = env ? strstr(env, "384w") != nullptr : false;
-  return (C == 256 && w256) || (C == 384 && (ws ? w384w : w384));
+  static const bool w256 = env ? strstr(env, "256") != nullptr : true, w384 = env ? strstr(env, "384") != nullptr : true;
+  (void)ws;
+  return (C == 256 && w256) || (C == 384 && w384);
 }
 
 template <int C>
