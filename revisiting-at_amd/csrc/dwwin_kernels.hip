@@ -23,6 +23,7 @@
 // residual gradient added: 10 B per element.  HBM-bound: 56 x 56 x 96, batch 256: 462 / 771 MB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "apgd_hip.h"
@@ -42,6 +43,14 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
+
+// compile-time ablations of the forward / input-gradient kernel (measurement builds only: `make EXTRA=-DDW_ABL=n`, profiles/r05_dw.md):
+// 1 = no dot products of filter rows 0..5, 2 = no row / add-row DMA in the steps, 4 = no output staging and no stores,
+// 8 = every store puts 1 KiB into a contiguous per-wavefront stream, 16 = every row load fetches 1 KiB of a contiguous per-wavefront stream,
+// 32 = the row loads go to registers (buffer_load_dwordx4, nobody reads them) instead of LDS        (8 - 32: wrong results, timing only)
+#ifndef DW_ABL
+#define DW_ABL 0
+#endif
 
 constexpr int kT = 7;                 // output columns of a strip
 constexpr int kCols = kT + 6;         // input columns a strip reads (13)
@@ -119,6 +128,13 @@ __device__ __forceinline__ void dma_lds16(uint32_t lds_dst, uint32_t voff, rsrc4
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
+// the same under a wave-uniform lane mask: only the lanes of `mask` fetch (and land at lds_dst + 16 l); one VMEM instruction whatever the mask
+__device__ __forceinline__ void dma_lds16_masked(uint32_t lds_dst, uint32_t voff, rsrc4_t rs, uint32_t soff, uint64_t mask) {
+  uint64_t sv;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %5\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b64 exec, %0"
+               : "=&s"(sv) : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff), "s"(mask) : "memory");
+}
+
 __device__ __forceinline__ rsrc4_t make_rsrc4(const void* p, uint32_t bytes) {
   const uint64_t a = reinterpret_cast<uint64_t>(p);
   rsrc4_t r;
@@ -142,23 +158,49 @@ __device__ __forceinline__ void pack_row_lds(uint32_t (&d)[kPairs], const uint32
   }
 }
 
-template <typename TI, typename TO, int CH, bool ADD>
+// SH (round 5, CH = 32 only): the two strips of a wavefront are NEIGHBOURS - columns 14 g - 3 .. 14 g + 16 of strip pair g - and
+// share their column halo: a slot is [20 columns][32 channels] (2.5 KiB fp32 / 1.25 KiB bf16) instead of [13 (16) columns][2 units x
+// 32 channels] (4 / 2 KiB), the add row and the output row are 14 contiguous columns x 32 channels (1.75 KiB instead of 2).  Unit u
+// of the wavefront reads slot columns 7 u .. 7 u + 12: at 128 (64) bytes per column the two units are 896 (448) bytes apart = 32 (48)
+// banks, so the 64 lanes of a ds_read still cover disjoint banks.  Why it pays: per output row a CU's 12 wavefronts took in
+// 12 x (4 + 0.875) KiB = 21 bytes per cycle at the VALU's pace (2880 cycles per row step) - the L2 -> LDS path of a CU delivers
+// 12 - 15, so the kernel ran at the ingest rate, not the VALU's (58 % busy); the shared halo asks for 14.5.
+//
+// K / AD (round 5): depth of the prefetch, a template parameter.  The row of step s + K is issued in step s (K ring slots per wavefront),
+// the add row of step s + AD at the top of step s (AD + 1 slots); LDS-DMA has no destination registers, so depth is paid in LDS only and
+// the slots are trimmed to the bytes that land.  Built because the ablations (profiles/r05_dw.md) show the kernel at the pace of its memory
+// pipeline (fp32 forward, 56 x 56 x 96: 130 us; 128 with 86 % of the dot products removed; 94 with loads AND stores removed, 100 / 102 with
+// either) - and measured flat: K = 2 .. 4, AD = 0 .. 3 all within the run-to-run spread.  What did move it is the ORDER of the items (below).
+template <typename TI, typename TO, int CH, bool ADD, bool SH, int K, int AD>
 __global__ __launch_bounds__(256, 3)
 void dwconv7x7_dma_kernel(const WinArgs a) {
-  constexpr int UPW = 64 / CH, K = 2, NS = 7;
-  // a row slot: 16 columns (13 used) x 64 lanes x sizeof(TI), written by NR wide loads of CPI columns each
-  constexpr int COLB = 64 * sizeof(TI);                                    // bytes of one column in a slot
-  constexpr int CPI = 1024 / COLB;                                         // columns per 1 KiB instruction: 4 (fp32) / 8 (bf16)
-  constexpr int NR = 16 / CPI;                                             // row loads per step: 4 (fp32) / 2 (bf16)
-  constexpr int NA = 2;                                                    // add-row loads per step (8 columns x 256 bytes, 7 used)
-  constexpr uint32_t SLOT = 16u * COLB;
-  static_assert((sizeof(TI) == 4 && NR == 4) || (sizeof(TI) == 2 && NR == 2), "row loads");
+  static_assert(!SH || CH == 32, "the shared halo is the two strips of a 32-channel wavefront");
+  static_assert(K >= 2 && K <= 6 && AD >= 0 && AD <= 4, "prefetch depth");
+  constexpr int UPW = 64 / CH, NS = 7;
+  // a row slot: 16 columns (13 used) x 64 lanes x sizeof(TI), written by NR wide loads of CPI columns each (SH: 20 columns x 32 channels)
+  constexpr int COLB = (SH ? 32 : 64) * sizeof(TI);                        // bytes of one column in a slot
+  constexpr int CPI = 1024 / COLB;                                         // columns per 1 KiB instruction: 4 (fp32) / 8 (bf16); SH: 8 / 16
+  constexpr int NCOL = SH ? 20 : 13;                                       // columns of a slot that are read
+  constexpr int NR = SH ? (NCOL + CPI - 1) / CPI : 16 / CPI;               // row loads per step: 4 (fp32) / 2 (bf16); SH: 3 / 2
+  constexpr int NA = 2;                                                    // add-row loads per step (8 columns x 256 bytes, 7 used; SH: 14 x 128)
+  constexpr uint32_t SLOT = SH ? NCOL * COLB : NR * 1024u;               // (SH: the last load lands under a lane mask - nothing behind column 19)
+  constexpr int CSTR = COLB / sizeof(TI);                                  // a column's stride in the slot, elements
+  static_assert(SH || (sizeof(TI) == 4 && NR == 4) || (sizeof(TI) == 2 && NR == 2), "row loads");
   // vmcnt of the row wait: VMEM instructions issued after the DMA group of the row a step needs (issued two steps before it, behind
   // that step's add-row DMA): NSO stores, [NA add DMA,] NR row DMA, NSO stores
   // output row: staged through LDS (the lane's 7 values -> [column][(unit, channel)]) and stored as NSO instructions of 16 bytes per lane
-  constexpr int COLBO = 64 * sizeof(TO), CPIO = 1024 / COLBO, LPCO = COLBO / 16, LPUO = LPCO / UPW, EPLO = 16 / sizeof(TO);
-  constexpr int NSO = (kT + CPIO - 1) / CPIO;                              // 1 (bf16) / 2 (fp32)
-  constexpr int WAIT_ROW = 2 * NSO + NR + (ADD ? NA : 0);
+  constexpr int COLBO = (SH ? 32 : 64) * sizeof(TO), CPIO = 1024 / COLBO, LPCO = COLBO / 16, LPUO = SH ? LPCO : LPCO / UPW, EPLO = 16 / sizeof(TO);
+  constexpr int NOUT = SH ? 2 * kT : kT;                                   // output columns of a wavefront's row
+  constexpr int NSO = (NOUT + CPIO - 1) / CPIO;                            // 1 (bf16) / 2 (fp32), either form
+  constexpr int CSTRO = COLBO / sizeof(TO);
+  // VMEM instructions of a step, in issue order: [NA add-row DMA] ... NR row DMA ... NSO stores.  Behind the DMA group of the row a step
+  // needs (issued K steps before it): the rest of that step and K - 1 whole steps; behind the add row it needs (issued AD steps before it, at
+  // the top): that step's row DMA and stores, AD - 1 whole steps, and its own add and row DMA
+  constexpr int NAE = ADD ? NA : 0, PER_STEP = NAE + NR + NSO;
+  constexpr int WAIT_ROW = NSO + (K - 1) * PER_STEP;
+  constexpr int WAIT_ADD = AD == 0 ? NR : (NR + NSO) + (AD - 1) * PER_STEP + NAE + NR;
+  static_assert(WAIT_ROW < 64 && WAIT_ADD < 64, "vmcnt is a 6-bit count");
+  constexpr uint32_t ASLOT = SH ? 2u * kT * 128u : 2048u;                  // an add-row slot: 14 x 128 bytes / 8 x 256 bytes
   const int lane = threadIdx.x & 63;
   long blk;
   {
@@ -168,16 +210,20 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
   }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long item = blk * 4 + wave;
-  const int cg = static_cast<int>(item / a.items_per_cg);
-  const long it = item % a.items_per_cg;
-  const bool item_ok = it < a.items_per_cg_real;
+  // item = (image, band, strip group, channel group), channel group FASTEST: the wavefronts that share a pixel's cache lines (its 96
+  // channels are 192 bytes of bf16 - three 64-byte pieces, half lines) sit next to each other in one workgroup / on one XCD, whose L2 then
+  // sees whole lines.  Round 4 had the channel group slowest - the pieces of a line went through three different L2s: 128 - 133 us for the
+  // fp32 forward at 56 x 56 x 96; this order 112 - 118; strip group fastest, then the channel group 117 - 124 (profiles/r05_dw.md)
+  const bool item_ok = item < a.items_per_cg_real * a.n_cg;
+  const int cg = static_cast<int>(item % a.n_cg);
+  const long it = item / a.n_cg;
   const int sg = static_cast<int>(it % a.n_sg);
   const int bd = static_cast<int>((it / a.n_sg) % a.n_bands);
   const long n = item_ok ? it / (static_cast<long>(a.n_sg) * a.n_bands) : 0;
   const int H = a.H, W = a.W, C = a.C;
   const int ul = lane / CH;
   const bool unit_ok = sg * UPW + ul < a.n_strips;
-  const int ulc = unit_ok ? ul : a.n_strips - 1 - sg * UPW;
+  const int ulc = (unit_ok || SH) ? ul : a.n_strips - 1 - sg * UPW;       // (SH: an idle unit's window lies beyond the row: all masks zero)
   const int w0 = (sg * UPW + ulc) * kT;
   const int c = cg * CH + (lane % CH);
   const int r_begin = bd * a.band, r_end = min(H, r_begin + a.band);
@@ -192,8 +238,6 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
   }
   const uint32_t zero_m[kPairs] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
 
-  const uint32_t voff = static_cast<uint32_t>(ulc * kT * C + (lane % CH));
-  const uint32_t vb_in = voff * static_cast<uint32_t>(sizeof(TI)), vb_out = voff * static_cast<uint32_t>(sizeof(TO)), vb_add = voff * 4u;
   const long goff = static_cast<long>(sg * UPW * kT - 3) * C + cg * CH;
   const long last_row = static_cast<long>(a.N) * H - 1;
   const uint32_t tensor_elems = static_cast<uint32_t>(static_cast<long>(a.N) * H * rs);
@@ -203,9 +247,9 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
   const uint32_t img_elem = static_cast<uint32_t>(n * H * rs);
 
   __shared__ __attribute__((aligned(16))) unsigned char ring[4][K][SLOT];
-  __shared__ __attribute__((aligned(16))) uint32_t aring[ADD ? 4 : 1][ADD ? 8 : 1][64];   // add row of the step (8 columns, 7 used)
-  __shared__ uint32_t sink[4][64];                                        // target of the loads that only keep the count
-  __shared__ __attribute__((aligned(16))) unsigned char stg[4][8 * COLBO]; // output row of the step on its way to 16-byte stores
+  __shared__ __attribute__((aligned(16))) unsigned char aring[ADD ? 4 : 1][ADD ? AD + 1 : 1][ADD ? ASLOT : 16];   // add rows of steps s .. s + AD
+  __shared__ uint32_t sink[64];                                           // target of the loads that only keep the count (never read)
+  __shared__ __attribute__((aligned(16))) unsigned char stg[4][(SH ? 16 : 8) * COLBO]; // output row of the step on its way to 16-byte stores
   if (!item_ok) return;
   // ---- the lane's packed filter in 56 registers (the register form above keeps it in LDS: with 13 load destinations and 7 store
   //      operands per row there was no room; here loads and stores go through LDS and the per-step filter reads - 14 KiB of LDS
@@ -229,34 +273,52 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
   typedef const volatile __attribute__((address_space(3))) u32x4_t* lds_v4_t;
   const uint32_t ring_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&ring[wave][0][0]));
   const uint32_t aring_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&aring[ADD ? wave : 0][0][0]));
-  const uint32_t sink_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&sink[wave][0]));
+  const uint32_t sink_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&sink[0]));
   // ---- per-lane source offsets of the wide loads.  A 1 KiB load covers CPI columns; inside a column the 64 (unit, channel) values
   //      are 256 / 128 contiguous bytes of LDS but UPW separate runs of memory (a unit's strip starts 7 columns after its
   //      neighbour's): lane l -> column l / LPC, unit (l % LPC) / LPU, 16-byte chunk l % LPU of the unit's CH-channel run.
-  constexpr int LPC = COLB / 16, LPU = LPC / UPW, EPL = 16 / sizeof(TI);   // lanes per column, per unit run; elements per lane
-  const int wcol = lane / LPC, wun = (lane % LPC) / LPU, wch = lane % LPU;
-  const int wun_c = (sg * UPW + wun < a.n_strips) ? wun : a.n_strips - 1 - sg * UPW;        // an idle unit shadows the last strip
+  //      SH: lane l -> column l / LPC of the pair's 20, 16-byte chunk l % LPC of its 32-channel run; the last load runs under a lane mask.
+  constexpr int LPC = COLB / 16, LPU = SH ? LPC : LPC / UPW, EPL = 16 / sizeof(TI);   // lanes per column, per unit run; elements per lane
+  const int wcol = lane / LPC, wun = SH ? 0 : (lane % LPC) / LPU, wch = lane % LPU;
+  const int wun_c = (SH || sg * UPW + wun < a.n_strips) ? wun : a.n_strips - 1 - sg * UPW;  // an idle unit shadows the last strip
   const uint32_t vw_in = static_cast<uint32_t>((wun_c * kT + wcol) * C + wch * EPL) * static_cast<uint32_t>(sizeof(TI));
   // the last load of a row starts at column (NR - 1) CPI: its lanes beyond column 12 re-read column 12 (valid memory, unused slot columns)
-  const int wcol_l = min(wcol, 12 - (NR - 1) * CPI);
+  const int wcol_l = min(wcol, NCOL - 1 - (NR - 1) * CPI);
   const uint32_t vw_in_l = static_cast<uint32_t>((wun_c * kT + wcol_l) * C + wch * EPL) * static_cast<uint32_t>(sizeof(TI));
+  constexpr uint64_t MASK_IN_L = SH ? ((NCOL - (NR - 1) * CPI) * LPC >= 64 ? ~0ull : (1ull << ((NCOL - (NR - 1) * CPI) * LPC)) - 1ull) : ~0ull;
   // output row: lane l of store k -> column k CPIO + l / LPCO (columns > 6: no store), unit, 16-byte chunk
   const uint32_t stg_w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)&stg[wave][0]));
-  const int ocol = lane / LPCO, oun = (lane % LPCO) / LPUO, och = lane % LPUO;
-  const bool oun_ok = sg * UPW + oun < a.n_strips;
-  const int ow0 = (sg * UPW + oun) * kT;                                   // first column of the lane's unit
+  const int ocol = lane / LPCO, oun = SH ? 0 : (lane % LPCO) / LPUO, och = lane % LPUO;
+  const bool oun_ok = SH || sg * UPW + oun < a.n_strips;
+  const int ow0 = (sg * UPW + oun) * kT;                                   // first column of the lane's unit (SH: of the pair)
   const uint32_t vw_o = static_cast<uint32_t>((oun * kT + ocol) * C + och * EPLO) * static_cast<uint32_t>(sizeof(TO));
-  // add row (fp32): 4 columns per load, two loads, the second one's fourth column re-reads column 6
-  const int acol = lane / 16, aun = (lane % 16) / (16 / UPW), ach = lane % (16 / UPW);
-  const int aun_c = (sg * UPW + aun < a.n_strips) ? aun : a.n_strips - 1 - sg * UPW;
+  // add row (fp32): 4 columns per load, two loads, the second one's fourth column re-reads column 6 (SH: 8 columns of 32 channels per
+  // load, the second one's six under a lane mask)
+  constexpr int LPA = SH ? 8 : 16, CPA = 64 / LPA;                         // lanes per add column, add columns per load
+  const int acol = lane / LPA, aun = SH ? 0 : (lane % 16) / (16 / UPW), ach = SH ? lane % 8 : lane % (16 / UPW);
+  const int aun_c = (SH || sg * UPW + aun < a.n_strips) ? aun : a.n_strips - 1 - sg * UPW;
+  const int acol_l = SH ? min(acol, NOUT - 1 - CPA) : min(acol, 2);
   const uint32_t vw_a = static_cast<uint32_t>((aun_c * kT + acol) * C + ach * 4) * 4u;
-  const uint32_t vw_a_l = static_cast<uint32_t>((aun_c * kT + min(acol, 2)) * C + ach * 4) * 4u;
+  const uint32_t vw_a_l = static_cast<uint32_t>((aun_c * kT + acol_l) * C + ach * 4) * 4u;
+  constexpr uint64_t MASK_A_L = SH ? (1ull << ((NOUT - CPA) * LPA)) - 1ull : ~0ull;
   const float b0 = a.bias ? a.bias[c] : 0.f;
 
   // NR wide DMA loads of input row `hrow` of this image (0 <= hrow < H) into ring slot `slot` - always NR instructions
   auto dma_row = [&](int slot, int hrow) {
     const uint32_t dst = ring_w + static_cast<uint32_t>(slot) * SLOT;
     const long grow = n * H + hrow;
+    if (DW_ABL & (16 | 32)) {
+      const uint32_t total = tensor_elems * static_cast<uint32_t>(sizeof(TI));
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        uint32_t so, vo;
+        if (DW_ABL & 16) { so = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>((((item * H + hrow) * NR + k) * 1024) % (total - 1024u)) & ~15u); vo = static_cast<uint32_t>(lane) * 16u; }
+        else { so = (static_cast<uint32_t>(static_cast<long>(img_elem) + hrow * rs + max(goff, 0L)) + static_cast<uint32_t>(k * CPI * C)) * static_cast<uint32_t>(sizeof(TI)); vo = k == NR - 1 ? vw_in_l : vw_in; }
+        if (DW_ABL & 32) { u32x4_t t; asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(t) : "v"(vo), "s"(rx), "s"(so) : "memory"); }
+        else dma_lds16(dst + k * 1024u, vo, rx, so);
+      }
+      return;
+    }
     if (grow == 0 || grow == last_row) {                                  // (wave-uniform, rare) per-lane offsets clamped into the row:
       const int row0 = static_cast<int>(img_elem) + hrow * static_cast<int>(rs);   // what a clamped lane fetches belongs to a column outside
       const int g0 = static_cast<int>(goff);                                        // the image, which the pair masks zero anyway
@@ -264,99 +326,128 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
       for (int k = 0; k < NR; ++k) {
         const int colk = (k == NR - 1) ? wcol_l + k * CPI : wcol + k * CPI;
         const int rel = min(max(g0 + (wun_c * kT + colk) * C + wch * EPL, 0), static_cast<int>(rs) - EPL);
-        dma_lds16(dst + k * 1024u, static_cast<uint32_t>(row0 + rel) * static_cast<uint32_t>(sizeof(TI)), rx, 0u);
+        if (SH && k == NR - 1) dma_lds16_masked(dst + k * 1024u, static_cast<uint32_t>(row0 + rel) * static_cast<uint32_t>(sizeof(TI)), rx, 0u, MASK_IN_L);
+        else dma_lds16(dst + k * 1024u, static_cast<uint32_t>(row0 + rel) * static_cast<uint32_t>(sizeof(TI)), rx, 0u);
       }
     } else {
       const uint32_t base = static_cast<uint32_t>(static_cast<long>(img_elem) + hrow * rs + goff);
       uint32_t Cs = static_cast<uint32_t>(C);
       asm volatile("" : "+s"(Cs));
 #pragma unroll
-      for (int k = 0; k < NR; ++k)
-        dma_lds16(dst + k * 1024u, k == NR - 1 ? vw_in_l : vw_in, rx, (base + static_cast<uint32_t>(k * CPI) * Cs) * static_cast<uint32_t>(sizeof(TI)));
+      for (int k = 0; k < NR; ++k) {
+        if (SH && k == NR - 1) dma_lds16_masked(dst + k * 1024u, vw_in_l, rx, (base + static_cast<uint32_t>(k * CPI) * Cs) * static_cast<uint32_t>(sizeof(TI)), MASK_IN_L);
+        else dma_lds16(dst + k * 1024u, k == NR - 1 ? vw_in_l : vw_in, rx, (base + static_cast<uint32_t>(k * CPI) * Cs) * static_cast<uint32_t>(sizeof(TI)));
+      }
     }
   };
   // the row a slot holds -> registers (the caller has waited for its DMA)
   auto read_row = [&](uint32_t (&r)[kCols], int slot) {
-    uint32_t ad = ring_w + static_cast<uint32_t>(slot) * SLOT + static_cast<uint32_t>(lane) * static_cast<uint32_t>(sizeof(TI));
+    const uint32_t le = SH ? static_cast<uint32_t>(ul * kT * CSTR + (lane % CH)) : static_cast<uint32_t>(lane);   // the lane's element of column 0
+    uint32_t ad = ring_w + static_cast<uint32_t>(slot) * SLOT + le * static_cast<uint32_t>(sizeof(TI));
     asm volatile("" : "+v"(ad));
     if constexpr (sizeof(TI) == 4) {
       lds_u32_t p = reinterpret_cast<lds_u32_t>(static_cast<uintptr_t>(ad));
 #pragma unroll
-      for (int j = 0; j < kCols; ++j) r[j] = p[j * 64];
+      for (int j = 0; j < kCols; ++j) r[j] = p[j * CSTR];
     } else {
       lds_u16_t p = reinterpret_cast<lds_u16_t>(static_cast<uintptr_t>(ad));
 #pragma unroll
-      for (int j = 0; j < kCols; ++j) r[j] = p[j * 64];
+      for (int j = 0; j < kCols; ++j) r[j] = p[j * CSTR];
     }
   };
 
   uint32_t win[NS][kPairs];
-  // prologue: input rows r_begin - 3 .. r_begin + 2 through the ring, two at a time (full waits: six rows per band.  Measured and
+  // prologue: input rows r_begin - 3 .. r_begin + 2 through the ring, K at a time (full waits: six rows per band.  Measured and
   // dropped: filling the window through six compute-less steps of the pipeline below - with nothing to overlap a fill step waits
   // for its row just the same, and pays the step's bookkeeping: 143 / 165 / 203 / 150 us against 138 / 135 / 180 / 134 at 56 x 56 x 96)
 #pragma unroll
-  for (int j0 = 0; j0 < 6; j0 += 2) {
-    dma_row(0, min(max(r_begin - 3 + j0, 0), H - 1));
-    dma_row(1, min(max(r_begin - 3 + j0 + 1, 0), H - 1));
+  for (int j0 = 0; j0 < 6; j0 += K) {
+#pragma unroll
+    for (int jj = 0; jj < K; ++jj)
+      if (j0 + jj < 6) dma_row(jj, min(max(r_begin - 3 + j0 + jj, 0), H - 1));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      uint32_t raw[kCols];
-      read_row(raw, jj);
-      const int hr = r_begin - 3 + j0 + jj;
-      if (hr >= 0 && hr < H) pack_row_lds(win[j0 + jj], raw, m, TI());
-      else pack_row_lds(win[j0 + jj], raw, zero_m, TI());
+    for (int jj = 0; jj < K; ++jj) {
+      if (j0 + jj < 6) {
+        uint32_t raw[kCols];
+        read_row(raw, jj);
+        const int hr = r_begin - 3 + j0 + jj;
+        if (hr >= 0 && hr < H) pack_row_lds(win[(j0 + jj) % NS], raw, m, TI());
+        else pack_row_lds(win[(j0 + jj) % NS], raw, zero_m, TI());
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the slots are read before they are re-issued
   }
-  // rows of steps 0 and 1 (input rows r_begin + 3, r_begin + 4) -> slots 0, 1
-  dma_row(0, min(r_begin + 3, H - 1));
-  dma_row(1, min(r_begin + 4, H - 1));
+  // rows of steps 0 .. K - 1 (input rows r_begin + 3 ...) -> slots 0 .. K - 1
+#pragma unroll
+  for (int j = 0; j < K; ++j) dma_row(j, min(r_begin + 3 + j, H - 1));
 
   const long gout = static_cast<long>(sg * UPW * kT) * C + cg * CH;
   const uint32_t out_base = img_elem + static_cast<uint32_t>(gout);
-  const bool ragged = W % kT != 0;
+  const bool ragged = W % kT != 0 || (SH && (a.n_strips & 1));           // the wavefront's columns may run beyond the row
 
+  // the add row of image row `h` -> add slot `as` (always NA instructions)
+  auto dma_add = [&](int as, int h) {
+    const uint32_t dst = aring_w + static_cast<uint32_t>(as) * ASLOT;
+    if (ragged && n * H + h == last_row) {                                 // (rare, wave-uniform) the last strip's columns beyond the row
+      const int row0 = static_cast<int>(img_elem) + h * static_cast<int>(rs);   // would leave the tensor: per-lane offsets clamped into the row
+      const int r0 = min(static_cast<int>(gout) + (aun_c * kT + acol) * C + ach * 4, static_cast<int>(rs) - 4);
+      const int r1 = min(static_cast<int>(gout) + (aun_c * kT + CPA + acol_l) * C + ach * 4, static_cast<int>(rs) - 4);
+      dma_lds16(dst, static_cast<uint32_t>(row0 + r0) * 4u, ra, 0u);
+      if (SH) dma_lds16_masked(dst + 1024u, static_cast<uint32_t>(row0 + r1) * 4u, ra, 0u, MASK_A_L);
+      else dma_lds16(dst + 1024u, static_cast<uint32_t>(row0 + r1) * 4u, ra, 0u);
+    } else {
+      const uint32_t so0 = (out_base + static_cast<uint32_t>(h * rs)) * 4u;
+      const uint32_t so1 = (out_base + static_cast<uint32_t>(h * rs) + static_cast<uint32_t>(CPA) * static_cast<uint32_t>(C)) * 4u;
+      dma_lds16(dst, vw_a, ra, so0);
+      if (SH) dma_lds16_masked(dst + 1024u, vw_a_l, ra, so1, MASK_A_L);
+      else dma_lds16(dst + 1024u, vw_a_l, ra, so1);
+    }
+  };
+  if (ADD && !(DW_ABL & 2)) {
+#pragma unroll
+    for (int j = 0; j < AD; ++j) dma_add(j, min(r_begin + j, H - 1));      // add rows of steps 0 .. AD - 1
+  }
+  int sl = 0, asl = 0;                                                     // ring slot of this step's row / add row (wave-uniform)
+
+  // counted waits of the first steps: the rows of steps 0 .. K - 1 and the add rows of steps 0 .. AD - 1 were issued back to back above
+#define DWDMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define DWDMA_STEP(P)                                                                                              \
   {                                                                                                                \
     const int st = i + (P);                                               /* step number inside the band */        \
     const int h0 = r_begin + st;                                                                                   \
-    const int slot = st & 1;                                                                                       \
     const int h = min(h0, H - 1);                                                                                  \
     const bool row_ok = st < n_rows;                                      /* wave-uniform */                       \
-    /* the row issued two steps ago (the first two steps: in the prologue, nothing else behind it that we may count on) */ \
-    if (st < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_ROW) : "memory");                                           \
-    if (ADD) {                                                             /* this step's add row: one slot, one step ahead of its use */ \
-      if (ragged && n * H + h == last_row) {                               /* (rare, wave-uniform) the last strip's columns beyond the row \
-                                                                              would leave the tensor: per-lane offsets clamped into the row */ \
-        const int row0 = static_cast<int>(img_elem) + h * static_cast<int>(rs);                                    \
-        const int r0 = min(static_cast<int>(gout) + (aun_c * kT + acol) * C + ach * 4, static_cast<int>(rs) - 4);  \
-        const int r1 = min(static_cast<int>(gout) + (aun_c * kT + 4 + min(acol, 2)) * C + ach * 4, static_cast<int>(rs) - 4); \
-        dma_lds16(aring_w, static_cast<uint32_t>(row0 + r0) * 4u, ra, 0u);                                         \
-        dma_lds16(aring_w + 1024u, static_cast<uint32_t>(row0 + r1) * 4u, ra, 0u);                                 \
-      } else {                                                                                                     \
-        dma_lds16(aring_w, vw_a, ra, (out_base + static_cast<uint32_t>(h * rs)) * 4u);                              \
-        dma_lds16(aring_w + 1024u, vw_a_l, ra, (out_base + static_cast<uint32_t>(h * rs) + 4u * static_cast<uint32_t>(C)) * 4u); \
-      }                                                                                                            \
+    /* the row issued K steps ago */                                                                               \
+    if ((P) < K && i == 0) DWDMA_WAIT(((P) < K ? (K - 1 - (P)) * NR : 0) + AD * NAE + (P) * PER_STEP);             \
+    else DWDMA_WAIT(WAIT_ROW);                                                                                     \
+    if (ADD && !(DW_ABL & 2)) {                                            /* the add row of step st + AD */       \
+      int as = asl + AD;                                                                                           \
+      if (as > AD) as -= AD + 1;                                                                                   \
+      dma_add(as, min(h0 + AD, H - 1));                                                                            \
     }                                                                                                              \
     /* the 13 LDS reads of the entering row are issued here and consumed behind six of the seven filter rows (the row is the \
        window's LAST: only kh = 6 needs it) - their latency runs under 168 dot products instead of in front of them */          \
     uint32_t raw[kCols];                                                                                           \
-    read_row(raw, slot);                                                                                           \
+    read_row(raw, sl);                                                                                             \
     float acc[kT];                                                                                                 \
     _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[t] = b0;                                                    \
-    _Pragma("unroll") for (int kh = 0; kh < 6; ++kh) {                                                             \
+    _Pragma("unroll") for (int kh = (DW_ABL & 1) ? 6 : 0; kh < 6; ++kh) {                                          \
       const uint32_t(&d)[kPairs] = win[((P) + kh) % NS];                                                           \
       _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                              \
           acc[t] = dot2(d[t / 2 + e], (t & 1) ? wo[kh][e] : we[kh][e], acc[t]);                                    \
       }                                                                                                            \
     }                                                                                                              \
+    /* (the compiler moves the packing - and with it the wait for the LDS reads - in front of the dot products above unless the row's \
+       registers depend on their results: an empty statement that takes both) */                                                       \
+    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]), \
+                 "+v"(raw[8]), "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12])                           \
+                 : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]));     \
     if (h0 + 3 < H) pack_row_lds(win[((P) + 6) % NS], raw, m, TI());                                               \
     else pack_row_lds(win[((P) + 6) % NS], raw, zero_m, TI());                                                     \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     /* slot read: free for the row of step st + 2 */ \
-    dma_row(slot, min(h0 + 3 + K, H - 1));                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     /* slot read: free for the row of step st + K */ \
+    if (!(DW_ABL & 2)) dma_row(sl, min(h0 + 3 + K, H - 1));                                                        \
     {                                                                                                              \
       const uint32_t(&d)[kPairs] = win[((P) + 6) % NS];                                                            \
       _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
@@ -365,32 +456,39 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
       }                                                                                                            \
     }                                                                                                              \
     if (ADD) {                                                                                                     \
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NR) : "memory");           /* behind the add row: this step's row loads */ \
-      uint32_t ad = aring_w + static_cast<uint32_t>(lane) * 4u;                                                    \
+      if ((P) < AD && i == 0) DWDMA_WAIT(((P) < AD ? (AD - 1 - (P)) * NAE : 0) + (P) * PER_STEP + NAE + NR);       \
+      else DWDMA_WAIT(WAIT_ADD);                                                                                   \
+      uint32_t ad = aring_w + static_cast<uint32_t>(asl) * ASLOT +                                                 \
+                    (SH ? static_cast<uint32_t>(ul * kT * 32 + (lane % CH)) : static_cast<uint32_t>(lane)) * 4u;   \
       asm volatile("" : "+v"(ad));                                                                                 \
       lds_u32_t ap = reinterpret_cast<lds_u32_t>(static_cast<uintptr_t>(ad));                                      \
-      _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[t] += __uint_as_float(ap[t * 64]);                        \
+      _Pragma("unroll") for (int t = 0; t < kT; ++t) acc[t] += __uint_as_float(ap[t * (SH ? 32 : 64)]);            \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   /* read before the next step re-issues the slot */ \
     }                                                                                                              \
-    {                                                                     /* the lane's 7 values -> stg[column][(unit, channel)] */ \
-      uint32_t sa = stg_w + static_cast<uint32_t>(lane) * static_cast<uint32_t>(sizeof(TO));                       \
+    if (DW_ABL & 4) { float z = 0.f; _Pragma("unroll") for (int t = 0; t < kT; ++t) z += acc[t]; asm volatile("" :: "v"(z)); } \
+    else {                                                                /* the lane's 7 values -> stg[column][(unit, channel)] */ \
+      uint32_t sa = stg_w + (SH ? static_cast<uint32_t>(ul * kT * CSTRO + (lane % CH)) : static_cast<uint32_t>(lane)) * static_cast<uint32_t>(sizeof(TO)); \
       asm volatile("" : "+v"(sa));                                                                                 \
       _Pragma("unroll") for (int t = 0; t < kT; ++t) {                                                             \
-        if constexpr (sizeof(TO) == 4) reinterpret_cast<lds_w32_t>(static_cast<uintptr_t>(sa))[t * 64] = __float_as_uint(acc[t]);   \
-        else reinterpret_cast<lds_w16_t>(static_cast<uintptr_t>(sa))[t * 64] = static_cast<uint16_t>(pack2_bf16(acc[t], 0.f));      \
+        if constexpr (sizeof(TO) == 4) reinterpret_cast<lds_w32_t>(static_cast<uintptr_t>(sa))[t * CSTRO] = __float_as_uint(acc[t]);   \
+        else reinterpret_cast<lds_w16_t>(static_cast<uintptr_t>(sa))[t * CSTRO] = static_cast<uint16_t>(pack2_bf16(acc[t], 0.f));      \
       }                                                                                                            \
     }                                                                                                              \
-    if (row_ok) {                                                                                                  \
+    if (DW_ABL & 4) {                                                                                              \
+    } else if (row_ok) {                                                                                           \
       uint32_t la = stg_w + static_cast<uint32_t>(lane) * 16u;                                                     \
       asm volatile("" : "+v"(la));                                                                                 \
       _Pragma("unroll") for (int k = 0; k < NSO; ++k) {                                                            \
         const u32x4_t v = *reinterpret_cast<lds_v4_t>(static_cast<uintptr_t>(la + k * 1024u));                     \
-        const bool st_ok = oun_ok && k * CPIO + ocol < kT && ow0 + k * CPIO + ocol < W;   /* (ragged widths: the last strip's columns inside the image) */ \
+        const bool st_ok = oun_ok && k * CPIO + ocol < NOUT && ow0 + k * CPIO + ocol < W;   /* (ragged widths: the last strip's columns inside the image) */ \
         /* the compiler guards a store under EXEC with s_cbranch_execz: a store NO lane of the wavefront takes (the ragged last  \
            strip, second 16-byte group) would not be issued and the counted vmcnt waits would run two instructions short - the   \
            wave-uniform test keeps the number of VMEM instructions per step independent of EXEC */                               \
         if (__builtin_amdgcn_ballot_w64(st_ok) != 0ull) {                                                          \
-          if (st_ok)                                                                                               \
+          if (DW_ABL & 8)                                                                                          \
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, static_cast<uint32_t>(lane) * 16u,                     \
+                static_cast<uint32_t>((((item * H + h) * NSO + k) * 1024) % (tensor_elems * static_cast<uint32_t>(sizeof(TO)) - 1024u)) & ~15u, 0); \
+          else if (st_ok)                                                                                          \
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, vw_o,                                                  \
                 (out_base + static_cast<uint32_t>(h * rs) + static_cast<uint32_t>(k * CPIO) * static_cast<uint32_t>(C)) * static_cast<uint32_t>(sizeof(TO)), 0); \
         } else {                                                                                                   \
@@ -400,19 +498,31 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
     } else {                                                               /* nothing to store: keep the count (loads nobody reads) */ \
       _Pragma("unroll") for (int k = 0; k < NSO; ++k) dma_lds<4>(sink_w, 0u, rx, 0u);                              \
     }                                                                                                              \
+    sl = sl + 1 == K ? 0 : sl + 1;                                                                                 \
+    asl = asl + 1 > AD ? 0 : asl + 1;                                                                              \
   }
 
   for (int i = 0; i < n_rows; i += NS) {
     DWDMA_STEP(0) DWDMA_STEP(1) DWDMA_STEP(2) DWDMA_STEP(3) DWDMA_STEP(4) DWDMA_STEP(5) DWDMA_STEP(6)
   }
+#undef DWDMA_WAIT
 #undef DWDMA_STEP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // no DMA may land in LDS that is no longer ours
 }
 
-template <typename TI, typename TO, int CH, bool ADD>
+// prefetch depth: K = 2 rows, add row in its own step (round 4's), after measuring K = 2 .. 4 x AD = 0 .. 3 at every stage shape: no
+// depth moves any of them by more than the run-to-run spread (profiles/r05_dw.md - the kernel is not waiting for latency).  Measurement
+// builds: make EXTRA="-DDW_DEPTH_K=4 -DDW_DEPTH_AD=2" (three workgroups per CU need <= 53 KiB of LDS each: tools/resource_usage.py)
+#ifndef DW_DEPTH_K
+#define DW_DEPTH_K 2
+#endif
+#ifndef DW_DEPTH_AD
+#define DW_DEPTH_AD 0
+#endif
+template <typename TI, typename TO, int CH, bool ADD, bool SH>
 int launch_dma(const WinArgs& a, hipStream_t s) {
   const long blocks = a.items_per_cg / 4 * a.n_cg;
-  hipLaunchKernelGGL((dwconv7x7_dma_kernel<TI, TO, CH, ADD>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((dwconv7x7_dma_kernel<TI, TO, CH, ADD, SH, DW_DEPTH_K, ADD ? DW_DEPTH_AD : 0>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }
 
@@ -446,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_win_kernel(const WinWg
     const long q = B / 8, r = B % 8, xcd = L % 8, k = L / 8;
     blk = xcd * q + (xcd < r ? xcd : r) + k;
   }
-  const int cg = static_cast<int>(blk / a.parts), part = static_cast<int>(blk % a.parts);
+  const int cg = static_cast<int>(blk % a.n_cg), part = static_cast<int>(blk / a.n_cg);   // channel group fastest: as the forward kernel
   const int H = a.H, W = a.W, C = a.C;
   const long rs = static_cast<long>(W) * C;
   const int ul = lane / CH;
@@ -635,7 +745,11 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   WinArgs a;
   a.x = x; a.w49c = w49c; a.bias = bias; a.add = add; a.out = out;
   a.N = static_cast<int>(N); a.H = H; a.W = W; a.C = C; a.flip = flip;
-  const int ch = (C % 64 == 0) ? 64 : 32;
+  // APGD_DW_SH: 1 (default) = 32-channel wavefronts share the column halo of their two strips; 2 = every width runs 32-channel
+  // wavefronts that way (64-channel wavefronts hold one strip: nothing to share); 0 = off
+  static const int sh_mode = getenv("APGD_DW_SH") ? atoi(getenv("APGD_DW_SH")) : 1;
+  const int ch = (C % 64 == 0 && sh_mode != 2) ? 64 : 32;
+  const bool sh = sh_mode != 0;
   a.n_strips = (W + kT - 1) / kT;
   a.n_sg = (a.n_strips + (64 / ch) - 1) / (64 / ch);
   a.n_cg = C / ch;
@@ -651,7 +765,7 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   a.n_bands = (H + a.band - 1) / a.band;
   a.items_per_cg_real = static_cast<long>(N) * a.n_sg * a.n_bands;
   a.items_per_cg = (a.items_per_cg_real + 3) / 4 * 4;
-#define WIN_GO(TI, TO, ADDV) return (ch == 64) ? launch_dma<TI, TO, 64, ADDV>(a, s) : launch_dma<TI, TO, 32, ADDV>(a, s);
+#define WIN_GO(TI, TO, ADDV) return (ch == 64) ? launch_dma<TI, TO, 64, ADDV, false>(a, s) : sh ? launch_dma<TI, TO, 32, ADDV, true>(a, s) : launch_dma<TI, TO, 32, ADDV, false>(a, s);
   if (x_dtype == APGD_F32) WIN_GO(float, uint16_t, false)
   if (out_dtype == APGD_F32) { if (add) WIN_GO(uint16_t, float, true) else WIN_GO(uint16_t, float, false) }
   if (add) WIN_GO(uint16_t, uint16_t, true)
