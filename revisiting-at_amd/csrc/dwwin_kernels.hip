@@ -745,11 +745,9 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   WinArgs a;
   a.x = x; a.w49c = w49c; a.bias = bias; a.add = add; a.out = out;
   a.N = static_cast<int>(N); a.H = H; a.W = W; a.C = C; a.flip = flip;
-  // APGD_DW_SH: 1 (default) = 32-channel wavefronts share the column halo of their two strips; 2 = every width runs 32-channel
-  // wavefronts that way (64-channel wavefronts hold one strip: nothing to share); 0 = off
-  static const int sh_mode = getenv("APGD_DW_SH") ? atoi(getenv("APGD_DW_SH")) : 1;
-  const int ch = (C % 64 == 0 && sh_mode != 2) ? 64 : 32;
-  const bool sh = sh_mode != 0;
+  // APGD_DW_SH=0: 32-channel wavefronts (C % 64 != 0) load their two strips separately, as in round 4 (measurement; default: shared halo)
+  static const bool sh = !(getenv("APGD_DW_SH") && atoi(getenv("APGD_DW_SH")) == 0);
+  const int ch = (C % 64 == 0) ? 64 : 32;
   a.n_strips = (W + kT - 1) / kT;
   a.n_sg = (a.n_strips + (64 / ch) - 1) / (64 / ch);
   a.n_cg = C / ch;
