@@ -485,7 +485,7 @@ def test_cfg5_standard_evaluation_on_convnext_base_replays_through_the_oracle(R,
         calls[-1]["x_init"] = out.detach().cpu().numpy()
         return out
 
-    def attack(m, xi, yi, norm, e, n_iter, loss, yt, use_rs, gen):
+    def attack(m, xi, yi, norm, e, n_iter, loss, yt, use_rs, gen, graph=False, n_real=None):
         rec = {"x": xi.cpu().numpy(), "y": yi.cpu().numpy(), "loss": loss, "yt": None if yt is None else yt.cpu().numpy(),
                "logits": [], "signs": []}
         calls.append(rec)
@@ -505,7 +505,7 @@ def test_cfg5_standard_evaluation_on_convnext_base_replays_through_the_oracle(R,
                 o = m(Tap.apply(t) if t.requires_grad else t)
                 rec["logits"].append(o.detach().float().cpu().numpy())
                 return o
-        out = orig_attack(Rec().eval(), xi, yi, norm, e, n_iter, loss, yt, use_rs, gen)
+        out = orig_attack(Rec().eval(), xi, yi, norm, e, n_iter, loss, yt, use_rs, gen, False, n_real)   # (a recording model cannot be captured)
         rec["out"] = [t.cpu().numpy() for t in out]                          # x_best_adv, acc, loss_best, x_best
         return out
 
