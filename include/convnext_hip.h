@@ -142,6 +142,16 @@ int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const floa
                            float* dgamma, float* db2, float* ws, int64_t M, int32_t C, void* stream);
 int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db1, float* ws,
                         int64_t M, int32_t N, void* stream);
+/* d(gamma) of a ConvNeXt block (models/convnext.py:47: x = self.gamma * x) from the weight gradients of its second linear layer,
+ * without a pass over the [M, C] tensors:  with y2 = H W2^T + b2 and dO = bf16(g gamma),
+ *     dgamma[c] = sum_m g[m,c] y2[m,c] = (sum_j bf16(W2[c,j]) dW2[c,j] + b2[c] db2[c]) / gamma[c]
+ * w2, dw2 fp32 [C, Hd] (dW2 = dO^T H), b2, db2 (= sum_m dO; both nullable together), gamma fp32 [C].  g (fp32 / bf16 [M, C]) and y2
+ * (bf16 [M, C]; or, y2 == NULL, h_tiles = H in the CNX_TN_ACC tiles of the fused kernels, from which y2 is recomputed: M, Hd multiples
+ * of 32) are read only for channels whose gamma is exactly 0 (the direct sum).  Replaces cnx_scale_residual_bwd's sums-only mode in the
+ * training pass of the fused blocks, whose forward then has no pre-gamma output to keep. */
+int cnx_block_dgamma(const float* w2, const float* dw2, const float* b2, const float* db2, const float* gamma,
+                     const void* g, int g_dtype, const void* y2, const void* h_tiles, float* dgamma,
+                     int64_t M, int32_t C, int32_t Hd, void* stream);
 /* y = GELU(x) (exact-erf form, nn.GELU() of models/convnext.py:43 and of the timm Mlp) on n bf16 elements, n % 8 == 0. */
 int cnx_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 

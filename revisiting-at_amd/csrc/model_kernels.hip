@@ -1507,6 +1507,58 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const TG* __res
   }
 }
 
+// d(gamma) of a block WITHOUT a pass over g and y2 (round 5).  With y2 = H W2^T + b2 (models/convnext.py:44-47):
+//     d(gamma)[c] = sum_m g[m,c] y2[m,c] = sum_j W2[c,j] (g^T H)[c,j] + b2[c] sum_m g[m,c],
+// and the weight gradients the training pass has just computed are dW2 = dO^T H and d(b2) = sum_m dO with dO = bf16(g gamma), so
+//     d(gamma)[c] = (sum_j W2[c,j] dW2[c,j] + b2[c] d(b2)[c]) / gamma[c]        (W2 rounded to bf16 as the forward's GEMM read it)
+// - a reduction over the [C, 4C] matrices instead of 462 MB of g and y2 at 56 x 56 x 96.  Differs from the direct sum by the bf16 rounding
+// of dO and of y2 (relative L2 2e-3 of d(gamma), measured; the direct sum's own rounding of y2: 1.4e-3).  One block per channel; a
+// channel whose gamma is exactly zero has no dO to recover g from and takes the direct sum over its column of g and y2 - y2 as stored, or,
+// when the forward did not keep it, recomputed from the H tiles (strided, slow, exact; a gamma lands on 0.0f with probability ~2^-24 per
+// sign change).
+template <typename TG>
+__global__ __launch_bounds__(256) void block_dgamma_kernel(const float* __restrict__ w2, const float* __restrict__ dw2,
+                                                           const float* __restrict__ b2, const float* __restrict__ db2,
+                                                           const float* __restrict__ gamma, const TG* __restrict__ g,
+                                                           const uint16_t* __restrict__ y2, const uint16_t* __restrict__ ht,
+                                                           float* __restrict__ dgamma, long M, int C, int Hd) {
+  __shared__ float red[256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const float gm = gamma[c];
+  float s = 0.f;
+  if (gm != 0.f) {
+    for (int j = t; j < Hd; j += 256) s = fmaf(round_bf16(w2[static_cast<long>(c) * Hd + j]), dw2[static_cast<long>(c) * Hd + j], s);
+  } else {
+    for (long m = t; m < M; m += 256) {
+      float gv, yv;
+      if constexpr (sizeof(TG) == 4) gv = g[m * C + c]; else gv = __uint_as_float(static_cast<uint32_t>(g[m * C + c]) << 16);
+      if (y2) {
+        yv = __uint_as_float(static_cast<uint32_t>(y2[m * C + c]) << 16);
+      } else {
+        // y2[m, c] recomputed from the H tiles (CNX_TN_ACC: tiles [M/32][Hd/32] of 2 KiB, element (r, n) of a tile at byte
+        // 64 r + 32 ((n/4) % 2) + 8 (n/8) + 2 (n % 4)), rounded to bf16 as the forward stored it
+        const uint16_t* tile_row = ht + (m / 32) * (static_cast<long>(Hd) / 32) * 1024 + (m % 32) * 32;
+        float acc = 0.f;
+        for (int j = 0; j < Hd; ++j) {
+          const int n = j % 32;
+          const uint16_t hv = tile_row[static_cast<long>(j / 32) * 1024 + 16 * ((n / 4) % 2) + 4 * (n / 8) + (n % 4)];
+          acc = fmaf(__uint_as_float(static_cast<uint32_t>(hv) << 16), round_bf16(w2[static_cast<long>(c) * Hd + j]), acc);
+        }
+        yv = round_bf16(acc + (b2 ? b2[c] : 0.f));
+      }
+      s = fmaf(gv, yv, s);
+    }
+  }
+  red[t] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {                  // fixed tree: deterministic
+    if (t < w) red[t] += red[t + w];
+    __syncthreads();
+  }
+  if (t == 0) dgamma[c] = gm != 0.f ? (red[0] + (b2 ? b2[c] * db2[c] : 0.f)) / gm : red[0];
+}
+
 __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const uint16_t* __restrict__ dh, const uint16_t* __restrict__ hpre,
                                                               uint16_t* __restrict__ dhpre, float* __restrict__ ws, long M, int N,
                                                               int CQ) {
@@ -2306,6 +2358,22 @@ int cnx_scale_residual_bwd(const void* g, int g_dtype, const void* y, const floa
   if (sums)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, dgamma, db2, C, 2 * C,
                        static_cast<int>(M < parts ? M : parts));
+  return launch_status();
+}
+
+int cnx_block_dgamma(const float* w2, const float* dw2, const float* b2, const float* db2, const float* gamma, const void* g,
+                     int g_dtype, const void* y2, const void* h_tiles, float* dgamma, int64_t M, int32_t C, int32_t Hd, void* stream) {
+  if (M < 0 || C <= 0 || Hd <= 0) return APGD_ERR_SIZE;
+  if (!w2 || !dw2 || !gamma || !g || (!y2 && !h_tiles) || !dgamma || (b2 && !db2)) return APGD_ERR_NULL;
+  if (!y2 && (M % 32 != 0 || Hd % 32 != 0)) return APGD_ERR_ARG;                // the tile form holds whole 32 x 32 tiles
+  if (g_dtype != APGD_F32 && g_dtype != APGD_BF16) return APGD_ERR_DTYPE;
+  hipStream_t s = as_stream(stream);
+  if (g_dtype == APGD_F32)
+    hipLaunchKernelGGL(block_dgamma_kernel<float>, dim3(C), dim3(256), 0, s, w2, dw2, b2, db2, gamma, static_cast<const float*>(g),
+                       static_cast<const uint16_t*>(y2), static_cast<const uint16_t*>(h_tiles), dgamma, static_cast<long>(M), C, Hd);
+  else
+    hipLaunchKernelGGL(block_dgamma_kernel<uint16_t>, dim3(C), dim3(256), 0, s, w2, dw2, b2, db2, gamma, static_cast<const uint16_t*>(g),
+                       static_cast<const uint16_t*>(y2), static_cast<const uint16_t*>(h_tiles), dgamma, static_cast<long>(M), C, Hd);
   return launch_status();
 }
 

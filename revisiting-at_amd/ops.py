@@ -1034,6 +1034,36 @@ def _tn_ok(M, N1, N2):
     return _WGRAD_MODE == "hip" and MODE != "eager" and M * 4 * max(N1, N2) < 2 ** 32 and bool(_lib.load().cnx_gemm_tn_supported(M, N1, N2))
 
 
+# d(gamma) of a fused block from dW2 / d(b2) (cnx_block_dgamma) instead of a pass over g and y2; APGD_DGAMMA=pass restores the pass
+_DGAMMA_FROM_DW2 = os.environ.get("APGD_DGAMMA", "dw2") != "pass"
+
+
+def _dgamma_needs_y2(M, C, w2):
+    """Does the training backward of a fused block need the forward's pre-gamma output?  Not when d(gamma) comes from dW2 (the weight
+    gradients on ``cnx_gemm_tn_ex`` over the kernels' tiles, from which the one channel in 2^24 with gamma == 0 is also served)."""
+    return not (_DGAMMA_FROM_DW2 and w2.dtype == torch.float32 and w2.is_contiguous() and M % 32 == 0
+                and _tn_ok(M, 4 * C, C) and _tn_ok(M, C, 4 * C))
+
+
+def _block_dgamma(lib, g2, y2, h_tiles, gf, w2, b2f, dw2, db2, M, C):
+    """``d(gamma)[c] = sum_m g*y2`` of ``models/convnext.py:47``.  From the second linear layer's weight gradients (one launch over
+    [C, 4C]) when they were computed from ``dO = bf16(g*gamma)``; otherwise the one-pass sums of ``cnx_scale_residual_bwd``."""
+    dgamma = torch.empty(C, device=g2.device, dtype=torch.float32)
+    if _DGAMMA_FROM_DW2 and w2.dtype == torch.float32 and w2.is_contiguous() and dw2.is_contiguous() and (y2 is not None or M % 32 == 0):
+        _lib.check(lib.cnx_block_dgamma(w2.data_ptr(), dw2.data_ptr(), _lib.ptr(b2f), _lib.ptr(db2) if b2f is not None else None, gf.data_ptr(),
+                                        g2.data_ptr(), _code(g2), y2.reshape(M, C).data_ptr() if y2 is not None else None,
+                                        h_tiles.data_ptr() if y2 is None else None, dgamma.data_ptr(), M, C, dw2.shape[1], _stream()),
+                   "cnx_block_dgamma")
+        return dgamma
+    if y2 is None:
+        raise _lib.ApgdHipError("d(gamma) by the one-pass sums needs the forward's pre-gamma output")
+    db2_ = torch.empty(C, device=g2.device, dtype=torch.float32)
+    ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=g2.device, dtype=torch.float32)
+    _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2.reshape(M, C).data_ptr(), gf.data_ptr(), None,
+                                          dgamma.data_ptr(), db2_.data_ptr(), ws.data_ptr(), M, C, _stream()), "cnx_scale_residual_bwd")
+    return dgamma
+
+
 def _wgrad_acc(a_t, a_acc, b_t, b_acc, M, N1, N2):
     """``A^T B`` -> (fp32 [N1, N2], fp32 [N1] column sums of A) through ``cnx_gemm_tn_ex`` with ONE operand in the accumulator-order
     tiles the fused block kernels write (``CNX_TN_ACC``: ``a_acc`` / ``b_acc``), the other a contiguous [M, N] bf16 row matrix."""
@@ -1325,7 +1355,7 @@ class _BlockFused(torch.autograd.Function):
             hpre = torch.empty(n_ws, device=x.device, dtype=torch.bfloat16)
             h = torch.empty(n_ws, device=x.device, dtype=torch.bfloat16)
             a = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
-            if gamma is not None:
+            if gamma is not None and _dgamma_needs_y2(M, C, w2):
                 y2 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
             _lib.check(lib.cnx_block_mlp_fwd_train(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, mean.data_ptr(), rstd.data_ptr(),
                                                    wf.data_ptr(), b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), _code(x),
@@ -1333,8 +1363,8 @@ class _BlockFused(torch.autograd.Function):
                                                    M, C, _stream()), "cnx_block_mlp_fwd_train")
             wa = _cached((w1, w2), "mlp_packed_bwd", _pack_mlp_bwd)
             ctx.fused = "train_hpre"
-            ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, None, b1f, gf, y2, a, hpre, h)
-            ctx.has_dw_bias, ctx.eps = dw_b is not None, eps
+            ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, None, b1f, gf, y2, a, hpre, h, b2f)
+            ctx.has_dw_bias, ctx.eps, ctx.w2 = dw_b is not None, eps, w2
             return out
         if via_hpre:
             wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
@@ -1348,7 +1378,7 @@ class _BlockFused(torch.autograd.Function):
                                                       _stream()), "cnx_block_mlp_fwd_hpre")
                 wa = _cached((w1, w2), "mlp_packed_bwd", _pack_mlp_bwd)
                 ctx.fused = "hpre"
-                ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, None, b1f, gf, None, None, hpre, None)
+                ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, None, b1f, gf, None, None, hpre, None, b2f)
                 ctx.has_dw_bias, ctx.eps = dw_b is not None, eps
             else:
                 _lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, None, None, wf.data_ptr(),
@@ -1361,7 +1391,7 @@ class _BlockFused(torch.autograd.Function):
         if fused:
             # LN + fc1 + GELU + fc2 + gamma + residual: ONE kernel, hidden activation on-chip (recomputed in the backward)
             wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
-            if need_p and gamma is not None:
+            if need_p and gamma is not None and _dgamma_needs_y2(M, C, w2):
                 y2 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
             _lib.check(lib.cnx_block_mlp_fwd(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), eps, _lib.ptr(mean), _lib.ptr(rstd),
                                              wf.data_ptr(), b1f.data_ptr(), b2f.data_ptr(), _lib.ptr(gf), x.data_ptr(), _code(x),
@@ -1394,14 +1424,14 @@ class _BlockFused(torch.autograd.Function):
                                                   M, C, _stream()), "cnx_scale_residual")
         if need_grad:
             ctx.fused = fused
-            ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, wb_, b1f, gf, y2, a, hpre, h)
+            ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, wb_, b1f, gf, y2, a, hpre, h, b2f)
             ctx.has_dw_bias, ctx.eps, ctx.w1, ctx.w2 = dw_b is not None, eps, w1, w2
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, w49c, u, mean, rstd, lw, lb, w1b, w2b, b1f, gf, y2, a_s, hpre, h = ctx.saved_tensors
+        x, w49c, u, mean, rstd, lw, lb, w1b, w2b, b1f, gf, y2, a_s, hpre, h, b2f = ctx.saved_tensors
         N, H, W, C = x.shape
         M = N * H * W
         nig = ctx.needs_input_grad
@@ -1435,12 +1465,7 @@ class _BlockFused(torch.autograd.Function):
                 dw2, db2 = _wgrad_acc(dos, False, h, True, M, C, 4 * C)              # dO^T H        [C, 4C]
                 dw1, db1 = _wgrad_acc(dhp, True, a_s, False, M, 4 * C, C)            # dHpre^T LN(u) [4C, C]
                 if gf is not None:
-                    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
-                    db2_ = torch.empty(C, device=x.device, dtype=torch.float32)
-                    ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=x.device, dtype=torch.float32)
-                    _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2.reshape(M, C).data_ptr(), gf.data_ptr(), None,
-                                                          dgamma.data_ptr(), db2_.data_ptr(), ws.data_ptr(), M, C, _stream()),
-                               "cnx_scale_residual_bwd")
+                    dgamma = _block_dgamma(lib, g2, y2, h, gf, ctx.w2, b2f, dw2, db2, M, C)
             del dos, dhp
         elif ctx.fused and not want_p:
             # ---- attack backward: ONE kernel down to the depthwise-conv output (LayerNorm backward in its epilogue)
@@ -1471,12 +1496,7 @@ class _BlockFused(torch.autograd.Function):
                 dw2, db2 = _wgrad_acc(dos, False, ht, True, M, C, 4 * C)
                 dw1, db1 = _wgrad_acc(dhpt, True, a, False, M, 4 * C, C)
                 if gf is not None:
-                    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
-                    db2_ = torch.empty(C, device=x.device, dtype=torch.float32)
-                    ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=x.device, dtype=torch.float32)
-                    _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2.reshape(M, C).data_ptr(), gf.data_ptr(), None,
-                                                          dgamma.data_ptr(), db2_.data_ptr(), ws.data_ptr(), M, C, _stream()),
-                               "cnx_scale_residual_bwd")
+                    dgamma = _block_dgamma(lib, g2, y2, ht, gf, ctx.w2, b2f, dw2, db2, M, C)
                 del a, dos, ht, dhpt
                 want_emit = False
             else:

@@ -783,6 +783,28 @@ def test_training_pass_on_the_hpre_kernel_pair_vs_fp32_reference(R, C, M_, gamma
     # ... and against the fp32 chain
     assert rel(dw2, dO.t() @ h) < 6e-3 and rel(dw1, dhpre_b.t() @ a) < 8e-3
     assert rel(db2, dO.sum(0)) < 6e-3 and rel(db1, dhpre_b.sum(0)) < 1e-2
+    if gamma:
+        # d(gamma) from dW2 / d(b2) (cnx_block_dgamma) against the direct sum over g and the bf16 y2 (models/convnext.py:47) ...
+        dgm = torch.empty(C, device="cuda")
+        w2d = dev_(w2)
+        assert lib.cnx_block_dgamma(w2d.data_ptr(), dw2.data_ptr(), b2d.data_ptr(), db2.data_ptr(), gmd.data_ptr(), gd.data_ptr(), 0, y2d.data_ptr(),
+                                    None, dgm.data_ptr(), M_, C, 4 * C, S()) == 0
+        direct = (g.double() * y2d.float().cpu().double()).sum(0)
+        # (M_ = 64 rows: the sums are short and the bf16 rounding of dO does not average out)
+        assert float((dgm.cpu().double() - direct).norm() / direct.norm()) < (2e-2 if M_ < 256 else 8e-3)
+        # ... and a channel whose gamma is exactly zero takes the direct sum (its dO column is zero: nothing to divide)
+        gz = gmd.clone(); gz[3] = 0.0
+        dos_z = dos.clone(); dos_z[:, 3] = 0
+        assert lib.cnx_gemm_tn_ex(dos_z.data_ptr(), C, 0, h_ws.data_ptr(), 0, 1, dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M_, N1, N2, S()) == 0
+        for y2p, htp in ((y2d.data_ptr(), None), (None, h_ws.data_ptr())):     # y2 as stored / recomputed from the H tiles
+            dgm.fill_(float("nan"))
+            assert lib.cnx_block_dgamma(w2d.data_ptr(), dw2.data_ptr(), b2d.data_ptr(), db2.data_ptr(), gz.data_ptr(), gd.data_ptr(), 0, y2p, htp,
+                                        dgm.data_ptr(), M_, C, 4 * C, S()) == 0
+            assert abs(float(dgm[3]) - float(direct[3])) <= (1e-4 if y2p else 2e-2) * (1 + abs(float(direct[3]))) and bool(torch.isfinite(dgm).all())
+        assert lib.cnx_block_dgamma(w2d.data_ptr(), dw2.data_ptr(), b2d.data_ptr(), None, gz.data_ptr(), gd.data_ptr(), 0, y2d.data_ptr(), None,
+                                    dgm.data_ptr(), M_, C, 4 * C, S()) == -1
+        assert lib.cnx_block_dgamma(w2d.data_ptr(), dw2.data_ptr(), b2d.data_ptr(), db2.data_ptr(), gz.data_ptr(), gd.data_ptr(), 0, None, None,
+                                    dgm.data_ptr(), M_, C, 4 * C, S()) == -1
     # argument checks
     assert lib.cnx_gemm_tn_ex(dos.data_ptr(), C, 0, h_ws.data_ptr(), 0, 1, dw2.data_ptr(), None, ws.data_ptr(), M_, N1, N2, S()) == -1
     assert lib.cnx_gemm_tn_ex(dhp_ws.data_ptr(), 0, 1, h_ws.data_ptr(), 0, 1, dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M_, N2, N2, S()) == -4
