@@ -152,6 +152,22 @@ int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db
 int cnx_block_dgamma(const float* w2, const float* dw2, const float* b2, const float* db2, const float* gamma,
                      const void* g, int g_dtype, const void* y2, const void* h_tiles, float* dgamma,
                      int64_t M, int32_t C, int32_t Hd, void* stream);
+/* The LayerNorm parameter gradients of a block (models/convnext.py:40-41 backward) from the first linear layer's weight gradients:
+ *     dlb[c] = sum_m da[m,c] = sum_j bf16(W1[j,c]) db1[j],     dlw[c] = (sum_j bf16(W1[j,c]) dW1[j,c] - ln_b[c] dlb[c]) / ln_w[c]
+ * w1, dw1 fp32 [Hd, C] (dW1 = dHpre^T LN(u)), db1 fp32 [Hd].  da (bf16 [M, C], gradient w.r.t. LN(u); or, da == NULL, dhpre_tiles = dHpre
+ * in CNX_TN_ACC tiles, from which da is recomputed), u (bf16 [M, C]), mean, rstd [M] are read only for channels whose ln_w is exactly 0
+ * (the direct sum).  The LayerNorm backward then needs no partial sums - and rides in the epilogue of the block's backward kernel:
+ * cnx_block_mlp_bwd_train_hpre_ln / cnx_block_mlp_bwd_acc_ln = cnx_block_mlp_bwd_train_hpre / cnx_block_mlp_bwd_acc with
+ * du = d(loss)/du (the gradient w.r.t. the depthwise-conv output) written where those write da. */
+int cnx_block_dln(const float* w1, const float* dw1, const float* db1, const float* ln_w, const float* ln_b,
+                  const void* da, const void* dhpre_tiles, const void* u, const float* mean, const float* rstd,
+                  float* dlw, float* dlb, int64_t M, int32_t C, int32_t Hd, void* stream);
+int cnx_block_mlp_bwd_train_hpre_ln(const void* u, const float* ln_w, const float* mean, const float* rstd,
+                                    const void* g, int g_dtype, const float* gamma, const void* Wb, const void* hpre_ws,
+                                    void* du, void* do_rows, void* dhpre_ws, int64_t M, int32_t C, void* stream);
+int cnx_block_mlp_bwd_acc_ln(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
+                             void* a_rows, void* do_rows, void* h_ws, void* dhpre_ws, int64_t M, int32_t C, void* stream);
 /* y = GELU(x) (exact-erf form, nn.GELU() of models/convnext.py:43 and of the timm Mlp) on n bf16 elements, n % 8 == 0. */
 int cnx_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 

@@ -1240,7 +1240,7 @@ struct GeoB {
 template <int C, typename TG, int EMIT, bool LNB, bool HPRE = false>
 __global__ __launch_bounds__(GeoB<C>::WAVES * 64, ((C <= 96 || (HPRE && C == 192)) ? 2 : 1)) void blk_mlp_bwd_kernel(const BlkBwdArgs p) {
   using G = GeoB<C>;
-  static_assert(!(HPRE && EMIT == 1) && !(EMIT && LNB), "emit modes: see above");
+  static_assert(!(HPRE && EMIT == 1) && !(EMIT == 1 && LNB), "emit modes: see above");
   // PIPE_R: the recomputing input-gradient kernel at one wavefront per SIMD (C >= 128) runs the software-pipelined loop too
   // (GEMM1 / dH of block t+1 interleaved with the unpacked GELU' of block t); C = 96 (two wavefronts per SIMD, power cap) and the
   // emit mode keep the straight loop.
@@ -1782,9 +1782,9 @@ int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, bool ln_bwd, hipStream_t s)
     hipLaunchKernelGGL(kfn, grid, block, (EM) == 1 ? G::LDS_EMIT : G::LDS, s, a);                                     \
   }
   if (g_dtype == APGD_F32) {
-    if (emit == 2) BLK_LAUNCH(float, 2, false) else if (emit) BLK_LAUNCH(float, 1, false) else if (ln_bwd) BLK_LAUNCH(float, 0, true) else BLK_LAUNCH(float, 0, false)
+    if (emit == 2 && ln_bwd) BLK_LAUNCH(float, 2, true) else if (emit == 2) BLK_LAUNCH(float, 2, false) else if (emit) BLK_LAUNCH(float, 1, false) else if (ln_bwd) BLK_LAUNCH(float, 0, true) else BLK_LAUNCH(float, 0, false)
   } else {
-    if (emit == 2) BLK_LAUNCH(uint16_t, 2, false) else if (emit) BLK_LAUNCH(uint16_t, 1, false) else if (ln_bwd) BLK_LAUNCH(uint16_t, 0, true) else BLK_LAUNCH(uint16_t, 0, false)
+    if (emit == 2 && ln_bwd) BLK_LAUNCH(uint16_t, 2, true) else if (emit == 2) BLK_LAUNCH(uint16_t, 2, false) else if (emit) BLK_LAUNCH(uint16_t, 1, false) else if (ln_bwd) BLK_LAUNCH(uint16_t, 0, true) else BLK_LAUNCH(uint16_t, 0, false)
   }
 #undef BLK_LAUNCH
   return launch_status();
@@ -1796,7 +1796,15 @@ int launch_blk_bwd_hpre(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
   constexpr int LDS_BYTES = G::DEPTH * (G::KS + 2 * G::CB) * 1024 + 16 * C;
   const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(G::WAVES * 64);
 #define BLK_LAUNCH(TG)                                                                                           \
-  if (a.dhpt_out) {                                                                                              \
+  if (a.dhpt_out && a.u) {                                               /* training backward, LayerNorm backward in the epilogue */ \
+    auto kfn = blk_mlp_bwd_kernel<C, TG, 2, true, true>;                                                         \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, LDS_BYTES, s, a);                                                       \
+  } else if (a.dhpt_out) {                                                                                       \
     auto kfn = blk_mlp_bwd_kernel<C, TG, 2, false, true>;                                                        \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
@@ -1948,6 +1956,27 @@ int cnx_block_mlp_bwd_train_hpre(const void* g, int g_dtype, const float* gamma,
   }
 }
 
+int cnx_block_mlp_bwd_train_hpre_ln(const void* u, const float* ln_w, const float* mean, const float* rstd, const void* g, int g_dtype,
+                                    const float* gamma, const void* Wb, const void* hpre_ws, void* du, void* do_rows, void* dhpre_ws,
+                                    int64_t M, int32_t C, void* stream) {
+  if (M < 0 || C <= 0) return APGD_ERR_SIZE;
+  if (M == 0) return APGD_OK;
+  if (!u || !ln_w || !mean || !rstd || !g || !Wb || !hpre_ws || !du || !do_rows || !dhpre_ws) return APGD_ERR_NULL;
+  if (g_dtype != APGD_F32 && g_dtype != APGD_BF16) return APGD_ERR_DTYPE;
+  BlkBwdArgs a;
+  a.u = static_cast<const uint16_t*>(u); a.ln_w = ln_w; a.ln_b = nullptr; a.mean = mean; a.rstd = rstd; a.g = g; a.gamma = gamma;
+  a.Wb = static_cast<const uint16_t*>(Wb); a.b1 = nullptr; a.da = static_cast<uint16_t*>(du);
+  a.a_out = nullptr; a.do_out = static_cast<uint16_t*>(do_rows); a.ht_out = nullptr; a.dhpt_out = static_cast<uint16_t*>(dhpre_ws);
+  a.hpre = static_cast<const uint16_t*>(hpre_ws); a.M = M; a.a_stride = C; a.emit_acc = 1;
+  switch (C) {
+    case 128: return launch_blk_bwd_hpre<128>(a, g_dtype, as_stream(stream));
+    case 192: return launch_blk_bwd_hpre<192>(a, g_dtype, as_stream(stream));
+    case 256: return launch_blk_bwd_hpre<256>(a, g_dtype, as_stream(stream));
+    case 384: return launch_blk_bwd_hpre<384>(a, g_dtype, as_stream(stream));
+    default: return APGD_ERR_ARG;
+  }
+}
+
 int64_t cnx_mlp_packed_bwd_elems(int32_t C) { return static_cast<int64_t>(12) * C * C; }
 
 int cnx_mlp_pack_weights_bwd(const void* W1, const void* W2, int w_dtype, void* Wb, int32_t C, void* stream) {
@@ -2014,6 +2043,14 @@ int cnx_block_mlp_bwd_acc(const void* u, const float* ln_w, const float* ln_b, c
                           void* a_rows, void* do_rows, void* h_ws, void* dhpre_ws, int64_t M, int32_t C, void* stream) {
   if (!a_rows || !do_rows || !h_ws || !dhpre_ws) return APGD_ERR_NULL;
   return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, da, a_rows, 0, do_rows, h_ws, dhpre_ws, false, M, C,
+                            stream, 1);
+}
+
+int cnx_block_mlp_bwd_acc_ln(const void* u, const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                             const void* g, int g_dtype, const float* gamma, const void* Wb, const float* b1, void* du,
+                             void* a_rows, void* do_rows, void* h_ws, void* dhpre_ws, int64_t M, int32_t C, void* stream) {
+  if (!a_rows || !do_rows || !h_ws || !dhpre_ws) return APGD_ERR_NULL;
+  return block_mlp_bwd_impl(u, ln_w, ln_b, mean, rstd, g, g_dtype, gamma, Wb, b1, du, a_rows, 0, do_rows, h_ws, dhpre_ws, true, M, C,
                             stream, 1);
 }
 

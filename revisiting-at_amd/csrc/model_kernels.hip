@@ -1559,6 +1559,58 @@ __global__ __launch_bounds__(256) void block_dgamma_kernel(const float* __restri
   if (t == 0) dgamma[c] = gm != 0.f ? (red[0] + (b2 ? b2[c] * db2[c] : 0.f)) / gm : red[0];
 }
 
+// The LayerNorm parameter gradients of a block the same way (round 5).  With a = LN(u) = xh ln_w + ln_b (bf16, the left operand of the
+// first linear layer), da = dHpre W1 and the weight gradients dW1 = dHpre^T a, d(b1) = sum_m dHpre:
+//     d(ln_b)[c] = sum_m da[m,c]           = sum_j W1[j,c] d(b1)[j]
+//     d(ln_w)[c] = sum_m da[m,c] xh[m,c]   = (sum_j W1[j,c] dW1[j,c] - ln_b[c] d(ln_b)[c]) / ln_w[c]
+// (W1 rounded to bf16 as the GEMMs read it).  A channel whose ln_w is exactly zero takes the direct sum over da, u, mean, rstd.
+__global__ __launch_bounds__(256) void block_dln_kernel(const float* __restrict__ w1, const float* __restrict__ dw1,
+                                                        const float* __restrict__ db1, const float* __restrict__ ln_w,
+                                                        const float* __restrict__ ln_b, const uint16_t* __restrict__ da,
+                                                        const uint16_t* __restrict__ dhpt, const uint16_t* __restrict__ u, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ dlw, float* __restrict__ dlb,
+                                                        long M, int C, int Hd) {
+  __shared__ float red[2][256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const float lw = ln_w[c];
+  float sw = 0.f, sb = 0.f;
+  for (int j = t; j < Hd; j += 256) {
+    const float w = round_bf16(w1[static_cast<long>(j) * C + c]);
+    sw = fmaf(w, dw1[static_cast<long>(j) * C + c], sw);
+    sb = fmaf(w, db1[j], sb);
+  }
+  if (lw == 0.f) {
+    sw = 0.f;
+    for (long m = t; m < M; m += 256) {
+      const float xh = (__uint_as_float(static_cast<uint32_t>(u[m * C + c]) << 16) - mean[m]) * rstd[m];
+      float dav;
+      if (da) {
+        dav = __uint_as_float(static_cast<uint32_t>(da[m * C + c]) << 16);
+      } else {                                           // da[m, c] = sum_j dHpre[m, j] W1[j, c] from the CNX_TN_ACC tiles (block_dgamma_kernel)
+        const uint16_t* tile_row = dhpt + (m / 32) * (static_cast<long>(Hd) / 32) * 1024 + (m % 32) * 32;
+        dav = 0.f;
+        for (int j = 0; j < Hd; ++j) {
+          const int n = j % 32;
+          const uint16_t dv = tile_row[static_cast<long>(j / 32) * 1024 + 16 * ((n / 4) % 2) + 4 * (n / 8) + (n % 4)];
+          dav = fmaf(__uint_as_float(static_cast<uint32_t>(dv) << 16), round_bf16(w1[static_cast<long>(j) * C + c]), dav);
+        }
+      }
+      sw = fmaf(dav, xh, sw);
+    }
+  }
+  red[0][t] = sw; red[1][t] = sb;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    dlb[c] = red[1][0];
+    dlw[c] = lw != 0.f ? (red[0][0] - ln_b[c] * red[1][0]) / lw : red[0][0];
+  }
+}
+
 __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const uint16_t* __restrict__ dh, const uint16_t* __restrict__ hpre,
                                                               uint16_t* __restrict__ dhpre, float* __restrict__ ws, long M, int N,
                                                               int CQ) {
@@ -2374,6 +2426,17 @@ int cnx_block_dgamma(const float* w2, const float* dw2, const float* b2, const f
   else
     hipLaunchKernelGGL(block_dgamma_kernel<uint16_t>, dim3(C), dim3(256), 0, s, w2, dw2, b2, db2, gamma, static_cast<const uint16_t*>(g),
                        static_cast<const uint16_t*>(y2), static_cast<const uint16_t*>(h_tiles), dgamma, static_cast<long>(M), C, Hd);
+  return launch_status();
+}
+
+int cnx_block_dln(const float* w1, const float* dw1, const float* db1, const float* ln_w, const float* ln_b, const void* da,
+                  const void* dhpre_tiles, const void* u, const float* mean, const float* rstd, float* dlw, float* dlb, int64_t M,
+                  int32_t C, int32_t Hd, void* stream) {
+  if (M < 0 || C <= 0 || Hd <= 0) return APGD_ERR_SIZE;
+  if (!w1 || !dw1 || !db1 || !ln_w || !ln_b || (!da && !dhpre_tiles) || !u || !mean || !rstd || !dlw || !dlb) return APGD_ERR_NULL;
+  if (!da && (M % 32 != 0 || Hd % 32 != 0)) return APGD_ERR_ARG;
+  hipLaunchKernelGGL(block_dln_kernel, dim3(C), dim3(256), 0, as_stream(stream), w1, dw1, db1, ln_w, ln_b, static_cast<const uint16_t*>(da),
+                     static_cast<const uint16_t*>(dhpre_tiles), static_cast<const uint16_t*>(u), mean, rstd, dlw, dlb, static_cast<long>(M), C, Hd);
   return launch_status();
 }
 

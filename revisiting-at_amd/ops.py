@@ -1036,6 +1036,20 @@ def _tn_ok(M, N1, N2):
 
 # d(gamma) of a fused block from dW2 / d(b2) (cnx_block_dgamma) instead of a pass over g and y2; APGD_DGAMMA=pass restores the pass
 _DGAMMA_FROM_DW2 = os.environ.get("APGD_DGAMMA", "dw2") != "pass"
+# the LayerNorm parameter gradients of a fused block from dW1 / d(b1) (cnx_block_dln); APGD_DLN=pass: the LayerNorm backward's own sums
+_DLN_FROM_DW1 = os.environ.get("APGD_DLN", "dw1") != "pass"
+# ... and with them the LayerNorm backward itself in the epilogue of the block's training backward kernel (APGD_DLN=kernel: identity
+# for the parameter gradients, but the separate LayerNorm backward kernel for du)
+_LN_IN_TRAIN_BWD = os.environ.get("APGD_DLN", "dw1") == "dw1"
+
+
+def _block_dln(lib, w1, dw1, db1, lw, lb, da, dhp_tiles, u, mean, rstd, M, C):
+    dlw = torch.empty(C, device=u.device, dtype=torch.float32)
+    dlb = torch.empty(C, device=u.device, dtype=torch.float32)
+    _lib.check(lib.cnx_block_dln(w1.data_ptr(), dw1.data_ptr(), db1.data_ptr(), lw.data_ptr(), lb.data_ptr(), _lib.ptr(da),
+                                 dhp_tiles.data_ptr() if da is None else None, u.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 dlw.data_ptr(), dlb.data_ptr(), M, C, 4 * C, _stream()), "cnx_block_dln")
+    return dlw, dlb
 
 
 def _dgamma_needs_y2(M, C, w2):
@@ -1364,7 +1378,7 @@ class _BlockFused(torch.autograd.Function):
             wa = _cached((w1, w2), "mlp_packed_bwd", _pack_mlp_bwd)
             ctx.fused = "train_hpre"
             ctx.save_for_backward(x, w49c, u, mean, rstd, lw, lb, wa, None, b1f, gf, y2, a, hpre, h, b2f)
-            ctx.has_dw_bias, ctx.eps, ctx.w2 = dw_b is not None, eps, w2
+            ctx.has_dw_bias, ctx.eps, ctx.w1, ctx.w2 = dw_b is not None, eps, w1, w2
             return out
         if via_hpre:
             wf = _cached((w1, w2), "mlp_packed", _pack_mlp)
@@ -1439,6 +1453,8 @@ class _BlockFused(torch.autograd.Function):
         g = g.contiguous()
         g2 = g.reshape(M, C)
         dw1 = db1 = dw2 = db2 = dgamma = None
+        dln_id = False                                                           # d(ln_w), d(ln_b) from dW1 / d(b1) (cnx_block_dln)
+        dlw_id = dlb_id = None                                                   # ... already computed (LayerNorm backward inside the block kernel)
         da = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)            # gradient w.r.t. LN(u)
         d_u = None
         if ctx.fused == "hpre":
@@ -1458,12 +1474,26 @@ class _BlockFused(torch.autograd.Function):
                 g2 = g2.float()
             dos = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)
             dhp = torch.empty(hpre.numel(), device=x.device, dtype=torch.bfloat16)
-            _lib.check(lib.cnx_block_mlp_bwd_train_hpre(g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), hpre.data_ptr(),
-                                                        da.data_ptr(), dos.data_ptr(), dhp.data_ptr(), M, C, _stream()),
-                       "cnx_block_mlp_bwd_train_hpre")
+            w1p = getattr(ctx, "w1", None)
+            ln_in = _LN_IN_TRAIN_BWD and want_p and w1p is not None and w1p.dtype == torch.float32 and w1p.is_contiguous() and M % 32 == 0
+            if ln_in:
+                # the LayerNorm backward in the kernel's epilogue (as in the attack's kernel): `da` comes out as d(loss)/du; the
+                # LayerNorm's parameter gradients follow from dW1 / d(b1) below
+                d_u = da.view(u.shape)
+                _lib.check(lib.cnx_block_mlp_bwd_train_hpre_ln(u.data_ptr(), lw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g2.data_ptr(),
+                                                               _code(g2), _lib.ptr(gf), w1b.data_ptr(), hpre.data_ptr(), d_u.data_ptr(),
+                                                               dos.data_ptr(), dhp.data_ptr(), M, C, _stream()),
+                           "cnx_block_mlp_bwd_train_hpre_ln")
+            else:
+                _lib.check(lib.cnx_block_mlp_bwd_train_hpre(g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), hpre.data_ptr(),
+                                                            da.data_ptr(), dos.data_ptr(), dhp.data_ptr(), M, C, _stream()),
+                           "cnx_block_mlp_bwd_train_hpre")
             if want_p:
                 dw2, db2 = _wgrad_acc(dos, False, h, True, M, C, 4 * C)              # dO^T H        [C, 4C]
                 dw1, db1 = _wgrad_acc(dhp, True, a_s, False, M, 4 * C, C)            # dHpre^T LN(u) [4C, C]
+                dln_id = _DLN_FROM_DW1
+                if ln_in:
+                    dlw_id, dlb_id = _block_dln(lib, w1p, dw1, db1, lw, lb, None, dhp, u, mean, rstd, M, C)
                 if gf is not None:
                     dgamma = _block_dgamma(lib, g2, y2, h, gf, ctx.w2, b2f, dw2, db2, M, C)
             del dos, dhp
@@ -1489,12 +1519,20 @@ class _BlockFused(torch.autograd.Function):
                 dhpt = torch.empty(M * 4 * C, device=x.device, dtype=torch.bfloat16)
                 if g2.dtype not in (torch.float32, torch.bfloat16):
                     g2 = g2.float()
-                _lib.check(lib.cnx_block_mlp_bwd_acc(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                     g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
-                                                     da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
-                                                     M, C, _stream()), "cnx_block_mlp_bwd_acc")
+                w1p = getattr(ctx, "w1", None)
+                ln_in = _LN_IN_TRAIN_BWD and w1p is not None and w1p.dtype == torch.float32 and w1p.is_contiguous()
+                if ln_in:
+                    d_u = da.view(u.shape)
+                fn = lib.cnx_block_mlp_bwd_acc_ln if ln_in else lib.cnx_block_mlp_bwd_acc
+                _lib.check(fn(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                              g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
+                              da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
+                              M, C, _stream()), "cnx_block_mlp_bwd_acc_ln" if ln_in else "cnx_block_mlp_bwd_acc")
                 dw2, db2 = _wgrad_acc(dos, False, ht, True, M, C, 4 * C)
                 dw1, db1 = _wgrad_acc(dhpt, True, a, False, M, 4 * C, C)
+                dln_id = _DLN_FROM_DW1
+                if ln_in:
+                    dlw_id, dlb_id = _block_dln(lib, w1p, dw1, db1, lw, lb, None, dhpt, u, mean, rstd, M, C)
                 if gf is not None:
                     dgamma = _block_dgamma(lib, g2, y2, ht, gf, ctx.w2, b2f, dw2, db2, M, C)
                 del a, dos, ht, dhpt
@@ -1556,17 +1594,24 @@ class _BlockFused(torch.autograd.Function):
                     dgamma = None
             del dhpre, dos
         # ---- LayerNorm backward (already done by the fused input-gradient kernel)
-        dlw = dlb = ws = None
+        dlw, dlb, ws = dlw_id, dlb_id, None
         if d_u is None:
             d_u = torch.empty_like(u)
+            w1p = getattr(ctx, "w1", None)
+            dln_id = dln_id and want_p and w1p is not None and w1p.dtype == torch.float32 and w1p.is_contiguous()
             if want_p:
                 dlw = torch.empty(C, device=x.device, dtype=torch.float32)
                 dlb = torch.empty(C, device=x.device, dtype=torch.float32)
-                ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device=x.device, dtype=torch.float32)
+                if not dln_id:
+                    ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device=x.device, dtype=torch.float32)
             _lib.check(lib.cnx_layernorm_bwd(da.data_ptr(), _code(da), u.data_ptr(), _code(u), lw.data_ptr(), None,
                                              mean.data_ptr(), rstd.data_ptr(), d_u.data_ptr(), _code(d_u),
-                                             _lib.ptr(dlw), _lib.ptr(dlb), _lib.ptr(ws), M, C, 0, _stream()),
+                                             None if dln_id else _lib.ptr(dlw), None if dln_id else _lib.ptr(dlb), _lib.ptr(ws), M, C, 0, _stream()),
                        "cnx_layernorm_bwd")
+            if dln_id:
+                _lib.check(lib.cnx_block_dln(w1p.data_ptr(), dw1.data_ptr(), db1.data_ptr(), lw.data_ptr(), lb.data_ptr(), da.data_ptr(), None,
+                                             u.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dlw.data_ptr(), dlb.data_ptr(), M, C, 4 * C,
+                                             _stream()), "cnx_block_dln")
         # ---- depthwise conv backward; the residual branch's gradient rides along as the stencil's `add` input
         dx = None
         if nig[0]:

@@ -783,6 +783,35 @@ def test_training_pass_on_the_hpre_kernel_pair_vs_fp32_reference(R, C, M_, gamma
     # ... and against the fp32 chain
     assert rel(dw2, dO.t() @ h) < 6e-3 and rel(dw1, dhpre_b.t() @ a) < 8e-3
     assert rel(db2, dO.sum(0)) < 6e-3 and rel(db1, dhpre_b.sum(0)) < 1e-2
+    # LayerNorm parameter gradients from dW1 / d(b1) (cnx_block_dln) against the direct sums over da and xh = (u - mean) rstd
+    xh = (ud.float() - mean[:, None]) * rstd[:, None]
+    d_lw, d_lb = (da.float().double() * xh.double()).sum(0).cpu(), da.float().double().sum(0).cpu()
+    dlw, dlb = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    w1d = dev_(w1)
+    lwz = lwd.clone()
+    for zero_ch in (None, 5):
+        if zero_ch is not None:
+            lwz[zero_ch] = 0.0                                          # (only the identity's divisor: the kernels above ran with lw)
+        for dap, tlp in ((da.data_ptr(), None), (None, dhp_ws.data_ptr())):       # da as stored / recomputed from the dHpre tiles
+            assert lib.cnx_block_dln(w1d.data_ptr(), dw1.data_ptr(), db1.data_ptr(), lwz.data_ptr(), lbd.data_ptr(), dap, tlp, ud.data_ptr(),
+                                     mean.data_ptr(), rstd.data_ptr(), dlw.data_ptr(), dlb.data_ptr(), M_, C, 4 * C, S()) == 0
+            tol = 3e-2 if M_ < 256 else 1e-2
+            keep = torch.ones(C, dtype=torch.bool)
+            if zero_ch is not None:
+                keep[zero_ch] = False
+                # (from the tiles da is not rounded to bf16 first: the difference is rounding noise of a sum of M_ signed terms)
+                assert abs(float(dlw[zero_ch]) - float(d_lw[zero_ch])) <= (1e-4 * (1 + abs(float(d_lw[zero_ch]))) if dap else 2e-2 * float(d_lw.abs().mean() * 4 + 1))
+            assert float((dlw.cpu().double()[keep] - d_lw[keep]).norm() / d_lw[keep].norm()) < tol
+            assert float((dlb.cpu().double() - d_lb).norm() / d_lb.norm()) < tol
+    # the same backward with the LayerNorm backward in its epilogue: du against the LayerNorm backward of the kernel's own da
+    du = torch.full((M_, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dos2 = torch.empty_like(dos); dhp2 = torch.zeros_like(dhp_ws)
+    assert lib.cnx_block_mlp_bwd_train_hpre_ln(ud.data_ptr(), lwd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(), 0, P(gmd), wb.data_ptr(),
+                                               hpre_ws.data_ptr(), du.data_ptr(), dos2.data_ptr(), dhp2.data_ptr(), M_, C, S()) == 0
+    assert torch.equal(dos2, dos) and torch.equal(dhp2, dhp_ws)
+    tt = da.float() * lwd
+    du_ref = rstd[:, None] * (tt - tt.mean(1, keepdim=True) - xh * (tt * xh).mean(1, keepdim=True))
+    assert float((du.float() - du_ref).norm() / du_ref.norm()) < 1e-2
     if gamma:
         # d(gamma) from dW2 / d(b2) (cnx_block_dgamma) against the direct sum over g and the bf16 y2 (models/convnext.py:47) ...
         dgm = torch.empty(C, device="cuda")
@@ -846,6 +875,16 @@ def test_recomputing_training_backward_with_accumulator_order_tiles(R, C, M_):
         assert lib.cnx_gemm_tn_ex(dw.data_ptr(), 0, 1, a1.data_ptr(), C, 0, d.data_ptr(), cs.data_ptr(), ws.data_ptr(), M_, 4 * C, C, S()) == 0
         ref = dhpt.float() @ a1.float()
         assert float((d - ref).norm() / ref.norm()) < 3e-6 and float((cs - dhpt.float().sum(1)).norm() / cs.norm()) < 3e-6
+    # the same kernel with the LayerNorm backward in its epilogue: identical emits, du = LayerNorm backward of the kernel's da
+    du, a2, do2, hw2, dw2_ = mk(M_, C), mk(M_, C), mk(M_, C), mk(M_ * 4 * C), mk(M_ * 4 * C)
+    assert lib.cnx_block_mlp_bwd_acc_ln(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mu.data_ptr(), rstd.data_ptr(), g.data_ptr(), 0, gm.data_ptr(),
+                                        wb.data_ptr(), b1.data_ptr(), du.data_ptr(), a2.data_ptr(), do2.data_ptr(), hw2.data_ptr(), dw2_.data_ptr(),
+                                        M_, C, S()) == 0
+    assert torch.equal(a2, a1) and torch.equal(do2, do1) and torch.equal(hw2, hw) and torch.equal(dw2_, dw)
+    xh = (u.float() - mu[:, None]) * rstd[:, None]
+    tt = da1.float() * lw
+    du_ref = rstd[:, None] * (tt - tt.mean(1, keepdim=True) - xh * (tt * xh).mean(1, keepdim=True))
+    assert float((du.float() - du_ref).norm() / du_ref.norm()) < 1e-2
     assert lib.cnx_block_mlp_bwd_acc(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), mu.data_ptr(), rstd.data_ptr(), g.data_ptr(), 0, gm.data_ptr(),
                                      wb.data_ptr(), b1.data_ptr(), da1.data_ptr(), a1.data_ptr(), do1.data_ptr(), hw.data_ptr(), dw.data_ptr(),
                                      M_ - 16, C, S()) == -4
