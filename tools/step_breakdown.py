@@ -54,11 +54,11 @@ for n, (c, t) in agg.items():
     g[0] += c
     g[1] += t
 tot = sum(t for _, t in grp.values())
-GROUPS = (("fused LN+MLP (`blk_mlp_*`)", r"blk_mlp_"), ("depthwise 7x7 (forward, input gradient, filter gradient)", r"dwconv7x7"),
+GROUPS = (("fused LN+MLP (`blk_mlp_*`, `blk2_*`)", r"blk_mlp_|blk2_"), ("depthwise 7x7 (forward, input gradient, filter gradient)", r"dwconv7x7"),
           ("hipBLASLt / rocBLAS GEMMs", r"^hipBLASLt|Cijk_"), ("`cnx_gemm_nt`", r"gemm_nt_kernel"),
           ("`cnx_gemm_tn` weight gradients (+ split sums)", r"gemm_tn_"), ("MIOpen / CK convolutions", r"^CK |igemm_|naive_conv|miopen|Conv|wrw"),
           ("LayerNorm kernels", r"layernorm_"),
-          ("element-wise tails around the library GEMMs + partial sums", r"gelu_|scale_residual|sum_parts|reduce_parts|colsum"),
+          ("element-wise tails around the library GEMMs + partial sums", r"gelu_|scale_residual|sum_parts|reduce_parts|colsum|block_dgamma|block_dln"),
           ("ConvStem convolutions (forward, input and filter gradients)", r"stem_conv|conv2_|wgrad_reduce"), ("attention", r"attn_"),
           ("attack kernels (K1, loss, state, tracking, init)", r"linf_step|track_rows|state_update|ce_pred|init_kernel|l2_step|dlr"),
           ("ATen copies / casts / optimizer / other", r""))
