@@ -1792,7 +1792,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const TX* __res
   }
 }
 
-template <typename TD, typename TX, typename TO, int G>
+// SUMS = false (round 5): the input-gradient-only calls of the attack, and the training calls whose parameter gradients come from
+// cnx_block_dln - without the 48 accumulator registers per lane the kernel fits more wavefronts per SIMD
+template <typename TD, typename TX, typename TO, int G, bool SUMS = true>
 __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __restrict__ dy, const TX* __restrict__ x,
                                                                  const float* __restrict__ weight,
                                                                  const float* __restrict__ bias,
@@ -1801,16 +1803,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
                                                                  float* __restrict__ ws, long M, int C, int gelu, int pH,
                                                                  int pW, const float* __restrict__ add) {
   constexpr int RPB = 256 / G;
-  __shared__ float red[2][RPB][G * 8];                // per row-group partial parameter gradients (one chunk)
+  __shared__ float red[SUMS ? 2 : 1][SUMS ? RPB : 1][SUMS ? G * 8 : 1];                // per row-group partial parameter gradients (one chunk)
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
   const float invC = 1.0f / static_cast<float>(C);
-  F8 w8[3], b8[3], aw[3], ab[3];
+  F8 w8[3], b8[3], aw[SUMS ? 3 : 1], ab[SUMS ? 3 : 1];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     w8[k] = load8(weight + (gl + k * G) * 8);
     if (gelu && bias) b8[k] = load8(bias + (gl + k * G) * 8);
     else b8[k] = F8{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
-    aw[k] = ab[k] = F8{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    if constexpr (SUMS) aw[k] = ab[k] = F8{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
   }
   for (long row = static_cast<long>(blockIdx.x) * RPB + gr; row < M; row += static_cast<long>(gridDim.x) * RPB) {
     const float mu = mean[row], rs = rstd[row];
@@ -1826,7 +1828,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
         const float h = (xh[k].v[e] - mu) * rs;
         float d = g[k].v[e];
         if (gelu) d *= gelu_grad_f(h * w8[k].v[e] + b8[k].v[e]);
-        if (ws) { aw[k].v[e] += d * h; ab[k].v[e] += d; }
+        if constexpr (SUMS) { if (ws) { aw[k].v[e] += d * h; ab[k].v[e] += d; } }
         const float t = d * w8[k].v[e];
         xh[k].v[e] = h;
         g[k].v[e] = t;
@@ -1847,6 +1849,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
       store8(dx + row * C + (gl + k * G) * 8, o);
     }
   }
+  if constexpr (SUMS) {
   if (!ws) return;
   float* pw = ws + static_cast<long>(blockIdx.x) * 2 * C;
 #pragma unroll
@@ -1863,6 +1866,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const TD* __res
       for (int r = 0; r < RPB; ++r) t += red[which][r][cc];
       pw[which * C + k * G * 8 + cc] = t;
     }
+  }
   }
 }
 
@@ -1949,8 +1953,12 @@ int launch_ln_bwd(const TD* dy, const TX* x, const float* w, const float* b, con
     const long rpb = 256 / G;                                                                                  \
     long nb = (M + rpb - 1) / rpb; if (nb > kLnBwdBlocks) nb = kLnBwdBlocks;                                   \
     *nblocks = static_cast<int>(nb);                                                                           \
-    hipLaunchKernelGGL((layernorm_bwd_wide_kernel<TD, TX, TO, G>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dy, \
-                       x, w, b, mean, rstd, dx, ws, M, C, gelu, pH, pW, add);                                  \
+    if (ws)                                                                                                    \
+      hipLaunchKernelGGL((layernorm_bwd_wide_kernel<TD, TX, TO, G, true>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dy, \
+                         x, w, b, mean, rstd, dx, ws, M, C, gelu, pH, pW, add);                                \
+    else                                                                                                       \
+      hipLaunchKernelGGL((layernorm_bwd_wide_kernel<TD, TX, TO, G, false>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dy, \
+                         x, w, b, mean, rstd, dx, ws, M, C, gelu, pH, pW, add);                                \
     return launch_status();                                                                                    \
   }
     if (g == 2) LN_BWD_W(2)

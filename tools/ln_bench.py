@@ -38,5 +38,7 @@ for C, HW, xdt, ydt, gelu, ddt, odt in CASES:
     ws = torch.empty(lib.cnx_layernorm_bwd_ws_floats(C), device="cuda")
     t_b = timeit(lambda: lib.cnx_layernorm_bwd(dy.data_ptr(), code[ddt], x.data_ptr(), code[xdt], w.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                dx.data_ptr(), code[odt], dw.data_ptr(), db.data_ptr(), ws.data_ptr(), M, C, gelu, S()))
+    t_n = timeit(lambda: lib.cnx_layernorm_bwd(dy.data_ptr(), code[ddt], x.data_ptr(), code[xdt], w.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               dx.data_ptr(), code[odt], None, None, None, M, C, gelu, S()))
     bf = M * C * (x.element_size() + y.element_size()); bb = M * C * (x.element_size() + dy.element_size() + dx.element_size())
-    print(f"C={C:4d} HW={HW:3d} {str(xdt)[6:]:>8s}->{str(ydt)[6:]:<8s} fwd {t_f:7.1f} us ({bf / t_f / 1e6:5.2f} TB/s) | bwd dy {str(ddt)[6:]} dx {str(odt)[6:]} {t_b:7.1f} us ({bb / t_b / 1e6:5.2f} TB/s)", flush=True)
+    print(f"C={C:4d} HW={HW:3d} {str(xdt)[6:]:>8s}->{str(ydt)[6:]:<8s} fwd {t_f:7.1f} us ({bf / t_f / 1e6:5.2f} TB/s) | bwd dy {str(ddt)[6:]} dx {str(odt)[6:]} {t_b:7.1f} us ({bb / t_b / 1e6:5.2f} TB/s) | without sums {t_n:7.1f} us ({bb / t_n / 1e6:5.2f} TB/s)", flush=True)
