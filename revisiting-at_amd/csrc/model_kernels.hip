@@ -1570,44 +1570,62 @@ __global__ __launch_bounds__(256) void block_dln_kernel(const float* __restrict_
                                                         const uint16_t* __restrict__ dhpt, const uint16_t* __restrict__ u, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ dlw, float* __restrict__ dlb,
                                                         long M, int C, int Hd) {
-  __shared__ float red[2][256];
-  const int c = blockIdx.x, t = threadIdx.x;
-  const float lw = ln_w[c];
+  // a block = 32 channels x 8 row lanes of [Hd, C]: every load is a 128-byte run of a row (one block per channel read its column
+  // with a stride of C floats: 10 us per launch, 15 launches per step)
+  __shared__ float red[2][8][32];
+  __shared__ float dsum[256];
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  const int c = blockIdx.x * 32 + tx;
   float sw = 0.f, sb = 0.f;
-  for (int j = t; j < Hd; j += 256) {
-    const float w = round_bf16(w1[static_cast<long>(j) * C + c]);
-    sw = fmaf(w, dw1[static_cast<long>(j) * C + c], sw);
-    sb = fmaf(w, db1[j], sb);
+  if (c < C) {
+    for (int j = ty; j < Hd; j += 8) {
+      const float w = round_bf16(w1[static_cast<long>(j) * C + c]);
+      sw = fmaf(w, dw1[static_cast<long>(j) * C + c], sw);
+      sb = fmaf(w, db1[j], sb);
+    }
   }
-  if (lw == 0.f) {
-    sw = 0.f;
+  red[0][ty][tx] = sw; red[1][ty][tx] = sb;
+  __syncthreads();
+  if (ty == 0) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { sw += red[0][r][tx]; sb += red[1][r][tx]; }     // fixed order
+    red[0][0][tx] = sw; red[1][0][tx] = sb;
+  }
+  __syncthreads();
+  // channels whose ln_w is exactly zero (wave-uniform loop over the block's 32 channels; none in practice): the direct sum by all threads
+  for (int k = 0; k < 32; ++k) {
+    const int ck = blockIdx.x * 32 + k;
+    if (ck >= C || ln_w[ck] != 0.f) continue;
+    float sd = 0.f;
     for (long m = t; m < M; m += 256) {
-      const float xh = (__uint_as_float(static_cast<uint32_t>(u[m * C + c]) << 16) - mean[m]) * rstd[m];
+      const float xh = (__uint_as_float(static_cast<uint32_t>(u[m * C + ck]) << 16) - mean[m]) * rstd[m];
       float dav;
       if (da) {
-        dav = __uint_as_float(static_cast<uint32_t>(da[m * C + c]) << 16);
+        dav = __uint_as_float(static_cast<uint32_t>(da[m * C + ck]) << 16);
       } else {                                           // da[m, c] = sum_j dHpre[m, j] W1[j, c] from the CNX_TN_ACC tiles (block_dgamma_kernel)
         const uint16_t* tile_row = dhpt + (m / 32) * (static_cast<long>(Hd) / 32) * 1024 + (m % 32) * 32;
         dav = 0.f;
         for (int j = 0; j < Hd; ++j) {
           const int n = j % 32;
           const uint16_t dv = tile_row[static_cast<long>(j / 32) * 1024 + 16 * ((n / 4) % 2) + 4 * (n / 8) + (n % 4)];
-          dav = fmaf(__uint_as_float(static_cast<uint32_t>(dv) << 16), round_bf16(w1[static_cast<long>(j) * C + c]), dav);
+          dav = fmaf(__uint_as_float(static_cast<uint32_t>(dv) << 16), round_bf16(w1[static_cast<long>(j) * C + ck]), dav);
         }
       }
-      sw = fmaf(dav, xh, sw);
+      sd = fmaf(dav, xh, sd);
     }
-  }
-  red[0][t] = sw; red[1][t] = sb;
-  __syncthreads();
-#pragma unroll
-  for (int w = 128; w > 0; w >>= 1) {
-    if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
+    dsum[t] = sd;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) dsum[t] += dsum[t + w];
+      __syncthreads();
+    }
+    if (t == 0) red[0][0][k] = dsum[0];
     __syncthreads();
   }
-  if (t == 0) {
-    dlb[c] = red[1][0];
-    dlw[c] = lw != 0.f ? (red[0][0] - ln_b[c] * red[1][0]) / lw : red[0][0];
+  if (ty == 0 && c < C) {
+    const float lw = ln_w[c], b = red[1][0][tx], w = red[0][0][tx];
+    dlb[c] = b;
+    dlw[c] = lw != 0.f ? (w - ln_b[c] * b) / lw : w;
   }
 }
 
@@ -2443,7 +2461,7 @@ int cnx_block_dln(const float* w1, const float* dw1, const float* db1, const flo
   if (M < 0 || C <= 0 || Hd <= 0) return APGD_ERR_SIZE;
   if (!w1 || !dw1 || !db1 || !ln_w || !ln_b || (!da && !dhpre_tiles) || !u || !mean || !rstd || !dlw || !dlb) return APGD_ERR_NULL;
   if (!da && (M % 32 != 0 || Hd % 32 != 0)) return APGD_ERR_ARG;
-  hipLaunchKernelGGL(block_dln_kernel, dim3(C), dim3(256), 0, as_stream(stream), w1, dw1, db1, ln_w, ln_b, static_cast<const uint16_t*>(da),
+  hipLaunchKernelGGL(block_dln_kernel, dim3((C + 31) / 32), dim3(256), 0, as_stream(stream), w1, dw1, db1, ln_w, ln_b, static_cast<const uint16_t*>(da),
                      static_cast<const uint16_t*>(dhpre_tiles), static_cast<const uint16_t*>(u), mean, rstd, dlw, dlb, static_cast<long>(M), C, Hd);
   return launch_status();
 }
