@@ -37,3 +37,15 @@ for M, N1, N2 in shapes:
     mb = M * (N1 + N2) * 2 / 1e6
     print(f"M={M:7d} N1={N1:5d} N2={N2:5d}: cnx_gemm_tn {own:7.1f} us ({gf / own * 1e3:6.0f} TFLOP/s, operands {mb / own:5.2f} TB/s, "
           f"splits x partial {ws.numel() * 4 / 1e6:6.1f} MB) | library bmm + sum {ref:7.1f} us | rel diff {err:.1e}", flush=True)
+
+# the tile-layout forms of the training pass (cnx_gemm_tn_ex: one operand in CNX_TN_ACC tiles, column sums of A): dW2 = dO^T H and
+# dW1 = dHpre^T LN(u) at the three fused stages
+print("cnx_gemm_tn_ex, one operand in accumulator-order tiles (timing only: the tile operand is random bits of small bf16 values)")
+for M, C in ((802816, 96), (200704, 192), (50176, 384)):
+    rows = torch.randn(M, C, device="cuda").to(torch.bfloat16)
+    tiles = (torch.randn(M * 4 * C, device="cuda") * 0.1).to(torch.bfloat16)
+    for name, a, lda, la, b, ldb, lb, N1, N2 in (("dW2 = dO^T H  ", rows, C, 0, tiles, 0, 1, C, 4 * C), ("dW1 = dHpre^T a", tiles, 0, 1, rows, C, 0, 4 * C, C)):
+        D = torch.empty(N1, N2, device="cuda"); cs = torch.empty(N1, device="cuda")
+        ws = torch.empty(max(4, lib.cnx_gemm_tn_ws_floats(M, N1, N2)), device="cuda")
+        us = t(lambda: lib.cnx_gemm_tn_ex(a.data_ptr(), lda, la, b.data_ptr(), ldb, lb, D.data_ptr(), cs.data_ptr(), ws.data_ptr(), M, N1, N2, S))
+        print(f"M={M:7d} C={C:4d} {name}: {us:7.1f} us (operands {M * 5 * C * 2 / 1e6 / us:5.2f} TB/s)", flush=True)
