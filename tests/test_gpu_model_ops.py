@@ -108,7 +108,9 @@ def _dwconv_case(R, lib, N, C, H, W, xdt, odt):
     close(db, gb, 1e-4, 1e-4 * float(gb.abs().max()) + 1e-5)
 
 
-@pytest.mark.parametrize("N,C,H,W", [(128, 128, 80, 80), (128, 768, 10, 10), (64, 64, 24, 64), (96, 192, 32, 32)])
+@pytest.mark.parametrize("N,C,H,W", [(128, 128, 80, 80), (128, 768, 10, 10), (64, 64, 24, 64), (96, 192, 32, 32), (128, 96, 24, 64), (96, 96, 32, 35),
+                                     (64, 160, 40, 22)])
+# (the last three: 32-channel wavefronts with the shared column halo - a ragged last strip, an odd strip count = an idle half-wavefront)
 def test_dwconv_dma_ragged_fp32_stores_under_load(R, N, C, H, W):
     """bf16 in, fp32 out, no add operand, widths with W % 7 in 1..4, the whole chip busy: the second 16-byte store group of the
     ragged last strip has no active lane in some wavefronts; the kernel must still issue a constant number of VMEM instructions
