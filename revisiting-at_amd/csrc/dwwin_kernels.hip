@@ -45,9 +45,9 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
 }
 
 // compile-time ablations of the forward / input-gradient kernel (measurement builds only: `make EXTRA=-DDW_ABL=n`, profiles/r05_dw.md):
-// 1 = no dot products of filter rows 0..5, 2 = no row / add-row DMA in the steps, 4 = no output staging and no stores,
-// 8 = every store puts 1 KiB into a contiguous per-wavefront stream, 16 = every row load fetches 1 KiB of a contiguous per-wavefront stream,
-// 32 = the row loads go to registers (buffer_load_dwordx4, nobody reads them) instead of LDS        (8 - 32: wrong results, timing only)
+// 1 = no dot products of filter rows 0..5, 2 = no row / add-row DMA in the steps, 4 = no output staging and no stores
+// (the address-pattern variants of profiles/r05_dw.md section 4 - contiguous stores / loads, loads into registers - were timing-only
+//  builds with wrong results; they are in the history of this file, not in it)
 #ifndef DW_ABL
 #define DW_ABL 0
 #endif
@@ -307,18 +307,6 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
   auto dma_row = [&](int slot, int hrow) {
     const uint32_t dst = ring_w + static_cast<uint32_t>(slot) * SLOT;
     const long grow = n * H + hrow;
-    if (DW_ABL & (16 | 32)) {
-      const uint32_t total = tensor_elems * static_cast<uint32_t>(sizeof(TI));
-#pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        uint32_t so, vo;
-        if (DW_ABL & 16) { so = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>((((item * H + hrow) * NR + k) * 1024) % (total - 1024u)) & ~15u); vo = static_cast<uint32_t>(lane) * 16u; }
-        else { so = (static_cast<uint32_t>(static_cast<long>(img_elem) + hrow * rs + max(goff, 0L)) + static_cast<uint32_t>(k * CPI * C)) * static_cast<uint32_t>(sizeof(TI)); vo = k == NR - 1 ? vw_in_l : vw_in; }
-        if (DW_ABL & 32) { u32x4_t t; asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(t) : "v"(vo), "s"(rx), "s"(so) : "memory"); }
-        else dma_lds16(dst + k * 1024u, vo, rx, so);
-      }
-      return;
-    }
     if (grow == 0 || grow == last_row) {                                  // (wave-uniform, rare) per-lane offsets clamped into the row:
       const int row0 = static_cast<int>(img_elem) + hrow * static_cast<int>(rs);   // what a clamped lane fetches belongs to a column outside
       const int g0 = static_cast<int>(goff);                                        // the image, which the pair masks zero anyway
@@ -485,10 +473,7 @@ void dwconv7x7_dma_kernel(const WinArgs a) {
            strip, second 16-byte group) would not be issued and the counted vmcnt waits would run two instructions short - the   \
            wave-uniform test keeps the number of VMEM instructions per step independent of EXEC */                               \
         if (__builtin_amdgcn_ballot_w64(st_ok) != 0ull) {                                                          \
-          if (DW_ABL & 8)                                                                                          \
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, static_cast<uint32_t>(lane) * 16u,                     \
-                static_cast<uint32_t>((((item * H + h) * NSO + k) * 1024) % (tensor_elems * static_cast<uint32_t>(sizeof(TO)) - 1024u)) & ~15u, 0); \
-          else if (st_ok)                                                                                          \
+          if (st_ok)                                                                                               \
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, vw_o,                                                  \
                 (out_base + static_cast<uint32_t>(h * rs) + static_cast<uint32_t>(k * CPIO) * static_cast<uint32_t>(C)) * static_cast<uint32_t>(sizeof(TO)), 0); \
         } else {                                                                                                   \
