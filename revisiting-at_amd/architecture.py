@@ -256,7 +256,7 @@ class _Head(nn.Module):
         self.fc = nn.Linear(dim, num_classes)
 
     def forward(self, x):
-        x = x.mean((-2, -1), keepdim=True)           # global_pool
+        x = ops.global_pool(x)                       # global_pool
         h = self.norm(x).flatten(1)
         if (ops._ATTACK_PASS and h.is_cuda and torch.is_autocast_enabled()
                 and torch.get_autocast_dtype("cuda") == torch.bfloat16):

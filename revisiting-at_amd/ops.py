@@ -201,6 +201,37 @@ def _f32(p):
     return p if p.dtype == torch.float32 else p.float()
 
 
+# ------------------------------------------------------------------------------ global average pool over channels-last rows
+class _GlobalPoolRows(torch.autograd.Function):
+    """``x.mean((-2, -1), keepdim=True)`` (the head's global pool, timm ``SelectAdaptivePool2d('avg')``) of an NCHW-shaped view of
+    channels-last rows.  autograd's own backward materialises the gradient NCHW-contiguous ([N, C, H, W] / HW) and the last block's
+    backward then copies it into rows: two strided element-wise kernels (55 us each at 7 x 7 x 768, batch 256).  Here the gradient is
+    written once, in rows."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        ctx.shape = (N, C, H, W)
+        rows = x.permute(0, 2, 3, 1)                                         # [N, H, W, C], contiguous by the caller's check
+        return rows.reshape(N, H * W, C).mean(1).view(N, C, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.shape
+        gr = (g.reshape(N, 1, C) * (1.0 / (H * W))).expand(N, H * W, C).contiguous()
+        return gr.view(N, H, W, C).permute(0, 3, 1, 2)
+
+
+_POOL_ROWS = os.environ.get("APGD_POOL_ROWS", "1") != "0"
+
+
+def global_pool(x):
+    """[N, C, H, W] -> [N, C, 1, 1] mean over the map."""
+    if _POOL_ROWS and MODE != "eager" and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.permute(0, 2, 3, 1).is_contiguous():
+        return _GlobalPoolRows.apply(x)
+    return x.mean((-2, -1), keepdim=True)
+
+
 # ------------------------------------------------------------------------------ LayerNorm (+GELU) over rows
 class _LayerNormRows(torch.autograd.Function):
     """y = [GELU](LN(x)) over the last dim of a contiguous [..., C] tensor."""
