@@ -1407,3 +1407,21 @@ def test_eval_attack_on_the_hip_model_agrees_with_the_library_composition(R, mon
     same = (xa_h == xa_e).float().mean().item()
     assert same > 0.8, same                                     # sign flips of near-zero gradients compound over the iterations
     assert float((outs["hip"][3] - x).abs().max()) <= 4 / 255 + 1e-6
+
+
+@pytest.mark.parametrize("N,C,H,W", [(4, 768, 7, 7), (3, 96, 5, 9), (2, 1536, 10, 10)])
+def test_global_pool_on_channels_last_rows_equals_the_mean_over_the_map(R, N, C, H, W):
+    """ops.global_pool (the head's pool, ``x.mean((-2, -1), keepdim=True)``): same value, same gradient - written once, in rows - for
+    an NCHW-shaped view of channels-last rows; any other layout takes torch's mean."""
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+    rows = torch.randn(N, H, W, C, device="cuda", generator=g)
+    x = rows.permute(0, 3, 1, 2).requires_grad_()
+    y = R.ops.global_pool(x)
+    ref = x.mean((-2, -1), keepdim=True)
+    assert y.shape == ref.shape and float((y - ref).abs().max()) <= 1e-6
+    gy = torch.randn_like(ref)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    (gr,) = torch.autograd.grad(ref, x, gy)
+    assert float((gx - gr).abs().max()) <= 1e-7 and gx.permute(0, 2, 3, 1).is_contiguous()
+    xc = torch.randn(N, C, H, W, device="cuda", generator=g)                   # NCHW-contiguous: torch's path
+    assert torch.equal(R.ops.global_pool(xc), xc.mean((-2, -1), keepdim=True))

@@ -19,15 +19,11 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     tr.step(x, y)
     torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if ev.name not in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::sum", "aten::mean", "aten::mul", "aten::add_", "aten::clone", "aten::contiguous"):
-        continue
+rows = []
+for ev in prof.key_averages(group_by_input_shape=True):
     dt = getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0)
-    if not dt:
-        continue
-    site = next((s for s in (ev.stack or []) if "revisiting" in s and "_lib.py" not in s), (ev.stack or ["?"])[0] if ev.stack else "?")
-    agg[(ev.name, str(ev.input_shapes)[:80], site[-90:])][0] += 1
-    agg[(ev.name, str(ev.input_shapes)[:80], site[-90:])][1] += dt
-for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    print(f"{t:9.1f} us {c:4d}  {k[0]:14s} {k[1]:80s} {k[2]}")
+    sdt = getattr(ev, "self_device_time_total", 0) or getattr(ev, "self_cuda_time_total", 0)
+    if ev.key.startswith("aten::") and sdt > 0:
+        rows.append((sdt, ev.count, ev.key, str(ev.input_shapes)[:110]))
+for sdt, c, k, sh in sorted(rows, reverse=True)[:45]:
+    print(f"{sdt:9.1f} us {c:4d}  {k:28s} {sh}")
