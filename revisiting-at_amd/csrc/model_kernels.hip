@@ -1564,40 +1564,56 @@ __global__ __launch_bounds__(256) void block_dgamma_kernel(const float* __restri
 //     d(ln_b)[c] = sum_m da[m,c]           = sum_j W1[j,c] d(b1)[j]
 //     d(ln_w)[c] = sum_m da[m,c] xh[m,c]   = (sum_j W1[j,c] dW1[j,c] - ln_b[c] d(ln_b)[c]) / ln_w[c]
 // (W1 rounded to bf16 as the GEMMs read it).  A channel whose ln_w is exactly zero takes the direct sum over da, u, mean, rstd.
-__global__ __launch_bounds__(256) void block_dln_kernel(const float* __restrict__ w1, const float* __restrict__ dw1,
-                                                        const float* __restrict__ db1, const float* __restrict__ ln_w,
-                                                        const float* __restrict__ ln_b, const uint16_t* __restrict__ da,
-                                                        const uint16_t* __restrict__ dhpt, const uint16_t* __restrict__ u, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, float* __restrict__ dlw, float* __restrict__ dlb,
-                                                        long M, int C, int Hd) {
-  // a block = 32 channels x 8 row lanes of [Hd, C]: every load is a 128-byte run of a row (one block per channel read its column
-  // with a stride of C floats: 10 us per launch, 15 launches per step)
-  __shared__ float red[2][8][32];
-  __shared__ float dsum[256];
+__global__ __launch_bounds__(1024) void block_dln_kernel(const float* __restrict__ w1, const float* __restrict__ dw1,
+                                                         const float* __restrict__ db1, const float* __restrict__ ln_w,
+                                                         const float* __restrict__ ln_b, const uint16_t* __restrict__ da,
+                                                         const uint16_t* __restrict__ dhpt, const uint16_t* __restrict__ u, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ dlw, float* __restrict__ dlb,
+                                                         long M, int C, int Hd) {
+  // a block = 32 channels x 32 row lanes of [Hd, C]: every load is a 128-byte run of a row, four rows per lane in flight (a launch is
+  // a handful of blocks: what it costs is the length of a lane's chain of load latencies - 8 row lanes and one row at a time ran
+  // 117 us, one block per channel with its column read at a stride of C floats 10 us)
+  constexpr int RL = 32;
+  __shared__ float red[2][RL][32];
+  __shared__ float dsum[1024];
+  __shared__ unsigned zmask;
   const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
   const int c = blockIdx.x * 32 + tx;
   float sw = 0.f, sb = 0.f;
   if (c < C) {
-    for (int j = ty; j < Hd; j += 8) {
-      const float w = round_bf16(w1[static_cast<long>(j) * C + c]);
-      sw = fmaf(w, dw1[static_cast<long>(j) * C + c], sw);
-      sb = fmaf(w, db1[j], sb);
+    int j = ty;
+    for (; j + 3 * RL < Hd; j += 4 * RL) {
+      float w[4], d[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        w[k] = w1[static_cast<long>(j + k * RL) * C + c]; d[k] = dw1[static_cast<long>(j + k * RL) * C + c]; b[k] = db1[j + k * RL];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float wr = round_bf16(w[k]); sw = fmaf(wr, d[k], sw); sb = fmaf(wr, b[k], sb); }
+    }
+    for (; j < Hd; j += RL) {
+      const float wr = round_bf16(w1[static_cast<long>(j) * C + c]);
+      sw = fmaf(wr, dw1[static_cast<long>(j) * C + c], sw);
+      sb = fmaf(wr, db1[j], sb);
     }
   }
   red[0][ty][tx] = sw; red[1][ty][tx] = sb;
+  if (t < 64) {                                          // channels whose ln_w is exactly zero (none in practice): one ballot finds them
+    const unsigned long long zb = __ballot(c < C && ln_w[c < C ? c : 0] == 0.f);
+    if (t == 0) zmask = static_cast<unsigned>(zb & 0xffffffffull);
+  }
   __syncthreads();
   if (ty == 0) {
 #pragma unroll
-    for (int r = 1; r < 8; ++r) { sw += red[0][r][tx]; sb += red[1][r][tx]; }     // fixed order
+    for (int r = 1; r < RL; ++r) { sw += red[0][r][tx]; sb += red[1][r][tx]; }    // fixed order
     red[0][0][tx] = sw; red[1][0][tx] = sb;
   }
   __syncthreads();
-  // channels whose ln_w is exactly zero (wave-uniform loop over the block's 32 channels; none in practice): the direct sum by all threads
-  for (int k = 0; k < 32; ++k) {
+  for (unsigned mk = zmask; mk != 0u; mk &= mk - 1u) {   // ... and take the direct sum, all threads per channel
+    const int k = __builtin_ctz(mk);
     const int ck = blockIdx.x * 32 + k;
-    if (ck >= C || ln_w[ck] != 0.f) continue;
     float sd = 0.f;
-    for (long m = t; m < M; m += 256) {
+    for (long m = t; m < M; m += 1024) {
       const float xh = (__uint_as_float(static_cast<uint32_t>(u[m * C + ck]) << 16) - mean[m]) * rstd[m];
       float dav;
       if (da) {
@@ -1615,7 +1631,7 @@ __global__ __launch_bounds__(256) void block_dln_kernel(const float* __restrict_
     }
     dsum[t] = sd;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
       if (t < w) dsum[t] += dsum[t + w];
       __syncthreads();
     }
@@ -2461,7 +2477,7 @@ int cnx_block_dln(const float* w1, const float* dw1, const float* db1, const flo
   if (M < 0 || C <= 0 || Hd <= 0) return APGD_ERR_SIZE;
   if (!w1 || !dw1 || !db1 || !ln_w || !ln_b || (!da && !dhpre_tiles) || !u || !mean || !rstd || !dlw || !dlb) return APGD_ERR_NULL;
   if (!da && (M % 32 != 0 || Hd % 32 != 0)) return APGD_ERR_ARG;
-  hipLaunchKernelGGL(block_dln_kernel, dim3((C + 31) / 32), dim3(256), 0, as_stream(stream), w1, dw1, db1, ln_w, ln_b, static_cast<const uint16_t*>(da),
+  hipLaunchKernelGGL(block_dln_kernel, dim3((C + 31) / 32), dim3(1024), 0, as_stream(stream), w1, dw1, db1, ln_w, ln_b, static_cast<const uint16_t*>(da),
                      static_cast<const uint16_t*>(dhpre_tiles), static_cast<const uint16_t*>(u), mean, rstd, dlw, dlb, static_cast<long>(M), C, Hd);
   return launch_status();
 }
