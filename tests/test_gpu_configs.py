@@ -570,3 +570,29 @@ def test_cfg5_standard_evaluation_on_convnext_base_replays_through_the_oracle(R,
     note("cfg5_assembled", attacks=len(calls), robust=int(robust.sum()), clean_correct=int(st["clean_correct"]), eps=eps,
          survivors_after_ce=int(len(calls[1]["y"])), targeted_batches=[int(len(c["y"])) for c in calls[1:]],
          broken_by_targeted=[int((~c["out"][1]).sum()) for c in calls[1:]])
+
+
+def test_at_train_step_is_bit_reproducible_run_to_run(R):
+    """Two trainers from the same seed, the same four batches (two eager warm-up steps, two replayed ones): every parameter bit-identical
+    afterwards.  Every partial sum of the step has a fixed order (cnx_gemm_tn's splits, the depthwise / LayerNorm / column-sum partials, the
+    gradient identities' trees); nothing accumulates through atomics."""
+    dev = torch.device("cuda")
+
+    def run():
+        torch.manual_seed(0)
+        model = R.get_new_model("convnext_tiny", pretrained=False, not_original=True, img_size=224)
+        tr = R.ATTrainStep(model, "convnext_tiny", R.AdvConfig(attack="apgd", norm="Linf", eps=4 / 255, n_iter=2, graph=1), dev, lr=1e-3,
+                           amp_dtype=torch.bfloat16, ema=True)
+        g = torch.Generator(device=dev).manual_seed(7)
+        losses = []
+        for _ in range(4):
+            x = torch.rand(16, 3, 224, 224, device=dev, generator=g)
+            y = torch.randint(0, 1000, (16,), device=dev, generator=g)
+            losses.append(float(tr.step(x, y)))
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    la, pa = run()
+    lb, pb = run()
+    assert la == lb and all(np.isfinite(la))
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
