@@ -64,6 +64,9 @@ def parse():
                    "backward, all-reduces between the graph segments) - the path every N > 1 rank takes; on one GPU the collectives "
                    "are no-ops, so N = 1 and N > 1 run the same code.  Default: 1 when --gpus > 1, else 0 (one backward call, one graph)")
     p.add_argument("--grad-sync", default=None, choices=("flat", "ddp"), help="N > 1: 'flat' (default) or torch DDP (eager training pass)")
+    p.add_argument("--ab-steps", type=int, default=10, help="steps per leg of the interleaved kernel-set A/B behind the main measurement "
+                   "(extra.ab: [default, round4, default, round4] in this process, on this box; ops.KERNEL_SETS); 0: skip.  Single-GPU "
+                   "headline runs only")
     p.add_argument("--strict", action="store_true", help="exit non-zero if any informational measurement (other_configs, model_kernel_"
                    "rooflines) failed; the failures are always visible as {'error': ...} entries and in extra.errors")
     return p.parse_args()
@@ -215,13 +218,30 @@ def other_configs(R, dev, graph=1, which=("cfg3", "cfg4", "cfg5")):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            tr.step(x, y)
+            loss = tr.step(x, y)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        del tr, model
+        # what the timed steps computed is checked, not only timed: the last step's loss is finite, and the attack of one more
+        # (untimed) call hands the training pass a batch inside the eps-ball around x and inside [0, 1] (autopgd_train_clean.py:224-226)
+        eps = 4 / 255
+        z = tr._perturbed(x, y)
+        dev_max = float((z.float() - x).abs().max())
+        lo, hi = float(z.min()), float(z.max())
+        res_d = {"img_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "per_gpu_batch": batch, "res": res,
+                 "n_iter": n_iter, "steps": steps, "loss": round(float(loss), 4), "linf_dist": round(dev_max, 6),
+                 "x_best_range": [round(lo, 6), round(hi, 6)]}
+        bad = []
+        if not torch.isfinite(loss).item():
+            bad.append("non-finite loss")
+        if not dev_max <= eps * (1 + 1e-5) + 1e-7:
+            bad.append(f"|x_best - x|_inf = {dev_max:.6f} > eps = {eps:.6f}")
+        if lo < 0.0 or hi > 1.0:
+            bad.append(f"x_best leaves [0, 1]: [{lo}, {hi}]")
+        if bad:
+            res_d["error"] = "; ".join(bad)
+        del tr, model, z
         torch.cuda.empty_cache()
-        return {"img_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "per_gpu_batch": batch, "res": res,
-                "n_iter": n_iter, "steps": steps}
+        return res_d
 
     def note(msg):
         print(f"[bench other_configs +{time.perf_counter() - t_start:.0f}s] {msg}", file=sys.stderr, flush=True)
@@ -317,6 +337,65 @@ def cfg5_eps_with_survivors(R, model, x, y, gen, n_iter=20):
         else:
             hi = eps
     return eps
+
+
+def ab_leg(R, args, dev, x, y, n_warm, order=("default", "round4", "default", "round4")):
+    """The round's kernel work against the round-4 kernel set, in THIS process on THIS box (the boxes of the pool sit at different
+    operating points - 1200 W / 2.2 GHz or 1010 W / 2.39 GHz - and differ by more than a round's kernel work): for each entry of
+    `order` select the kernel set (ops.kernel_set - module switches + cnx_runtime_switch), drop every captured graph, build a fresh
+    seeded model + ATTrainStep, run the same warm-up as the main measurement (captures included) and time `--ab-steps` steps with the
+    same bracket.  Reports the per-leg times, power and clock, the medians, and shader cycles per step (ms x MHz), which takes the
+    box's clock out of the comparison."""
+    legs = []
+    start = R.ops.kernel_set("default")
+    try:
+        for name in order:
+            R.ops.kernel_set(name)
+            R.graphed.reset()
+            torch.cuda.empty_cache()
+            torch.manual_seed(0)
+            model = R.get_new_model(args.arch, pretrained=False, not_original=True)
+            tr = R.ATTrainStep(model, args.arch, R.AdvConfig(attack="apgd", norm="Linf", eps=args.eps, n_iter=args.n_iter, graph=args.graph),
+                               dev, lr=1e-3, channels_last=True, amp_dtype=torch.bfloat16, ema=True,
+                               mixup=object() if args.soft_labels else None, soft_targets=args.soft_labels, gemm_table=True,
+                               graph_train=bool(args.graph) and bool(args.graph_train))
+            for _ in range(n_warm):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            power = PowerSampler(dev.index or 0)
+            power.start()
+            t0 = time.perf_counter()
+            for _ in range(args.ab_steps):
+                loss = tr.step(x, y)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / args.ab_steps * 1e3
+            pw = power.stop() or {}
+            captured = sum(v is not None for v in tr._tg.values())
+            leg = {"set": name, "ms_per_step": round(ms, 3), "avg_W": pw.get("avg_W"), "avg_sclk_MHz": pw.get("avg_sclk_MHz"),
+                   "mcycles_per_step": round(ms * pw["avg_sclk_MHz"] * 1e-3, 2) if pw.get("avg_sclk_MHz") else None,
+                   "loss": round(float(loss), 4), "train_graph_captured": captured}
+            if not torch.isfinite(loss).item():
+                leg["error"] = "non-finite loss"
+            legs.append(leg)
+            del tr, model
+    finally:
+        R.ops.kernel_set(start)
+        R.graphed.reset()
+        torch.cuda.empty_cache()
+
+    def med(key, name):
+        v = sorted(l[key] for l in legs if l["set"] == name and l.get(key) is not None)
+        return v[len(v) // 2] if len(v) % 2 else (round(0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), 3) if v else None)
+    out = {"order": list(order), "steps_per_leg": args.ab_steps, "warmup_per_leg": n_warm, "legs": legs,
+           "default_ms": med("ms_per_step", "default"), "r4_ms": med("ms_per_step", "round4"),
+           "default_mcycles": med("mcycles_per_step", "default"), "r4_mcycles": med("mcycles_per_step", "round4"),
+           "sclk_MHz": med("avg_sclk_MHz", "default"), "W": med("avg_W", "default"),
+           "round4_set": "ops.KERNEL_SETS['round4']: library weight gradients (GEMM + ConvStem), recomputing training backward, per-channel "
+                         "gradient passes, separate tracking pass, single-wavefront C = 256 / 384 forward, head pool on NCHW, round-4 "
+                         "depthwise strips - the end-of-round-4 kernel selection inside today's library"}
+    if out["default_ms"] and out["r4_ms"]:
+        out["r4_over_default"] = round(out["r4_ms"] / out["default_ms"], 4)
+    return out
 
 
 def spawn_ranks(args, child_argv=None, ndev=None) -> int:
@@ -735,6 +814,18 @@ def main():
                 extra["model_kernel_rooflines"] = model_kernel_rooflines(R, dev, B)
             except Exception as e:                       # informational: the line still prints; --strict fails the run
                 extra["model_kernel_rooflines"] = {"error": repr(e)}
+        if power_stats and power_stats.get("avg_sclk_MHz"):
+            # shader cycles per step of the contract's window: the box's operating point taken out of ms_per_step
+            extra["mcycles_per_step"] = round(dt / args.steps * 1e3 * power_stats["avg_sclk_MHz"] * 1e-3, 2)
+        if rank == 0 and world == 1 and args.ab_steps > 0 and R.ops.MODE != "eager" and args.arch.startswith("convnext") and not args.attack_only:
+            trainer = model = base = None                    # the headline model, its optimizer state and graphs go first
+            R.graphed.reset()
+            torch.cuda.empty_cache()
+            try:
+                extra["ab"] = ab_leg(R, args, dev, x, y, n_warm)
+            except Exception as e:                           # informational: the line still prints; --strict fails the run
+                extra["ab"] = {"error": repr(e)}
+            print(f"[bench ab] {extra['ab']}", file=sys.stderr, flush=True)
         if (rank == 0 and world == 1 and args.arch == "convnext_tiny" and R.ops.MODE != "eager" and not args.no_other_configs
                 and (args.other_configs is not None or not args.no_cpu_baseline)):
             del trainer, model, base, x, y

@@ -37,6 +37,17 @@ int cnx_dwconv7x7_nhwc(const void* x, int x_dtype, const float* w49c, const floa
  * Returns the previous setting; a negative `policy` only queries.  Process-wide, not synchronised: set it before launching. */
 int cnx_dwconv7x7_win_policy(int policy);
 
+/* Process-wide kernel-selection switches that a RUNNING process may flip between launches (bench.py's interleaved A/B leg times the
+ * default tree against the round-4 kernel set on one box, in one process; the environment variables named below only set the
+ * start-up values).  Returns the previous value; a negative `value` only queries; an unknown `which` returns -1.  Not synchronised:
+ * set it between launches, and drop captured hipGraphs that contain the kernels concerned.  No switch changes results beyond the
+ * summation order of the kernels it selects.
+ *   CNX_SWITCH_BLK2_WIDTHS     widths served by the wavefront-pair forward blk2_fwd_kernel: bit 0 = C 256, bit 1 = C 384 (APGD_BLK2)
+ *   CNX_SWITCH_DW_SHARED_HALO  shared column halo of the 32-channel sliding-window depthwise wavefronts, 0 / 1 (APGD_DW_SH) */
+#define CNX_SWITCH_BLK2_WIDTHS 0
+#define CNX_SWITCH_DW_SHARED_HALO 1
+int cnx_runtime_switch(int32_t which, int32_t value);
+
 /* Filter / bias gradient of the same convolution:
  *   dw49c[(kh*7+kw)*C + c] = sum_{n,h,w} dy[n,h,w,c] * x[n,h+kh-3,w+kw-3,c];  dbias[c] = sum dy.
  * Deterministic two-stage reduction; ws is scratch of cnx_dwconv7x7_wgrad_ws_floats(C) floats.  With a bf16 dy (the

@@ -40,6 +40,7 @@ PROTOTYPES = {
     # include/convnext_hip.h
     "cnx_dwconv7x7_nhwc": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, C.c_int, _i64, _i32, _i32, _i32, _i32, _p]),
     "cnx_dwconv7x7_win_policy": (C.c_int, [C.c_int]),
+    "cnx_runtime_switch": (C.c_int, [_i32, _i32]),
     "cnx_dwconv7x7_wgrad_ws_floats": (C.c_int64, [_i32]),
     "cnx_dwconv7x7_wgrad_nhwc": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_block_dgamma": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _p]),

@@ -32,6 +32,7 @@
 #include "apgd_hip.h"
 #include "convnext_hip.h"
 #include "mlp_internal.h"
+#include "dw_internal.h"
 
 // Timing experiments (APGD_BLK_DBG) are compiled in only with -DMLP_ABLATE=1: tested at run time inside the hidden loop they
 // become branches that split the scheduling region (see mlp_kernels.hip).
@@ -1084,12 +1085,19 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
 
 // Which forward kernel serves width C?  Measured (tools/mlp_bench.py, batch 256, profiles/r05_fused_mlp.md): the wavefront-pair kernel is
 // ahead of the single-wavefront one at C = 384 and C = 256 in all three forms (no workspace / Hpre / training outputs).  APGD_BLK2
-// overrides: a list of widths ("" = the single-wavefront kernel everywhere).
+// sets the start-up value: a list of widths ("" = the single-wavefront kernel everywhere); cnx_runtime_switch(CNX_SWITCH_BLK2_WIDTHS)
+// changes it in a running process (bench.py's interleaved A/B leg).  Bit 0: C = 256, bit 1: C = 384.
+int& blk2_widths() {
+  static int m = [] {
+    const char* env = getenv("APGD_BLK2");
+    return env ? ((strstr(env, "256") ? 1 : 0) | (strstr(env, "384") ? 2 : 0)) : 3;
+  }();
+  return m;
+}
 inline bool use_blk2(int C, bool ws) {
-  static const char* env = getenv("APGD_BLK2");
-  static const bool w256 = env ? strstr(env, "256") != nullptr : true, w384 = env ? strstr(env, "384") != nullptr : true;
   (void)ws;
-  return (C == 256 && w256) || (C == 384 && w384);
+  const int m = blk2_widths();
+  return (C == 256 && (m & 1)) || (C == 384 && (m & 2));
 }
 
 template <int C>
@@ -1829,6 +1837,19 @@ int launch_blk_bwd_hpre(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
 }  // namespace
 
 extern "C" {
+
+int cnx_runtime_switch(int32_t which, int32_t value) {
+  switch (which) {
+    case CNX_SWITCH_BLK2_WIDTHS: {
+      int& m = blk2_widths();
+      const int prev = m;
+      if (value >= 0) m = value & 3;
+      return prev;
+    }
+    case CNX_SWITCH_DW_SHARED_HALO: return dw_shared_halo_switch(value);
+    default: return -1;
+  }
+}
 
 int cnx_block_mlp_supported(int32_t C) { return (C == 96 || C == 128 || C == 192 || C == 256 || C == 384) ? 1 : 0; }
 

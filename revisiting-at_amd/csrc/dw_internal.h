@@ -11,3 +11,7 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
 // Filter / bias gradient partials ws[parts][50][C] by the register-window kernel: -> parts (> 0), 0 = shape not supported, < 0 = -(1 + HIP error)
 int dw_win_wgrad_launch(const void* x, int x_dtype, const void* dy, float* ws, int max_parts, int64_t N, int32_t H, int32_t W, int32_t C,
                         hipStream_t s);
+
+// Shared column halo of the 32-channel wavefronts (round 5) on / off; -> the previous setting, a negative value only queries
+// (behind cnx_runtime_switch(CNX_SWITCH_DW_SHARED_HALO, .), block_kernels.hip).
+int dw_shared_halo_switch(int value);

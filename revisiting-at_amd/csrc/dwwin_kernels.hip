@@ -709,6 +709,13 @@ int& win_policy() {
 
 }  // namespace
 
+int dw_shared_halo_switch(int value) {
+  static int sh = !(getenv("APGD_DW_SH") && atoi(getenv("APGD_DW_SH")) == 0) ? 1 : 0;
+  const int prev = sh;
+  if (value >= 0) sh = value ? 1 : 0;
+  return prev;
+}
+
 extern "C" int cnx_dwconv7x7_win_policy(int policy) {
   int& p = win_policy();
   const int prev = p;
@@ -730,8 +737,9 @@ int dw_win_launch(const void* x, int x_dtype, const float* w49c, const float* bi
   WinArgs a;
   a.x = x; a.w49c = w49c; a.bias = bias; a.add = add; a.out = out;
   a.N = static_cast<int>(N); a.H = H; a.W = W; a.C = C; a.flip = flip;
-  // APGD_DW_SH=0: 32-channel wavefronts (C % 64 != 0) load their two strips separately, as in round 4 (measurement; default: shared halo)
-  static const bool sh = !(getenv("APGD_DW_SH") && atoi(getenv("APGD_DW_SH")) == 0);
+  // APGD_DW_SH=0 / cnx_runtime_switch(CNX_SWITCH_DW_SHARED_HALO, 0): 32-channel wavefronts (C % 64 != 0) load their two strips
+  // separately, as in round 4 (measurement; default: shared halo)
+  const bool sh = dw_shared_halo_switch(-1) != 0;
   const int ch = (C % 64 == 0) ? 64 : 32;
   a.n_strips = (W + kT - 1) / kT;
   a.n_sg = (a.n_strips + (64 / ch) - 1) / (64 / ch);

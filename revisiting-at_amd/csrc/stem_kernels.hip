@@ -143,7 +143,6 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
     const int ow = static_cast<int>(pos % OW);
     const long r = pos / OW;
     const int oh = static_cast<int>(r % OH);
-    const float* xn = x + (r / OH) * 3 * static_cast<long>(H) * W;
     // element index of (channel 0, row 2 oh - 1, column 2 ow - 1) of this image: may be negative (first row / column); a quad outside
     // the image or absent is fetched from offset 0xffffffff - beyond the buffer's range, the hardware returns zeros
     const long e0 = (r / OH) * 3 * static_cast<long>(H) * W + static_cast<long>(2 * oh - 1) * W + (2 * ow - 1);

@@ -1800,3 +1800,59 @@ def attention(qkv, num_heads, scale):
     q, k, v = qkv.reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)
     a = ((q @ k.transpose(-2, -1)) * scale).softmax(dim=-1)
     return (a @ v).transpose(1, 2).reshape(B, N, C)
+
+
+# ------------------------------------------------------------------------------ kernel sets (run-time A/B)
+# The kernel-selection switches above are module globals read at call time (their APGD_* variables only set the start-up values), and
+# the two that live in the library (APGD_BLK2, APGD_DW_SH) are behind cnx_runtime_switch: a RUNNING process can put the whole tree on
+# another kernel set, drop its captured graphs and time both on one box - bench.py's interleaved A/B leg (`extra.ab`).
+KERNEL_SETS = {
+    # the tree as shipped
+    "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
+                    blk2=3, pool_rows=True, dw_shared_halo=1),
+    # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_STEM_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
+    # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
+    # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
+    "round4": dict(wgrad="lib", stem_wgrad=False, train_hpre=set(), dgamma=False, dln="pass", fused_tracking=False, blk2=0,
+                   pool_rows=False, dw_shared_halo=0),
+}
+
+
+def kernel_set(name_or_dict):
+    """Select a kernel set in the running process; returns the settings that were in force (a dict ``kernel_set`` accepts).  The caller
+    drops what was captured or cached under the old set (``graphed.reset()``, a fresh ``ATTrainStep``); results stay inside the parity
+    bars either way - the sets differ in kernels and summation order, not in arithmetic."""
+    global _WGRAD_MODE, STEM_WGRAD_HIP, _TRAIN_HPRE_WIDTHS, _DGAMMA_FROM_DW2, _DLN_FROM_DW1, _LN_IN_TRAIN_BWD, _POOL_ROWS
+    from . import apgd as _apgd
+    new = KERNEL_SETS[name_or_dict] if isinstance(name_or_dict, str) else dict(name_or_dict)
+    unknown = set(new) - set(KERNEL_SETS["default"])
+    if unknown:
+        raise ValueError(f"kernel_set: unknown switch(es) {sorted(unknown)}")
+    lib = _lib.load()
+    prev = dict(wgrad=_WGRAD_MODE, stem_wgrad=STEM_WGRAD_HIP, train_hpre=set(_TRAIN_HPRE_WIDTHS), dgamma=_DGAMMA_FROM_DW2,
+                dln="dw1" if _LN_IN_TRAIN_BWD else ("kernel" if _DLN_FROM_DW1 else "pass"), fused_tracking=_apgd.FUSED_TRACKING,
+                blk2=int(lib.cnx_runtime_switch(0, -1)), pool_rows=_POOL_ROWS, dw_shared_halo=int(lib.cnx_runtime_switch(1, -1)))
+    if "wgrad" in new:
+        if new["wgrad"] not in ("hip", "lib"):
+            raise ValueError(f"kernel_set: wgrad={new['wgrad']!r}")
+        _WGRAD_MODE = new["wgrad"]
+    if "stem_wgrad" in new:
+        STEM_WGRAD_HIP = bool(new["stem_wgrad"])
+    if "train_hpre" in new:
+        _TRAIN_HPRE_WIDTHS = {int(v) for v in new["train_hpre"]}
+    if "dgamma" in new:
+        _DGAMMA_FROM_DW2 = bool(new["dgamma"])
+    if "dln" in new:
+        if new["dln"] not in ("dw1", "kernel", "pass"):
+            raise ValueError(f"kernel_set: dln={new['dln']!r}")
+        _DLN_FROM_DW1, _LN_IN_TRAIN_BWD = new["dln"] != "pass", new["dln"] == "dw1"
+    if "fused_tracking" in new:
+        _apgd.FUSED_TRACKING = bool(new["fused_tracking"])
+    if "pool_rows" in new:
+        _POOL_ROWS = bool(new["pool_rows"])
+    if "blk2" in new:
+        lib.cnx_runtime_switch(0, int(new["blk2"]) & 3)
+    if "dw_shared_halo" in new:
+        lib.cnx_runtime_switch(1, 1 if new["dw_shared_halo"] else 0)
+    invalidate_weight_cache()
+    return prev

@@ -144,3 +144,28 @@ def test_evaluation_batch_buckets():
         sizes = {aa_eval._bucket(k, bs) for k in range(1, bs + 1)}
         assert len(sizes) <= 6 and max(sizes) == bs and all(aa_eval._bucket(k, bs) >= k for k in range(1, bs + 1))
     assert aa_eval._bucket(150, 100) == 150                            # (a subset larger than bs cannot happen; it is not truncated)
+
+
+def test_kernel_sets_switch_in_a_running_process_and_restore():
+    """bench.py's A/B leg: the whole kernel selection (module switches + the two inside the library) flips at run time and comes back."""
+    lib = R._lib.load()
+    ops, apgd = R.ops, R.apgd
+    start = ops.kernel_set("default")
+    try:
+        assert lib.cnx_runtime_switch(0, -1) == 3 and lib.cnx_runtime_switch(1, -1) == 1 and lib.cnx_runtime_switch(99, 1) == -1
+        prev = ops.kernel_set("round4")
+        assert prev == ops.KERNEL_SETS["default"]
+        assert (ops._WGRAD_MODE, ops.STEM_WGRAD_HIP, ops._TRAIN_HPRE_WIDTHS) == ("lib", False, set())
+        assert (ops._DGAMMA_FROM_DW2, ops._DLN_FROM_DW1, ops._LN_IN_TRAIN_BWD, ops._POOL_ROWS) == (False, False, False, False)
+        assert apgd.FUSED_TRACKING is False
+        assert lib.cnx_runtime_switch(0, -1) == 0 and lib.cnx_runtime_switch(1, -1) == 0
+        assert ops.kernel_set(prev) == ops.KERNEL_SETS["round4"]
+        assert ops.kernel_set({"dln": "kernel"})["dln"] == "dw1"
+        assert (ops._DLN_FROM_DW1, ops._LN_IN_TRAIN_BWD) == (True, False)
+        with pytest.raises(ValueError):
+            ops.kernel_set({"no_such_switch": 1})
+        with pytest.raises(ValueError):
+            ops.kernel_set({"wgrad": "cuda"})
+    finally:
+        ops.kernel_set(start)
+    assert ops.kernel_set({}) == start
