@@ -158,21 +158,28 @@ int cnx_gelu_bwd_colsum(const void* dh, const void* hpre, void* dhpre, float* db
  *     dgamma[c] = sum_m g[m,c] y2[m,c] = (sum_j bf16(W2[c,j]) dW2[c,j] + b2[c] db2[c]) / gamma[c]
  * w2, dw2 fp32 [C, Hd] (dW2 = dO^T H), b2, db2 (= sum_m dO; both nullable together), gamma fp32 [C].  g (fp32 / bf16 [M, C]) and y2
  * (bf16 [M, C]; or, y2 == NULL, h_tiles = H in the CNX_TN_ACC tiles of the fused kernels, from which y2 is recomputed: M, Hd multiples
- * of 32) are read only for channels whose gamma is exactly 0 (the direct sum).  Replaces cnx_scale_residual_bwd's sums-only mode in the
+ * of 32) are read only for channels with |gamma| < 1e-30 (dO = bf16(g gamma) has flushed: the direct sum; the layer-scale init 1e-6 and
+ * anything a model can hold is served by the identity).  No cancellation guard is needed: the two terms add up to sum_m dO y2 exactly,
+ * so the identity's error is the bf16 rounding of dO, the same size as the reference's own rounding of y2.  Replaces cnx_scale_residual_bwd's sums-only mode in the
  * training pass of the fused blocks, whose forward then has no pre-gamma output to keep. */
 int cnx_block_dgamma(const float* w2, const float* dw2, const float* b2, const float* db2, const float* gamma,
                      const void* g, int g_dtype, const void* y2, const void* h_tiles, float* dgamma,
                      int64_t M, int32_t C, int32_t Hd, void* stream);
 /* The LayerNorm parameter gradients of a block (models/convnext.py:40-41 backward) from the first linear layer's weight gradients:
  *     dlb[c] = sum_m da[m,c] = sum_j bf16(W1[j,c]) db1[j],     dlw[c] = (sum_j bf16(W1[j,c]) dW1[j,c] - ln_b[c] dlb[c]) / ln_w[c]
- * w1, dw1 fp32 [Hd, C] (dW1 = dHpre^T LN(u)), db1 fp32 [Hd].  da (bf16 [M, C], gradient w.r.t. LN(u); or, da == NULL, dhpre_tiles = dHpre
- * in CNX_TN_ACC tiles, from which da is recomputed), u (bf16 [M, C]), mean, rstd [M] are read only for channels whose ln_w is exactly 0
- * (the direct sum).  The LayerNorm backward then needs no partial sums - and rides in the epilogue of the block's backward kernel:
- * cnx_block_mlp_bwd_train_hpre_ln / cnx_block_mlp_bwd_acc_ln = cnx_block_mlp_bwd_train_hpre / cnx_block_mlp_bwd_acc with
- * du = d(loss)/du (the gradient w.r.t. the depthwise-conv output) written where those write da. */
+ * w1, dw1 fp32 [Hd, C] (dW1 = dHpre^T LN(u)), db1 fp32 [Hd].  The dlw identity recovers xh from LN(u) = bf16(xh ln_w + ln_b): its error is
+ * ~2^-9 max(1, |ln_b| / |ln_w|) per channel.  A channel with |ln_b| > 4 |ln_w| (or ln_w == 0, or NaN parameters) is ill-conditioned for
+ * it and gets the DIRECT sum dlw[c] = sum_m da[m,c] xh[m,c] instead, from da (bf16 [M, C], gradient w.r.t. LN(u); or, da == NULL,
+ * dhpre_tiles = dHpre in CNX_TN_ACC tiles, from which da is recomputed for those channels), u (bf16 [M, C]), mean, rstd [M] - which are
+ * read for such channels only.  ws: cnx_block_dln_ws_floats(C) floats for the direct sums (a 256-workgroup pass that leaves at once
+ * when no channel is ill-conditioned, fixed-order partials: deterministic); ws == NULL: the direct sums run serially inside the small
+ * kernel (correct, slow).  The LayerNorm backward then needs no partial sums of its own - and rides in the epilogue of the block's
+ * backward kernel: cnx_block_mlp_bwd_train_hpre_ln / cnx_block_mlp_bwd_acc_ln = cnx_block_mlp_bwd_train_hpre / cnx_block_mlp_bwd_acc
+ * with du = d(loss)/du (the gradient w.r.t. the depthwise-conv output) written where those write da. */
+int64_t cnx_block_dln_ws_floats(int32_t C);
 int cnx_block_dln(const float* w1, const float* dw1, const float* db1, const float* ln_w, const float* ln_b,
                   const void* da, const void* dhpre_tiles, const void* u, const float* mean, const float* rstd,
-                  float* dlw, float* dlb, int64_t M, int32_t C, int32_t Hd, void* stream);
+                  float* dlw, float* dlb, float* ws, int64_t M, int32_t C, int32_t Hd, void* stream);
 int cnx_block_mlp_bwd_train_hpre_ln(const void* u, const float* ln_w, const float* mean, const float* rstd,
                                     const void* g, int g_dtype, const float* gamma, const void* Wb, const void* hpre_ws,
                                     void* du, void* do_rows, void* dhpre_ws, int64_t M, int32_t C, void* stream);

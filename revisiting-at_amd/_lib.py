@@ -44,7 +44,8 @@ PROTOTYPES = {
     "cnx_dwconv7x7_wgrad_ws_floats": (C.c_int64, [_i32]),
     "cnx_dwconv7x7_wgrad_nhwc": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "cnx_block_dgamma": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _p]),
-    "cnx_block_dln": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "cnx_block_dln_ws_floats": (C.c_int64, [_i32]),
+    "cnx_block_dln": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "cnx_block_mlp_bwd_train_hpre_ln": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "cnx_block_mlp_bwd_acc_ln": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "cnx_layernorm_fwd": (C.c_int, [_p, C.c_int, _p, _p, _f, _p, C.c_int, _p, _p, _i64, _i32, _i32, _p]),

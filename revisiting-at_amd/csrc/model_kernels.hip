@@ -1525,8 +1525,12 @@ __global__ __launch_bounds__(256) void block_dgamma_kernel(const float* __restri
   __shared__ float red[256];
   const int c = blockIdx.x, t = threadIdx.x;
   const float gm = gamma[c];
+  // the identity divides by gamma what dO = bf16(g gamma) carried: sound while that product is a normal bf16 number, i.e. for every
+  // gamma a model can hold (the layer-scale init 1e-6 included: tests/test_gpu_model_ops.py); below 1e-30 (and at 0 or NaN) dO has
+  // flushed and the channel takes the direct sum
+  const bool ident = fabsf(gm) >= 1e-30f;
   float s = 0.f;
-  if (gm != 0.f) {
+  if (ident) {
     for (int j = t; j < Hd; j += 256) s = fmaf(round_bf16(w2[static_cast<long>(c) * Hd + j]), dw2[static_cast<long>(c) * Hd + j], s);
   } else {
     for (long m = t; m < M; m += 256) {
@@ -1556,20 +1560,128 @@ __global__ __launch_bounds__(256) void block_dgamma_kernel(const float* __restri
     if (t < w) red[t] += red[t + w];
     __syncthreads();
   }
-  if (t == 0) dgamma[c] = gm != 0.f ? (red[0] + (b2 ? b2[c] * db2[c] : 0.f)) / gm : red[0];
+  if (t == 0) dgamma[c] = ident ? (red[0] + (b2 ? b2[c] * db2[c] : 0.f)) / gm : red[0];
 }
 
 // The LayerNorm parameter gradients of a block the same way (round 5).  With a = LN(u) = xh ln_w + ln_b (bf16, the left operand of the
 // first linear layer), da = dHpre W1 and the weight gradients dW1 = dHpre^T a, d(b1) = sum_m dHpre:
 //     d(ln_b)[c] = sum_m da[m,c]           = sum_j W1[j,c] d(b1)[j]
 //     d(ln_w)[c] = sum_m da[m,c] xh[m,c]   = (sum_j W1[j,c] dW1[j,c] - ln_b[c] d(ln_b)[c]) / ln_w[c]
-// (W1 rounded to bf16 as the GEMMs read it).  A channel whose ln_w is exactly zero takes the direct sum over da, u, mean, rstd.
+// (W1 rounded to bf16 as the GEMMs read it).  Conditioning (round 6): the second identity recovers xh from a = bf16(xh ln_w + ln_b), whose
+// rounding error 2^-9 |a| comes back divided by ln_w - a relative error of ~2^-9 max(1, |ln_b| / |ln_w|) on the channel, where the
+// reference's fp32 LayerNorm backward has none.  A channel with |ln_b| > 4 |ln_w| (or ln_w == 0, or a NaN) is ILL-CONDITIONED for the
+// identity and takes the direct sum over da, u, mean, rstd: dln_ill() is the one predicate both kernels below evaluate.
+//   block_dln_direct_kernel (wide grid, launched first when the caller passes a workspace): every workgroup derives the list of
+//       ill-conditioned channels from ln_w / ln_b and leaves at once when it is empty (the benchmarked model at its init and every
+//       LayerNorm with |ln_b| <= 4 |ln_w|: ~2 us); otherwise it sums da xh over its rows for the listed channels - da as stored, or
+//       recomputed row by row from the dHpre tiles and the listed columns of W1 (staged in LDS) - and writes ws[wg][c];
+//   block_dln_kernel: the identities; for a listed channel the fixed-order sum of the partials (without a workspace: its own serial
+//       direct sum, correct and slow - the pre-round-6 path for an exactly-zero ln_w).
+__device__ __forceinline__ bool dln_ill(float lw, float lb) { return !(fabsf(lw) * 4.0f >= fabsf(lb)) || lw == 0.f; }
+
+constexpr int kDlnParts = 256, kDlnChunk = 8;
+
+__global__ __launch_bounds__(256) void block_dln_direct_kernel(const float* __restrict__ w1, const float* __restrict__ ln_w,
+                                                                const float* __restrict__ ln_b, const uint16_t* __restrict__ da,
+                                                                const uint16_t* __restrict__ dhpt, const uint16_t* __restrict__ u,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                float* __restrict__ ws, long M, int C, int Hd) {
+  extern __shared__ float w1s[];                           // [Hd][kDlnChunk]: bf16-rounded W1 columns of the chunk's channels (tile form)
+  __shared__ int list[2048];
+  __shared__ int nlist;
+  __shared__ float red[256];
+  const int t = threadIdx.x;
+  if (t < 64) {                                            // ordered compaction of the ill-conditioned channels by the first wavefront
+    int base = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + t;
+      const bool ill = c < C && dln_ill(ln_w[c < C ? c : 0], ln_b[c < C ? c : 0]);
+      const unsigned long long mk = __ballot(ill);
+      if (ill) list[base + __popcll(mk & ((1ull << t) - 1ull))] = c;
+      base += __popcll(mk);
+    }
+    if (t == 0) nlist = base;
+  }
+  __syncthreads();
+  const int nf = nlist;
+  if (nf == 0) return;
+  // rows of this workgroup: whole 32-row tiles
+  const long tiles = (M + 31) / 32, per = (tiles + gridDim.x - 1) / gridDim.x;
+  const long m_lo = static_cast<long>(blockIdx.x) * per * 32;
+  long m_hi = m_lo + per * 32;
+  if (m_hi > M) m_hi = M;
+  for (int f0 = 0; f0 < nf; f0 += kDlnChunk) {
+    const int nfc = nf - f0 < kDlnChunk ? nf - f0 : kDlnChunk;
+    if (!da) {
+      __syncthreads();
+      for (int i = t; i < Hd * kDlnChunk; i += 256) {
+        const int j = i / kDlnChunk, f = i % kDlnChunk;
+        w1s[i] = f < nfc ? round_bf16(w1[static_cast<long>(j) * C + list[f0 + f]]) : 0.f;
+      }
+      __syncthreads();
+    }
+    float acc[kDlnChunk];
+#pragma unroll
+    for (int f = 0; f < kDlnChunk; ++f) acc[f] = 0.f;
+    for (long m = m_lo + t; m < m_hi; m += 256) {
+      float dav[kDlnChunk];
+#pragma unroll
+      for (int f = 0; f < kDlnChunk; ++f) dav[f] = 0.f;
+      if (da) {
+#pragma unroll
+        for (int f = 0; f < kDlnChunk; ++f)
+          if (f < nfc) dav[f] = __uint_as_float(static_cast<uint32_t>(da[m * C + list[f0 + f]]) << 16);
+      } else {
+        // row m of the dHpre tiles (CNX_TN_ACC): 64 contiguous bytes per hidden block, value p of them is hidden unit
+        // 8 ((p / 4) % 4) + 4 (p / 16) + p % 4 of the block (the inverse of byte 64 r + 32 ((n/4) % 2) + 8 (n/8) + 2 (n % 4))
+        const uint4* trow = reinterpret_cast<const uint4*>(dhpt + (m / 32) * (static_cast<long>(Hd) / 32) * 1024 + (m % 32) * 32);
+        for (int jb = 0; jb < Hd / 32; ++jb) {
+          uint4 q[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q[k] = trow[static_cast<long>(jb) * 128 + k];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t wd[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int pidx = 8 * k + e;
+              const int n = 8 * ((pidx / 4) % 4) + 4 * (pidx / 16) + pidx % 4;
+              const float dv = (e & 1) ? __uint_as_float(wd[e / 2] & 0xffff0000u) : __uint_as_float(wd[e / 2] << 16);
+              const float* wr = w1s + (jb * 32 + n) * kDlnChunk;
+#pragma unroll
+              for (int f = 0; f < kDlnChunk; ++f) dav[f] = fmaf(dv, wr[f], dav[f]);
+            }
+          }
+        }
+      }
+      const float mu = mean[m], rs = rstd[m];
+#pragma unroll
+      for (int f = 0; f < kDlnChunk; ++f)
+        if (f < nfc) {
+          const float xh = (__uint_as_float(static_cast<uint32_t>(u[m * C + list[f0 + f]]) << 16) - mu) * rs;
+          acc[f] = fmaf(dav[f], xh, acc[f]);
+        }
+    }
+    for (int f = 0; f < nfc; ++f) {                        // fixed tree per channel: deterministic
+      __syncthreads();
+      red[t] = acc[f];
+      __syncthreads();
+#pragma unroll
+      for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+      }
+      if (t == 0) ws[static_cast<long>(blockIdx.x) * C + list[f0 + f]] = red[0];
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void block_dln_kernel(const float* __restrict__ w1, const float* __restrict__ dw1,
                                                          const float* __restrict__ db1, const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, const uint16_t* __restrict__ da,
                                                          const uint16_t* __restrict__ dhpt, const uint16_t* __restrict__ u, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* __restrict__ dlw, float* __restrict__ dlb,
-                                                         long M, int C, int Hd) {
+                                                         const float* __restrict__ ws, int parts, long M, int C, int Hd) {
   // a block = 32 channels x 32 row lanes of [Hd, C]: every load is a 128-byte run of a row, four rows per lane in flight (a launch is
   // a handful of blocks: what it costs is the length of a lane's chain of load latencies - 8 row lanes and one row at a time ran
   // 117 us, one block per channel with its column read at a stride of C floats 10 us)
@@ -1598,8 +1710,8 @@ __global__ __launch_bounds__(1024) void block_dln_kernel(const float* __restrict
     }
   }
   red[0][ty][tx] = sw; red[1][ty][tx] = sb;
-  if (t < 64) {                                          // channels whose ln_w is exactly zero (none in practice): one ballot finds them
-    const unsigned long long zb = __ballot(c < C && ln_w[c < C ? c : 0] == 0.f);
+  if (t < 64) {                                          // the ill-conditioned channels of this block (none in practice): one ballot finds them
+    const unsigned long long zb = __ballot(c < C && dln_ill(ln_w[c < C ? c : 0], ln_b[c < C ? c : 0]));
     if (t == 0) zmask = static_cast<unsigned>(zb & 0xffffffffull);
   }
   __syncthreads();
@@ -1609,39 +1721,60 @@ __global__ __launch_bounds__(1024) void block_dln_kernel(const float* __restrict
     red[0][0][tx] = sw; red[1][0][tx] = sb;
   }
   __syncthreads();
-  for (unsigned mk = zmask; mk != 0u; mk &= mk - 1u) {   // ... and take the direct sum, all threads per channel
-    const int k = __builtin_ctz(mk);
-    const int ck = blockIdx.x * 32 + k;
-    float sd = 0.f;
-    for (long m = t; m < M; m += 1024) {
-      const float xh = (__uint_as_float(static_cast<uint32_t>(u[m * C + ck]) << 16) - mean[m]) * rstd[m];
-      float dav;
-      if (da) {
-        dav = __uint_as_float(static_cast<uint32_t>(da[m * C + ck]) << 16);
-      } else {                                           // da[m, c] = sum_j dHpre[m, j] W1[j, c] from the CNX_TN_ACC tiles (block_dgamma_kernel)
-        const uint16_t* tile_row = dhpt + (m / 32) * (static_cast<long>(Hd) / 32) * 1024 + (m % 32) * 32;
-        dav = 0.f;
-        for (int j = 0; j < Hd; ++j) {
-          const int n = j % 32;
-          const uint16_t dv = tile_row[static_cast<long>(j / 32) * 1024 + 16 * ((n / 4) % 2) + 4 * (n / 8) + (n % 4)];
-          dav = fmaf(__uint_as_float(static_cast<uint32_t>(dv) << 16), round_bf16(w1[static_cast<long>(j) * C + ck]), dav);
-        }
+  if (ws) {
+    // the direct sums of block_dln_direct_kernel: `parts` partials per listed channel, summed in a fixed order (32 row lanes of
+    // parts / 32 consecutive partials each, then the lanes in order)
+    if (zmask != 0u) {
+      float pd = 0.f;
+      if (c < C && ((zmask >> tx) & 1u)) {
+        const int per = (parts + RL - 1) / RL;
+        for (int q = ty * per; q < (ty + 1) * per && q < parts; ++q) pd += ws[static_cast<long>(q) * C + c];
       }
-      sd = fmaf(dav, xh, sd);
-    }
-    dsum[t] = sd;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-      if (t < w) dsum[t] += dsum[t + w];
+      dsum[ty * 32 + tx] = pd;
+      __syncthreads();
+      if (ty == 0 && ((zmask >> tx) & 1u)) {
+        float sdir = 0.f;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) sdir += dsum[r * 32 + tx];
+        red[0][0][tx] = sdir;
+      }
       __syncthreads();
     }
-    if (t == 0) red[0][0][k] = dsum[0];
-    __syncthreads();
+  } else {
+    for (unsigned mk = zmask; mk != 0u; mk &= mk - 1u) {   // no workspace: the serial direct sum, all threads per channel
+      const int k = __builtin_ctz(mk);
+      const int ck = blockIdx.x * 32 + k;
+      float sd = 0.f;
+      for (long m = t; m < M; m += 1024) {
+        const float xh = (__uint_as_float(static_cast<uint32_t>(u[m * C + ck]) << 16) - mean[m]) * rstd[m];
+        float dav;
+        if (da) {
+          dav = __uint_as_float(static_cast<uint32_t>(da[m * C + ck]) << 16);
+        } else {                                           // da[m, c] = sum_j dHpre[m, j] W1[j, c] from the CNX_TN_ACC tiles (block_dgamma_kernel)
+          const uint16_t* tile_row = dhpt + (m / 32) * (static_cast<long>(Hd) / 32) * 1024 + (m % 32) * 32;
+          dav = 0.f;
+          for (int j = 0; j < Hd; ++j) {
+            const int n = j % 32;
+            const uint16_t dv = tile_row[static_cast<long>(j / 32) * 1024 + 16 * ((n / 4) % 2) + 4 * (n / 8) + (n % 4)];
+            dav = fmaf(__uint_as_float(static_cast<uint32_t>(dv) << 16), round_bf16(w1[static_cast<long>(j) * C + ck]), dav);
+          }
+        }
+        sd = fmaf(dav, xh, sd);
+      }
+      dsum[t] = sd;
+      __syncthreads();
+      for (int w = 512; w > 0; w >>= 1) {
+        if (t < w) dsum[t] += dsum[t + w];
+        __syncthreads();
+      }
+      if (t == 0) red[0][0][k] = dsum[0];
+      __syncthreads();
+    }
   }
   if (ty == 0 && c < C) {
     const float lw = ln_w[c], b = red[1][0][tx], w = red[0][0][tx];
     dlb[c] = b;
-    dlw[c] = lw != 0.f ? (w - ln_b[c] * b) / lw : w;
+    dlw[c] = !dln_ill(lw, ln_b[c]) ? (w - ln_b[c] * b) / lw : w;
   }
 }
 
@@ -2471,14 +2604,28 @@ int cnx_block_dgamma(const float* w2, const float* dw2, const float* b2, const f
   return launch_status();
 }
 
+int64_t cnx_block_dln_ws_floats(int32_t C) { return C > 0 ? static_cast<int64_t>(kDlnParts) * C : 0; }
+
 int cnx_block_dln(const float* w1, const float* dw1, const float* db1, const float* ln_w, const float* ln_b, const void* da,
-                  const void* dhpre_tiles, const void* u, const float* mean, const float* rstd, float* dlw, float* dlb, int64_t M,
+                  const void* dhpre_tiles, const void* u, const float* mean, const float* rstd, float* dlw, float* dlb, float* ws, int64_t M,
                   int32_t C, int32_t Hd, void* stream) {
   if (M < 0 || C <= 0 || Hd <= 0) return APGD_ERR_SIZE;
   if (!w1 || !dw1 || !db1 || !ln_w || !ln_b || (!da && !dhpre_tiles) || !u || !mean || !rstd || !dlw || !dlb) return APGD_ERR_NULL;
   if (!da && (M % 32 != 0 || Hd % 32 != 0)) return APGD_ERR_ARG;
+  const size_t lds = da ? 0 : static_cast<size_t>(Hd) * kDlnChunk * sizeof(float);
+  if (C > 2048 || lds > 96 * 1024) ws = nullptr;                                // beyond the direct kernel's channel list / LDS image: serial sums
+  if (ws) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_dln_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(block_dln_direct_kernel, dim3(kDlnParts), dim3(256), lds, as_stream(stream), w1, ln_w, ln_b,
+                       static_cast<const uint16_t*>(da), static_cast<const uint16_t*>(dhpre_tiles), static_cast<const uint16_t*>(u), mean, rstd,
+                       ws, static_cast<long>(M), C, Hd);
+  }
   hipLaunchKernelGGL(block_dln_kernel, dim3((C + 31) / 32), dim3(1024), 0, as_stream(stream), w1, dw1, db1, ln_w, ln_b, static_cast<const uint16_t*>(da),
-                     static_cast<const uint16_t*>(dhpre_tiles), static_cast<const uint16_t*>(u), mean, rstd, dlw, dlb, static_cast<long>(M), C, Hd);
+                     static_cast<const uint16_t*>(dhpre_tiles), static_cast<const uint16_t*>(u), mean, rstd, dlw, dlb, ws, kDlnParts, static_cast<long>(M), C, Hd);
   return launch_status();
 }
 

@@ -1085,9 +1085,11 @@ _LN_IN_TRAIN_BWD = os.environ.get("APGD_DLN", "dw1") == "dw1"
 def _block_dln(lib, w1, dw1, db1, lw, lb, da, dhp_tiles, u, mean, rstd, M, C):
     dlw = torch.empty(C, device=u.device, dtype=torch.float32)
     dlb = torch.empty(C, device=u.device, dtype=torch.float32)
+    # (workspace of the direct sums that ill-conditioned channels - |ln_b| > 4 |ln_w| - take instead of the identity)
+    ws = torch.empty(lib.cnx_block_dln_ws_floats(C), device=u.device, dtype=torch.float32)
     _lib.check(lib.cnx_block_dln(w1.data_ptr(), dw1.data_ptr(), db1.data_ptr(), lw.data_ptr(), lb.data_ptr(), _lib.ptr(da),
                                  dhp_tiles.data_ptr() if da is None else None, u.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                 dlw.data_ptr(), dlb.data_ptr(), M, C, 4 * C, _stream()), "cnx_block_dln")
+                                 dlw.data_ptr(), dlb.data_ptr(), ws.data_ptr(), M, C, 4 * C, _stream()), "cnx_block_dln")
     return dlw, dlb
 
 
@@ -1648,9 +1650,7 @@ class _BlockFused(torch.autograd.Function):
                                              None if dln_id else _lib.ptr(dlw), None if dln_id else _lib.ptr(dlb), _lib.ptr(ws), M, C, 0, _stream()),
                        "cnx_layernorm_bwd")
             if dln_id:
-                _lib.check(lib.cnx_block_dln(w1p.data_ptr(), dw1.data_ptr(), db1.data_ptr(), lw.data_ptr(), lb.data_ptr(), da.data_ptr(), None,
-                                             u.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dlw.data_ptr(), dlb.data_ptr(), M, C, 4 * C,
-                                             _stream()), "cnx_block_dln")
+                dlw, dlb = _block_dln(lib, w1p, dw1, db1, lw, lb, da, None, u, mean, rstd, M, C)
         # ---- depthwise conv backward; the residual branch's gradient rides along as the stencil's `add` input
         dx = None
         if nig[0]:

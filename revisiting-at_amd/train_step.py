@@ -208,17 +208,35 @@ class FlatGradSync:
         exchange runs behind ONE whole backward (same gradients as ``loss.backward()``, no overlap of the first all-reduce)."""
         full = torch.autograd.grad([loss], self.late + self.early, allow_unused=True, retain_graph=True)
         g1 = torch.autograd.grad([loss], self.late + [h], allow_unused=True, retain_graph=True)
-        g2 = torch.autograd.grad([h], self.early, grad_outputs=[g1[-1]], allow_unused=True, retain_graph=True)
-        split = list(g1[:-1]) + list(g2)
-        lost = [i for i, (a, b) in enumerate(zip(full, split)) if a is not None and b is None]
-        short = [i for i, (a, b) in enumerate(zip(full, split))
-                 if a is not None and b is not None       # (5 % in norm: far above the run-to-run noise of the library's
-                 and float((a.float() - b.float()).norm()) > 0.05 * float(a.float().norm()) + 1e-12]    # split-K filter gradients)
+        dev = self.flat[0].device
+        n_short = torch.zeros((), device=dev)
+        if g1[-1] is None:
+            # the cut activation is not on the loss path at all: every early parameter the whole backward reaches would be lost
+            lost = [i for i, a in enumerate(full) if a is not None and (i >= len(self.late) or g1[i] is None)]
+        else:
+            g2 = torch.autograd.grad([h], self.early, grad_outputs=[g1[-1]], allow_unused=True, retain_graph=True)
+            split = list(g1[:-1]) + list(g2)
+            lost = [i for i, (a, b) in enumerate(zip(full, split)) if a is not None and b is None]
+            both = [(a.float(), b.float()) for a, b in zip(full, split) if a is not None and b is not None]
+            if both:
+                # ONE device-side verdict (no host round trip per parameter): 5 % in norm - far above the run-to-run noise of the
+                # library's split-K filter gradients
+                ref = torch.stack(torch._foreach_norm([a for a, _ in both]))
+                dif = torch.stack(torch._foreach_norm(torch._foreach_sub([a for a, _ in both], [b for _, b in both])))
+                n_short = (dif > 0.05 * ref + 1e-12).sum().to(torch.float32)
+        verdict = torch.stack([torch.tensor(float(len(lost)), device=dev), n_short.to(dev)])
+        if self.world > 1:
+            # the ranks decide TOGETHER (MAX over ranks): a data-dependent verdict of one rank's own batch must not leave the ranks
+            # with different graph segmentations
+            import torch.distributed as dist
+            dist.all_reduce(verdict, op=dist.ReduceOp.MAX)
+        n_lost, n_bad = (int(v) for v in verdict.tolist())
         self.verified = True
-        if lost or short:
+        if n_lost or n_bad:
             import warnings
-            warnings.warn(f"FlatGradSync: the model's ddp_cut() does not partition its parameters ({len(lost)} parameters would lose "
-                          f"their gradient, {len(short)} would get a part of it): cut point dropped, one whole backward per step")
+            warnings.warn(f"FlatGradSync: the model's ddp_cut() does not partition its parameters ({n_lost} parameters would lose "
+                          f"their gradient, {n_bad} would get a part of it; maximum over the ranks): cut point dropped, one whole "
+                          "backward per step")
             self.cut = None
 
     def start_reduce(self, which: int):
@@ -301,6 +319,10 @@ class ATTrainStep:
     the same replayed step as the single GPU; ``"ddp"``: ``torch.nn.parallel.DistributedDataParallel`` around the wrapped model
     (``main.py:889-890`` literally; its hooks keep the training pass eager).  ``grad_sync="flat"`` with ``distributed=False`` runs
     the N > 1 code path on one GPU (``bench.py --ddp-path 1``)."""
+
+    # what captures and replays the training pass (a seam for the process-group tests: a rank whose capture failed runs the pass
+    # eagerly next to ranks that replay - both issue the same two all-reduces per step, tests/test_ddp_gloo.py)
+    _graph_cls = _TrainPassGraph
 
     def __init__(self, model: nn.Module, arch: str, adv: AdvConfig, device, lr: float = 1e-3,
                  weight_decay: float = 0.05, distributed: bool = False, channels_last: bool = True,
@@ -464,12 +486,13 @@ class ATTrainStep:
         if prog is None:
             try:
                 # (a replayed attack under borrow_outputs hands out its graph's own static tensor: stable address)
-                prog = self._tg[key] = _TrainPassGraph(self, z, target, x_is_static=graphed.STATS["replays"] > replays0)
+                prog = self._tg[key] = self._graph_cls(self, z, target, x_is_static=graphed.STATS["replays"] > replays0)
             except Exception as e:                                         # noqa: BLE001 - any capture failure means "run eagerly"
                 import warnings
                 warnings.warn(f"training-pass graph capture failed ({type(e).__name__}: {e}); this batch shape runs eagerly")
                 self._tg[key] = None
-                torch.cuda.synchronize()
+                if self.device.type == 'cuda':
+                    torch.cuda.synchronize()
                 if self.sync is None:
                     self.optimizer.zero_grad(set_to_none=True)
                 loss = self._train_pass(z, target)
@@ -483,7 +506,7 @@ class ATTrainStep:
         self._set_lr(self.lr if lr is None else lr)
         if self.mixup_fn is not None:
             images, target = self.mixup_fn(images, target)                 # main.py:965-966 (soft labels [B, n_cls])
-        if self.graph_train and images.is_cuda:
+        if self.graph_train and (images.is_cuda or self._graph_cls is not _TrainPassGraph):
             loss = self._graph_step(images, target)
             if loss is not None:
                 return loss

@@ -156,6 +156,87 @@ def test_ddp_world2_matches_single_process(grad_sync, kind):
     torch.testing.assert_close(res["params"], flat, rtol=1e-4, atol=1e-5)
 
 
+class _RecordedPass:
+    """CPU stand-in for train_step._TrainPassGraph (hipGraph capture needs the device): "captures" by recording nothing and "replays" by
+    running the recorded pass - what matters here is ATTrainStep's control flow around it under a process group: warm-up count, capture,
+    the fallback of a rank whose capture fails, and that both kinds of rank issue the same collectives."""
+    fail = False
+
+    def __init__(self, step, x, target, x_is_static=False):
+        if _RecordedPass.fail:
+            raise RuntimeError("capture refused (test)")
+        self.step, self.n_graphs, self.steps = step, 3, []
+        self.replays = 0
+
+    def __call__(self, x, target):
+        self.replays += 1
+        return self.step._train_pass(x, target)
+
+
+def _mixed_capture_worker(rank, world, port, q, fail_rank):
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    R.setup_distributed()
+    _RecordedPass.fail = rank == fail_rank
+    tr = R.ATTrainStep(_model("cut"), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=True, channels_last=False, amp_dtype=None,
+                       ema=True, perturb=_sign_attack, grad_sync="flat")
+    tr._graph_cls = _RecordedPass
+    tr.graph_train = True                                   # (the constructor only switches it on for a device model)
+    x, y = _data(8)
+    xs, ys = x[rank::world], y[rank::world]
+    n_steps = R.train_step.TRAIN_GRAPH_WARMUP + 3
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        for _ in range(n_steps):
+            tr.step(xs, ys)
+    progs = list(tr._tg.values())
+    mine = dict(rank=rank, reduces=tr.sync.reduces, captured=sum(v is not None for v in progs), failed=sum(v is None for v in progs),
+                replays=sum(v.replays for v in progs if v is not None),
+                warned=any("capture failed" in str(w.message) for w in wl))
+    alls = [None] * world
+    dist.all_gather_object(alls, mine)
+    flat = torch.cat([p.detach().flatten() for p in tr.inner.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        q.put(dict(params=flat, same=bool(all(torch.equal(gathered[0], t) for t in gathered)), ranks=alls, n_steps=n_steps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [1, 0, None])
+def test_a_rank_whose_training_pass_capture_failed_stays_in_step_with_the_ranks_that_replay(fail_rank):
+    """under a process group the ranks need not agree on replay-versus-eager for the training pass - a rank
+    whose capture failed runs ``_train_pass`` from Python, the others replay their three segments, and BOTH issue the flat path's two
+    all-reduces per step in the same order (the collectives live between the segments, never inside one).  Two gloo ranks, one of them
+    (or none) refused its capture: no hang, identical parameters on both, the same trajectory as single-process training."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_capture_worker, args=(r, 2, port, q, fail_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res["same"], "ranks diverged"
+    for st in res["ranks"]:
+        failed = st["rank"] == fail_rank
+        assert st["reduces"] == 2 * res["n_steps"], st            # two exchanges per step on every rank, replaying or not
+        assert (st["captured"], st["failed"], st["warned"]) == ((0, 1, True) if failed else (1, 0, False)), st
+        assert st["replays"] == (0 if failed else 3), st
+    torch.set_num_threads(1)
+    tr = R.ATTrainStep(_model("cut"), "toy", R.AdvConfig(), "cpu", lr=1e-2, distributed=False, channels_last=False,
+                       amp_dtype=None, ema=False, perturb=_sign_attack)
+    x, y = _data(8)
+    for _ in range(res["n_steps"]):
+        tr.step(x, y)
+    flat = torch.cat([p.detach().flatten() for p in tr.inner.parameters()])
+    torch.testing.assert_close(res["params"], flat, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("kind", ["seq", "cut"])
 def test_flat_gradient_path_on_one_rank_equals_the_plain_backward(kind):
     """``grad_sync="flat"`` without a process group (``bench.py --ddp-path 1``): the two-call backward into the flat buffers is the
