@@ -299,6 +299,8 @@ def other_configs(R, dev, graph=1, which=("cfg3", "cfg4", "cfg5")):
             "attack_runs": st["attack_runs"], "sample_iters": st["sample_iters"],
             "sample_iters_per_s": round(st["sample_iters"] / dt, 1), "robust_after": st["robust"],
             # a random-init model has no point left after APGD-CE at eps = 4/255: the line then times the CE leg alone
+            "mode": "buckets + graph replay: a throughput mode whose real rows agree with the unpadded eager evaluation to rounding, not bit for "
+                    "bit (aa_eval.run_standard_evaluation); robust accuracy is reported from buckets=False, graph=False",
             "legs": "CE + T" if st["attack_runs"] >= 2 else "CE only (no point survived APGD-CE: the targeted runs had nothing to attack)"}
         # the same evaluation at an eps small enough that about half the points survive APGD-CE, so that the targeted leg
         # (dlr-targeted on the product model, targets from the clean logits, still-robust subset) is inside a timed figure too
@@ -716,6 +718,10 @@ def main():
                 # launch read; `frac_sum_8d`: with 8d's K3 rule added literally (it re-counts the sources the step already reads)
                 "algorithmic_bytes_step": step_alg, "algorithmic_bytes_row_moves": round(alg_launch - step_alg),
                 "frac_sum_8d": round(alg8d_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # the algorithmic bytes AT THE DTYPES THE LAUNCH RUNS WITH (int8 gradient signs: 17 (13) B/element for the step, + 4 / 4 / 1
+                # B/element per destination written, a restore 8 + 1): what the bus has to carry, so this reading cannot pass 1.0 while
+                # `frac` (SURVEY 8d's fp32 accounting) can
+                "algorithmic_bytes_as_run": round(mov_launch), "frac_as_run": round(mov_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "bytes_moved": round(mov_launch), "moved_GBs": round(mov_launch / (avg_ms * 1e-3) / 1e9, 1),
                 # the PHYSICAL reading: bytes the kernel is designed to move (= the PMC traffic) / time / 8 TB/s
                 "frac_moved": round(mov_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -106,8 +106,16 @@ def run_standard_evaluation(model, x, y, bs=200, norm='Linf', eps=4. / 255.,
     ``buckets``: the still-robust subset an attack runs on has an arbitrary size - every one a batch shape the libraries (and a
     captured program) have not met.  With ``buckets`` it is padded to the next of a few fixed sizes (``bs``, then halves down to
     8) with copies of its first row; the padding rows are never read back (samples are independent: eval mode, LayerNorm models)
-    and draw no random numbers, so every real row's result is the unpadded evaluation's.  ``graph``: the attack runs replay
-    from hipGraphs (``graphed.run``: captured on the third call with a shape, which the buckets make recur).
+    and draw no random numbers.  ``graph``: the attack runs replay from hipGraphs (``graphed.run``: captured on the third call
+    with a shape, which the buckets make recur).
+
+    Both are THROUGHPUT options and a tolerance, not an identity: a padded (or replayed) run shows the GEMM / convolution kernels
+    another batch shape - other tiles and split-K choices, under autocast ``cnx_gemm_nt`` and two streams - so a real row's logits
+    agree with the unpadded eager run's to rounding (fp32: ~1e-6 relative), not bit for bit, and a sample whose margin sits inside
+    that rounding can end on the other side of robust / non-robust.  ``buckets=False, graph=False`` (the defaults) is the
+    evaluation whose attack runs replay through the oracle bit for bit (tests/test_gpu_configs.py) and the one to report robust
+    accuracy from; ``tests/test_gpu_apgd.py::test_run_standard_evaluation_with_padded_batches_and_graph_replay`` bounds the
+    difference between the two on a fixed seed (robust masks, counts).
     """
     assert not model.training
     for a in attacks_to_run:

@@ -394,6 +394,9 @@ def _apgd_core(model, x, y, norm, eps, n_iter, kind, soft=False, verbose=False, 
     sign_ok = norm == 'Linf'
     grad = _model_fwd_bwd_split(model, cur, y_hard, y_soft, ws, ws.loss_best, ws.acc, True, kind, y_target, sign_ok, sign_ok, splits,
                                 attack_gemm)
+    if fused and K1_SHAPE is not None:
+        raise _lib.ApgdHipError("apgd.K1_SHAPE (launch-shape sweep of the plain update kernel) has no effect with FUSED_TRACKING: set "
+                                "apgd.FUSED_TRACKING = False for the sweep")
     grad_best = torch.empty_like(grad)                                       # :189
     if fused and getattr(grad, "apgd_blocked", False):
         # (blocked signs, APGD_SIGN_BLOCKED=1: an experiment of round 3, slower) the prologue's clones after all

@@ -23,7 +23,6 @@
 // residual gradient added: 10 B per element.  HBM-bound: 56 x 56 x 96, batch 256: 462 / 771 MB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdio.h>
 #include <stdlib.h>
 
 #include "apgd_hip.h"

@@ -25,6 +25,10 @@
 #include "apgd_hip.h"
 #include "convnext_hip.h"
 
+#ifndef TN_ABLATE
+#define TN_ABLATE 0
+#endif
+
 namespace {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -554,7 +558,13 @@ int launch_gemm_tn(const uint16_t* A, long lda, const uint16_t* B, long ldb, flo
   }();
   (void)attr;
   const long grid = static_cast<long>(N1 / BM) * (N2 / BN) * n_split;
-  static const int dbg = getenv("APGD_TN_DBG") ? atoi(getenv("APGD_TN_DBG")) : 0;     // experiments: 1 = no DMA after stage 0, 2 = no MFMAs, 4 = no reduce
+  // timing experiments (1 = no DMA after stage 0, 2 = no MFMAs, 4 = no reduce: all return WRONG gradients) exist in measurement
+  // builds only (`make EXTRA=-DTN_ABLATE=1`): a stray environment variable must not be able to corrupt training
+#if TN_ABLATE
+  static const int dbg = getenv("APGD_TN_DBG") ? atoi(getenv("APGD_TN_DBG")) : 0;
+#else
+  constexpr int dbg = 0;
+#endif
   // (a single split with no column sums writes D directly; everything else goes through the workspace and the fixed-order sum)
   const bool direct = n_split == 1 && !CS;
   hipLaunchKernelGGL((gemm_tn_kernel<F, WI, WJ, LA, LB, CS>), dim3(static_cast<unsigned>(grid)), dim3(64 * WI * WJ), lds_bytes, s, A, lda, B,
@@ -577,7 +587,11 @@ inline int gemm_tn_shape(int N1, int N2) {
 // per split.  Measured (tools/gemm_tn_bench.py): 512 workgroups double the partial results' traffic and run 20 - 30 % longer.
 inline void gemm_tn_split(int M, int tiles, int* rows_per_split, int* n_split) {
   const int stages = M / 64;
-  static const int wgs = getenv("APGD_TN_WGS") ? atoi(getenv("APGD_TN_WGS")) : 256;
+#if TN_ABLATE
+  static const int wgs = getenv("APGD_TN_WGS") ? atoi(getenv("APGD_TN_WGS")) : 256;   // (measurement builds: the split sweep)
+#else
+  constexpr int wgs = 256;
+#endif
   int want = (wgs + tiles - 1) / tiles;
   if (want < 1) want = 1;
   int per = (stages + want - 1) / want;

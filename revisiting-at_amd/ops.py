@@ -474,12 +474,14 @@ class _DownsampleLnConv(torch.autograd.Function):
         if want_p:
             dwt = _wgrad(gb, yp).view(Co, 2, 2, C).permute(0, 3, 1, 2)          # [Co, C, 2, 2] like the parameter
             if ctx.has_bias:
-                if g2.dtype in (torch.float32, torch.bfloat16) and g2.is_contiguous() and Co % 4 == 0:
-                    # the column sums by the one-pass kernel (fixed-order partials) instead of torch's reduction (1.3 TB/s on [200704, 192])
+                if g2.dtype == torch.bfloat16 and g2.is_contiguous() and Co % 4 == 0:
+                    # the column sums by the one-pass kernel (fixed-order partials) instead of torch's reduction (1.3 TB/s on [200704, 192]).
+                    # bf16 gradients only (the autocast backward): the kernel sums its bf16-ROUNDED dO = g * 1, which is g itself there
+                    # and would not be the fp32 column sum of an fp32 gradient
                     db = torch.empty(Co, device=g2.device, dtype=torch.float32)
-                    zeros = torch.empty(Co, device=g2.device, dtype=torch.float32)
+                    unused_dgamma = torch.empty(Co, device=g2.device, dtype=torch.float32)      # the kernel's d(gamma) output: no y, no meaning
                     ws2 = torch.empty(lib.cnx_colsum_ws_floats(Co), device=g2.device, dtype=torch.float32)
-                    _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), None, None, None, zeros.data_ptr(), db.data_ptr(),
+                    _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), None, None, None, unused_dgamma.data_ptr(), db.data_ptr(),
                                                           ws2.data_ptr(), g2.shape[0], Co, _stream()), "cnx_scale_residual_bwd(colsum)")
                 else:
                     db = g2.sum(0, dtype=torch.float32)

@@ -20,6 +20,8 @@ y = torch.randint(0, 1000, (B,), device=dev, generator=g)
 for _ in range(30):
     tr.step(x, y)
 torch.cuda.synchronize()
+A.FUSED_TRACKING = False      # the launch-shape sweep is of the plain update kernel (the fused one has one shape)
+R.graphed.reset()
 shapes = [None, (0, 1, 0), (0, 2, 0), (0, 4, 0), (0, 1, 1), (0, 2, 1), (16, 1, 0), (32, 1, 0), (64, 2, 0), (32, 4, 0), None]
 for rep in range(2):
     for sh in shapes:
