@@ -67,6 +67,8 @@ def parse():
     p.add_argument("--ab-steps", type=int, default=10, help="steps per leg of the interleaved kernel-set A/B behind the main measurement "
                    "(extra.ab: [default, round4, default, round4] in this process, on this box; ops.KERNEL_SETS); 0: skip.  Single-GPU "
                    "headline runs only")
+    p.add_argument("--ab-order", default="default,round4,default,round4", help="the legs of the A/B (names of ops.KERNEL_SETS; each leg "
+                   "starts from 'default' and applies its set on top)")
     p.add_argument("--strict", action="store_true", help="exit non-zero if any informational measurement (other_configs, model_kernel_"
                    "rooflines) failed; the failures are always visible as {'error': ...} entries and in extra.errors")
     return p.parse_args()
@@ -352,6 +354,7 @@ def ab_leg(R, args, dev, x, y, n_warm, order=("default", "round4", "default", "r
     start = R.ops.kernel_set("default")
     try:
         for name in order:
+            R.ops.kernel_set("default")
             R.ops.kernel_set(name)
             R.graphed.reset()
             torch.cuda.empty_cache()
@@ -391,8 +394,10 @@ def ab_leg(R, args, dev, x, y, n_warm, order=("default", "round4", "default", "r
     out = {"order": list(order), "steps_per_leg": args.ab_steps, "warmup_per_leg": n_warm, "legs": legs,
            "default_ms": med("ms_per_step", "default"), "r4_ms": med("ms_per_step", "round4"),
            "default_mcycles": med("mcycles_per_step", "default"), "r4_mcycles": med("mcycles_per_step", "round4"),
+           "median_ms": {n: med("ms_per_step", n) for n in dict.fromkeys(order)},
+           "median_mcycles": {n: med("mcycles_per_step", n) for n in dict.fromkeys(order)},
            "sclk_MHz": med("avg_sclk_MHz", "default"), "W": med("avg_W", "default"),
-           "round4_set": "ops.KERNEL_SETS['round4']: library weight gradients (GEMM + ConvStem), recomputing training backward, per-channel "
+           "round4_set": "ops.KERNEL_SETS['round4']: library weight gradients (the GEMM ones; the ConvStem's stay hand-written), recomputing training backward, per-channel "
                          "gradient passes, separate tracking pass, single-wavefront C = 256 / 384 forward, head pool on NCHW, round-4 "
                          "depthwise strips - the end-of-round-4 kernel selection inside today's library"}
     if out["default_ms"] and out["r4_ms"]:
@@ -828,7 +833,7 @@ def main():
             R.graphed.reset()
             torch.cuda.empty_cache()
             try:
-                extra["ab"] = ab_leg(R, args, dev, x, y, n_warm)
+                extra["ab"] = ab_leg(R, args, dev, x, y, n_warm, tuple(args.ab_order.split(",")))
             except Exception as e:                           # informational: the line still prints; --strict fails the run
                 extra["ab"] = {"error": repr(e)}
             print(f"[bench ab] {extra['ab']}", file=sys.stderr, flush=True)

@@ -64,7 +64,17 @@ __device__ unsigned long long g_blk_trace[BLK_TRACE_WGS * BLK_TRACE_SLOTS];
 #define TRACE(slot)
 #endif
 
+// measurement builds only (`make EXTRA=-DBLK_FWD_W8_BUILD=1`): the eight-wavefront forward workgroups of round 6 (13 - 23 % slower than two
+// independent four-wavefront workgroups per CU, profiles/r06_fused_mlp.md) are not instantiated in the product library
+#ifndef BLK_FWD_W8_BUILD
+#define BLK_FWD_W8_BUILD 0
+#endif
+#ifndef BLK_FWD_W8_DEFAULT
+#define BLK_FWD_W8_DEFAULT 0
+#endif
+
 namespace {
+constexpr int kFwdW8Default = BLK_FWD_W8_DEFAULT;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -253,26 +263,30 @@ __device__ __forceinline__ void gelu_grad_uop(int u, const float (&z)[4], const 
   }
 }
 
-template <int C>
+// W: wavefronts per workgroup = 32-row tiles that share one weight stream (4: rounds 1 - 5; 8 - round 6 - halves the weight bytes a CU
+// pulls through L2 -> LDS per row where the registers allow two wavefronts per SIMD: C = 128, 192)
+template <int C, int W = 4>
 struct Geo {
   static constexpr int KS = C / 16;                 // k-steps of a GEMM whose contraction runs over channels
   static constexpr int CB = C / 32;                 // 32-wide blocks of channels
   static constexpr int NHB = C / 8;                 // 32-wide slices of the hidden dimension (4C / 32)
   static constexpr int FWD_PIECES = KS + 2 * CB;    // 1 KiB operand fragments per slice: W1 (KS) + W2 (2 CB)
   static constexpr int FWD_SLICE = FWD_PIECES * 1024;
-  static constexpr int FWD_ROUNDS = FWD_PIECES / 4; // DMA instructions per wavefront per slice (4 wavefronts)
+  static constexpr int FWD_ROUNDS = FWD_PIECES / W; // DMA instructions per wavefront per slice
 #ifndef BLK_FWD96_DEPTH
 #define BLK_FWD96_DEPTH 3
 #endif
   static constexpr int DEPTH = (C <= 96) ? BLK_FWD96_DEPTH : 3;   // ring slots (DEPTH - 1 slices in flight ahead of the one being read)
   static constexpr int FWD_LDS = DEPTH * FWD_SLICE + 32 * C;   // + b1 (4C), b2 (C), gamma (C), ln_w (C), ln_b (C) fp32
   static_assert(FWD_LDS <= 160 * 1024, "ring + constants must fit the CU's LDS");
-  static constexpr int BM = 128;                    // rows per workgroup
+  static constexpr int BM = 32 * W;                 // rows per workgroup
+  static constexpr int RP = (W * 16 * C * 4 <= DEPTH * FWD_SLICE) ? 16 : 8;   // rows per epilogue pass (the tile leaves through the dead ring)
+  static_assert(W * RP * C * 4 <= DEPTH * FWD_SLICE, "the epilogue's passes fit the ring");
   // PIPE: the hidden loop is software-pipelined inside every wavefront - GEMM1 of hidden block t runs while the (unpacked) GELU
   // of block t-1 is evaluated - and the packed weights carry one more slice: slice t = [W1(t) | W2(t-1)], t = 0..NHB.
   static constexpr bool PIPE = blk_fwd_pipe(C);
   static constexpr int NSL = NHB + (PIPE ? 1 : 0);  // weight slices streamed through the ring
-  static_assert(FWD_PIECES % 4 == 0, "pieces must divide over 4 wavefronts");
+  static_assert(FWD_PIECES % W == 0, "pieces must divide over the wavefronts");
 };
 
 // ------------------------------------------------------------------ weight pre-arrangement
@@ -322,9 +336,10 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const TW* __restrict__ W1
 // LN(u) rows - the operands of the weight-gradient contractions (cnx_gemm_tn_ex).  Workspace tile (32 rows x 32 hidden units, 2 KiB,
 // tile index = (row tile, hidden block)): the lane (row m = lane % 32, half = lane / 32) stores its 16 accumulator values as bf16 at
 // byte 64 m + 32 half: rows of 64 bytes = the CNX_TN_ACC layout of include/convnext_hip.h (opaque to every other caller).
-template <int C, typename TX, typename TO, int WS = 0>
-__global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(const BlkFwdArgs p) {
-  using G = Geo<C>;
+template <int C, typename TX, typename TO, int WS = 0, int W = 4>
+__global__ __launch_bounds__(64 * W, (W == 8 ? 2 : C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) void blk_mlp_fwd_kernel(const BlkFwdArgs p) {
+  using G = Geo<C, W>;
+  constexpr int NT = 64 * W;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* ring = lds;
   float* b1s = reinterpret_cast<float*>(lds + G::DEPTH * G::FWD_SLICE);
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
   }
 #endif
 
-  // ---- weight stream: slice s -> ring slot s % DEPTH, 1 KiB pieces, piece = round*4 + wave
+  // ---- weight stream: slice s -> ring slot s % DEPTH, 1 KiB pieces, piece = round*W + wave
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wf);    // wave-uniform; the lane's part is lane16
   const uint32_t lane16 = lane * 16, ring0 = __builtin_amdgcn_readfirstlane(lds_addr(ring));
 #define DMA_SLICE(S)                                                                                       \
@@ -351,7 +366,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
     const unsigned char* gs = wsrc + static_cast<long>(S) * G::FWD_SLICE;                                  \
     const uint32_t ls = ring0 + ((S) % G::DEPTH) * G::FWD_SLICE;                                           \
     _Pragma("unroll") for (int i = 0; i < G::FWD_ROUNDS; ++i) {                                            \
-      const int piece = i * 4 + wave;                                                                      \
+      const int piece = i * W + wave;                                                                      \
       glds16(gs + piece * 1024, lane16, ls + piece * 1024); \
     }                                                                                                      \
   }
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
   {                                                                                                        \
     const unsigned char* gs = wsrc + static_cast<long>(S) * G::FWD_SLICE;                                  \
     const uint32_t ls = ring0 + ((S) % G::DEPTH) * G::FWD_SLICE;                                           \
-    const int piece = (R) * 4 + wave;                                                                      \
+    const int piece = (R) * W + wave;                                                                      \
     glds16(gs + piece * 1024, lane16, ls + piece * 1024); \
   }
   if (DBG(p, 16) && blockIdx.x < 1024) {                // timing experiment: de-phase the co-resident workgroups of the first round
@@ -372,8 +387,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
   //      96 KB of DMA first and every wavefront sat in `vmcnt(3)` for its u row until both slices had landed, then fetched the
   //      LayerNorm weights from global memory in C/64 rounds of eight loads and a vmcnt(0) each (13.6 us of a 95 us workgroup at
   //      C = 384, tools/blk_trace.py).
-  for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
-  for (int i = tid; i < C; i += 256) {                                  // b2, gamma (1 when absent), LayerNorm weight / bias
+  for (int i = tid; i < C; i += NT) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  for (int i = tid; i < C; i += NT) {                                   // b2, gamma (1 when absent), LayerNorm weight / bias
     b1s[4 * C + i] = p.b2[i];
     b1s[5 * C + i] = p.gamma ? p.gamma[i] : 1.0f;
     b1s[6 * C + i] = p.ln_w ? p.ln_w[i] : 1.0f;
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       SLICE_SYNC(T, ST)                                                                                        \
       if constexpr (WS) {   /* Hpre of block T-1 for the input-gradient kernel: 16 bf16 per lane, accumulator order */ \
         uint4* dst = reinterpret_cast<uint4*>(p.hpre) +                                                        \
-                     ((static_cast<long>(blockIdx.x) * 4 + wave) * G::NHB + ((T) - 1)) * 128 + l32 * 4 + half * 2; \
+                     ((static_cast<long>(blockIdx.x) * W + wave) * G::NHB + ((T) - 1)) * 128 + l32 * 4 + half * 2; \
         dst[0] = make_uint4(cvt_pk_bf16(ZIN[0], ZIN[1]), cvt_pk_bf16(ZIN[2], ZIN[3]), cvt_pk_bf16(ZIN[4], ZIN[5]),   \
                             cvt_pk_bf16(ZIN[6], ZIN[7]));                                                      \
         dst[1] = make_uint4(cvt_pk_bf16(ZIN[8], ZIN[9]), cvt_pk_bf16(ZIN[10], ZIN[11]), cvt_pk_bf16(ZIN[12], ZIN[13]), \
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
       hf1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));                                \
       if constexpr (WS == 2) {   /* H of block T-1 (the GEMM2 operand pairs just formed), same tile as its Hpre */ \
         uint4* hdst = reinterpret_cast<uint4*>(p.hact) +                                                       \
-                      ((static_cast<long>(blockIdx.x) * 4 + wave) * G::NHB + ((T) - 1)) * 128 + l32 * 4 + half * 2; \
+                      ((static_cast<long>(blockIdx.x) * W + wave) * G::NHB + ((T) - 1)) * 128 + l32 * 4 + half * 2; \
         hdst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);                                                      \
         hdst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);                                                      \
       }                                                                                                        \
@@ -678,25 +693,26 @@ __global__ __launch_bounds__(256, (C <= 96 ? BLK_FWD96_OCC : C <= 192 ? 2 : 1)) 
   TRACE(2)                                                              // this wavefront's hidden loop is done
   __syncthreads();                                                      // every wavefront is past its last fragment read
   TRACE(3)
-  float* scr = reinterpret_cast<float*>(ring) + wave * (16 * C);        // 16 rows x C fp32 per wavefront (<= 2/3 of the ring)
+  constexpr int RP = G::RP;                                             // rows per pass: 16 (registers 8 pass .. 8 pass + 7), or 8 (4 pass .. 4 pass + 3)
+  float* scr = reinterpret_cast<float*>(ring) + wave * (RP * C);        // RP rows x C fp32 per wavefront
   const float4* b2v = reinterpret_cast<const float4*>(b1s + 4 * C);
   const float4* gav = reinterpret_cast<const float4*>(b1s + 5 * C);
   const TX* resid = static_cast<const TX*>(p.resid);
   TO* out = static_cast<TO*>(p.out);
   constexpr int C4 = C / 4;                                             // float4 chunks per row
-  constexpr int NCH = 16 * C4 / 64;                                     // chunks per lane and pass
-  constexpr int GRP = (NCH % 6 == 0) ? 6 : 4;                           // chunks in flight per lane (C/16 is a multiple of 6 or of 4)
+  constexpr int NCH = RP * C4 / 64;                                     // chunks per lane and pass
+  constexpr int GRP = (NCH % 6 == 0) ? 6 : 4;                           // chunks in flight per lane
   static_assert(NCH % GRP == 0, "chunk groups");
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const long e0 = (m0 + 16 * pass) * C;                               // first element of this pass
+  for (int pass = 0; pass < 32 / RP; ++pass) {
+    const long e0 = (m0 + RP * pass) * C;                               // first element of this pass
     const long e_end = p.M * C;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int cb = 0; cb < G::CB; ++cb)
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc2[cb][8 * pass + r];
+      for (int r = 0; r < RP / 2; ++r)
+        scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc2[cb][(RP / 2) * pass + r];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int g0 = 0; g0 < NCH; g0 += GRP) {
@@ -1124,14 +1140,24 @@ int launch_blk2_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStre
   return launch_status();
 }
 
-template <int C>
-int launch_blk_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
-  using G = Geo<C>;
-  const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(256);
+// Wavefronts per workgroup of blk_mlp_fwd_kernel at width C: 8 (256 rows share one weight stream, round 6) where the registers allow two
+// wavefronts per SIMD, else 4.  cnx_runtime_switch(CNX_SWITCH_FWD_WAVES8, mask) / APGD_FWD_W8: bit 0 = C 128, bit 1 = C 192.
+int& fwd_w8_widths() {
+  static int m = [] {
+    const char* env = getenv("APGD_FWD_W8");
+    return env ? ((strstr(env, "128") ? 1 : 0) | (strstr(env, "192") ? 2 : 0)) : kFwdW8Default;
+  }();
+  return m;
+}
+
+template <int C, int W>
+int launch_blk_fwd_w(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
+  using G = Geo<C, W>;
+  const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(64 * W);
 #define BLK_LAUNCH(TX, TO) { if (a.hpre) { if constexpr (G::PIPE) { if (a.hact) BLK_LAUNCH_WS(TX, TO, 2) else BLK_LAUNCH_WS(TX, TO, 1) } else return APGD_ERR_ARG; } else BLK_LAUNCH_WS(TX, TO, 0) }
 #define BLK_LAUNCH_WS(TX, TO, WSV)                                                                               \
   {                                                                                                              \
-    auto kfn = blk_mlp_fwd_kernel<C, TX, TO, WSV>;                                                               \
+    auto kfn = blk_mlp_fwd_kernel<C, TX, TO, WSV, W>;                                                            \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,  \
@@ -1147,6 +1173,16 @@ int launch_blk_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStrea
 #undef BLK_LAUNCH
 #undef BLK_LAUNCH_WS
   return launch_status();
+}
+
+template <int C>
+int launch_blk_fwd(const BlkFwdArgs& a, int resid_dtype, int out_dtype, hipStream_t s) {
+#if BLK_FWD_W8_BUILD
+  if constexpr (C == 128 || C == 192) {
+    if (fwd_w8_widths() & (C == 128 ? 1 : 2)) return launch_blk_fwd_w<C, 8>(a, resid_dtype, out_dtype, s);
+  }
+#endif
+  return launch_blk_fwd_w<C, 4>(a, resid_dtype, out_dtype, s);
 }
 
 
@@ -1847,6 +1883,13 @@ int cnx_runtime_switch(int32_t which, int32_t value) {
       return prev;
     }
     case CNX_SWITCH_DW_SHARED_HALO: return dw_shared_halo_switch(value);
+    case CNX_SWITCH_FWD_WAVES8: {
+      if (!BLK_FWD_W8_BUILD) return -1;
+      int& m = fwd_w8_widths();
+      const int prev = m;
+      if (value >= 0) m = value & 3;
+      return prev;
+    }
     default: return -1;
   }
 }
