@@ -1834,9 +1834,367 @@ int launch_blk_bwd(const BlkBwdArgs& a, int g_dtype, bool ln_bwd, hipStream_t s)
   return launch_status();
 }
 
+// =====================================================================================================================
+// The Hpre backward on wavefront PAIRS (round 6): blk_mlp_bwd_kernel<C, TG, EMIT, LNB, HPRE = true> with the chain of a row tile split
+// as blk2_fwd_kernel splits the forward's -
+//   producer (wavefronts 0-3)  dO = bf16(g gamma) rows in registers; per hidden block b: dH(b)^T = W2[:, b]^T x dO^T (KS MFMAs, one
+//                              accumulator), the block's Hpre tile from the forward's workspace by LDS-DMA (2 KiB as it lies in memory, two
+//                              instructions counted by hand next to the weight pieces - a compiler-visible load would make the compiler
+//                              wait for every weight piece in flight, and an inline-asm load into registers cannot be waited for without
+//                              the compiler reading those registers first), dHpre(b - 1) = dH(b - 1) * GELU'(Hpre(b - 1)) in unpacked VALU instructions
+//                              between those MFMAs, dHpre(b - 1) as bf16 operand pairs -> 2 KiB of LDS;
+//   consumer (wavefronts 4-7)  da += dHpre(b - 2) x W1[b - 2] (2 CB MFMAs into the 32 x C fp32 tile), the dHpre tile to the workspace
+//                              (EMIT == 2), epilogue: LayerNorm backward (LNB) or the plain da rows.
+// Rings as blk2_fwd_kernel: W2^T pieces three slots (two blocks ahead), GEMM3 pieces two slots (one block ahead), both straight out of
+// the packed backward slices (cnx_mlp_pack_weights_bwd: [W1 | W2^T | GEMM3] per hidden block; the W1 pieces are not read).  Results are
+// bit-identical to the single-wavefront kernel's (same MFMA order per accumulator, same activation arithmetic).
+template <int C, typename TG, int EMIT, bool LNB>
+__global__ __launch_bounds__(512, 2) void blk2_bwd_kernel(const BlkBwdArgs p) {
+  using G = Geo2<C>;
+  static_assert(EMIT == 0 || EMIT == 2, "emit modes of the Hpre backward");
+  constexpr int SLICE_B = (2 * G::KS + 2 * G::CB) * 1024;             // a packed backward slice: [W1 (KS) | W2^T (KS) | GEMM3 (2 CB)] KiB
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* hbuf = lds + G::W1_RING + G::W2_RING;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave & 3;
+  const int l32 = lane & 31, half = lane >> 5;
+  const long m0 = static_cast<long>(blockIdx.x) * 128 + pair * 32;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wb);
+  const uint32_t lane16 = lane * 16, ring1 = __builtin_amdgcn_readfirstlane(lds_addr(lds)), ring2 = ring1 + G::W1_RING;
+  // A pieces: W2^T of block T -> ring slot T % 3;  B pieces: the GEMM3 fragments of block T -> ring slot T % 2
+#define DMA_A_PIECE(T, I)                                                                                  \
+  {                                                                                                        \
+    const int q_ = (I) * 8 + wave;                                                                         \
+    glds16(wsrc + static_cast<long>(T) * SLICE_B + (G::KS + q_) * 1024, lane16, ring1 + ((T) % 3) * (G::KS * 1024) + q_ * 1024); \
+  }
+#define DMA_B_PIECE(T, I)                                                                                  \
+  {                                                                                                        \
+    const int q_ = (I) * 8 + wave;                                                                         \
+    glds16(wsrc + static_cast<long>(T) * SLICE_B + (2 * G::KS + q_) * 1024, lane16, ring2 + ((T) % 2) * (2 * G::CB * 1024) + q_ * 1024); \
+  }
+  constexpr int R1W = G::KS / 8, R2W = 2 * G::CB / 8, NDMA = R1W + R2W;
+  // block B, DMA instruction K of this wavefront: first its GEMM3 pieces of block B - 1 (read in block B + 1), then its W2^T pieces of
+  // block B + 2 (read in block B + 2)
+#define BLK_DMA(B, K, ST)                                                                                  \
+  if ((K) < R2W) { if (ST || ((B) >= 1 && (B) - 1 < G::NHB)) DMA_B_PIECE((B) - 1, (K)) }                   \
+  else { if (ST || (B) + 2 < G::NHB) DMA_A_PIECE((B) + 2, (K) - R2W) }
+  const long tile = static_cast<long>(blockIdx.x) * 4 + pair;
+  unsigned char* hb_lane = hbuf + pair * 8192 + lane * 32;           // buffer i at + 4096 i: the dHpre tile of a block
+  // the Hpre tile of block b ((tile NHB + b) 2048 bytes into the workspace) goes, as it lies, into the second half of buffer b & 1: issued
+  // by the CONSUMER at the top of its block b (it has the lighter instruction stream), read by the producer at the top of block b + 1
+  const unsigned char* hp_base = reinterpret_cast<const unsigned char*>(p.hpre) + tile * G::NHB * 2048;
+  const uint32_t hp_lds = __builtin_amdgcn_readfirstlane(lds_addr(hbuf)) + pair * 8192 + 2048;
+
+  if (wave < 4) {
+    // ================================================================ producer: dO rows, dH, GELU', dHpre -> LDS
+    long row = m0 + l32;
+    const bool row_ok = row < p.M;
+    if (!row_ok) row = p.M - 1;
+    bf16x8 gf[G::KS];
+    {
+      const float4* gmp = p.gamma ? reinterpret_cast<const float4*>(p.gamma + half * (C / 2)) : nullptr;
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        float v[8];
+        if constexpr (sizeof(TG) == 4) {
+          const float4* gp = reinterpret_cast<const float4*>(static_cast<const float*>(p.g) + row * C + half * (C / 2));
+          const float4 g0 = gp[2 * ks], g1 = gp[2 * ks + 1];
+          v[0] = g0.x; v[1] = g0.y; v[2] = g0.z; v[3] = g0.w; v[4] = g1.x; v[5] = g1.y; v[6] = g1.z; v[7] = g1.w;
+        } else {
+          const uint4 raw = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.g) + row * C + half * (C / 2))[ks];
+          v[0] = bf16_lo(raw.x); v[1] = bf16_hi(raw.x); v[2] = bf16_lo(raw.y); v[3] = bf16_hi(raw.y);
+          v[4] = bf16_lo(raw.z); v[5] = bf16_hi(raw.z); v[6] = bf16_lo(raw.w); v[7] = bf16_hi(raw.w);
+        }
+        if (gmp) {
+          const float4 m0v = gmp[2 * ks], m1v = gmp[2 * ks + 1];
+          v[0] *= m0v.x; v[1] *= m0v.y; v[2] *= m0v.z; v[3] *= m0v.w; v[4] *= m1v.x; v[5] *= m1v.y; v[6] *= m1v.z; v[7] *= m1v.w;
+        }
+        const uint4 packed = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        gf[ks] = __builtin_bit_cast(bf16x8, packed);
+        if (EMIT && row_ok) reinterpret_cast<uint4*>(p.do_out + row * C + half * (C / 2))[ks] = packed;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) asm volatile("" : "+v"(gf[ks]));   // the rows are in registers before the DMA is issued
+#pragma unroll
+    for (int i = 0; i < R1W; ++i) DMA_A_PIECE(0, i)
+#pragma unroll
+    for (int i = 0; i < R1W; ++i) DMA_A_PIECE(1, i)
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // W2^T(0), W2^T(1): this wavefront's pieces (and its dO row stores)
+    __syncthreads();                                                  // ... everybody's
+    float c6v = 1.8761737253e-03f;
+    asm volatile("" : "+v"(c6v));
+    // the lane's 16 values of a Hpre tile: + 64 l32 + 32 half of the copy in the hand-over buffer
+    const unsigned char* hp_lane = hbuf + pair * 8192 + 2048 + l32 * 64 + half * 32;
+    // Block b:  MFMA stream  dH(b) = W2[:, b]^T x dO^T (KS MFMAs, b < NHB); the Hpre(b) tile is requested at the top
+    //           VALU stream  dHpre(b - 1) = dH(b - 1) * GELU'(Hpre(b - 1)) between those MFMAs (b >= 1) -> hand-over buffer
+    constexpr int PF = 4, NUOP = 4 * 62;
+    constexpr int P_DMA_EVERY = G::KS / NDMA;
+    static_assert(P_DMA_EVERY >= 1 && P_DMA_EVERY * NDMA <= G::KS, "one DMA instruction per P_DMA_EVERY MFMAs");
+    // the end of a block: everything but this block's W2^T pieces is in; barrier
+#define PB_SYNC(B, ST)                                                                                     \
+    if (ST || (B) + 2 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R1W) : "memory");                 \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+    __builtin_amdgcn_s_barrier();
+#define PB_BLOCK(B, DCUR, DPREV, ST)                                                                       \
+    {                                                                                                      \
+      uint32_t pk[8];                                                                                      \
+      float gx[4], ge[4], gw[4], zq[16];                                                                   \
+      if (ST || (B) >= 1) {                                                                                \
+        const uint4* hr_ = reinterpret_cast<const uint4*>(hp_lane + (((B) - 1) & 1) * 4096);               \
+        const uint4 h0_ = hr_[0], h1_ = hr_[1];                                                            \
+        const uint32_t hw_[8] = {h0_.x, h0_.y, h0_.z, h0_.w, h1_.x, h1_.y, h1_.z, h1_.w};                  \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) { zq[2 * k] = bf16_lo(hw_[k]); zq[2 * k + 1] = bf16_hi(hw_[k]); } \
+      }                                                                                                    \
+      if (ST || (B) < G::NHB) {                                                                            \
+        const unsigned char* sl = lds + ((B) % 3) * (G::KS * 1024) + lane * 16;                            \
+        bf16x8 fr[PF];                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(sl + i * 1024); \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) DCUR[r] = 0.f;                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        _Pragma("unroll") for (int i = 0; i < G::KS; ++i) {                                                \
+          DCUR = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % PF], gf[i], DCUR, 0, 0, 0);                \
+          if (i + PF < G::KS) fr[i % PF] = *reinterpret_cast<const bf16x8*>(sl + (i + PF) * 1024);         \
+          if (i % P_DMA_EVERY == 0 && i / P_DMA_EVERY < NDMA) { BLK_DMA(B, i / P_DMA_EVERY, ST) }          \
+          __builtin_amdgcn_sched_barrier(0);                                                               \
+          if (ST || (B) >= 1) {                                                                            \
+            _Pragma("unroll") for (int uo = NUOP * i / G::KS; uo < NUOP * (i + 1) / G::KS; ++uo) {         \
+              const int qd = uo / 62;                                                                      \
+              const float z4[4] = {zq[4 * qd], zq[4 * qd + 1], zq[4 * qd + 2], zq[4 * qd + 3]};            \
+              const float d4[4] = {DPREV[4 * qd], DPREV[4 * qd + 1], DPREV[4 * qd + 2], DPREV[4 * qd + 3]}; \
+              gelu_grad_uop(uo % 62, z4, d4, gx, ge, gw, pk[2 * qd], pk[2 * qd + 1], c6v);                 \
+            }                                                                                              \
+          }                                                                                                \
+          __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                  \
+        /* the chain's result is read by inline-asm VALU instructions in the next block: the wait states by hand (blk2_fwd_kernel) */ \
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(DCUR));                                                  \
+      } else {                                                                                             \
+        _Pragma("unroll") for (int k_ = 0; k_ < NDMA; ++k_) { BLK_DMA(B, k_, false) }                      \
+        if ((B) >= 1) {                                                                                    \
+          _Pragma("unroll") for (int qd = 0; qd < 4; ++qd) {                                               \
+            const float z4[4] = {zq[4 * qd], zq[4 * qd + 1], zq[4 * qd + 2], zq[4 * qd + 3]};              \
+            const float d4[4] = {DPREV[4 * qd], DPREV[4 * qd + 1], DPREV[4 * qd + 2], DPREV[4 * qd + 3]};  \
+            _Pragma("unroll") for (int uo = 0; uo < 62; ++uo) gelu_grad_uop(uo, z4, d4, gx, ge, gw, pk[2 * qd], pk[2 * qd + 1], c6v); \
+          }                                                                                                \
+        }                                                                                                  \
+      }                                                                                                    \
+      if (ST || (B) >= 1) {                                                                                \
+        uint4* hw = reinterpret_cast<uint4*>(hb_lane + (((B) - 1) & 1) * 4096);                            \
+        hw[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);                                                    \
+        hw[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);                                                    \
+      }                                                                                                    \
+      PB_SYNC(B, ST)                                                                                       \
+    }
+    static_assert(G::NHB % 2 == 0 && G::NHB >= 6, "two-block unroll, steady blocks 1 .. NHB - 3");
+    f32x16 da_, db_;
+    PB_BLOCK(0, da_, db_, false)
+    for (int b = 1; b + 1 < G::NHB - 2; b += 2) {                     // blocks 1 .. NHB - 4 (pairs), all conditions true
+      PB_BLOCK(b, db_, da_, true)
+      PB_BLOCK(b + 1, da_, db_, true)
+    }
+    PB_BLOCK(G::NHB - 3, db_, da_, true)
+    PB_BLOCK(G::NHB - 2, da_, db_, false)
+    PB_BLOCK(G::NHB - 1, db_, da_, false)
+    PB_BLOCK(G::NHB, da_, db_, false)
+    __builtin_amdgcn_s_barrier();                                     // block NHB + 1: the consumers' last GEMM3
+#undef PB_BLOCK
+#undef PB_SYNC
+    __syncthreads();                                                  // the consumers' rings are dead: their epilogue may begin
+    return;
+  }
+
+  // ================================================================== consumer: weight DMA, GEMM3, epilogue
+  f32x16 acc3[G::CB];
+#pragma unroll
+  for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc3[cb][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < R1W; ++i) DMA_A_PIECE(0, i)
+#pragma unroll
+  for (int i = 0; i < R1W; ++i) DMA_A_PIECE(1, i)
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  constexpr int PFC = 4, DMA_EVERY = 2 * G::CB / NDMA;
+  static_assert(DMA_EVERY >= 1 && DMA_EVERY * NDMA <= 2 * G::CB, "one DMA instruction per DMA_EVERY MFMAs");
+  // fragment j of a block's GEMM3 stream -> piece of the ring slot: (t, cb) order (consecutive MFMAs update different accumulators) out of
+  // the packed (cb, t) order
+#define G3_PIECE(J) ((((J) % G::CB) * 2) + ((J) / G::CB))
+#define CB_SYNC(B, ST)                                                                                     \
+  if (ST || (B) + 2 < G::NHB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R1W) : "memory");                   \
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+  __builtin_amdgcn_s_barrier();
+#define CB_BLOCK(B, ST)                                                                                    \
+  {                                                                                                        \
+    if (ST || (B) < G::NHB) {                              /* the Hpre tile of block B for the producer's block B + 1 */ \
+      glds16(hp_base + static_cast<long>(B) * 2048, lane16, hp_lds + ((B) & 1) * 4096);                    \
+      glds16(hp_base + static_cast<long>(B) * 2048 + 1024, lane16, hp_lds + ((B) & 1) * 4096 + 1024);      \
+    }                                                                                                      \
+    if (ST || ((B) >= 2 && (B) - 2 < G::NHB)) {                                                            \
+      const uint4* hr = reinterpret_cast<const uint4*>(hb_lane + (((B) - 2) & 1) * 4096);                  \
+      const uint4 hq0 = hr[0], hq1 = hr[1];                                                                \
+      const bf16x8 hf0 = __builtin_bit_cast(bf16x8, hq0), hf1 = __builtin_bit_cast(bf16x8, hq1);           \
+      if constexpr (EMIT == 2) {   /* dHpre of block B - 2 in its Hpre's tile (CNX_TN_ACC), in front of this block's DMA */ \
+        uint4* dd_ = reinterpret_cast<uint4*>(p.dhpt_out) + (tile * G::NHB + ((B) - 2)) * 128 + l32 * 4 + half * 2; \
+        dd_[0] = hq0; dd_[1] = hq1;                                                                        \
+      }                                                                                                    \
+      const unsigned char* sl = lds + G::W1_RING + (((B) - 2) % 2) * (2 * G::CB * 1024) + lane * 16;       \
+      bf16x8 fr[PFC];                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < PFC; ++j) fr[j] = *reinterpret_cast<const bf16x8*>(sl + G3_PIECE(j) * 1024); \
+      _Pragma("unroll") for (int j = 0; j < 2 * G::CB; ++j) {                                              \
+        acc3[j % G::CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(j < G::CB ? hf0 : hf1, fr[j % PFC], acc3[j % G::CB], 0, 0, 0); \
+        if (j + PFC < 2 * G::CB) fr[j % PFC] = *reinterpret_cast<const bf16x8*>(sl + G3_PIECE(j + PFC) * 1024); \
+        if (j % DMA_EVERY == 0 && j / DMA_EVERY < NDMA) { BLK_DMA(B, j / DMA_EVERY, ST) }                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+      }                                                                                                    \
+    } else {                                                                                               \
+      _Pragma("unroll") for (int k = 0; k < NDMA; ++k) { BLK_DMA(B, k, false) }                            \
+    }                                                                                                      \
+    CB_SYNC(B, ST)                                                                                         \
+  }
+  CB_BLOCK(0, false)
+  CB_BLOCK(1, false)
+  for (int b = 2; b + 2 < G::NHB; ++b) CB_BLOCK(b, true)
+  CB_BLOCK(G::NHB - 2, false)
+  CB_BLOCK(G::NHB - 1, false)
+  CB_BLOCK(G::NHB, false)
+  CB_BLOCK(G::NHB + 1, false)
+#undef CB_BLOCK
+#undef CB_SYNC
+#undef G3_PIECE
+#undef BLK_DMA
+#undef DMA_A_PIECE
+#undef DMA_B_PIECE
+  // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32], through the dead rings, 16 rows per pass (as
+  //      blk_mlp_bwd_kernel; the u row is read twice instead of held: this wavefront shares its SIMD, 256 registers)
+  __syncthreads();
+  if constexpr (LNB) {
+    constexpr int CP = C + 4;
+    static_assert(4 * 16 * CP * 4 <= G::W1_RING + G::W2_RING, "the epilogue tile reuses the weight rings");
+    float* scr = reinterpret_cast<float*>(lds) + pair * (16 * CP);
+    constexpr int NJ = C / 32;
+    const int rl = lane >> 2, q = lane & 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          scr[((r & 3) + 8 * (r >> 2) + 4 * half) * CP + cb * 32 + l32] = acc3[cb][8 * pass + r];
+      __builtin_amdgcn_wave_barrier();
+      const long m = m0 + 16 * pass + rl;
+      const long mc = m < p.M ? m : p.M - 1;
+      const float mean = p.mean[mc], rstd = p.rstd[mc];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c0 = (q + 4 * j) * 8;
+        const uint4 ur = *reinterpret_cast<const uint4*>(p.u + mc * C + c0);
+        const float4 d0 = *reinterpret_cast<const float4*>(scr + rl * CP + c0), d1 = *reinterpret_cast<const float4*>(scr + rl * CP + c0 + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + c0), w1 = *reinterpret_cast<const float4*>(p.ln_w + c0 + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const uint32_t uw[4] = {ur.x, ur.y, ur.z, ur.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float uv = (e & 1) ? bf16_hi(uw[e >> 1]) : bf16_lo(uw[e >> 1]);
+          const float t = wv[e] * dv[e], xh = (uv - mean) * rstd;
+          s1 += t;
+          s2 = fmaf(t, xh, s2);
+        }
+      }
+      s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+      s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+      s1 *= (1.0f / C); s2 *= (1.0f / C);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c0 = (q + 4 * j) * 8;
+        const uint4 ur = *reinterpret_cast<const uint4*>(p.u + mc * C + c0);
+        const float4 d0 = *reinterpret_cast<const float4*>(scr + rl * CP + c0), d1 = *reinterpret_cast<const float4*>(scr + rl * CP + c0 + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + c0), w1 = *reinterpret_cast<const float4*>(p.ln_w + c0 + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const uint32_t uw[4] = {ur.x, ur.y, ur.z, ur.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float uv = (e & 1) ? bf16_hi(uw[e >> 1]) : bf16_lo(uw[e >> 1]);
+          const float t = wv[e] * dv[e], xh = (uv - mean) * rstd;
+          o[e] = rstd * (t - s1 - xh * s2);
+        }
+        if (m < p.M)
+          *reinterpret_cast<uint4*>(p.da + m * C + c0) = make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+      }
+    }
+  } else {
+    float* scr = reinterpret_cast<float*>(lds) + pair * (16 * C);
+    constexpr int NCH = 16 * C / 8 / 64;                                  // 8-element chunks per lane and pass (C / 32)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const long e0 = (m0 + 16 * pass) * C;
+      const long e_end = p.M * C;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc3[cb][8 * pass + r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int idx = k * 64 + lane;
+        const long e = e0 + idx * 8;
+        const float4 d0 = reinterpret_cast<const float4*>(scr)[2 * idx], d1 = reinterpret_cast<const float4*>(scr)[2 * idx + 1];
+        if (e < e_end)
+          *reinterpret_cast<uint4*>(p.da + e) = make_uint4(pack_bf16(d0.x, d0.y), pack_bf16(d0.z, d0.w), pack_bf16(d1.x, d1.y), pack_bf16(d1.z, d1.w));
+      }
+    }
+  }
+}
+
+// Which Hpre backward serves width C: the wavefront-pair kernel at C = 256 / 384 (cnx_runtime_switch(CNX_SWITCH_BLK2_BWD_WIDTHS) /
+// APGD_BLK2B: bit 0 = C 256, bit 1 = C 384)
+int& blk2b_widths() {
+  static int m = [] {
+    const char* env = getenv("APGD_BLK2B");
+    return env ? ((strstr(env, "256") ? 1 : 0) | (strstr(env, "384") ? 2 : 0)) : 3;
+  }();
+  return m;
+}
+
+template <int C>
+int launch_blk2_bwd_hpre(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
+  using G = Geo2<C>;
+  const dim3 grid(static_cast<unsigned>((a.M + 127) / 128)), block(512);
+#define BLK2B_GO(TG, EM, LN)                                                                                     \
+  {                                                                                                              \
+    auto kfn = blk2_bwd_kernel<C, TG, EM, LN>;                                                                   \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, G::LDS, s, a);                                                          \
+  }
+#define BLK2B_LAUNCH(TG) { if (a.dhpt_out && a.u) BLK2B_GO(TG, 2, true) else if (a.dhpt_out) BLK2B_GO(TG, 2, false) else BLK2B_GO(TG, 0, true) }
+  if (g_dtype == APGD_F32) BLK2B_LAUNCH(float) else BLK2B_LAUNCH(uint16_t)
+#undef BLK2B_LAUNCH
+#undef BLK2B_GO
+  return launch_status();
+}
+
 template <int C>
 int launch_blk_bwd_hpre(const BlkBwdArgs& a, int g_dtype, hipStream_t s) {
   using G = GeoB<C>;
+  if constexpr (C == 256 || C == 384) {
+    if (blk2b_widths() & (C == 256 ? 1 : 2)) return launch_blk2_bwd_hpre<C>(a, g_dtype, s);
+  }
   constexpr int LDS_BYTES = G::DEPTH * (G::KS + 2 * G::CB) * 1024 + 16 * C;
   const dim3 grid(static_cast<unsigned>((a.M + G::BM - 1) / G::BM)), block(G::WAVES * 64);
 #define BLK_LAUNCH(TG)                                                                                           \
@@ -1883,6 +2241,12 @@ int cnx_runtime_switch(int32_t which, int32_t value) {
       return prev;
     }
     case CNX_SWITCH_DW_SHARED_HALO: return dw_shared_halo_switch(value);
+    case CNX_SWITCH_BLK2_BWD_WIDTHS: {
+      int& m = blk2b_widths();
+      const int prev = m;
+      if (value >= 0) m = value & 3;
+      return prev;
+    }
     case CNX_SWITCH_FWD_WAVES8: {
       if (!BLK_FWD_W8_BUILD) return -1;
       int& m = fwd_w8_widths();

@@ -1811,7 +1811,7 @@ def attention(qkv, num_heads, scale):
 KERNEL_SETS = {
     # the tree as shipped
     "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
-                    blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0),
+                    blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3),
     # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
     # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
     # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
@@ -1819,7 +1819,9 @@ KERNEL_SETS = {
     #  convolution_backward under hipGraph replay returned a non-finite bias gradient for the second ConvStem convolution in one of five
     #  fresh trainers, gpurun_out/r6b - a hazard of the round-4 tree that went unnoticed there - and a NaN leg is no measurement)
     "round4": dict(wgrad="lib", stem_wgrad=True, train_hpre=set(), dgamma=False, dln="pass", fused_tracking=False, blk2=0,
-                   pool_rows=False, dw_shared_halo=0),
+                   pool_rows=False, dw_shared_halo=0, blk2b=0),
+    # the end-of-round-5 selection: today's tree without round 6's wavefront-pair Hpre backward
+    "round5": dict(blk2b=0),
     # round 6's measured negative: eight wavefronts (256 rows) per workgroup on one weight stream at C = 128 / 192
     # (profiles/r06_fused_mlp.md; needs a library built with -DBLK_FWD_W8_BUILD=1, else the switch reads back -1 and nothing changes)
     "w8": dict(fwd_w8=3),
@@ -1840,7 +1842,7 @@ def kernel_set(name_or_dict):
     prev = dict(wgrad=_WGRAD_MODE, stem_wgrad=STEM_WGRAD_HIP, train_hpre=set(_TRAIN_HPRE_WIDTHS), dgamma=_DGAMMA_FROM_DW2,
                 dln="dw1" if _LN_IN_TRAIN_BWD else ("kernel" if _DLN_FROM_DW1 else "pass"), fused_tracking=_apgd.FUSED_TRACKING,
                 blk2=int(lib.cnx_runtime_switch(0, -1)), pool_rows=_POOL_ROWS, dw_shared_halo=int(lib.cnx_runtime_switch(1, -1)),
-                fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))))
+                fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))), blk2b=int(lib.cnx_runtime_switch(3, -1)))
     if "wgrad" in new:
         if new["wgrad"] not in ("hip", "lib"):
             raise ValueError(f"kernel_set: wgrad={new['wgrad']!r}")
@@ -1865,5 +1867,7 @@ def kernel_set(name_or_dict):
         lib.cnx_runtime_switch(1, 1 if new["dw_shared_halo"] else 0)
     if "fwd_w8" in new:
         lib.cnx_runtime_switch(2, int(new["fwd_w8"]) & 3)
+    if "blk2b" in new:
+        lib.cnx_runtime_switch(3, int(new["blk2b"]) & 3)
     invalidate_weight_cache()
     return prev

@@ -718,6 +718,57 @@ def _acc_to_rows(ws, M_, N_):
     return t.permute(0, 2, 1, 4, 3, 5).reshape(M_, N_)
 
 
+@pytest.mark.parametrize("C,M_", [(256, 64), (256, 448), (384, 96), (384, 448), (384, 2048), (384, 6272)])
+@pytest.mark.parametrize("gdt", [torch.float32, torch.bfloat16])
+def test_hpre_backward_on_wavefront_pairs_is_bit_identical_to_the_single_wavefront_kernel(R, C, M_, gdt):
+    """Round 6: blk2_bwd_kernel (producer: dH, GELU'; consumer: GEMM3, epilogue - two wavefronts per row tile on one SIMD) against
+    blk_mlp_bwd_kernel<..., HPRE> in its three forms (attack: du; training: da + dO rows + dHpre tiles; training with the LayerNorm
+    backward in the epilogue), selected in one process by cnx_runtime_switch(CNX_SWITCH_BLK2_BWD_WIDTHS): same MFMA order per
+    accumulator, same activation arithmetic - every output bit for bit, ragged last workgroups included.  (The single-wavefront
+    kernel itself is checked against fp32 references in the tests below.)"""
+    lib = R._lib.load()
+    gen = torch.Generator().manual_seed(7 * C + M_)
+    dev_ = lambda t: t.detach().cuda().contiguous()
+    u = dev_((torch.randn(M_, C, generator=gen) * 1.5 + 0.3).to(torch.bfloat16))
+    xres = dev_(torch.randn(M_, C, generator=gen))
+    w1 = torch.randn(4 * C, C, generator=gen) * C ** -0.5
+    w2 = torch.randn(C, 4 * C, generator=gen) * (4 * C) ** -0.5
+    lw, lb = dev_(1 + 0.2 * torch.randn(C, generator=gen)), dev_(0.2 * torch.randn(C, generator=gen))
+    b1, b2 = dev_(torch.randn(4 * C, generator=gen) * 0.3), dev_(torch.randn(C, generator=gen) * 0.3)
+    gm = dev_(torch.randn(C, generator=gen))
+    g = dev_(torch.randn(M_, C, generator=gen).to(gdt))
+    wf, wb = R.ops._pack_mlp(w1.cuda(), w2.cuda()), R.ops._pack_mlp_bwd(w1.cuda(), w2.cuda())
+    n_ws = lib.cnx_block_mlp_hpre_elems(M_, C)
+    mean, rstd = torch.empty(M_, device="cuda"), torch.empty(M_, device="cuda")
+    out = torch.empty(M_, C, device="cuda")
+    hp = torch.zeros(n_ws, device="cuda", dtype=torch.bfloat16)
+    assert lib.cnx_block_mlp_fwd_hpre(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, mean.data_ptr(), rstd.data_ptr(), wf.data_ptr(), b1.data_ptr(),
+                                      b2.data_ptr(), gm.data_ptr(), xres.data_ptr(), 0, out.data_ptr(), 0, hp.data_ptr(), M_, C, S()) == 0
+    code = R._lib.dtype_code(gdt)
+    res = {}
+    prev = lib.cnx_runtime_switch(3, -1)
+    try:
+        for w in (0, 3):
+            assert lib.cnx_runtime_switch(3, w) >= 0
+            mk = lambda *sh: torch.full(sh, float("nan"), device="cuda", dtype=torch.bfloat16)
+            du0, da1, do1, dh1, du2, do2, dh2 = mk(M_, C), mk(M_, C), mk(M_, C), mk(n_ws), mk(M_, C), mk(M_, C), mk(n_ws)
+            assert lib.cnx_block_mlp_bwd_input_hpre(u.data_ptr(), lw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), code, gm.data_ptr(),
+                                                    wb.data_ptr(), hp.data_ptr(), du0.data_ptr(), M_, C, S()) == 0
+            assert lib.cnx_block_mlp_bwd_train_hpre(g.data_ptr(), code, gm.data_ptr(), wb.data_ptr(), hp.data_ptr(), da1.data_ptr(), do1.data_ptr(),
+                                                    dh1.data_ptr(), M_, C, S()) == 0
+            assert lib.cnx_block_mlp_bwd_train_hpre_ln(u.data_ptr(), lw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), code, gm.data_ptr(),
+                                                       wb.data_ptr(), hp.data_ptr(), du2.data_ptr(), do2.data_ptr(), dh2.data_ptr(), M_, C, S()) == 0
+            torch.cuda.synchronize()
+            nt = (M_ + 31) // 32 * 32 * 4 * C                       # tiles of rows that exist (the workspace is padded to 128 rows)
+            res[w] = (du0, da1, do1, dh1[:nt], du2, do2, dh2[:nt])
+    finally:
+        lib.cnx_runtime_switch(3, prev)
+    for a, b, name in zip(res[0], res[3], ("du (attack)", "da", "dO rows", "dHpre tiles", "du (training)", "dO rows (LN form)", "dHpre tiles (LN form)")):
+        assert not torch.isnan(b.float()).any(), name
+        assert torch.equal(a, b), name
+    assert torch.equal(res[3][0], res[3][4]) and torch.equal(res[3][3], res[3][6])      # the forms agree with each other
+
+
 def _hpre_pair_training_pass(R, C, M_, lw, lb, gm, seed):
     """Forward (cnx_block_mlp_fwd_train) + backward with the LayerNorm backward in its epilogue (cnx_block_mlp_bwd_train_hpre_ln and the
     plain cnx_block_mlp_bwd_train_hpre for da) + both weight gradients on cnx_gemm_tn_ex, with the given LayerNorm parameters and layer

@@ -153,13 +153,16 @@ def test_kernel_sets_switch_in_a_running_process_and_restore():
     start = ops.kernel_set("default")
     try:
         assert lib.cnx_runtime_switch(0, -1) == 3 and lib.cnx_runtime_switch(1, -1) == 1 and lib.cnx_runtime_switch(99, 1) == -1
+        assert lib.cnx_runtime_switch(3, -1) == 3 and ops.kernel_set("round5")["blk2b"] == 3 and lib.cnx_runtime_switch(3, -1) == 0
+        ops.kernel_set("default")
         prev = ops.kernel_set("round4")
         assert prev == ops.KERNEL_SETS["default"]
         assert (ops._WGRAD_MODE, ops.STEM_WGRAD_HIP, ops._TRAIN_HPRE_WIDTHS) == ("lib", True, set())
         assert (ops._DGAMMA_FROM_DW2, ops._DLN_FROM_DW1, ops._LN_IN_TRAIN_BWD, ops._POOL_ROWS) == (False, False, False, False)
         assert apgd.FUSED_TRACKING is False
-        assert lib.cnx_runtime_switch(0, -1) == 0 and lib.cnx_runtime_switch(1, -1) == 0
-        assert ops.kernel_set(prev) == ops.KERNEL_SETS["round4"]
+        assert lib.cnx_runtime_switch(0, -1) == 0 and lib.cnx_runtime_switch(1, -1) == 0 and lib.cnx_runtime_switch(3, -1) == 0
+        assert ops.kernel_set(prev) == dict(ops.KERNEL_SETS["round4"], fwd_w8=0)          # (a set names only what it changes)
+        assert lib.cnx_runtime_switch(2, 3) == -1 and ops.kernel_set("w8")["fwd_w8"] == 0   # measurement builds only: a no-op here
         assert ops.kernel_set({"dln": "kernel"})["dln"] == "dw1"
         assert (ops._DLN_FROM_DW1, ops._LN_IN_TRAIN_BWD) == (True, False)
         with pytest.raises(ValueError):
