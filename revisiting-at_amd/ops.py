@@ -630,6 +630,9 @@ class _StemConvLnGelu(torch.autograd.Function):
         return dx, dw, db, dlw, dlb, None
 
 
+_STEM_LN_FUSED = os.environ.get("APGD_STEM_LN_FUSED", "0") not in ("0", "")
+
+
 def stem_fused_ln():
     """The one-kernel stem (convolution + LayerNorm + GELU on the tile in LDS) or convolution + LayerNorm-GELU kernel.  Measured on
     MI355X (``tools/stem_bench.py``, batch 256 / 128, 224 x 224, after the convolution's move to 16-byte quad loads - 112 us alone,
@@ -637,7 +640,7 @@ def stem_fused_ln():
     282 / 147 and 278 / 141 us.  In the step (three interleaved pairs, ``gpurun_out/r4sf``) the two compositions are inside each
     other's noise (49.16 / 49.49 / 49.32 vs 49.78 / 49.22 / 49.28 ms): the two-kernel composition stays the default, the fused kernel
     stays in the library behind this constant."""
-    return False
+    return _STEM_LN_FUSED
 
 
 def stem_conv_ln_gelu(x, weight, bias, ln_w, ln_b, eps):
@@ -1811,7 +1814,7 @@ def attention(qkv, num_heads, scale):
 KERNEL_SETS = {
     # the tree as shipped
     "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
-                    blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3),
+                    blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2),
     # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
     # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
     # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
@@ -1822,6 +1825,8 @@ KERNEL_SETS = {
                    pool_rows=False, dw_shared_halo=0, blk2b=0),
     # the end-of-round-5 selection: today's tree without round 6's wavefront-pair Hpre backward
     "round5": dict(blk2b=0),
+    # single-switch experiments of round 6 (profiles/r06_ab.md)
+    "stemln": dict(stem_ln_fused=True), "streams3": dict(attack_streams=3), "streams1": dict(attack_streams=1),
     # round 6's measured negative: eight wavefronts (256 rows) per workgroup on one weight stream at C = 128 / 192
     # (profiles/r06_fused_mlp.md; needs a library built with -DBLK_FWD_W8_BUILD=1, else the switch reads back -1 and nothing changes)
     "w8": dict(fwd_w8=3),
@@ -1832,8 +1837,9 @@ def kernel_set(name_or_dict):
     """Select a kernel set in the running process; returns the settings that were in force (a dict ``kernel_set`` accepts).  The caller
     drops what was captured or cached under the old set (``graphed.reset()``, a fresh ``ATTrainStep``); results stay inside the parity
     bars either way - the sets differ in kernels and summation order, not in arithmetic."""
-    global _WGRAD_MODE, STEM_WGRAD_HIP, _TRAIN_HPRE_WIDTHS, _DGAMMA_FROM_DW2, _DLN_FROM_DW1, _LN_IN_TRAIN_BWD, _POOL_ROWS
+    global _WGRAD_MODE, STEM_WGRAD_HIP, _TRAIN_HPRE_WIDTHS, _DGAMMA_FROM_DW2, _DLN_FROM_DW1, _LN_IN_TRAIN_BWD, _POOL_ROWS, _STEM_LN_FUSED
     from . import apgd as _apgd
+    from . import graphed as _graphed
     new = KERNEL_SETS[name_or_dict] if isinstance(name_or_dict, str) else dict(name_or_dict)
     unknown = set(new) - set(KERNEL_SETS["default"])
     if unknown:
@@ -1842,7 +1848,8 @@ def kernel_set(name_or_dict):
     prev = dict(wgrad=_WGRAD_MODE, stem_wgrad=STEM_WGRAD_HIP, train_hpre=set(_TRAIN_HPRE_WIDTHS), dgamma=_DGAMMA_FROM_DW2,
                 dln="dw1" if _LN_IN_TRAIN_BWD else ("kernel" if _DLN_FROM_DW1 else "pass"), fused_tracking=_apgd.FUSED_TRACKING,
                 blk2=int(lib.cnx_runtime_switch(0, -1)), pool_rows=_POOL_ROWS, dw_shared_halo=int(lib.cnx_runtime_switch(1, -1)),
-                fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))), blk2b=int(lib.cnx_runtime_switch(3, -1)))
+                fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))), blk2b=int(lib.cnx_runtime_switch(3, -1)),
+                stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS)
     if "wgrad" in new:
         if new["wgrad"] not in ("hip", "lib"):
             raise ValueError(f"kernel_set: wgrad={new['wgrad']!r}")
@@ -1869,5 +1876,9 @@ def kernel_set(name_or_dict):
         lib.cnx_runtime_switch(2, int(new["fwd_w8"]) & 3)
     if "blk2b" in new:
         lib.cnx_runtime_switch(3, int(new["blk2b"]) & 3)
+    if "stem_ln_fused" in new:
+        _STEM_LN_FUSED = bool(new["stem_ln_fused"])
+    if "attack_streams" in new:
+        _graphed.STREAMS = max(1, int(new["attack_streams"]))
     invalidate_weight_cache()
     return prev
