@@ -49,6 +49,11 @@
 #ifndef BLK2_ABL
 #define BLK2_ABL 0
 #endif
+// issue priority inside a wavefront pair (s_setprio): 0 = none, 1 = the producer (a chain of DEPENDENT MFMAs: whenever its next one is ready
+// it should go ahead of the consumer's independent ones), 2 = the consumer.  Measured in round 6 (profiles/r06_fused_mlp.md)
+#ifndef BLK2_PRIO
+#define BLK2_PRIO 0
+#endif
 #if MLP_ABLATE
 // per-workgroup phase stamps (100 MHz wall clock) of the forward kernel, read back with cnx_dbg_blk_trace (tools/blk_trace.py)
 #define BLK_TRACE_SLOTS 12
@@ -825,6 +830,7 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
 
   if (wave < 4) {
     // ================================================================ producer: LN, GEMM1, GELU, H -> LDS
+    if constexpr (BLK2_PRIO == 1) __builtin_amdgcn_s_setprio(2);
     // (its own loop: the register allocation is per kernel, and a loop shared with the consumer would keep the producer's operand
     //  rows AND the consumer's accumulators live through it - 96 + 192 registers at C = 384)
     long row = m0 + l32;
@@ -982,6 +988,7 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
   }
 
   // ================================================================== consumer: weight DMA, GEMM2, epilogue
+  if constexpr (BLK2_PRIO == 2) __builtin_amdgcn_s_setprio(2);
   f32x16 acc2[G::CB];
 #pragma unroll
   for (int cb = 0; cb < G::CB; ++cb)
@@ -1888,6 +1895,7 @@ __global__ __launch_bounds__(512, 2) void blk2_bwd_kernel(const BlkBwdArgs p) {
 
   if (wave < 4) {
     // ================================================================ producer: dO rows, dH, GELU', dHpre -> LDS
+    if constexpr (BLK2_PRIO == 1) __builtin_amdgcn_s_setprio(2);
     long row = m0 + l32;
     const bool row_ok = row < p.M;
     if (!row_ok) row = p.M - 1;
@@ -2007,6 +2015,7 @@ __global__ __launch_bounds__(512, 2) void blk2_bwd_kernel(const BlkBwdArgs p) {
   }
 
   // ================================================================== consumer: weight DMA, GEMM3, epilogue
+  if constexpr (BLK2_PRIO == 2) __builtin_amdgcn_s_setprio(2);
   f32x16 acc3[G::CB];
 #pragma unroll
   for (int cb = 0; cb < G::CB; ++cb)

@@ -1375,11 +1375,21 @@ class _BlockFused(torch.autograd.Function):
 
         x [N,H,W,C] -> u = dw7x7(x) (bf16)  ->  x + gamma * fc2(GELU(fc1(LN(u))))
 
-    Widths with fused block kernels (96, 192): forward = the depthwise stencil + ``cnx_block_mlp_fwd`` (LN prologue, two
-    chained MFMA GEMMs, hidden activation on-chip, bias / layer-scale / residual epilogue); saved for backward: x, u and the
-    LN statistics only (the hidden activation is recomputed by ``cnx_block_mlp_bwd``).  Other widths (384, 768): the four
-    GEMMs per direction run in hipBLASLt between our one-pass kernels (LN, scale+residual, dO/d(gamma)/d(b2), GELU'/d(b1)),
-    weight gradients as split-K batched GEMMs.  Either way the residual gradient rides into the depthwise input-gradient
+    The depthwise stencil is its own kernel (``cnx_dwconv7x7_nhwc``); what follows it runs, by width and pass (round 6 state):
+
+    * C = 128 ... 384, attack passes: ``cnx_block_mlp_fwd_hpre`` (LN prologue, two chained MFMA GEMMs, hidden activation on chip,
+      bias / layer-scale / residual epilogue, Hpre tiles into a workspace) and ``cnx_block_mlp_bwd_input_hpre`` (dH, GELU', da and the
+      LayerNorm backward in ONE kernel; at C = 256 / 384 both directions on wavefront pairs, ``blk2_fwd_kernel`` / ``blk2_bwd_kernel``);
+    * C = 96, attack passes: ``cnx_block_mlp_fwd`` and the recomputing ``cnx_block_mlp_bwd_input`` (saved: x, u, the LN statistics);
+    * C = 128 ... 384, training pass (row counts that are multiples of 64): ``cnx_block_mlp_fwd_train`` / ``cnx_block_mlp_bwd_train_hpre_ln``
+      - H, Hpre, dHpre leave as accumulator-order tiles, both weight gradients (and d(b1), d(b2) as column sums) are ``cnx_gemm_tn_ex``
+      contractions over those tiles, d(gamma) / d(ln_w) / d(ln_b) algebraic functions of them (``cnx_block_dgamma``, ``cnx_block_dln``,
+      with direct sums for ill-conditioned channels); C = 96: the recomputing backward with the same emit (``cnx_block_mlp_bwd_acc_ln``);
+    * C >= 512 (and every width under ``APGD_OPS`` / kernel-set fallbacks): LayerNorm, ``cnx_gemm_nt`` with fused epilogues (fc1 + bias +
+      GELU + Hpre, fc2 + bias + layer scale + residual, dH with GELU') inside the attack, library GEMMs between the one-pass kernels in
+      the training pass, weight gradients on ``cnx_gemm_tn``.
+
+    Either way the residual gradient rides into the depthwise input-gradient
     kernel as its ``add`` operand, and parameter gradients are skipped entirely inside the attack."""
 
     @staticmethod
