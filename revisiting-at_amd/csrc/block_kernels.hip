@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "apgd_hip.h"
 #include "convnext_hip.h"
@@ -53,6 +54,12 @@
 // it should go ahead of the consumer's independent ones), 2 = the consumer.  Measured in round 6 (profiles/r06_fused_mlp.md)
 #ifndef BLK2_PRIO
 #define BLK2_PRIO 0
+#endif
+// epilogue of the wavefront-pair forward: 0 = the consumer does all of it (round 5); 1 = the PRODUCER - idle from its last block on -
+// loads the pair's residual tile into its dead registers under the consumer's last GEMM2 block and then does the arithmetic and the
+// stores of both passes, the consumer only scatters its accumulators to LDS (round 6)
+#ifndef BLK2_EPI
+#define BLK2_EPI 1
 #endif
 #if MLP_ABLATE
 // per-workgroup phase stamps (100 MHz wall clock) of the forward kernel, read back with cnx_dbg_blk_trace (tools/blk_trace.py)
@@ -980,10 +987,68 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
     P_BLOCK(G::NHB - 2, za, zb, false)
     P_BLOCK(G::NHB - 1, zb, za, false)
     P_BLOCK(G::NHB, za, zb, false)
+#if BLK2_EPI
+    // the pair's residual tile (32 rows x C, both passes of the epilogue) into this wavefront's registers - its operand rows and
+    // accumulators are dead - while the consumer runs its last GEMM2 block: the epilogue then starts with the data on chip instead of
+    // with 2 x NCH / GRP dependent round trips to HBM
+    constexpr int EC4 = C / 4, ENCH = 16 * EC4 / 64;
+    typedef typename std::conditional<sizeof(TX) == 4, float4, uint2>::type XT;
+    XT xr[2][ENCH];
+    {
+      const TX* resid = static_cast<const TX*>(p.resid);
+      const long e_end = p.M * C;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int k = 0; k < ENCH; ++k) {
+          const long e = (m0 + 16 * pass) * C + (k * 64 + lane) * 4;
+          if constexpr (sizeof(TX) == 4) {
+            xr[pass][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (resid && e < e_end) xr[pass][k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resid) + e);
+          } else {
+            xr[pass][k] = make_uint2(0u, 0u);
+            if (resid && e < e_end) xr[pass][k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(resid) + e);
+          }
+        }
+    }
+#endif
     __builtin_amdgcn_s_barrier();                                     // block NHB + 1: the consumers' last GEMM2
 #undef P_BLOCK
-    for (int i = tid; i < C; i += 256) { cst[i] = p.b2[i]; cst[C + i] = p.gamma ? p.gamma[i] : 1.0f; }   // for the consumers' epilogue
+    for (int i = tid; i < C; i += 256) { cst[i] = p.b2[i]; cst[C + i] = p.gamma ? p.gamma[i] : 1.0f; }   // b2 | gamma for the epilogue
     __syncthreads();
+#if BLK2_EPI
+    {
+      const float* scr = reinterpret_cast<const float*>(lds) + pair * (16 * C);
+      const float4* b2v = reinterpret_cast<const float4*>(cst);
+      const float4* gav = reinterpret_cast<const float4*>(cst + C);
+      TO* out = static_cast<TO*>(p.out);
+      const long e_end = p.M * C;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                                              // the consumer has scattered this pass's 16 rows
+#pragma unroll
+        for (int k = 0; k < ENCH; ++k) {
+          const int idx = k * 64 + lane;
+          const long e = (m0 + 16 * pass) * C + idx * 4;
+          const int c4 = idx % EC4;
+          const float4 o = reinterpret_cast<const float4*>(scr)[idx];
+          const float4 bb = b2v[c4], gg = gav[c4];
+          float4 xv;
+          if constexpr (sizeof(TX) == 4) xv = xr[pass][k];
+          else xv = make_float4(bf16_lo(xr[pass][k].x), bf16_hi(xr[pass][k].x), bf16_lo(xr[pass][k].y), bf16_hi(xr[pass][k].y));
+          const float y0 = o.x + bb.x, y1 = o.y + bb.y, y2v = o.z + bb.z, y3 = o.w + bb.w;
+          if (e < e_end) {
+            if (p.y2) *reinterpret_cast<uint2*>(p.y2 + e) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2v, y3));
+            const float o0 = fmaf(y0, gg.x, xv.x), o1 = fmaf(y1, gg.y, xv.y);
+            const float o2 = fmaf(y2v, gg.z, xv.z), o3 = fmaf(y3, gg.w, xv.w);
+            if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + e) = make_float4(o0, o1, o2, o3);
+            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + e) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+          }
+        }
+        if (pass == 0) __syncthreads();                               // the scratch rows are free for the second pass
+      }
+    }
+#endif
     return;
   }
 
@@ -1051,6 +1116,20 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
   // ---- epilogue: b2 / gamma through the H buffers (written by the producers), the tile through the dead rings, as blk_mlp_fwd_kernel
   __syncthreads();
   float* scr = reinterpret_cast<float*>(lds) + pair * (16 * C);
+#if BLK2_EPI
+  // (BLK2_EPI: this wavefront only scatters its accumulators, 16 rows per pass; the producer of the pair - which holds the residual
+  //  tile - does the arithmetic and the stores)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        scr[((r & 3) + 8 * (r >> 2) + 4 * half) * C + cb * 32 + l32] = acc2[cb][8 * pass + r];
+    __syncthreads();                                                  // scattered: the producer reads
+    if (pass == 0) __syncthreads();                                   // ... and is done with these rows
+  }
+#else
   const float4* b2v = reinterpret_cast<const float4*>(cst);
   const float4* gav = reinterpret_cast<const float4*>(cst + C);
   const TX* resid = static_cast<const TX*>(p.resid);
@@ -1104,6 +1183,7 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
       }
     }
   }
+#endif
 }
 
 // Which forward kernel serves width C?  Measured (tools/mlp_bench.py, batch 256, profiles/r05_fused_mlp.md): the wavefront-pair kernel is
@@ -2007,10 +2087,98 @@ __global__ __launch_bounds__(512, 2) void blk2_bwd_kernel(const BlkBwdArgs p) {
     PB_BLOCK(G::NHB - 2, da_, db_, false)
     PB_BLOCK(G::NHB - 1, db_, da_, false)
     PB_BLOCK(G::NHB, da_, db_, false)
+#if BLK2_EPI
+    // (as blk2_fwd_kernel) this wavefront is idle from here on: it fetches what the epilogue reads from memory - the pair's u rows and
+    // LayerNorm statistics - under the consumer's last GEMM3 block, and then does the epilogue's arithmetic and stores; the consumer only
+    // scatters its accumulators
+    constexpr int ENJ = C / 32;                                         // 8-channel chunks per lane (4 lanes per row, 16 rows per pass)
+    const int erl = lane >> 2, eq = lane & 3;
+    uint4 eur[LNB ? 2 : 1][LNB ? ENJ : 1];
+    float emean[2], erstd[2];
+    if constexpr (LNB) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const long m = m0 + 16 * pass + erl;
+        const long mc = m < p.M ? m : p.M - 1;
+        emean[pass] = p.mean[mc]; erstd[pass] = p.rstd[mc];
+#pragma unroll
+        for (int j = 0; j < ENJ; ++j) eur[pass][j] = *reinterpret_cast<const uint4*>(p.u + mc * C + (eq + 4 * j) * 8);
+      }
+    }
+#endif
     __builtin_amdgcn_s_barrier();                                     // block NHB + 1: the consumers' last GEMM3
 #undef PB_BLOCK
 #undef PB_SYNC
     __syncthreads();                                                  // the consumers' rings are dead: their epilogue may begin
+#if BLK2_EPI
+    if constexpr (LNB) {
+      constexpr int CP = C + 4;
+      const float* scr = reinterpret_cast<const float*>(lds) + pair * (16 * CP);
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                                              // the consumer has scattered this pass's 16 rows
+        const long m = m0 + 16 * pass + erl;
+        const float mean = emean[pass], rstd = erstd[pass];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < ENJ; ++j) {
+          const int c0 = (eq + 4 * j) * 8;
+          const float4 d0 = *reinterpret_cast<const float4*>(scr + erl * CP + c0), d1 = *reinterpret_cast<const float4*>(scr + erl * CP + c0 + 4);
+          const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + c0), w1 = *reinterpret_cast<const float4*>(p.ln_w + c0 + 4);
+          const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          const uint32_t uw[4] = {eur[pass][j].x, eur[pass][j].y, eur[pass][j].z, eur[pass][j].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float uv = (e & 1) ? bf16_hi(uw[e >> 1]) : bf16_lo(uw[e >> 1]);
+            const float t = wv[e] * dv[e], xh = (uv - mean) * rstd;
+            s1 += t;
+            s2 = fmaf(t, xh, s2);
+          }
+        }
+        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+        s1 *= (1.0f / C); s2 *= (1.0f / C);
+#pragma unroll
+        for (int j = 0; j < ENJ; ++j) {
+          const int c0 = (eq + 4 * j) * 8;
+          const float4 d0 = *reinterpret_cast<const float4*>(scr + erl * CP + c0), d1 = *reinterpret_cast<const float4*>(scr + erl * CP + c0 + 4);
+          const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + c0), w1 = *reinterpret_cast<const float4*>(p.ln_w + c0 + 4);
+          const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          const uint32_t uw[4] = {eur[pass][j].x, eur[pass][j].y, eur[pass][j].z, eur[pass][j].w};
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float uv = (e & 1) ? bf16_hi(uw[e >> 1]) : bf16_lo(uw[e >> 1]);
+            const float t = wv[e] * dv[e], xh = (uv - mean) * rstd;
+            o[e] = rstd * (t - s1 - xh * s2);
+          }
+          if (m < p.M)
+            *reinterpret_cast<uint4*>(p.da + m * C + c0) = make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+        }
+        if (pass == 0) __syncthreads();                               // the scratch rows are free for the second pass
+      }
+    } else {
+      const float* scr = reinterpret_cast<const float*>(lds) + pair * (16 * C);
+      constexpr int NCH = 16 * C / 8 / 64;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        const long e0 = (m0 + 16 * pass) * C;
+        const long e_end = p.M * C;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+          const int idx = k * 64 + lane;
+          const long e = e0 + idx * 8;
+          const float4 d0 = reinterpret_cast<const float4*>(scr)[2 * idx], d1 = reinterpret_cast<const float4*>(scr)[2 * idx + 1];
+          if (e < e_end)
+            *reinterpret_cast<uint4*>(p.da + e) = make_uint4(pack_bf16(d0.x, d0.y), pack_bf16(d0.z, d0.w), pack_bf16(d1.x, d1.y), pack_bf16(d1.z, d1.w));
+        }
+        if (pass == 0) __syncthreads();
+      }
+    }
+#endif
     return;
   }
 
@@ -2080,8 +2248,26 @@ __global__ __launch_bounds__(512, 2) void blk2_bwd_kernel(const BlkBwdArgs p) {
 #undef DMA_A_PIECE
 #undef DMA_B_PIECE
   // ---- epilogue: acc3[cb][r] = da[m0 + (r&3) + 8*(r>>2) + 4*half][cb*32 + l32], through the dead rings, 16 rows per pass (as
-  //      blk_mlp_bwd_kernel; the u row is read twice instead of held: this wavefront shares its SIMD, 256 registers)
+  //      blk_mlp_bwd_kernel)
   __syncthreads();
+#if BLK2_EPI
+  {
+    // this wavefront only scatters; the producer of the pair - which holds the u rows - does the LayerNorm backward and the stores
+    constexpr int CPS = LNB ? C + 4 : C;                                 // (LNB: padded rows, the 4 lanes x 16 rows spread over the banks)
+    static_assert(4 * 16 * CPS * 4 <= G::W1_RING + G::W2_RING, "the epilogue tile reuses the weight rings");
+    float* scr = reinterpret_cast<float*>(lds) + pair * (16 * CPS);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          scr[((r & 3) + 8 * (r >> 2) + 4 * half) * CPS + cb * 32 + l32] = acc3[cb][8 * pass + r];
+      __syncthreads();                                                // scattered: the producer reads
+      if (pass == 0) __syncthreads();                                 // ... and is done with these rows
+    }
+  }
+#else
   if constexpr (LNB) {
     constexpr int CP = C + 4;
     static_assert(4 * 16 * CP * 4 <= G::W1_RING + G::W2_RING, "the epilogue tile reuses the weight rings");
@@ -2165,6 +2351,7 @@ __global__ __launch_bounds__(512, 2) void blk2_bwd_kernel(const BlkBwdArgs p) {
       }
     }
   }
+#endif
 }
 
 // Which Hpre backward serves width C: the wavefront-pair kernel at C = 256 / 384 (cnx_runtime_switch(CNX_SWITCH_BLK2_BWD_WIDTHS) /
