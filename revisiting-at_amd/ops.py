@@ -1824,7 +1824,7 @@ def attention(qkv, num_heads, scale):
 KERNEL_SETS = {
     # the tree as shipped
     "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
-                    blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2),
+                    blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2, gemm_auto_max=0),
     # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
     # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
     # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
@@ -1837,6 +1837,8 @@ KERNEL_SETS = {
     "round5": dict(blk2b=0),
     # single-switch experiments of round 6 (profiles/r06_ab.md)
     "stemln": dict(stem_ln_fused=True), "streams3": dict(attack_streams=3), "streams1": dict(attack_streams=1),
+    # the C = 768 blocks of the TRAINING pass on cnx_gemm_nt with its fused epilogues instead of library GEMMs + one-pass tails
+    "gemmtrain": dict(gemm_auto_max=40_000_000),
     # round 6's measured negative: eight wavefronts (256 rows) per workgroup on one weight stream at C = 128 / 192
     # (profiles/r06_fused_mlp.md; needs a library built with -DBLK_FWD_W8_BUILD=1, else the switch reads back -1 and nothing changes)
     "w8": dict(fwd_w8=3),
@@ -1847,7 +1849,7 @@ def kernel_set(name_or_dict):
     """Select a kernel set in the running process; returns the settings that were in force (a dict ``kernel_set`` accepts).  The caller
     drops what was captured or cached under the old set (``graphed.reset()``, a fresh ``ATTrainStep``); results stay inside the parity
     bars either way - the sets differ in kernels and summation order, not in arithmetic."""
-    global _WGRAD_MODE, STEM_WGRAD_HIP, _TRAIN_HPRE_WIDTHS, _DGAMMA_FROM_DW2, _DLN_FROM_DW1, _LN_IN_TRAIN_BWD, _POOL_ROWS, _STEM_LN_FUSED
+    global _WGRAD_MODE, STEM_WGRAD_HIP, _TRAIN_HPRE_WIDTHS, _DGAMMA_FROM_DW2, _DLN_FROM_DW1, _LN_IN_TRAIN_BWD, _POOL_ROWS, _STEM_LN_FUSED, _GEMM_AUTO_MAX
     from . import apgd as _apgd
     from . import graphed as _graphed
     new = KERNEL_SETS[name_or_dict] if isinstance(name_or_dict, str) else dict(name_or_dict)
@@ -1859,7 +1861,7 @@ def kernel_set(name_or_dict):
                 dln="dw1" if _LN_IN_TRAIN_BWD else ("kernel" if _DLN_FROM_DW1 else "pass"), fused_tracking=_apgd.FUSED_TRACKING,
                 blk2=int(lib.cnx_runtime_switch(0, -1)), pool_rows=_POOL_ROWS, dw_shared_halo=int(lib.cnx_runtime_switch(1, -1)),
                 fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))), blk2b=int(lib.cnx_runtime_switch(3, -1)),
-                stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS)
+                stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS, gemm_auto_max=_GEMM_AUTO_MAX)
     if "wgrad" in new:
         if new["wgrad"] not in ("hip", "lib"):
             raise ValueError(f"kernel_set: wgrad={new['wgrad']!r}")
@@ -1890,5 +1892,7 @@ def kernel_set(name_or_dict):
         _STEM_LN_FUSED = bool(new["stem_ln_fused"])
     if "attack_streams" in new:
         _graphed.STREAMS = max(1, int(new["attack_streams"]))
+    if "gemm_auto_max" in new:
+        _GEMM_AUTO_MAX = int(new["gemm_auto_max"])
     invalidate_weight_cache()
     return prev
