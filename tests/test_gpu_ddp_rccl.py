@@ -112,6 +112,13 @@ for name in ("all_reduce",):
     setattr(dist, name, counted)
 tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, graph=1 if GS == "flat" else 0), dev, lr=1e-3,
                    distributed=True, ema=True, perturb=attack if GS == "ddp" else None, grad_sync=GS)
+FAIL_RANK = int(os.environ.get("APGD_TEST_FAIL_CAPTURE_RANK", "-1"))
+if rank == FAIL_RANK:
+    # this rank's training-pass capture is refused: it runs the pass from Python while the other rank replays its three segments
+    class _Refused:
+        def __init__(self, *a, **k):
+            raise RuntimeError("capture refused (test)")
+    tr._graph_cls = _Refused
 if GS == "ddp":
     def hook(_, bucket):
         st["hook_total"] += 1
@@ -143,6 +150,10 @@ if GS == "flat":
     st["train_graph_segments"] = [v.n_graphs for v in tr._tg.values() if v is not None]
     st["reduces"] = tr.sync.reduces
     st["attack_replays"] = R.graphed.STATS["replays"]
+    mine = dict(rank=rank, segments=st["train_graph_segments"], failed=sum(v is None for v in tr._tg.values()), reduces=tr.sync.reduces)
+    alls = [None] * world
+    dist.all_gather_object(alls, mine)
+    st["ranks"] = alls
 flat = torch.cat([p.detach().flatten() for p in tr.inner.parameters()])
 other = [torch.zeros_like(flat) for _ in range(world)]
 dist.all_gather(other, flat)
@@ -154,7 +165,7 @@ dist.destroy_process_group()
 """
 
 
-def _run_two_ranks(tmp_path, backend, grad_sync="flat"):
+def _run_two_ranks(tmp_path, backend, grad_sync="flat", fail_rank=None):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     with socket.socket() as sk:
@@ -163,7 +174,8 @@ def _run_two_ranks(tmp_path, backend, grad_sync="flat"):
     procs = []
     for r in range(2):
         env = dict(_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", APGD_DIST_BACKEND=backend, APGD_TEST_GRAD_SYNC=grad_sync)
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", APGD_DIST_BACKEND=backend, APGD_TEST_GRAD_SYNC=grad_sync,
+                   APGD_TEST_FAIL_CAPTURE_RANK=str(-1 if fail_rank is None else fail_rank))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, text=True))
     out = procs[0].communicate(timeout=900)[0]
     for p in procs:
@@ -190,6 +202,19 @@ def test_two_ranks_on_one_gpu_with_the_product_model(tmp_path):
     the HIP attack replayed from hipGraphs, bf16 autocast, the training pass replayed from three graph segments with
     ``FlatGradSync``'s all-reduces between them, capturable AdamW, EMA.  Parameters stay identical across the ranks."""
     _check_flat(_run_two_ranks(tmp_path, "gloo"))
+
+
+def test_two_ranks_on_one_gpu_one_of_them_without_its_training_graph(tmp_path):
+    """Round 6 (the device twin of tests/test_ddp_gloo.py::test_a_rank_whose_training_pass_capture_failed_*): rank 1's capture of the
+    training pass is refused, so it runs the pass from Python (real kernels, eager) while rank 0 replays its three hipGraph segments -
+    both issue the flat path's two all-reduces per step between the same points of the pass: no hang, 12 exchanges in 6 steps on each,
+    identical parameters."""
+    res = _run_two_ranks(tmp_path, "gloo", fail_rank=1)
+    assert res["same"] and res["hook_in_attack"] == 0, res
+    by = {r["rank"]: r for r in res["ranks"]}
+    assert by[0]["segments"] == [3] and by[0]["failed"] == 0, res
+    assert by[1]["segments"] == [] and by[1]["failed"] == 1, res
+    assert by[0]["reduces"] == 12 and by[1]["reduces"] == 12, res
 
 
 def test_two_ranks_on_one_gpu_with_torch_ddp(tmp_path):
