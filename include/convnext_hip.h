@@ -42,9 +42,9 @@ int cnx_dwconv7x7_win_policy(int policy);
  * start-up values).  Returns the previous value; a negative `value` only queries; an unknown `which` returns -1.  Not synchronised:
  * set it between launches, and drop captured hipGraphs that contain the kernels concerned.  No switch changes results beyond the
  * summation order of the kernels it selects.
- *   CNX_SWITCH_BLK2_WIDTHS     widths served by the wavefront-pair forward blk2_fwd_kernel: bit 0 = C 256, bit 1 = C 384 (APGD_BLK2)
+ *   CNX_SWITCH_BLK2_WIDTHS     widths served by the wavefront-pair forward blk2_fwd_kernel: bit 0 = C 256, bit 1 = C 384, bit 2 = C 192 (APGD_BLK2)
  *   CNX_SWITCH_DW_SHARED_HALO  shared column halo of the 32-channel sliding-window depthwise wavefronts, 0 / 1 (APGD_DW_SH)
- *   CNX_SWITCH_BLK2_BWD_WIDTHS widths served by the wavefront-pair Hpre backward blk2_bwd_kernel (round 6): bit 0 = C 256, bit 1 = C 384
+ *   CNX_SWITCH_BLK2_BWD_WIDTHS widths served by the wavefront-pair Hpre backward blk2_bwd_kernel (round 6): bit 0 = C 256, bit 1 = C 384, bit 2 = C 192
  *                              (APGD_BLK2B)
  *   CNX_SWITCH_FWD_WAVES8      widths whose single-wavefront-per-tile forward runs eight wavefronts (256 rows) per workgroup on one weight
  *                              stream instead of four: bit 0 = C 128, bit 1 = C 192 (APGD_FWD_W8).  A measured negative of round 6

@@ -34,3 +34,6 @@ struct BlkFwdArgs {
   int dbg;                 // timing experiments only (APGD_BLK_DBG)
 };
 
+
+// widths served by the wavefront-pair Hpre backward (block_bwd_kernels.hip): -> the previous mask, a negative value only queries
+int blk2b_widths_switch(int value);

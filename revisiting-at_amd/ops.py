@@ -1839,6 +1839,8 @@ KERNEL_SETS = {
     "stemln": dict(stem_ln_fused=True), "streams3": dict(attack_streams=3), "streams1": dict(attack_streams=1),
     # the C = 768 blocks of the TRAINING pass on cnx_gemm_nt with its fused epilogues instead of library GEMMs + one-pass tails
     "gemmtrain": dict(gemm_auto_max=40_000_000),
+    # the wavefront-pair kernels also at C = 192 (both directions; a library built with -DBLK2_C192_BUILD=1, else nothing changes): slower
+    "pair192": dict(blk2=7, blk2b=7),
     # round 6's measured negative: eight wavefronts (256 rows) per workgroup on one weight stream at C = 128 / 192
     # (profiles/r06_fused_mlp.md; needs a library built with -DBLK_FWD_W8_BUILD=1, else the switch reads back -1 and nothing changes)
     "w8": dict(fwd_w8=3),
@@ -1881,13 +1883,13 @@ def kernel_set(name_or_dict):
     if "pool_rows" in new:
         _POOL_ROWS = bool(new["pool_rows"])
     if "blk2" in new:
-        lib.cnx_runtime_switch(0, int(new["blk2"]) & 3)
+        lib.cnx_runtime_switch(0, int(new["blk2"]) & 7)
     if "dw_shared_halo" in new:
         lib.cnx_runtime_switch(1, 1 if new["dw_shared_halo"] else 0)
     if "fwd_w8" in new:
         lib.cnx_runtime_switch(2, int(new["fwd_w8"]) & 3)
     if "blk2b" in new:
-        lib.cnx_runtime_switch(3, int(new["blk2b"]) & 3)
+        lib.cnx_runtime_switch(3, int(new["blk2b"]) & 7)
     if "stem_ln_fused" in new:
         _STEM_LN_FUSED = bool(new["stem_ln_fused"])
     if "attack_streams" in new:

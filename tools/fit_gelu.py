@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fit of the polynomial behind the fused kernels' GELU (csrc/block_kernels.hip::erfc_q):
+"""Fit of the polynomial behind the fused kernels' GELU (csrc/blk_common.h::erfc_q):
    erfc(|z|/sqrt 2) ~= 2^Q(|z|), Q of degree 5, minimising the worst-case error of GELU(z) = max(z,0) - |z|/2 * 2^Q(|z|)
 evaluated in fp32.  Prints the coefficients (highest power first) and the achieved max |error| (~1.2e-6)."""
 import numpy as np

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fit behind the fused backward's GELU' (csrc/block_kernels.hip::gelu_grad2):
+"""Fit behind the fused backward's GELU' (csrc/blk_common.h::gelu_grad2):
    GELU'(-a) = 0.5 erfc(a/sqrt 2) - a phi(a) = E(a) W(x),   E = exp(-a^2/2) = 2^(-x^2),  x = a sqrt(log2(e)/2)
    W(x) = 0.5 erfcx(a/sqrt 2) - a/sqrt(2 pi)  ~  polynomial in x  (one v_exp_f32 per value instead of two)
    GELU'(z) = 0.5 + copysign(0.5 - E W, z);   GELU(z) = z (GELU'(z) - z phi(z)),  phi = E / sqrt(2 pi).
