@@ -769,6 +769,44 @@ def test_hpre_backward_on_wavefront_pairs_is_bit_identical_to_the_single_wavefro
     assert torch.equal(res[3][0], res[3][4]) and torch.equal(res[3][3], res[3][6])      # the forms agree with each other
 
 
+def test_wavefront_pair_kernels_repeat_bit_for_bit(R):
+    """Race hunt (tools/pair_stress.py runs it at full size, 3000 launches): the pair kernels hand tiles over through LDS, count their DMA
+    by hand and split the epilogue between the two wavefronts of a pair - 25 launches of the forward (training form) and of the Hpre
+    backward (attack form) on the same inputs give the same bits every time, on a ragged row count."""
+    lib = R._lib.load()
+    C, M_ = 384, 6272 + 96
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    u = torch.randn(M_, C, device="cuda", generator=gen).to(torch.bfloat16)
+    x = torch.randn(M_, C, device="cuda", generator=gen)
+    w1 = torch.randn(4 * C, C, device="cuda", generator=gen) * C ** -0.5
+    w2 = torch.randn(C, 4 * C, device="cuda", generator=gen) * (4 * C) ** -0.5
+    lw, lb = 1 + 0.1 * torch.randn(C, device="cuda", generator=gen), 0.1 * torch.randn(C, device="cuda", generator=gen)
+    b1, b2 = 0.1 * torch.randn(4 * C, device="cuda", generator=gen), 0.1 * torch.randn(C, device="cuda", generator=gen)
+    gm = 0.5 + 0.1 * torch.randn(C, device="cuda", generator=gen)
+    g = torch.randn(M_, C, device="cuda", generator=gen)
+    wf, wb = R.ops._pack_mlp(w1, w2), R.ops._pack_mlp_bwd(w1, w2)
+    n_ws = lib.cnx_block_mlp_hpre_elems(M_, C)
+    mean, rstd = torch.empty(M_, device="cuda"), torch.empty(M_, device="cuda")
+    z = lambda *sh, dt=torch.bfloat16: torch.zeros(sh, device="cuda", dtype=dt)
+    out, hp, hact, arows, y2, du = z(M_, C, dt=torch.float32), z(n_ws), z(n_ws), z(M_, C), z(M_, C), z(M_, C)
+    first = None
+    for rep in range(25):
+        for t in (out, hp, hact, arows, y2, du):
+            t.add_(1)
+        assert lib.cnx_block_mlp_fwd_train(u.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, mean.data_ptr(), rstd.data_ptr(), wf.data_ptr(), b1.data_ptr(),
+                                           b2.data_ptr(), gm.data_ptr(), x.data_ptr(), 0, out.data_ptr(), 0, y2.data_ptr(), hp.data_ptr(), hact.data_ptr(),
+                                           arows.data_ptr(), M_, C, S()) == 0
+        assert lib.cnx_block_mlp_bwd_input_hpre(u.data_ptr(), lw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), 0, gm.data_ptr(), wb.data_ptr(),
+                                                hp.data_ptr(), du.data_ptr(), M_, C, S()) == 0
+        torch.cuda.synchronize()
+        nt = (M_ + 31) // 32 * 32 * 4 * C
+        cur = [t.clone() for t in (out, hp[:nt], hact[:nt], arows, y2, du)]
+        if first is None:
+            first = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(cur, first)), rep
+
+
 def _hpre_pair_training_pass(R, C, M_, lw, lb, gm, seed):
     """Forward (cnx_block_mlp_fwd_train) + backward with the LayerNorm backward in its epilogue (cnx_block_mlp_bwd_train_hpre_ln and the
     plain cnx_block_mlp_bwd_train_hpre for da) + both weight gradients on cnx_gemm_tn_ex, with the given LayerNorm parameters and layer
