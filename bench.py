@@ -397,7 +397,7 @@ def ab_leg(R, args, dev, x, y, n_warm, order=("default", "round4", "default", "r
            "median_ms": {n: med("ms_per_step", n) for n in dict.fromkeys(order)},
            "median_mcycles": {n: med("mcycles_per_step", n) for n in dict.fromkeys(order)},
            "sclk_MHz": med("avg_sclk_MHz", "default"), "W": med("avg_W", "default"),
-           "round4_set": "ops.KERNEL_SETS['round4']: library weight gradients (the GEMM ones; the ConvStem's stay hand-written), recomputing training backward, per-channel "
+           "round4_set": "ops.KERNEL_SETS['round4']: library weight gradients (GEMM + ConvStem filter gradients; bias gradients by ops.conv_bias_grad), recomputing training backward, per-channel "
                          "gradient passes, separate tracking pass, single-wavefront C = 256 / 384 forward, head pool on NCHW, round-4 "
                          "depthwise strips - the end-of-round-4 kernel selection inside today's library"}
     if out["default_ms"] and out["r4_ms"]:

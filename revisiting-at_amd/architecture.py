@@ -102,7 +102,7 @@ class _ImageConv(nn.Conv2d):
     def forward(self, x):
         if ops.stem_conv_supported(x, self.weight, self.stride, self.padding):
             return ops.stem_conv(x, self.weight, self.bias)
-        return super().forward(x)
+        return ops.conv2d_lib(x, self)
 
 
 class _StemConv2(nn.Conv2d):
@@ -117,7 +117,16 @@ class _StemConv2(nn.Conv2d):
             # some narrow widths (8 -> 12 and 16 -> 24 on 8x8 maps fault when the tensor ends a mapped segment:
             # profiles/r02_miopen_nhwc_bwd_fault.md, tools/probe/conv_fault_fuzz.py); its NCHW solvers do not.
             x = x.contiguous()
-        return super().forward(x)
+        return ops.conv2d_lib(x, self)
+
+
+class _LibConv(nn.Conv2d):
+    """A ConvStem convolution that always runs in the library (stride 1, the 1x1 projection): a plain ``nn.Conv2d`` for the state dict
+    whose backward takes the input and filter gradients from the library and sums the bias gradient itself (``ops.conv_bias_grad``:
+    the library's came back non-finite under hipGraph replay of the training pass)."""
+
+    def forward(self, x):
+        return ops.conv2d_lib(x, self)
 
 
 class _StemSequential(nn.Sequential):
@@ -143,10 +152,10 @@ class _StemSequential(nn.Sequential):
 def _stem(chans, strides, final_1x1=None):
     layers = []
     for cin, cout, s in zip(chans[:-1], chans[1:], strides):
-        conv = _ImageConv if (cin == 3 and s == 2) else (_StemConv2 if s == 2 else nn.Conv2d)
+        conv = _ImageConv if (cin == 3 and s == 2) else (_StemConv2 if s == 2 else _LibConv)
         layers += [conv(cin, cout, kernel_size=3, stride=s, padding=1), _CfLnGelu(cout), nn.Identity()]
     if final_1x1 is not None:
-        layers.append(nn.Conv2d(chans[-1], final_1x1, kernel_size=1, stride=1, padding=0))
+        layers.append(_LibConv(chans[-1], final_1x1, kernel_size=1, stride=1, padding=0))
     return _StemSequential(*layers)
 
 
@@ -236,7 +245,7 @@ class ConvNeXtStage(nn.Module):
             self.downsample = nn.Identity()
         else:
             self.downsample = nn.Sequential(LayerNorm2d(in_chs, eps=1e-6),
-                                            nn.Conv2d(in_chs, out_chs, kernel_size=2, stride=2))
+                                            _LibConv(in_chs, out_chs, kernel_size=2, stride=2))   # (library path: widths that are no multiple of 24)
         self.blocks = nn.Sequential(*[ConvNeXtBlock(out_chs, ls_init_value) for _ in range(depth)])
 
     def forward(self, x):
@@ -277,7 +286,7 @@ class ConvNeXt(nn.Module):
         # (ConvNeXt-T / -S: the late stages' kernels have 98 - 392 workgroups for 256 CUs); the wide ones and the isotropic /
         # transformer models are GEMM-bound at every depth and keep one stream (and the library's GEMMs, measured faster there)
         self.apgd_two_streams = max(dims) <= 768
-        self.stem = nn.Sequential(nn.Conv2d(3, dims[0], kernel_size=4, stride=4), LayerNorm2d(dims[0], eps=1e-6))
+        self.stem = nn.Sequential(_LibConv(3, dims[0], kernel_size=4, stride=4), LayerNorm2d(dims[0], eps=1e-6))
         self.stages = nn.Sequential(*[ConvNeXtStage(dims[max(i - 1, 0)], dims[i], depths[i], i == 0, ls_init_value)
                                       for i in range(4)])
         self.norm_pre = nn.Identity()
@@ -329,7 +338,7 @@ class ConvNeXtIsotropic(nn.Module):
 
     def __init__(self, in_chans=3, num_classes=1000, depth=18, dim=384):
         super().__init__()
-        self.stem = nn.Conv2d(in_chans, dim, kernel_size=16, stride=16)
+        self.stem = _LibConv(in_chans, dim, kernel_size=16, stride=16)
         self.blocks = nn.Sequential(*[_IsoBlock(dim) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         self.head = nn.Linear(dim, num_classes)
@@ -410,7 +419,7 @@ class PatchEmbed(nn.Module):
         self.patch_size = (patch_size, patch_size)
         self.grid_size = (img_size // patch_size, img_size // patch_size)
         self.num_patches = self.grid_size[0] * self.grid_size[1]
-        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.proj = _LibConv(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.norm = nn.Identity()
 
     def forward(self, x):

@@ -527,9 +527,10 @@ def _stem_wgrad(lib, x, gr, weight, has_bias):
         return dw.to(weight.dtype), db
     xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     gb = gr.permute(0, 3, 1, 2)                                    # NCHW view of channels-last memory
-    _, dw, db = torch.ops.aten.convolution_backward(gb, xb, weight.to(torch.bfloat16), [P], [2, 2], [1, 1], [1, 1],
-                                                    False, [0, 0], 1, [False, True, has_bias])
-    return dw.to(weight.dtype), (db.float() if has_bias else None)
+    # (filter gradient from the library, the bias gradient never: conv_bias_grad)
+    _, dw, _ = torch.ops.aten.convolution_backward(gb, xb, weight.to(torch.bfloat16), None, [2, 2], [1, 1], [1, 1],
+                                                   False, [0, 0], 1, [False, True, False])
+    return dw.to(weight.dtype), (conv_bias_grad(gb) if has_bias else None)
 
 
 class _StemConv(torch.autograd.Function):
@@ -748,18 +749,86 @@ class _Conv3x3s2(torch.autograd.Function):
             want_w = False
         if need_lib_dx or want_w:
             wl = _cached((weight,), "bf16_cl", lambda w: w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
-            r = torch.ops.aten.convolution_backward(g, x, wl, [CO] if ctx.has_bias else None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
-                                                    [bool(need_lib_dx), bool(want_w), bool(want_w and ctx.has_bias)])
+            # (never the library's bias gradient: under hipGraph replay MIOpen's returned non-finite values, see conv_bias_grad)
+            r = torch.ops.aten.convolution_backward(g, x, wl, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                    [bool(need_lib_dx), bool(want_w), False])
             if need_lib_dx:
                 dx = r[0]
             if want_w:
                 dw = r[1].to(weight.dtype)
-                db = r[2].to(weight.dtype) if ctx.has_bias else None
+                db = conv_bias_grad(g).to(weight.dtype) if ctx.has_bias else None
         return dx, dw, db
 
 
 def conv3x3s2(x, weight, bias):
     return _Conv3x3s2.apply(x, weight, bias)
+
+
+def conv_bias_grad(g):
+    """``d(loss)/d(bias)`` of a convolution = the sum of the output gradient ``g`` [N, C, H, W] over N, H, W, in fp32, by a plain
+    reduction of ours / ATen's - never the library's.  Found in round 6 (``tools/ab_nan_hunt.py``, ``gpurun_out/r6z``): under hipGraph
+    REPLAY of the training pass MIOpen's bias gradient of a ConvStem convolution came back non-finite (ConvNeXt-B, the 96 -> 128
+    stride-1 convolution: 5 of 6 fresh trainers within ten steps; the 48 -> 96 stride-2 one through the library: 1 of 5) while the
+    eager pass never showed it - one NaN bias gradient, and AdamW has put a NaN into the model."""
+    if g.is_cuda and g.dim() == 4 and g.dtype == torch.bfloat16 and g.is_contiguous(memory_format=torch.channels_last) and MODE != "eager" \
+            and g.shape[1] % 4 == 0 and g.numel() > 0:
+        lib = _lib.load()
+        N, C, H, W = g.shape
+        rows = g.permute(0, 2, 3, 1).reshape(N * H * W, C)              # a view: channels-last rows
+        db = torch.empty(C, device=g.device, dtype=torch.float32)
+        unused_dgamma = torch.empty(C, device=g.device, dtype=torch.float32)
+        ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=g.device, dtype=torch.float32)
+        _lib.check(lib.cnx_scale_residual_bwd(rows.data_ptr(), _code(rows), None, None, None, unused_dgamma.data_ptr(), db.data_ptr(),
+                                              ws.data_ptr(), rows.shape[0], C, _stream()), "cnx_scale_residual_bwd(colsum)")
+        return db
+    return g.sum((0, 2, 3), dtype=torch.float32)
+
+
+class _ConvLib(torch.autograd.Function):
+    """A convolution that stays with the library (the ConvStem convolutions without a hand-written kernel: ``ConvBlock3``'s second and
+    third, the ViT stems' later ones, the 1x1 projections) with ITS backward asked for the input and filter gradients only; the bias
+    gradient is ``conv_bias_grad``.  The casts autocast would make are made here (``aten.convolution`` on already-cast operands)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, groups):
+        dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else None
+        xc = x if dt is None or x.dtype == dt else x.to(dt)
+        if dt is None:
+            wc = weight
+        else:
+            wc = _cached((weight,), "conv_cast", lambda w: w.to(dt)) if weight.dtype != dt else weight
+        bc = None if bias is None else (bias if dt is None or bias.dtype == dt else bias.to(dt))
+        out = torch.ops.aten.convolution(xc, wc, bc, list(stride), list(padding), list(dilation), False, [0, 0], groups)
+        ctx.save_for_backward(xc, wc)
+        ctx.conf = (list(stride), list(padding), list(dilation), groups, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        xc, wc = ctx.saved_tensors
+        stride, padding, dilation, groups, x_dt, w_dt, b_dt = ctx.conf
+        nig = ctx.needs_input_grad
+        want_w = nig[1] and not _INPUT_GRAD_ONLY
+        want_b = b_dt is not None and nig[2] and not _INPUT_GRAD_ONLY
+        if g.dtype != xc.dtype:
+            g = g.to(xc.dtype)
+        dx = dw = db = None
+        if nig[0] or want_w:
+            r = torch.ops.aten.convolution_backward(g, xc, wc, None, stride, padding, dilation, False, [0, 0], groups,
+                                                    [bool(nig[0]), bool(want_w), False])
+            dx = r[0].to(x_dt) if nig[0] else None
+            dw = r[1].to(w_dt) if want_w else None
+        if want_b:
+            db = conv_bias_grad(g).to(b_dt)
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d_lib(x, conv):
+    """``conv(x)`` for an ``nn.Conv2d`` that has no hand-written kernel, with the bias gradient kept away from the library."""
+    if MODE == "eager" or not x.is_cuda or conv.bias is None or conv.padding_mode != "zeros" or isinstance(conv.padding, str):
+        return F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return _ConvLib.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 # ------------------------------------------------------------------------------ depthwise 7x7 + LayerNorm
@@ -1825,13 +1894,12 @@ KERNEL_SETS = {
     # the tree as shipped
     "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
                     blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2, gemm_auto_max=0),
-    # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
+    # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_STEM_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
     # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
     # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
-    # (stem_wgrad stays on the hand-written kernels - 0.14 ms of round 5's gain is therefore NOT in the comparison: the library's
-    #  convolution_backward under hipGraph replay returned a non-finite bias gradient for the second ConvStem convolution in one of five
-    #  fresh trainers, gpurun_out/r6b - a hazard of the round-4 tree that went unnoticed there - and a NaN leg is no measurement)
-    "round4": dict(wgrad="lib", stem_wgrad=True, train_hpre=set(), dgamma=False, dln="pass", fused_tracking=False, blk2=0,
+    # (library convolutions are never asked for a bias gradient any more - ops.conv_bias_grad: under hipGraph replay MIOpen's came back
+    #  non-finite, which is how this set's first run found the hazard, gpurun_out/r6b - so the set runs the library stem gradients again)
+    "round4": dict(wgrad="lib", stem_wgrad=False, train_hpre=set(), dgamma=False, dln="pass", fused_tracking=False, blk2=0,
                    pool_rows=False, dw_shared_halo=0, blk2b=0),
     # the end-of-round-5 selection: today's tree without round 6's wavefront-pair Hpre backward
     "round5": dict(blk2b=0),

@@ -392,3 +392,60 @@ def test_captured_programs_are_bounded_and_follow_the_model(R, monkeypatch):
     del model, x, y
     gc.collect()
     assert not [k for k in R.graphed._programs if k[0] == mid]
+
+
+def test_library_convolution_keeps_its_bias_gradient_away_from_the_library(R):
+    """``ops.conv2d_lib`` (the ConvStem convolutions without a hand-written kernel): output and the three gradients against autograd of
+    ``F.conv2d`` - fp32 and under bf16 autocast - with the bias gradient summed by ``ops.conv_bias_grad`` (fixed-order fp32 sum of the
+    output gradient)."""
+    torch.manual_seed(0)
+    for cin, cout, k, s, p in ((96, 128, 3, 1, 1), (144, 192, 3, 1, 1), (48, 96, 3, 2, 1), (192, 384, 1, 1, 0), (256, 512, 2, 2, 0)):
+        conv = torch.nn.Conv2d(cin, cout, k, s, p).cuda().to(memory_format=torch.channels_last)
+        x = torch.randn(6, cin, 20, 20, device="cuda").to(memory_format=torch.channels_last)
+        for amp in (False, True):
+            xr1, xr2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                y1 = R.ops.conv2d_lib(xr1, conv)
+                y2 = torch.nn.functional.conv2d(xr2, conv.weight, conv.bias, conv.stride, conv.padding)
+            # (two library calls of one convolution need not pick the same algorithm: equal up to the library's own rounding)
+            assert y1.dtype == y2.dtype and y1.shape == y2.shape
+            assert float((y1.float() - y2.float()).norm()) <= (1e-2 if amp else 1e-5) * float(y2.float().norm())
+            g = torch.randn_like(y1)
+            g1 = torch.autograd.grad(y1, [xr1, conv.weight, conv.bias], g)
+            g2 = torch.autograd.grad(y2, [xr2, conv.weight, conv.bias], g)
+            # (the library may pick another algorithm when it is not asked for the bias gradient: same values up to its own rounding)
+            for a, b in ((g1[0], g2[0]), (g1[1], g2[1])):
+                assert float((a.float() - b.float()).norm()) <= (2e-2 if amp else 1e-4) * float(b.float().norm()) + 1e-6
+            ref = g.float().sum((0, 2, 3))
+            assert g1[2].dtype == conv.bias.dtype
+            assert float((g1[2] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6          # exact fp32 sums, another order
+            assert float((g2[2] - ref).abs().max()) <= (2e-2 if amp else 1e-4) * float(ref.abs().max()) + 1e-4
+
+
+def test_replayed_training_pass_on_a_model_with_library_stem_convolutions_keeps_finite_gradients(R):
+    """Round 6 regression (tools/ab_nan_hunt.py, gpurun_out/r6z): ConvNeXt-B-CvSt - whose third ConvStem convolution (96 -> 128, stride 1)
+    runs in the library - trained with the training pass replayed from hipGraphs had a NON-FINITE bias gradient on that convolution in 5
+    of 6 fresh trainers within ten steps (MIOpen's bias gradient under graph replay; never in the eager pass).  The library is no longer
+    asked for bias gradients: four fresh trainers, eight steps each, every parameter and gradient finite, identical trajectories."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(1234)
+    x = torch.rand(32, 3, 224, 224, device=dev, generator=g)
+    y = torch.randint(0, 1000, (32,), device=dev, generator=g)
+    runs = []
+    for rep in range(4):
+        R.graphed.reset()
+        torch.manual_seed(0)
+        model = R.get_new_model("convnext_base", pretrained=False, not_original=True)
+        tr = R.ATTrainStep(model, "convnext_base", R.AdvConfig(attack="apgd", norm="Linf", eps=4 / 255, n_iter=2, graph=1), dev, lr=1e-3,
+                           channels_last=True, amp_dtype=torch.bfloat16, ema=True, graph_train=True)
+        losses = []
+        for i in range(8):
+            losses.append(float(tr.step(x, y)))
+            bad = [n for n, p in tr.inner.named_parameters() if not torch.isfinite(p).all() or (p.grad is not None and not torch.isfinite(p.grad).all())]
+            assert not bad, (rep, i, bad[:4])
+        assert sum(v is not None for v in tr._tg.values()) == 1            # the training pass really was captured and replayed
+        runs.append(losses)
+        del tr, model
+    R.graphed.reset()
+    assert all(np.isfinite(r).all() for r in runs)
+    assert all(abs(a - b) <= 2e-2 for r in runs[1:] for a, b in zip(r, runs[0])), runs

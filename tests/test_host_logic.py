@@ -157,7 +157,7 @@ def test_kernel_sets_switch_in_a_running_process_and_restore():
         ops.kernel_set("default")
         prev = ops.kernel_set("round4")
         assert prev == ops.KERNEL_SETS["default"]
-        assert (ops._WGRAD_MODE, ops.STEM_WGRAD_HIP, ops._TRAIN_HPRE_WIDTHS) == ("lib", True, set())
+        assert (ops._WGRAD_MODE, ops.STEM_WGRAD_HIP, ops._TRAIN_HPRE_WIDTHS) == ("lib", False, set())
         assert (ops._DGAMMA_FROM_DW2, ops._DLN_FROM_DW1, ops._LN_IN_TRAIN_BWD, ops._POOL_ROWS) == (False, False, False, False)
         assert apgd.FUSED_TRACKING is False
         assert lib.cnx_runtime_switch(0, -1) == 0 and lib.cnx_runtime_switch(1, -1) == 0 and lib.cnx_runtime_switch(3, -1) == 0
