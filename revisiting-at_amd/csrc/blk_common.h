@@ -41,6 +41,13 @@
 #endif
 // measurement builds only (`make EXTRA=-DBLK2_C192_BUILD=1`): the wavefront-pair kernels at C = 192 - bit-identical and 10 - 32 % SLOWER than the
 // two independent four-wavefront workgroups per CU that serve that width (profiles/r06_fused_mlp.md section 1b); not instantiated otherwise
+// operand fragments a pair's producer / consumer keeps in flight ahead of its MFMAs (LDS reads issued PF fragments early)
+#ifndef BLK2_PF
+#define BLK2_PF 4
+#endif
+#ifndef BLK2_PFC
+#define BLK2_PFC 4
+#endif
 #ifndef BLK2_C192_BUILD
 #define BLK2_C192_BUILD 0
 #endif

@@ -756,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void blk2_bwd_kernel(const BlkBwdArgs p) {
     const unsigned char* hp_lane = hbuf + pair * 8192 + 2048 + l32 * 64 + half * 32;
     // Block b:  MFMA stream  dH(b) = W2[:, b]^T x dO^T (KS MFMAs, b < NHB); the Hpre(b) tile is requested at the top
     //           VALU stream  dHpre(b - 1) = dH(b - 1) * GELU'(Hpre(b - 1)) between those MFMAs (b >= 1) -> hand-over buffer
-    constexpr int PF = 4, NUOP = 4 * 62;
+    constexpr int PF = BLK2_PF, NUOP = 4 * 62;
     constexpr int P_DMA_EVERY = G::KS / NDMA;
     static_assert(P_DMA_EVERY >= 1 && P_DMA_EVERY * NDMA <= G::KS, "one DMA instruction per P_DMA_EVERY MFMAs");
     // the end of a block: everything but this block's W2^T pieces is in; barrier
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(512, 2) void blk2_bwd_kernel(const BlkBwdArgs p) {
   __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  constexpr int PFC = 4, DMA_EVERY = 2 * G::CB / NDMA;
+  constexpr int PFC = BLK2_PFC, DMA_EVERY = 2 * G::CB / NDMA;
   static_assert(DMA_EVERY >= 1 && DMA_EVERY * NDMA <= 2 * G::CB, "one DMA instruction per DMA_EVERY MFMAs");
   // fragment j of a block's GEMM3 stream -> piece of the ring slot: (t, cb) order (consecutive MFMAs update different accumulators) out of
   // the packed (cb, t) order

@@ -667,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
     // Block b:  MFMA stream  Hpre(b) = W1[b] x LN(u)^T + b1 (KS MFMAs, b < NHB)
     //           VALU stream  GELU of Hpre(b - 1) in unpacked instructions between those MFMAs (b >= 1); H(b - 1) -> hand-over buffer
     // ST: compile-time promise 1 <= b < NHB (straight-line code, no branch inside the block)
-    constexpr int PF = 4, NUOP = 4 * 38;
+    constexpr int PF = BLK2_PF, NUOP = 4 * 38;
 #define P_BLOCK(B, ZCUR, ZPREV, ST)                                                                        \
     {                                                                                                      \
       uint32_t pk[8];                                                                                      \
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(512, 2) void blk2_fwd_kernel(const BlkFwdArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // Block b:  O += H(b - 2) x W2[b - 2]^T (2 CB MFMAs, b >= 2); between them this wavefront's share of the weight DMA
-  constexpr int PFC = 4, DMA_EVERY = 2 * G::CB / NDMA;
+  constexpr int PFC = BLK2_PFC, DMA_EVERY = 2 * G::CB / NDMA;
   static_assert(DMA_EVERY >= 1 && DMA_EVERY * NDMA <= 2 * G::CB, "one DMA instruction per DMA_EVERY MFMAs");
 #define C_BLOCK(B, ST)                                                                                     \
   {                                                                                                        \
