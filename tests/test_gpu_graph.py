@@ -90,20 +90,28 @@ def test_graph_mode_leaves_error_behaviour_alone(R):
                      eps=EPS, n_iter=2, use_rs=True, graph=True)
 
 
+@pytest.mark.parametrize("widths", ["tiny", "base"])
 @pytest.mark.parametrize("graph_train", [False, True])
-def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R, graph_train):
+def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R, graph_train, widths):
     """Seven full AT steps (attack + train forward / backward + AdamW + EMA, a different learning rate at every step) with
     adv.graph = 1 and 0 from the same seeds: the same loss trajectory, the same final parameters and the same EMA copy (to the
     run-to-run noise of the library's backward kernels) - the replayed attack reads the parameters the optimizer just wrote.
-    ``graph_train``: the training pass is replayed from a hipGraph too (from the fourth step on), with the capturable AdamW."""
+    ``graph_train``: the training pass is replayed from a hipGraph too (from the fourth step on), with the capturable AdamW.
+    ``widths`` = "base" (round 6): ConvNeXt-B's widths and ConvStem - a third ConvStem convolution, downsample convolutions (widths that
+    are no multiple of 24) and C = 512 / 1024 blocks that stay in the LIBRARY, i.e. library kernels inside the captured passes (where
+    MIOpen's bias gradient under replay used to come back non-finite: ops.conv_bias_grad)."""
     lrs = [1e-3, 8e-4, 1.2e-3, 5e-4, 9e-4, 1e-3, 7e-4]
 
     def run(graph):
         R.graphed.reset()
         torch.manual_seed(5)
         A = R.architecture
-        m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=12)
-        m.stem = A.ConvBlock1(48)
+        if widths == "tiny":
+            m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=12)
+            m.stem = A.ConvBlock1(48)
+        else:
+            m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(128, 256, 512, 1024), num_classes=12)
+            m.stem = A.ConvBlock3(64)
         tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=graph), "cuda", lr=1e-3,
                            amp_dtype=torch.bfloat16, ema=True, ema_decay=0.9, graph_train=bool(graph) and graph_train)
         g = torch.Generator(device="cuda").manual_seed(9)
@@ -112,6 +120,7 @@ def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R, graph_train):
             x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
             y = torch.randint(0, 10, (4,), device="cuda", generator=g)
             losses.append(float(tr.step(x, y, lr=lr)))
+            assert all(torch.isfinite(p).all() for p in tr.inner.parameters()), "a non-finite parameter"
         if graph and graph_train:
             assert [v is not None for v in tr._tg.values()] == [True], "the training pass was not captured"
         else:
@@ -122,11 +131,16 @@ def test_at_steps_with_the_graphed_attack_equal_the_eager_steps(R, graph_train):
     l0, p0, e0 = run(0)
     # the attack is bit-reproducible (test above), the TRAINING backward is not: the library's convolution filter-gradient kernels
     # differ in the last bits from run to run (profiles/r02_determinism.log) - compare at that level
-    assert max(abs(a - b) for a, b in zip(l1, l0)) <= 2e-3 * max(abs(v) for v in l0), (l1, l0)
+    # "base": the library's kernels (C = 512 / 1024 GEMMs, ConvStem / downsample convolutions and their filter gradients) are not
+    # run-to-run reproducible and pick other kernels for the captured attack's half-batch chunks; seven steps at these learning rates
+    # amplify that - two EAGER runs of this model differ by up to 1.5 % in a step's loss and 1.2 % in the parameters (gpurun_out/r7k),
+    # the replayed run differs from an eager one by the same
+    ltol, ptol = (2e-3, 1e-3) if widths == "tiny" else (3e-2, 2e-2)
+    assert max(abs(a - b) for a, b in zip(l1, l0)) <= ltol * max(abs(v) for v in l0), (l1, l0)
     for got, want in ((p1, p0), (e1, e0)):
         num = sum(float((a.float() - b.float()).pow(2).sum()) for a, b in zip(got, want))
         den = sum(float(b.float().pow(2).sum()) for b in want)
-        assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+        assert (num / den) ** 0.5 <= ptol, (num / den) ** 0.5
 
 
 def test_training_pass_graph_runs_other_batch_shapes_eagerly_and_keeps_training(R):
