@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define APGD_HIP_VERSION 10700 /* major*10000 + minor*100 + patch */
+#define APGD_HIP_VERSION 10800 /* major*10000 + minor*100 + patch */
 
 #define APGD_OK 0
 #define APGD_ERR_NULL (-1)    /* required pointer is NULL */

@@ -347,6 +347,19 @@ int cnx_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* D
 #define CNX_TN_ACC 1
 int cnx_gemm_tn_ex(const void* A, int64_t lda, int32_t a_layout, const void* B, int64_t ldb, int32_t b_layout,
                    float* D, float* colsum_a, float* ws, int64_t M, int32_t N1, int32_t N2, void* stream);
+/* BOTH weight gradients of one block in one launch (round 6): two contractions over the same M rows,
+ *     D0 [N1][N2] = A0^T B0,  colsum_a0 [N1] = sum_m A0[m][.]      A0 CNX_TN_ACC tiles [M, N1], B0 rows [M, N2] (row stride ldb0)
+ *     D1 [N2][N1] = B1^T A1,  colsum_b1 [N2] = sum_m B1[m][.]      A1 CNX_TN_ACC tiles [M, N1], B1 rows [M, N2] (row stride ldb1)
+ * i.e. dW1 = dHpre^T LN(u) with d(b1), and dW2 = dO^T H with d(b2) (A0 = dhpre_ws, B0 = a_rows, A1 = h_ws, B1 = do_rows; N1 = 4C, N2 = C;
+ * models/convnext.py:42-46 backward).  A split of M is shared by the tiles of both problems, so the chip is filled with half the splits
+ * two cnx_gemm_tn_ex launches need: half the fp32 partial results written and summed (fixed order: deterministic), one launch + one sum
+ * instead of two + two.  D1 is accumulated transposed (tile operand on the A side for both) and transposed back by the sum.
+ * Shapes: M % 64 == 0 and (N1, N2) multiples of one of the tiles 384x192, 256x128, 384x96, 256x64 (cnx_gemm_tn_pair_supported);
+ * ws: cnx_gemm_tn_pair_ws_floats floats; 16-byte aligned pointers; ldb0, ldb1 multiples of 8; operands below 4 GB. */
+int cnx_gemm_tn_pair_supported(int64_t M, int32_t N1, int32_t N2);
+int64_t cnx_gemm_tn_pair_ws_floats(int64_t M, int32_t N1, int32_t N2);
+int cnx_gemm_tn_pair(const void* A0, const void* B0, int64_t ldb0, const void* A1, const void* B1, int64_t ldb1, float* D0,
+                     float* colsum_a0, float* D1, float* colsum_b1, float* ws, int64_t M, int32_t N1, int32_t N2, void* stream);
 
 /* bf16 GEMM with a fused epilogue (csrc/gemm_kernels.hip) for the pointwise convolutions / linears without a fused-block kernel:
  * models/convnext.py:42-46 (pwconv1 / act / pwconv2 / gamma / residual) at the widths and passes the fused kernels do not cover,

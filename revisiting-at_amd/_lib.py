@@ -103,6 +103,9 @@ PROTOTYPES = {
     "cnx_gemm_tn_ws_floats": (C.c_int64, [_i64, _i32, _i32]),
     "cnx_gemm_tn": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p]),
     "cnx_gemm_tn_ex": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "cnx_gemm_tn_pair_supported": (C.c_int, [_i64, _i32, _i32]),
+    "cnx_gemm_tn_pair_ws_floats": (C.c_int64, [_i64, _i32, _i32]),
+    "cnx_gemm_tn_pair": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "cnx_gemm_nt_supported": (C.c_int, [_i64, _i32, _i32]),
     "cnx_gemm_nt": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, C.c_int, _i64, _i32, _i32, _i32, _p, _p, _p, _i64, C.c_int, _p, _p, _i64, _p]),
     "cnx_layernorm_bwd_patch2": (C.c_int, [_p, C.c_int, _p, C.c_int, _p, _p, _p, _p, C.c_int, _p, _p, _p, _i64, _i32, _i32, _i32,

@@ -381,10 +381,17 @@ __device__ __forceinline__ uint32_t tn_lane_off(int lane) {            // the la
   if (LAYOUT == kRows) return static_cast<uint32_t>(row * 64 + hq * 8);
   return static_cast<uint32_t>(row * 64 + (hq & 1) * 32 + (hq >> 1) * 8);
 }
-template <int F, int WI, int WJ, int LA, int LB, bool CS>
+// PAIR: TWO contractions of the same shape and row count in one launch - the two weight gradients of one block,
+//   problem 0:  D0 [N1][N2] = A^T B,    column sums of A     (dW1 = dHpre^T LN(u), d(b1) = sum dHpre:  A = dHpre tiles, B = LN(u) rows)
+//   problem 1:  T  [N1][N2] = A2^T B2,  column sums of B2    (dW2^T = H^T dO,      d(b2) = sum dO:     A2 = H tiles,    B2 = dO rows)
+// - dW2 is computed TRANSPOSED so that both problems have the tile operand on the A side and one kernel body serves both (the fixed-
+// order sum writes it back as [N2][N1]).  A split's workgroups are the tiles of BOTH problems: half as many splits as two launches
+// need to fill the chip, i.e. half the partial results to write and to sum (75 -> 37 MB per contraction at C = 384).
+template <int F, int WI, int WJ, int LA, int LB, bool CS, bool PAIR = false>
 __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_kernel(
     const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, float* __restrict__ ws, int M, int N1, int N2,
-    int rows_per_split, int n_split, int dbg) {
+    int rows_per_split, int n_split, int dbg, const uint16_t* __restrict__ A2, const uint16_t* __restrict__ B2, long ldb2) {
+  static_assert(!PAIR || (LA == 1 && LB == 0 && CS), "the pair: tile operand on the A side, row operand on the B side, column sums");
   constexpr int NW = WI * WJ, BM = 32 * F * WI, BN = 32 * F * WJ, KT = 64;
   constexpr int SUBA = BM / 32, SUBB = BN / 32;
   constexpr uint32_t A_BYTES = SUBA * KT * 64, B_BYTES = SUBB * KT * 64, STAGE = A_BYTES + B_BYTES;
@@ -401,7 +408,11 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
     const long q = G / 8, r = G % 8, xcd = L % 8, k = L / 8;
     lid = xcd * q + (xcd < r ? xcd : r) + k;
   }
-  const int split = static_cast<int>(lid / (TI * TJ)), tile = static_cast<int>(lid - static_cast<long>(split) * (TI * TJ));
+  constexpr int NPROB = PAIR ? 2 : 1;
+  const int split = static_cast<int>(lid / (NPROB * TI * TJ));
+  int tile = static_cast<int>(lid - static_cast<long>(split) * (NPROB * TI * TJ));
+  const int prob = PAIR && tile >= TI * TJ ? 1 : 0;                    // (workgroup-uniform)
+  if (PAIR && prob) { tile -= TI * TJ; A = A2; B = B2; ldb = ldb2; }
   const int ti = tile / TJ, tj = tile - ti * TJ;
   const int i0 = ti * BM, j0 = tj * BN;
   const int m_begin = split * rows_per_split;
@@ -446,17 +457,21 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
     for (int fj = 0; fj < F; ++fj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[fi][fj][r] = 0.f;
-  f32x16 accs[CS ? F : 1];
-  bf16x8 ones;
-  const bool cs_wave = CS && tj == 0 && wj == 0;
+  // column sums: ONE more accumulator tile for all F blocks - block f is multiplied with a constant fragment whose column f (row f
+  // for the sums of B) is ones, so its sums land in column (row) f of the tile
+  f32x16 accs;
+  bf16x8 ones[CS ? F : 1];
+  // the column sums ride on the wavefronts of the first tile column (of A: x ones) / the first tile row (problem 1, of B: ones x)
+  const bool cs_wave = CS && (prob == 0 ? (tj == 0 && wj == 0) : (ti == 0 && wi == 0));
   if constexpr (CS) {
 #pragma unroll
-    for (int fi = 0; fi < F; ++fi)
+    for (int r = 0; r < 16; ++r) accs[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accs[fi][r] = 0.f;
-    const uint32_t v = (lane & 31) == 0 ? 0x3f803f80u : 0u;
-    const u32x4 t = {v, v, v, v};
-    ones = __builtin_bit_cast(bf16x8, t);
+    for (int f = 0; f < F; ++f) {
+      const uint32_t v = (lane & 31) == f ? 0x3f803f80u : 0u;
+      const u32x4 t = {v, v, v, v};
+      ones[f] = __builtin_bit_cast(bf16x8, t);
+    }
   }
 
   if (n_stage > 0) dma_stage(0, 0, -1);
@@ -493,16 +508,22 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
           acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][fi], bfr[ks & 1][fj], acc[fi][fj], 0, 0, 0);
       if constexpr (CS) {
         if (cs_wave) {
+          if (PAIR && prob) {                                          // (a scalar branch: one of the two products, never both + a select)
 #pragma unroll
-          for (int fi = 0; fi < F; ++fi) accs[fi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][fi], ones, accs[fi], 0, 0, 0);
+            for (int fj = 0; fj < F; ++fj) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones[fj], bfr[ks & 1][fj], accs, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int fi = 0; fi < F; ++fi) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][fi], ones[fi], accs, 0, 0, 0);
+          }
         }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  // partial tile -> ws[split][N1][N2] (then [N1] column sums of A)
-  float* out = ws + static_cast<long>(split) * (static_cast<long>(N1) * N2 + (CS ? N1 : 0));
+  // partial tile -> ws[split][N1][N2] (then [N1] column sums of A); the pair: [D0][N1 sums][T][N2 sums] per split
+  const long len_d = static_cast<long>(N1) * N2;
+  float* out = ws + static_cast<long>(split) * (PAIR ? 2 * len_d + N1 + N2 : len_d + (CS ? N1 : 0)) + (PAIR && prob ? len_d + N1 : 0);
   const int col = lane & 31, kb = lane >> 5;
 #pragma unroll
   for (int fi = 0; fi < F; ++fi)
@@ -515,13 +536,77 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
         out[static_cast<long>(i) * N2 + j] = acc[fi][fj][r];
       }
   if constexpr (CS) {
-    if (cs_wave && col == 0) {
+    if (PAIR && prob) {
+      // ones x B: row f of the tile = the column sums of B's block f (accumulator value f of the lanes of k-half 0)
+      if (cs_wave && kb == 0) {
 #pragma unroll
-      for (int fi = 0; fi < F; ++fi)
+        for (int fj = 0; fj < F; ++fj) out[len_d + j0 + 32 * (wj * F + fj) + col] = accs[fj];
+      }
+    } else if (cs_wave && col < F) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          out[static_cast<long>(N1) * N2 + i0 + 32 * (wi * F + fi) + (r & 3) + 8 * (r >> 2) + 4 * kb] = accs[fi][r];
+      for (int r = 0; r < 16; ++r) out[len_d + i0 + 32 * (wi * F + col) + (r & 3) + 8 * (r >> 2) + 4 * kb] = accs[r];
     }
+  }
+}
+
+// The pair's fixed-order sum: D0 [N1][N2] and its [N1] sums as they lie in the partials, T [N1][N2] transposed into D1 [N2][N1]
+// through LDS (32 x 32 tiles: 128-byte segments on both sides), then its [N2] sums.  1024 threads = 4 split-lanes x 256 positions
+// (a float4 each): lane q adds the splits q, q + 4, ... in order, the four lanes are added as (0 + 1) + (2 + 3).
+__global__ __launch_bounds__(1024) void gemm_tn_pair_reduce_kernel(const float* __restrict__ ws, float* __restrict__ D0, float* __restrict__ cs0,
+                                                                   float* __restrict__ D1, float* __restrict__ cs1, int N1, int N2, int n_split) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  __shared__ f32x4 part[4][256];
+  __shared__ float tr[32][33];
+  const int q = threadIdx.x >> 8, pos = threadIdx.x & 255;
+  const long len_d = static_cast<long>(N1) * N2, part_len = 2 * len_d + N1 + N2;
+  const int tiles_j = N2 / 32, tiles = (N1 / 32) * tiles_j;
+  int b = blockIdx.x;
+  const bool mat = b < 2 * tiles;
+  const int prob = mat && b >= tiles ? 1 : 0;
+  long off, e = 0;                                                     // this thread's float4 inside a split's partials; -1: none
+  int ti = 0, tj = 0;
+  if (mat) {
+    if (prob) b -= tiles;
+    ti = b / tiles_j, tj = b - ti * tiles_j;
+    off = (prob ? len_d + N1 : 0) + static_cast<long>(ti * 32 + (pos >> 3)) * N2 + tj * 32 + (pos & 7) * 4;
+  } else {
+    e = (static_cast<long>(b - 2 * tiles) * 256 + pos) * 4;            // the N1 + N2 sums: [N1] behind D0, [N2] behind T
+    off = e < N1 ? len_d + e : e < N1 + N2 ? 2 * len_d + e : -1;
+  }
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (off >= 0) {
+    const float* p = ws + off;
+    int k = q;
+    for (; k + 12 < n_split; k += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + k * part_len), bq = *reinterpret_cast<const f32x4*>(p + (k + 4) * part_len),
+                  c = *reinterpret_cast<const f32x4*>(p + (k + 8) * part_len), d = *reinterpret_cast<const f32x4*>(p + (k + 12) * part_len);
+      s += a; s += bq; s += c; s += d;
+    }
+    for (; k < n_split; k += 4) s += *reinterpret_cast<const f32x4*>(p + k * part_len);
+  }
+  part[q][pos] = s;
+  __syncthreads();
+  if (q == 0) s = (part[0][pos] + part[1][pos]) + (part[2][pos] + part[3][pos]);
+  if (!mat) {
+    if (q == 0 && off >= 0) {
+      if (e < N1) *reinterpret_cast<f32x4*>(cs0 + e) = s;
+      else *reinterpret_cast<f32x4*>(cs1 + (e - N1)) = s;
+    }
+    return;
+  }
+  if (!prob) {
+    if (q == 0) *reinterpret_cast<f32x4*>(D0 + off) = s;
+    return;
+  }
+  if (q == 0) {
+    const int il = pos >> 3, jl = (pos & 7) * 4;
+    tr[il][jl] = s.x; tr[il][jl + 1] = s.y; tr[il][jl + 2] = s.z; tr[il][jl + 3] = s.w;
+  }
+  __syncthreads();
+  if (q == 0) {
+    const int jl = pos >> 3, il = (pos & 7) * 4;
+    const f32x4 v = {tr[il][jl], tr[il + 1][jl], tr[il + 2][jl], tr[il + 3][jl]};
+    *reinterpret_cast<f32x4*>(D1 + static_cast<long>(tj * 32 + jl) * N1 + ti * 32 + il) = v;
   }
 }
 
@@ -568,11 +653,33 @@ int launch_gemm_tn(const uint16_t* A, long lda, const uint16_t* B, long ldb, flo
   // (a single split with no column sums writes D directly; everything else goes through the workspace and the fixed-order sum)
   const bool direct = n_split == 1 && !CS;
   hipLaunchKernelGGL((gemm_tn_kernel<F, WI, WJ, LA, LB, CS>), dim3(static_cast<unsigned>(grid)), dim3(64 * WI * WJ), lds_bytes, s, A, lda, B,
-                     ldb, direct ? D : ws, M, N1, N2, rows_per_split, n_split, dbg);
+                     ldb, direct ? D : ws, M, N1, N2, rows_per_split, n_split, dbg, static_cast<const uint16_t*>(nullptr),
+                     static_cast<const uint16_t*>(nullptr), 0L);
   int rc = launch_status();
   if (rc || direct || (dbg & 4)) return rc;
   const long len_d = static_cast<long>(N1) * N2, part = len_d + (CS ? N1 : 0);
   hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(static_cast<unsigned>((part / 4 + 255) / 256)), dim3(256), 0, s, ws, D, cs, len_d, part, n_split);
+  return launch_status();
+}
+
+template <int F, int WI, int WJ>
+int launch_gemm_tn_pair(const uint16_t* A0, const uint16_t* B0, long ldb0, const uint16_t* A1, const uint16_t* B1, long ldb1, float* D0,
+                        float* cs0, float* D1, float* cs1, float* ws, int M, int N1, int N2, int rows_per_split, int n_split, hipStream_t s) {
+  constexpr int BM = 32 * F * WI, BN = 32 * F * WJ;
+  constexpr size_t lds_bytes = 2 * (BM / 32 + BN / 32) * 64 * 64;
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr;
+  const long grid = 2L * (N1 / BM) * (N2 / BN) * n_split;
+  hipLaunchKernelGGL((gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true>), dim3(static_cast<unsigned>(grid)), dim3(64 * WI * WJ), lds_bytes, s,
+                     A0, static_cast<long>(N1), B0, ldb0, ws, M, N1, N2, rows_per_split, n_split, 0, A1, B1, ldb1);
+  int rc = launch_status();
+  if (rc) return rc;
+  const long blocks = 2L * (N1 / 32) * (N2 / 32) + (N1 + N2 + 1023) / 1024;
+  hipLaunchKernelGGL(gemm_tn_pair_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(1024), 0, s, ws, D0, cs0, D1, cs1, N1, N2, n_split);
   return launch_status();
 }
 
@@ -751,6 +858,53 @@ int cnx_gemm_tn_ex(const void* A, int64_t lda, int32_t a_layout, const void* B, 
   }
   TN_CASE(3, 4, 2) TN_CASE(3, 2, 4) TN_CASE(2, 4, 2) TN_CASE(2, 2, 4) TN_CASE(3, 4, 1) TN_CASE(3, 1, 4) TN_CASE(2, 4, 1) TN_CASE(2, 1, 4)
 #undef TN_CASE
+  return APGD_ERR_ARG;
+}
+
+// the pair runs on the tiles with WI >= WJ (what gemm_tn_shape picks for N1 = 4 N2, the two weight gradients of a block)
+static int gemm_tn_pair_shape(int N1, int N2) {
+  const int code = gemm_tn_shape(N1, N2);
+  return (code / 10) % 10 >= code % 10 ? code : 0;
+}
+
+int cnx_gemm_tn_pair_supported(int64_t M, int32_t N1, int32_t N2) {
+  return (M > 0 && M % 64 == 0 && M < (1L << 31) && N1 > 0 && N2 > 0 && gemm_tn_pair_shape(N1, N2) != 0) ? 1 : 0;
+}
+
+int64_t cnx_gemm_tn_pair_ws_floats(int64_t M, int32_t N1, int32_t N2) {
+  if (!cnx_gemm_tn_pair_supported(M, N1, N2)) return 0;
+  const int code = gemm_tn_pair_shape(N1, N2);
+  const int F = code / 100, WI = (code / 10) % 10, WJ = code % 10;
+  int rows, ns;
+  gemm_tn_split(static_cast<int>(M), 2 * (N1 / (32 * F * WI)) * (N2 / (32 * F * WJ)), &rows, &ns);
+  return static_cast<int64_t>(ns) * (2 * static_cast<int64_t>(N1) * N2 + N1 + N2);
+}
+
+int cnx_gemm_tn_pair(const void* A0, const void* B0, int64_t ldb0, const void* A1, const void* B1, int64_t ldb1, float* D0, float* colsum_a0,
+                     float* D1, float* colsum_b1, float* ws, int64_t M, int32_t N1, int32_t N2, void* stream) {
+  if (M < 0 || N1 <= 0 || N2 <= 0) return APGD_ERR_SIZE;
+  if (!A0 || !B0 || !A1 || !B1 || !D0 || !D1 || !colsum_a0 || !colsum_b1 || !ws) return APGD_ERR_NULL;
+  if (!cnx_gemm_tn_pair_supported(M, N1, N2)) return APGD_ERR_ARG;
+  if (ldb0 < N2 || ldb0 % 8 != 0 || ldb1 < N2 || ldb1 % 8 != 0) return APGD_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(A0) | reinterpret_cast<uintptr_t>(B0) | reinterpret_cast<uintptr_t>(A1) | reinterpret_cast<uintptr_t>(B1) |
+       reinterpret_cast<uintptr_t>(D0) | reinterpret_cast<uintptr_t>(D1) | reinterpret_cast<uintptr_t>(colsum_a0) |
+       reinterpret_cast<uintptr_t>(colsum_b1) | reinterpret_cast<uintptr_t>(ws)) % 16 != 0)
+    return APGD_ERR_ARG;
+  if (M * N1 * 2 >= (1L << 32) || M * ldb0 * 2 >= (1L << 32) || M * ldb1 * 2 >= (1L << 32)) return APGD_ERR_ARG;   // 32-bit byte offsets
+  const int code = gemm_tn_pair_shape(N1, N2);
+  const int F = code / 100, WI = (code / 10) % 10, WJ = code % 10;
+  int rows, ns;
+  gemm_tn_split(static_cast<int>(M), 2 * (N1 / (32 * F * WI)) * (N2 / (32 * F * WJ)), &rows, &ns);
+  hipStream_t s = as_stream(stream);
+  const auto* a0 = static_cast<const uint16_t*>(A0);
+  const auto* b0 = static_cast<const uint16_t*>(B0);
+  const auto* a1 = static_cast<const uint16_t*>(A1);
+  const auto* b1 = static_cast<const uint16_t*>(B1);
+  const int m = static_cast<int>(M);
+#define TN_PAIR(FF, II, JJ) \
+  if (code == FF * 100 + II * 10 + JJ) return launch_gemm_tn_pair<FF, II, JJ>(a0, b0, ldb0, a1, b1, ldb1, D0, colsum_a0, D1, colsum_b1, ws, m, N1, N2, rows, ns, s);
+  TN_PAIR(3, 4, 2) TN_PAIR(2, 4, 2) TN_PAIR(3, 4, 1) TN_PAIR(2, 4, 1)
+#undef TN_PAIR
   return APGD_ERR_ARG;
 }
 

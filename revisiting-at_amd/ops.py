@@ -1205,6 +1205,28 @@ def _wgrad_acc(a_t, a_acc, b_t, b_acc, M, N1, N2):
     return d, cs
 
 
+# both weight gradients of a fused block in ONE cnx_gemm_tn_pair launch (round 6; half the partial results of two cnx_gemm_tn_ex calls)
+_TN_PAIR = os.environ.get("APGD_TN_PAIR", "1") != "0"
+
+
+def _wgrad_block(dhp, a_rows, h, dos, M, C):
+    """The two weight gradients of one block from the tiles / rows its backward kernel left: ``(dW1 [4C, C], db1 [4C], dW2 [C, 4C],
+    db2 [C])`` = ``(dHpre^T LN(u), sum dHpre, dO^T H, sum dO)``; ``dhp``, ``h``: ``CNX_TN_ACC`` tiles, ``a_rows``, ``dos``: [M, C] bf16."""
+    lib = _lib.load()
+    if _TN_PAIR and lib.cnx_gemm_tn_pair_supported(M, 4 * C, C):
+        dev = a_rows.device
+        dw1 = torch.empty(4 * C, C, device=dev, dtype=torch.float32)
+        dw2 = torch.empty(C, 4 * C, device=dev, dtype=torch.float32)
+        db = torch.empty(5 * C, device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.cnx_gemm_tn_pair_ws_floats(M, 4 * C, C), device=dev, dtype=torch.float32)
+        _lib.check(lib.cnx_gemm_tn_pair(dhp.data_ptr(), a_rows.data_ptr(), C, h.data_ptr(), dos.data_ptr(), C, dw1.data_ptr(), db.data_ptr(),
+                                        dw2.data_ptr(), db[4 * C:].data_ptr(), ws.data_ptr(), M, 4 * C, C, _stream()), "cnx_gemm_tn_pair")
+        return dw1, db[:4 * C], dw2, db[4 * C:]
+    dw2, db2 = _wgrad_acc(dos, False, h, True, M, C, 4 * C)              # dO^T H        [C, 4C]
+    dw1, db1 = _wgrad_acc(dhp, True, a_rows, False, M, 4 * C, C)         # dHpre^T LN(u) [4C, C]
+    return dw1, db1, dw2, db2
+
+
 def _wgrad_lib(x, y):
     """``x^T y`` for tall operands (``x`` [M, N1], ``y`` [M, N2], M >> N) -> fp32 [N1, N2].
 
@@ -1614,8 +1636,7 @@ class _BlockFused(torch.autograd.Function):
                                                             da.data_ptr(), dos.data_ptr(), dhp.data_ptr(), M, C, _stream()),
                            "cnx_block_mlp_bwd_train_hpre")
             if want_p:
-                dw2, db2 = _wgrad_acc(dos, False, h, True, M, C, 4 * C)              # dO^T H        [C, 4C]
-                dw1, db1 = _wgrad_acc(dhp, True, a_s, False, M, 4 * C, C)            # dHpre^T LN(u) [4C, C]
+                dw1, db1, dw2, db2 = _wgrad_block(dhp, a_s, h, dos, M, C)
                 dln_id = _DLN_FROM_DW1
                 if ln_in:
                     dlw_id, dlb_id = _block_dln(lib, w1p, dw1, db1, lw, lb, None, dhp, u, mean, rstd, M, C)
@@ -1653,8 +1674,7 @@ class _BlockFused(torch.autograd.Function):
                               g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
                               da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
                               M, C, _stream()), "cnx_block_mlp_bwd_acc_ln" if ln_in else "cnx_block_mlp_bwd_acc")
-                dw2, db2 = _wgrad_acc(dos, False, ht, True, M, C, 4 * C)
-                dw1, db1 = _wgrad_acc(dhpt, True, a, False, M, 4 * C, C)
+                dw1, db1, dw2, db2 = _wgrad_block(dhpt, a, ht, dos, M, C)
                 dln_id = _DLN_FROM_DW1
                 if ln_in:
                     dlw_id, dlb_id = _block_dln(lib, w1p, dw1, db1, lw, lb, None, dhpt, u, mean, rstd, M, C)
@@ -1893,16 +1913,19 @@ def attention(qkv, num_heads, scale):
 KERNEL_SETS = {
     # the tree as shipped
     "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
-                    blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2, gemm_auto_max=0),
+                    blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2, gemm_auto_max=0,
+                    tn_pair=True),
     # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_STEM_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
     # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
     # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
     # (library convolutions are never asked for a bias gradient any more - ops.conv_bias_grad: under hipGraph replay MIOpen's came back
     #  non-finite, which is how this set's first run found the hazard, gpurun_out/r6b - so the set runs the library stem gradients again)
     "round4": dict(wgrad="lib", stem_wgrad=False, train_hpre=set(), dgamma=False, dln="pass", fused_tracking=False, blk2=0,
-                   pool_rows=False, dw_shared_halo=0, blk2b=0),
-    # the end-of-round-5 selection: today's tree without round 6's wavefront-pair Hpre backward
-    "round5": dict(blk2b=0),
+                   pool_rows=False, dw_shared_halo=0, blk2b=0, tn_pair=False),
+    # the end-of-round-5 selection: today's tree without round 6's wavefront-pair Hpre backward and paired weight-gradient launch
+    "round5": dict(blk2b=0, tn_pair=False),
+    # one launch per weight gradient (two cnx_gemm_tn_ex calls per block) instead of the paired launch
+    "tn2": dict(tn_pair=False),
     # single-switch experiments of round 6 (profiles/r06_ab.md)
     "stemln": dict(stem_ln_fused=True), "streams3": dict(attack_streams=3), "streams1": dict(attack_streams=1),
     # the C = 768 blocks of the TRAINING pass on cnx_gemm_nt with its fused epilogues instead of library GEMMs + one-pass tails
@@ -1920,6 +1943,7 @@ def kernel_set(name_or_dict):
     drops what was captured or cached under the old set (``graphed.reset()``, a fresh ``ATTrainStep``); results stay inside the parity
     bars either way - the sets differ in kernels and summation order, not in arithmetic."""
     global _WGRAD_MODE, STEM_WGRAD_HIP, _TRAIN_HPRE_WIDTHS, _DGAMMA_FROM_DW2, _DLN_FROM_DW1, _LN_IN_TRAIN_BWD, _POOL_ROWS, _STEM_LN_FUSED, _GEMM_AUTO_MAX
+    global _TN_PAIR
     from . import apgd as _apgd
     from . import graphed as _graphed
     new = KERNEL_SETS[name_or_dict] if isinstance(name_or_dict, str) else dict(name_or_dict)
@@ -1931,7 +1955,9 @@ def kernel_set(name_or_dict):
                 dln="dw1" if _LN_IN_TRAIN_BWD else ("kernel" if _DLN_FROM_DW1 else "pass"), fused_tracking=_apgd.FUSED_TRACKING,
                 blk2=int(lib.cnx_runtime_switch(0, -1)), pool_rows=_POOL_ROWS, dw_shared_halo=int(lib.cnx_runtime_switch(1, -1)),
                 fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))), blk2b=int(lib.cnx_runtime_switch(3, -1)),
-                stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS, gemm_auto_max=_GEMM_AUTO_MAX)
+                stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS, gemm_auto_max=_GEMM_AUTO_MAX, tn_pair=_TN_PAIR)
+    if "tn_pair" in new:
+        _TN_PAIR = bool(new["tn_pair"])
     if "wgrad" in new:
         if new["wgrad"] not in ("hip", "lib"):
             raise ValueError(f"kernel_set: wgrad={new['wgrad']!r}")

@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(R):
     lib = R._lib.load()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in apgd_hip.h but not exported"
-    assert lib.apgd_hip_version() == 10700
+    assert lib.apgd_hip_version() == 10800
     assert lib.apgd_hip_strerror(0) == b"ok" and b"NULL" in lib.apgd_hip_strerror(-1)
     assert lib.apgd_l2_parts() == 64
 

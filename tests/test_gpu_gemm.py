@@ -198,3 +198,66 @@ def test_gemm_tn_vs_fp32_reference_through_the_c_abi(M, N1, N2):
     assert torch.equal(D, D2)
     assert lib.cnx_gemm_tn(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), D.data_ptr(), ws.data_ptr(), M + 8, N1, N2, S) == -4
     assert lib.cnx_gemm_tn_supported(M, N1 + 32, N2) in (0, 1) and lib.cnx_gemm_tn_supported(M, 1000, 768) == 0
+
+
+def _rows_to_acc(x):
+    """[M, N] -> CNX_TN_ACC tiles ([M/32][N/32] x 2 KiB; element (m, n) of a tile at byte 64 m + 32 ((n/4) % 2) + 8 (n/8) + 2 (n % 4))."""
+    M, N = x.shape
+    t = x.reshape(M // 32, 32, N // 32, 4, 2, 4)                    # (row tile, m, column tile, q, half, e): n = 8 q + 4 half + e
+    return t.permute(0, 2, 1, 4, 3, 5).contiguous().reshape(-1)
+
+
+@pytest.mark.parametrize("M,C", [(64, 96), (8192, 96), (448, 192), (12544, 192), (6272, 384), (50176, 384), (1024, 128), (3136, 256),
+                                 (640, 64), (1536, 768)])
+def test_gemm_tn_pair_vs_fp32_reference_and_the_two_single_launches(M, C):
+    """cnx_gemm_tn_pair (round 6): both weight gradients of a block - dW1 = dHpre^T a with d(b1) = sum dHpre, dW2 = dO^T H with
+    d(b2) = sum dO - from ONE launch whose splits of M are shared by the tiles of both problems (dW2 accumulated transposed, written
+    back by the fixed-order sum).  Against the fp32 products of the same bf16 values, against two cnx_gemm_tn_ex launches (same
+    products, another split of M: fp32 rounding apart), bit-for-bit repeatable; all four tile shapes, one and many splits, a row
+    operand that is a view into a wider tensor."""
+    import revisiting_at_amd as R
+    lib = R._lib.load()
+    N1, N2 = 4 * C, C
+    assert lib.cnx_gemm_tn_pair_supported(M, N1, N2) == 1
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    sc1, sc2 = torch.linspace(0.5, 2.0, N1, device="cuda"), torch.linspace(2.0, 0.5, N2 + 16, device="cuda")
+    dhp = (torch.randn(M, N1, device="cuda", generator=g) * sc1 + 0.1).to(torch.bfloat16)
+    h = (torch.randn(M, N1, device="cuda", generator=g) * sc1.flip(0) + 0.2).to(torch.bfloat16)
+    a_w = (torch.randn(M, N2 + 16, device="cuda", generator=g) * sc2).to(torch.bfloat16)
+    do_w = (torch.randn(M, N2 + 16, device="cuda", generator=g) * sc2.flip(0) - 0.1).to(torch.bfloat16)
+    a, do = a_w[:, :N2], do_w[:, 8:8 + N2]
+    dhp_t, h_t = _rows_to_acc(dhp), _rows_to_acc(h)
+    S = torch.cuda.current_stream().cuda_stream
+    nws = lib.cnx_gemm_tn_pair_ws_floats(M, N1, N2)
+    assert nws > 0
+    ws = torch.full((nws,), float("nan"), device="cuda")
+
+    def run():
+        dw1 = torch.full((N1, N2), float("nan"), device="cuda"); db1 = torch.full((N1,), float("nan"), device="cuda")
+        dw2 = torch.full((N2, N1), float("nan"), device="cuda"); db2 = torch.full((N2,), float("nan"), device="cuda")
+        assert lib.cnx_gemm_tn_pair(dhp_t.data_ptr(), a.data_ptr(), a.stride(0), h_t.data_ptr(), do.data_ptr(), do.stride(0), dw1.data_ptr(),
+                                    db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M, N1, N2, S) == 0
+        return dw1, db1, dw2, db2
+    dw1, db1, dw2, db2 = run()
+    rel = lambda t, r: float((t - r).norm() / r.norm())
+    assert rel(dw1, dhp.float().t() @ a.float()) < 2e-6 and rel(dw2, do.float().t() @ h.float()) < 2e-6
+    assert rel(db1, dhp.float().sum(0)) < 2e-6 and rel(db2, do.float().sum(0)) < 2e-6
+    for x, y in zip(run(), (dw1, db1, dw2, db2)):
+        assert torch.equal(x, y)
+    # the two single launches
+    ws1 = torch.empty(max(lib.cnx_gemm_tn_ws_floats(M, N1, N2), lib.cnx_gemm_tn_ws_floats(M, N2, N1)), device="cuda")
+    e1 = torch.empty(N1, N2, device="cuda"); c1 = torch.empty(N1, device="cuda")
+    e2 = torch.empty(N2, N1, device="cuda"); c2 = torch.empty(N2, device="cuda")
+    doc = do.contiguous()
+    assert lib.cnx_gemm_tn_ex(dhp_t.data_ptr(), 0, 1, a.data_ptr(), a.stride(0), 0, e1.data_ptr(), c1.data_ptr(), ws1.data_ptr(), M, N1, N2, S) == 0
+    assert lib.cnx_gemm_tn_ex(doc.data_ptr(), N2, 0, h_t.data_ptr(), 0, 1, e2.data_ptr(), c2.data_ptr(), ws1.data_ptr(), M, N2, N1, S) == 0
+    assert rel(dw1, e1) < 2e-6 and rel(dw2, e2) < 2e-6 and rel(db1, c1) < 2e-6 and rel(db2, c2) < 2e-6
+    # argument checks
+    assert lib.cnx_gemm_tn_pair(dhp_t.data_ptr(), a.data_ptr(), a.stride(0), h_t.data_ptr(), do.data_ptr(), do.stride(0), dw1.data_ptr(),
+                                None, dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M, N1, N2, S) == -1
+    assert lib.cnx_gemm_tn_pair(dhp_t.data_ptr(), a.data_ptr(), N2 - 8, h_t.data_ptr(), do.data_ptr(), do.stride(0), dw1.data_ptr(),
+                                db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M, N1, N2, S) == -4
+    assert lib.cnx_gemm_tn_pair(dhp_t.data_ptr(), a.data_ptr(), a.stride(0), h_t.data_ptr(), do.data_ptr(), do.stride(0), dw1.data_ptr(),
+                                db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M + 8, N1, N2, S) == -4
+    assert lib.cnx_gemm_tn_pair_supported(M, 96, 384) == 0 and lib.cnx_gemm_tn_pair_ws_floats(M, 96, 384) == 0   # (tiles with WI >= WJ only)
+    assert lib.cnx_gemm_tn_pair_supported(M, 1000, 768) == 0 and lib.cnx_gemm_tn_pair_supported(M + 8, N1, N2) == 0

@@ -159,7 +159,7 @@ def test_kernel_sets_switch_in_a_running_process_and_restore():
         assert prev == ops.KERNEL_SETS["default"]
         assert (ops._WGRAD_MODE, ops.STEM_WGRAD_HIP, ops._TRAIN_HPRE_WIDTHS) == ("lib", False, set())
         assert (ops._DGAMMA_FROM_DW2, ops._DLN_FROM_DW1, ops._LN_IN_TRAIN_BWD, ops._POOL_ROWS) == (False, False, False, False)
-        assert apgd.FUSED_TRACKING is False
+        assert apgd.FUSED_TRACKING is False and ops._TN_PAIR is False
         assert lib.cnx_runtime_switch(0, -1) == 0 and lib.cnx_runtime_switch(1, -1) == 0 and lib.cnx_runtime_switch(3, -1) == 0
         assert ops.kernel_set(prev) == dict(ops.KERNEL_SETS["default"], **ops.KERNEL_SETS["round4"])   # (a set names only what it changes)
         assert lib.cnx_runtime_switch(2, 3) == -1 and ops.kernel_set("w8")["fwd_w8"] == 0   # measurement builds only: a no-op here

@@ -49,3 +49,46 @@ for M, C in ((802816, 96), (200704, 192), (50176, 384)):
         ws = torch.empty(max(4, lib.cnx_gemm_tn_ws_floats(M, N1, N2)), device="cuda")
         us = t(lambda: lib.cnx_gemm_tn_ex(a.data_ptr(), lda, la, b.data_ptr(), ldb, lb, D.data_ptr(), cs.data_ptr(), ws.data_ptr(), M, N1, N2, S))
         print(f"M={M:7d} C={C:4d} {name}: {us:7.1f} us (operands {M * 5 * C * 2 / 1e6 / us:5.2f} TB/s)", flush=True)
+
+# both weight gradients of a block: two cnx_gemm_tn_ex launches (+ two sums) against one cnx_gemm_tn_pair launch (+ one sum)
+print("block weight gradients: 2 x cnx_gemm_tn_ex against cnx_gemm_tn_pair (alternating medians)")
+
+
+def med(fn, it=15):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(it):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort(); return ts[len(ts) // 2]
+
+
+for M, C in ((802816, 96), (200704, 192), (50176, 384), (200704, 128), (50176, 256)):
+    N1, N2 = 4 * C, C
+    a_rows = torch.randn(M, C, device="cuda").to(torch.bfloat16)
+    do_rows = torch.randn(M, C, device="cuda").to(torch.bfloat16)
+    dhp = (torch.randn(M * 4 * C, device="cuda") * 0.1).to(torch.bfloat16)
+    h = (torch.randn(M * 4 * C, device="cuda") * 0.1).to(torch.bfloat16)
+    dw1 = torch.empty(N1, N2, device="cuda"); db1 = torch.empty(N1, device="cuda")
+    dw2 = torch.empty(N2, N1, device="cuda"); db2 = torch.empty(N2, device="cuda")
+    ws1 = torch.empty(max(lib.cnx_gemm_tn_ws_floats(M, N1, N2), lib.cnx_gemm_tn_ws_floats(M, N2, N1)), device="cuda")
+    wsp = torch.empty(lib.cnx_gemm_tn_pair_ws_floats(M, N1, N2), device="cuda")
+
+    def two():
+        lib.cnx_gemm_tn_ex(do_rows.data_ptr(), C, 0, h.data_ptr(), 0, 1, dw2.data_ptr(), db2.data_ptr(), ws1.data_ptr(), M, N2, N1, S)
+        lib.cnx_gemm_tn_ex(dhp.data_ptr(), 0, 1, a_rows.data_ptr(), C, 0, dw1.data_ptr(), db1.data_ptr(), ws1.data_ptr(), M, N1, N2, S)
+
+    def pair():
+        R._lib.check(lib.cnx_gemm_tn_pair(dhp.data_ptr(), a_rows.data_ptr(), C, h.data_ptr(), do_rows.data_ptr(), C, dw1.data_ptr(), db1.data_ptr(),
+                                          dw2.data_ptr(), db2.data_ptr(), wsp.data_ptr(), M, N1, N2, S), "pair")
+    two(); r = (dw1.clone(), dw2.clone())
+    pair()
+    err = max(float((dw1 - r[0]).norm() / r[0].norm()), float((dw2 - r[1]).norm() / r[1].norm()))
+    res = []
+    for _ in range(3):
+        res.append((med(two), med(pair)))
+    t2, tp = sorted(v[0] for v in res)[1], sorted(v[1] for v in res)[1]
+    gf = 4.0 * M * N1 * N2 / 1e9
+    print(f"M={M:7d} C={C:4d}: two launches {t2:7.1f} us ({gf / t2 * 1e3:5.0f} TF/s; partials {ws1.numel() * 4 / 1e6 * 2:6.1f} MB) | pair {tp:7.1f} us "
+          f"({gf / tp * 1e3:5.0f} TF/s; partials {wsp.numel() * 4 / 1e6:6.1f} MB) | {t2 / tp:5.3f} x | rel diff {err:.1e}", flush=True)
