@@ -202,6 +202,10 @@ class _Program:
 
 
 BORROW = False
+# The program whose replay produced the most recent attack (None: that attack ran eagerly).  ATTrainStep reads it right behind its
+# attack call: a training-pass graph captured behind a replay of program P may read P's derived weight copies (P.derived - rebuilt by
+# every replay of P from the live parameters) instead of rebuilding its own, as long as P is what ran in front of it.
+LAST = None
 
 
 class borrow_outputs:
@@ -243,6 +247,8 @@ def run(model, x, y, norm, eps, n_iter, kind, soft, y_target=None, x_init=None):
     ``y_target`` / ``x_init`` (the evaluation attacks of ``aa_eval``: target classes, random start) are replay inputs like x and y."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and isinstance(y, torch.Tensor) and y.is_cuda):
         return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, y_target=y_target, x_init=x_init)     # raises the usual errors
+    global LAST
+    LAST = None
     x = x.detach()
     if not apgd._dense_rows(x):
         x = x.contiguous()
@@ -287,4 +293,6 @@ def run(model, x, y, norm, eps, n_iter, kind, soft, y_target=None, x_init=None):
             torch.cuda.synchronize()
             return apgd._apgd_core(model, x, y, norm, eps, n_iter, kind, soft=soft, attack_gemm=ag, **ext)
     STATS["replays"] += 1
-    return prog(x, y, y_target, x_init)
+    out = prog(x, y, y_target, x_init)
+    LAST = prog
+    return out

@@ -950,6 +950,11 @@ def load_gemm_table(path=None):
         return False
 
 
+# The training-pass graph reads the derived copies of the attack program that replays in front of it instead of rebuilding them
+# (train_step._TrainPassGraph, round 6): each copy is made once per step.
+SHARE_DERIVED = os.environ.get("APGD_SHARE_DERIVED", "1") != "0"
+
+
 # Set (to a dict) while graphed.py captures the attack into hipGraphs: derived weight copies are then built INSIDE the capture,
 # once per capture, from the live parameters - a replay re-packs them on the device and never reads a copy made before the last
 # optimizer step - and the ordinary cache is neither read nor written.
@@ -1914,16 +1919,18 @@ KERNEL_SETS = {
     # the tree as shipped
     "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
                     blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2, gemm_auto_max=0,
-                    tn_pair=True),
+                    tn_pair=True, share_derived=True),
     # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_STEM_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
     # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
     # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
     # (library convolutions are never asked for a bias gradient any more - ops.conv_bias_grad: under hipGraph replay MIOpen's came back
     #  non-finite, which is how this set's first run found the hazard, gpurun_out/r6b - so the set runs the library stem gradients again)
     "round4": dict(wgrad="lib", stem_wgrad=False, train_hpre=set(), dgamma=False, dln="pass", fused_tracking=False, blk2=0,
-                   pool_rows=False, dw_shared_halo=0, blk2b=0, tn_pair=False),
+                   pool_rows=False, dw_shared_halo=0, blk2b=0, tn_pair=False, share_derived=False),
     # the end-of-round-5 selection: today's tree without round 6's wavefront-pair Hpre backward and paired weight-gradient launch
-    "round5": dict(blk2b=0, tn_pair=False),
+    "round5": dict(blk2b=0, tn_pair=False, share_derived=False),
+    # every graph rebuilds its own derived weight copies (packed / bf16 weights twice per step)
+    "own_copies": dict(share_derived=False),
     # one launch per weight gradient (two cnx_gemm_tn_ex calls per block) instead of the paired launch
     "tn2": dict(tn_pair=False),
     # single-switch experiments of round 6 (profiles/r06_ab.md)
@@ -1943,7 +1950,7 @@ def kernel_set(name_or_dict):
     drops what was captured or cached under the old set (``graphed.reset()``, a fresh ``ATTrainStep``); results stay inside the parity
     bars either way - the sets differ in kernels and summation order, not in arithmetic."""
     global _WGRAD_MODE, STEM_WGRAD_HIP, _TRAIN_HPRE_WIDTHS, _DGAMMA_FROM_DW2, _DLN_FROM_DW1, _LN_IN_TRAIN_BWD, _POOL_ROWS, _STEM_LN_FUSED, _GEMM_AUTO_MAX
-    global _TN_PAIR
+    global _TN_PAIR, SHARE_DERIVED
     from . import apgd as _apgd
     from . import graphed as _graphed
     new = KERNEL_SETS[name_or_dict] if isinstance(name_or_dict, str) else dict(name_or_dict)
@@ -1955,7 +1962,10 @@ def kernel_set(name_or_dict):
                 dln="dw1" if _LN_IN_TRAIN_BWD else ("kernel" if _DLN_FROM_DW1 else "pass"), fused_tracking=_apgd.FUSED_TRACKING,
                 blk2=int(lib.cnx_runtime_switch(0, -1)), pool_rows=_POOL_ROWS, dw_shared_halo=int(lib.cnx_runtime_switch(1, -1)),
                 fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))), blk2b=int(lib.cnx_runtime_switch(3, -1)),
-                stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS, gemm_auto_max=_GEMM_AUTO_MAX, tn_pair=_TN_PAIR)
+                stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS, gemm_auto_max=_GEMM_AUTO_MAX, tn_pair=_TN_PAIR,
+                share_derived=SHARE_DERIVED)
+    if "share_derived" in new:
+        SHARE_DERIVED = bool(new["share_derived"])
     if "tn_pair" in new:
         _TN_PAIR = bool(new["tn_pair"])
     if "wgrad" in new:

@@ -260,7 +260,7 @@ class _TrainPassGraph:
     launch (three with the gradient exchange of ``FlatGradSync`` issued eagerly between them).  Same capture rules as
     ``graphed._Program``: parameters are read and written in place, derived weight copies are rebuilt inside the graph."""
 
-    def __init__(self, step: "ATTrainStep", x, target, x_is_static: bool = False):
+    def __init__(self, step: "ATTrainStep", x, target, x_is_static: bool = False, attack_prog=None):
         # x_is_static: x is the static output of the attack's own graph (graphed.borrow_outputs) - the same tensor at every
         # step, read in place; anything else is copied into a buffer of this graph
         self.x = x if x_is_static else torch.empty_like(x)
@@ -268,7 +268,14 @@ class _TrainPassGraph:
         if not x_is_static:
             self.x.copy_(x)
         self.t.copy_(target)
-        self.derived = {}
+        # attack_prog: the attack program whose replay ran in front of this capture and will run in front of every replay of this
+        # graph (ATTrainStep._graph_step checks it): its derived weight copies - packed / bf16 weights, rebuilt by each of its replays
+        # from the parameters the optimizer last wrote, unchanged until this graph's own optimizer step - are READ here instead of
+        # being rebuilt (~75 five-microsecond kernels per step).  Entries keep their tensors (the attack graph's pool memory) alive;
+        # segment -1: complete by stream order, never waited for (ops._cached).
+        self.attack_prog = attack_prog
+        self.derived = {} if attack_prog is None else {k: (v[0], v[1], None, None, -1) for k, v in attack_prog.derived.items()}
+        self.shared_derived = len(self.derived)
         rec = graphed._Recorder()
         if step.sync is None:
             step.optimizer.zero_grad(set_to_none=True)         # the captured backward allocates every .grad in the graph's pool
@@ -338,8 +345,11 @@ class ATTrainStep:
         if graph_train is None:
             graph_train = bool(getattr(adv, "graph", 0)) and os.environ.get("APGD_GRAPH_TRAIN", "1") != "0"
         self.graph_train = bool(graph_train) and grad_sync != "ddp" and self.device.type == 'cuda'
-        self._tg = {}                                                      # (shapes, dtypes) -> _TrainPassGraph | None (failed)
+        self._tg = {}                                                      # (shapes, dtypes, id of the attack program whose derived
+        #                                                                    copies it reads | None) -> _TrainPassGraph | None (failed)
         self._tg_seen = {}                                                 # (shapes, dtypes) -> eager steps so far
+        self._tg_attack = {}                                               # (shapes, dtypes) -> that attack program (None: none)
+        self._tg_failed = set()                                            # (shapes, dtypes) whose capture failed: eager from then on
         if gemm_table and self.device.type == 'cuda':
             # opt-in: points PyTorch's process-wide TunableOp at the shipped, read-only hipBLASLt solution table
             ops.load_gemm_table()
@@ -474,23 +484,37 @@ class ATTrainStep:
 
     def _graph_step(self, images, target):
         """The step with the training pass replayed from a hipGraph; None if this batch has to run eagerly."""
-        key = (tuple(images.shape), images.dtype, tuple(target.shape), target.dtype)
-        if key in self._tg and self._tg[key] is None:
+        shape = (tuple(images.shape), images.dtype, tuple(target.shape), target.dtype)
+        if shape in self._tg_failed:
             return None
-        if key not in self._tg and self._tg_seen.get(key, 0) < TRAIN_GRAPH_WARMUP:
-            self._tg_seen[key] = self._tg_seen.get(key, 0) + 1            # libraries meet every shape outside a capture first
+        if shape not in self._tg_attack and self._tg_seen.get(shape, 0) < TRAIN_GRAPH_WARMUP:
+            self._tg_seen[shape] = self._tg_seen.get(shape, 0) + 1        # libraries meet every shape outside a capture first
             return None
         replays0 = graphed.STATS["replays"]
+        graphed.LAST = None
         z = self._perturbed(images, target, borrow=True)
+        replayed = graphed.STATS["replays"] > replays0
+        # The attack program that just replayed.  The training-pass graph of a batch shape READS the derived weight copies of the FIRST
+        # program it was captured behind (that program rebuilds them at every replay from the live parameters); behind any other
+        # attack - another program (a new eps, an evicted program) or an eager attack - a second, self-contained graph of the same
+        # pass runs: a graph never reads copies that were not rebuilt in front of it in THIS step.
+        aprog = graphed.LAST if (replayed and ops.SHARE_DERIVED) else None
+        if self._tg_attack.setdefault(shape, aprog) is None:
+            self._tg_attack[shape] = aprog                                 # (captured behind an eager attack first: shares from now on)
+        if self._tg_attack[shape] is not aprog:
+            aprog = None
+        key = shape + (None if aprog is None else id(aprog),)
         prog = self._tg.get(key)
         if prog is None:
             try:
                 # (a replayed attack under borrow_outputs hands out its graph's own static tensor: stable address)
-                prog = self._tg[key] = self._graph_cls(self, z, target, x_is_static=graphed.STATS["replays"] > replays0)
+                kw = {} if aprog is None else {"attack_prog": aprog}
+                prog = self._tg[key] = self._graph_cls(self, z, target, x_is_static=replayed, **kw)
             except Exception as e:                                         # noqa: BLE001 - any capture failure means "run eagerly"
                 import warnings
                 warnings.warn(f"training-pass graph capture failed ({type(e).__name__}: {e}); this batch shape runs eagerly")
                 self._tg[key] = None
+                self._tg_failed.add(shape)
                 if self.device.type == 'cuda':
                     torch.cuda.synchronize()
                 if self.sync is None:

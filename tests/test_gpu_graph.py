@@ -171,6 +171,51 @@ def test_training_pass_graph_runs_other_batch_shapes_eagerly_and_keeps_training(
     assert sum(v is not None for v in tr._tg.values()) >= 1
 
 
+def test_training_graph_reads_the_attack_programs_weight_copies_and_never_stale_ones(R):
+    """Round 6: the training-pass graph READS the derived weight copies (packed / bf16 weights) of the attack program that replays in
+    front of it instead of rebuilding them.  It must never read copies that were not rebuilt in this step: after the attack programs
+    are dropped (graphed.reset(): eager attacks, then a NEW program) the pass runs from a second, self-contained graph.  The whole
+    trajectory - shared graph, eager attacks, self-contained graph - equals the eager steps of the same seeds at the run-to-run level
+    (a pass on weights one optimizer step old would be percents off), and the switch ops.SHARE_DERIVED = False gives the same."""
+    lrs = [1e-3, 8e-4, 1.2e-3, 5e-4, 9e-4, 1e-3, 7e-4, 1.1e-3, 6e-4, 1e-3, 8e-4]
+
+    def run(graph, share=True):
+        R.graphed.reset()
+        prev = R.ops.kernel_set({"share_derived": share})
+        try:
+            torch.manual_seed(5)
+            A = R.architecture
+            m = A.ConvNeXt(depths=(1, 1, 1, 1), dims=(96, 192, 384, 768), num_classes=12)
+            m.stem = A.ConvBlock1(48)
+            tr = R.ATTrainStep(m, "convnext_tiny", R.AdvConfig(attack="apgd", n_iter=2, eps=EPS, graph=graph), "cuda", lr=1e-3,
+                               amp_dtype=torch.bfloat16, ema=True, ema_decay=0.9, graph_train=bool(graph))
+            g = torch.Generator(device="cuda").manual_seed(9)
+            losses, info = [], []
+            for i, lr in enumerate(lrs):
+                if graph and i == 6:
+                    R.graphed.reset()                              # the attack program is gone: eager attacks, then a new program
+                x = torch.rand(4, 3, 64, 64, device="cuda", generator=g)
+                y = torch.randint(0, 10, (4,), device="cuda", generator=g)
+                losses.append(float(tr.step(x, y, lr=lr)))
+                info.append(sorted((k[-1] is not None, v.shared_derived, len(v.derived)) for k, v in tr._tg.items() if v is not None))
+            return losses, [p.detach().clone() for p in tr.inner.parameters()], info
+        finally:
+            R.ops.kernel_set(prev)
+    l1, p1, info = run(1)
+    # steps 4 - 6: ONE graph, every derived copy it needs is the attack program's (nothing rebuilt inside the training capture)
+    assert len(info[5]) == 1 and info[5][0][0] and info[5][0][1] > 10 and info[5][0][2] == info[5][0][1], info[5]
+    # after the reset: a self-contained second graph (no shared entries) next to it; a third graph never appears
+    assert len(info[-1]) == 2 and info[-1][0][:2] == (False, 0) and info[-1][0][2] > 10 and info[-1][1] == info[5][0], info[-1]
+    l0, p0, _ = run(0)
+    l2, p2, info2 = run(1, share=False)
+    assert len(info2[-1]) == 1 and info2[-1][0][:2] == (False, 0)
+    for ls, ps in ((l1, p1), (l2, p2)):
+        assert max(abs(a - b) for a, b in zip(ls, l0)) <= 2e-3 * max(abs(v) for v in l0), (ls, l0)
+        num = sum(float((a.float() - b.float()).pow(2).sum()) for a, b in zip(ps, p0))
+        den = sum(float(b.float().pow(2).sum()) for b in p0)
+        assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+
+
 def test_sign_sink_steps_aside_when_the_iterate_has_a_second_consumer(R):
     """Round-2 advice: the int8 gradient-sign sink assumed the stem convolution is the ONLY consumer of the attack iterate.  A
     model with an input skip gets the fp32 gradient instead (detected on the first backward, which is repeated), and its attack

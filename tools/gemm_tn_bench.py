@@ -21,11 +21,14 @@ def t(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+PAIR_ONLY = "--pair-only" in sys.argv
+if PAIR_ONLY:
+    sys.argv.remove("--pair-only")
 shapes = [(802816, 384, 96), (802816, 96, 384), (200704, 768, 192), (200704, 192, 768), (50176, 1536, 384), (50176, 384, 1536),
           (12544, 3072, 768), (12544, 768, 3072), (50432, 2304, 768), (50432, 768, 768), (50432, 3072, 768), (50432, 768, 3072)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
-for M, N1, N2 in shapes:
+for M, N1, N2 in ([] if PAIR_ONLY else shapes):
     A = torch.randn(M, N1, device="cuda").to(torch.bfloat16)
     B = torch.randn(M, N2, device="cuda").to(torch.bfloat16)
     D = torch.empty(N1, N2, device="cuda")
@@ -41,7 +44,7 @@ for M, N1, N2 in shapes:
 # the tile-layout forms of the training pass (cnx_gemm_tn_ex: one operand in CNX_TN_ACC tiles, column sums of A): dW2 = dO^T H and
 # dW1 = dHpre^T LN(u) at the three fused stages
 print("cnx_gemm_tn_ex, one operand in accumulator-order tiles (timing only: the tile operand is random bits of small bf16 values)")
-for M, C in ((802816, 96), (200704, 192), (50176, 384)):
+for M, C in (() if PAIR_ONLY else ((802816, 96), (200704, 192), (50176, 384))):
     rows = torch.randn(M, C, device="cuda").to(torch.bfloat16)
     tiles = (torch.randn(M * 4 * C, device="cuda") * 0.1).to(torch.bfloat16)
     for name, a, lda, la, b, ldb, lb, N1, N2 in (("dW2 = dO^T H  ", rows, C, 0, tiles, 0, 1, C, 4 * C), ("dW1 = dHpre^T a", tiles, 0, 1, rows, C, 0, 4 * C, C)):
