@@ -349,6 +349,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
   return launch_status();
 }
 
+int g_tile_force = 0;
+
 template <int BM, int BN, int WM>
 int dispatch(const GemmArgs& a, int epi, int d_dtype, int r_dtype, hipStream_t s) {
   switch (epi) {
@@ -365,6 +367,12 @@ int dispatch(const GemmArgs& a, int epi, int d_dtype, int r_dtype, hipStream_t s
 }
 
 }  // namespace
+
+int gemm_nt_tile_switch(int value) {
+  const int prev = g_tile_force;
+  if (value >= 0) g_tile_force = value & 3;
+  return prev;
+}
 
 extern "C" {
 
@@ -394,8 +402,10 @@ int cnx_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* D,
   a.M = M; a.N = N; a.K = K;
   // tile: 256 x 256 (128 FLOP per staged byte) where N is a multiple of 256 and the grid still has >= ~2 rounds of workgroups;
   // else 256 x 192 (every N of the models is a multiple of 192) when that gives >= ~3 rounds; else 128 x 192
-  constexpr int bm_env = 0;      // tuning experiments only
-  constexpr int bn_env = 0;
+  // (cnx_runtime_switch(CNX_SWITCH_GEMM_NT_TILE): 0 = this rule; 1 / 2 / 3 force 128 x 192 / 256 x 192 / 256 x 256 where N allows - A/B runs)
+  const int force = g_tile_force;
+  const int bm_env = force == 1 ? 128 : force >= 2 ? 256 : 0;
+  const int bn_env = force == 3 && N % 256 == 0 ? 256 : force ? 192 : 0;
   constexpr int pw_env = 0;
   const long rows256 = (M + 255) / 256;
   int bn = (N % 256 == 0 && rows256 * (N / 256) >= 512) ? 256 : 192;
