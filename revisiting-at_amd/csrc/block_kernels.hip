@@ -1037,6 +1037,7 @@ int cnx_runtime_switch(int32_t which, int32_t value) {
     case CNX_SWITCH_DW_SHARED_HALO: return dw_shared_halo_switch(value);
     case CNX_SWITCH_BLK2_BWD_WIDTHS: return blk2b_widths_switch(value);
     case CNX_SWITCH_GEMM_NT_TILE: return gemm_nt_tile_switch(value);
+    case CNX_SWITCH_TN_PAIR_RING: return tn_pair_ring_switch(value);
     case CNX_SWITCH_FWD_WAVES8: {
       if (!BLK_FWD_W8_BUILD) return -1;
       int& m = fwd_w8_widths();

@@ -37,4 +37,5 @@ struct BlkFwdArgs {
 
 // widths served by the wavefront-pair Hpre backward (block_bwd_kernels.hip): -> the previous mask, a negative value only queries
 int blk2b_widths_switch(int value);
+int tn_pair_ring_switch(int value);   // wgrad_kernels.hip: CNX_SWITCH_TN_PAIR_RING
 int gemm_nt_tile_switch(int value);   // gemm_kernels.hip: CNX_SWITCH_GEMM_NT_TILE

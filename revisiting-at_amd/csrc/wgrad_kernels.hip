@@ -387,17 +387,37 @@ __device__ __forceinline__ uint32_t tn_lane_off(int lane) {            // the la
 // - dW2 is computed TRANSPOSED so that both problems have the tile operand on the A side and one kernel body serves both (the fixed-
 // order sum writes it back as [N2][N1]).  A split's workgroups are the tiles of BOTH problems: half as many splits as two launches
 // need to fill the chip, i.e. half the partial results to write and to sum (75 -> 37 MB per contraction at C = 384).
-template <int F, int WI, int WJ, int LA, int LB, bool CS, bool PAIR = false>
+// KT / NBUF: rows per stage and stages in LDS.  64 / 2 (the single contractions): stage t + 1 in flight while stage t is multiplied.
+// 32 / 4 (the pair at its 384 x 192 tile, 36 KiB per stage): THREE stages in flight - the stage period of the two-buffer loop
+// (2.5 us per 64 rows at C = 384) was the round trip of one stage's DMA, not its MFMA time (1.1 us): s_waitcnt vmcnt(n) leaves the
+// younger stages' loads outstanding, one barrier per stage.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+template <int PER>
+__device__ __forceinline__ void wait_stages_ahead(int ahead) {        // until at most `ahead` stages of PER loads each are outstanding
+  static_assert(4 * PER < 64, "vmcnt is a 6-bit counter");
+  switch (ahead) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<PER>(); break;
+    case 2: wait_vmcnt<2 * PER>(); break;
+    case 3: wait_vmcnt<3 * PER>(); break;
+    default: wait_vmcnt<4 * PER>(); break;
+  }
+}
+
+template <int F, int WI, int WJ, int LA, int LB, bool CS, bool PAIR = false, int KT = 64, int NBUF = 2>
 __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_kernel(
     const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, float* __restrict__ ws, int M, int N1, int N2,
     int rows_per_split, int n_split, int dbg, const uint16_t* __restrict__ A2, const uint16_t* __restrict__ B2, long ldb2) {
   static_assert(!PAIR || (LA == 1 && LB == 0 && CS), "the pair: tile operand on the A side, row operand on the B side, column sums");
-  constexpr int NW = WI * WJ, BM = 32 * F * WI, BN = 32 * F * WJ, KT = 64;
-  constexpr int SUBA = BM / 32, SUBB = BN / 32;
-  constexpr uint32_t A_BYTES = SUBA * KT * 64, B_BYTES = SUBB * KT * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int NW = WI * WJ, BM = 32 * F * WI, BN = 32 * F * WJ;
+  constexpr int SUBA = BM / 32, SUBB = BN / 32, KS = KT / 16;         // KS: k-steps = 16-row DMA blocks per sub-image and stage
+  constexpr uint32_t SUB = KT * 64;                                    // bytes of a sub-image (32 columns x KT rows)
+  constexpr uint32_t A_BYTES = SUBA * SUB, B_BYTES = SUBB * SUB, STAGE = A_BYTES + B_BYTES;
   constexpr int NBLK = STAGE / 1024;
-  static_assert(NBLK % NW == 0, "DMA blocks per wavefront");
-  constexpr int NDMA = NBLK / NW;
+  static_assert(NBUF > 2 || NBLK % NW == 0, "DMA blocks per wavefront");
+  static_assert(KT == 32 || KT == 64, "stage rows");
+  constexpr int NDMA = (NBLK + NW - 1) / NW;                           // (ring: the last wavefronts may hold one block fewer)
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / WJ, wj = wave - wi * WJ;
@@ -432,23 +452,24 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
     const long m0 = m_begin + static_cast<long>(t) * KT;
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
-      if (part >= 0 && (k & 3) != part) continue;
+      if (part >= 0 && (k % KS) != part) continue;
       const int b = wave + NW * k;                                     // wave-uniform block: (operand, sub-image, 16-row block)
-      if (b < SUBA * 4) {
-        const int sub = b >> 2, rb = b & 3;
+      if (NBLK % NW != 0 && b >= NBLK) continue;
+      if (b < SUBA * KS) {
+        const int sub = b / KS, rb = b % KS;
         const long src = LA == kRows ? ((m0 + rb * 16) * lda + i0 + 32 * sub) * 2
                                      : (((m0 >> 5) + (rb >> 1)) * (N1 >> 5) + (i0 >> 5) + sub) * 2048 + (rb & 1) * 1024;
-        dma_lds16(sb + static_cast<uint32_t>(sub * 4096 + rb * 1024), va, rsa, static_cast<uint32_t>(src));
+        dma_lds16(sb + static_cast<uint32_t>(sub) * SUB + static_cast<uint32_t>(rb * 1024), va, rsa, static_cast<uint32_t>(src));
       } else {
-        const int bb = b - SUBA * 4, sub = bb >> 2, rb = bb & 3;
+        const int bb = b - SUBA * KS, sub = bb / KS, rb = bb % KS;
         const long src = LB == kRows ? ((m0 + rb * 16) * ldb + j0 + 32 * sub) * 2
                                      : (((m0 >> 5) + (rb >> 1)) * (N2 >> 5) + (j0 >> 5) + sub) * 2048 + (rb & 1) * 1024;
-        dma_lds16(sb + A_BYTES + static_cast<uint32_t>(sub * 4096 + rb * 1024), vb, rsb, static_cast<uint32_t>(src));
+        dma_lds16(sb + A_BYTES + static_cast<uint32_t>(sub) * SUB + static_cast<uint32_t>(rb * 1024), vb, rsb, static_cast<uint32_t>(src));
       }
     }
   };
-  const uint32_t a_lane = lds0 + tn_lane_off<LA>(lane) + static_cast<uint32_t>(wi * F) * 4096u;
-  const uint32_t b_lane = lds0 + A_BYTES + tn_lane_off<LB>(lane) + static_cast<uint32_t>(wj * F) * 4096u;
+  const uint32_t a_lane = lds0 + tn_lane_off<LA>(lane) + static_cast<uint32_t>(wi * F) * SUB;
+  const uint32_t b_lane = lds0 + A_BYTES + tn_lane_off<LB>(lane) + static_cast<uint32_t>(wj * F) * SUB;
 
   f32x16 acc[F][F];
 #pragma unroll
@@ -474,31 +495,27 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
     }
   }
 
-  if (n_stage > 0) dma_stage(0, 0, -1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int t = 0; t < n_stage; ++t) {
-    const int buf = t & 1;
-    const bool more = t + 1 < n_stage && !(dbg & 1);                   // (the other buffer's readers passed the barrier below)
+  // one stage's MFMAs from buffer `buf` (k-step ks + 1's fragments are read while the MFMAs of k-step ks run: two register sets);
+  // `next`: issued in front of k-step ks - the share `ks` of a later stage's DMA
+  auto multiply_stage = [&](int buf, auto&& next) {
     const uint32_t ab = a_lane + static_cast<uint32_t>(buf) * STAGE, bb = b_lane + static_cast<uint32_t>(buf) * STAGE;
-    // the fragments of k-step ks + 1 are read while the MFMAs of k-step ks run (two register sets)
     bf16x8 af[2][F], bfr[2][F];
     if (!(dbg & 2)) {
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        af[0][f] = tr_fragment(ab + static_cast<uint32_t>(f * 4096), 64u);
-        bfr[0][f] = tr_fragment(bb + static_cast<uint32_t>(f * 4096), 64u);
+        af[0][f] = tr_fragment(ab + static_cast<uint32_t>(f) * SUB, 64u);
+        bfr[0][f] = tr_fragment(bb + static_cast<uint32_t>(f) * SUB, 64u);
       }
     }
 #pragma unroll
-    for (int ks = 0; ks < KT / 16; ++ks) {
-      if (more) dma_stage(t + 1, buf ^ 1, ks);
+    for (int ks = 0; ks < KS; ++ks) {
+      next(ks);
       if (dbg & 2) continue;
-      if (ks + 1 < KT / 16) {
+      if (ks + 1 < KS) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-          af[(ks + 1) & 1][f] = tr_fragment(ab + static_cast<uint32_t>(f * 4096 + (ks + 1) * 1024), 64u);
-          bfr[(ks + 1) & 1][f] = tr_fragment(bb + static_cast<uint32_t>(f * 4096 + (ks + 1) * 1024), 64u);
+          af[(ks + 1) & 1][f] = tr_fragment(ab + static_cast<uint32_t>(f) * SUB + static_cast<uint32_t>((ks + 1) * 1024), 64u);
+          bfr[(ks + 1) & 1][f] = tr_fragment(bb + static_cast<uint32_t>(f) * SUB + static_cast<uint32_t>((ks + 1) * 1024), 64u);
         }
       }
 #pragma unroll
@@ -518,8 +535,35 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if constexpr (NBUF == 2) {
+    if (n_stage > 0) dma_stage(0, 0, -1);
+    wait_vmcnt<0>();
     __syncthreads();
+    for (int t = 0; t < n_stage; ++t) {
+      const int buf = t & 1;
+      const bool more = t + 1 < n_stage && !(dbg & 1);                 // (the other buffer's readers passed the barrier below)
+      multiply_stage(buf, [&](int ks) { if (more) dma_stage(t + 1, buf ^ 1, ks); });
+      wait_vmcnt<0>();
+      __syncthreads();
+    }
+  } else {
+    // ring of NBUF stages, D = NBUF - 1 of them in flight.  Iteration t: wait until stage t has landed (the D - 1 younger stages
+    // stay outstanding), barrier (everybody's share of stage t is in LDS; everybody has finished stage t - 1, whose buffer is the
+    // one of stage t + D), issue stage t + D over the k-steps of stage t.
+    constexpr int D = NBUF - 1;
+    const bool full = NBLK % NW == 0 || wave < NBLK % NW;              // this wavefront issues NDMA loads per stage (else NDMA - 1)
+    for (int sg = 0; sg < D && sg < n_stage; ++sg) dma_stage(sg, sg, -1);
+    int buf = 0;
+    for (int t = 0; t < n_stage; ++t) {
+      const int ahead = min(D - 1, n_stage - 1 - t);
+      if (full) wait_stages_ahead<NDMA>(ahead); else wait_stages_ahead<(NDMA > 1 ? NDMA - 1 : 1)>(ahead);
+      __syncthreads();
+      const bool more = t + D < n_stage && !(dbg & 1);
+      const int nbuf = buf == 0 ? NBUF - 1 : buf - 1;                  // (t + D) % NBUF
+      multiply_stage(buf, [&](int ks) { if (more) dma_stage(t + D, nbuf, ks); });
+      buf = buf + 1 == NBUF ? 0 : buf + 1;
+    }
   }
   // partial tile -> ws[split][N1][N2] (then [N1] column sums of A); the pair: [D0][N1 sums][T][N2 sums] per split
   const long len_d = static_cast<long>(N1) * N2;
@@ -662,19 +706,26 @@ int launch_gemm_tn(const uint16_t* A, long lda, const uint16_t* B, long ldb, flo
   return launch_status();
 }
 
-template <int F, int WI, int WJ>
+// cnx_runtime_switch(CNX_SWITCH_TN_PAIR_RING): 1 = the ring where it measured faster - the HBM-bound shapes, N2 = C <= 128 (C = 96:
+// 295 -> 278 us, C = 128: 109 -> 105 us; at C = 256 / 384, where half the staged bytes are L2 hits, the ring's barrier per 32 rows costs
+// more than its third stage in flight returns: 87 -> 96 us, 150 -> 175 us; C = 192: equal); 0 = never; 2 = always
+int g_pair_ring = 1;
+
+template <int F, int WI, int WJ, int KT, int NBUF>
 int launch_gemm_tn_pair(const uint16_t* A0, const uint16_t* B0, long ldb0, const uint16_t* A1, const uint16_t* B1, long ldb1, float* D0,
                         float* cs0, float* D1, float* cs1, float* ws, int M, int N1, int N2, int rows_per_split, int n_split, hipStream_t s) {
   constexpr int BM = 32 * F * WI, BN = 32 * F * WJ;
-  constexpr size_t lds_bytes = 2 * (BM / 32 + BN / 32) * 64 * 64;
+  constexpr size_t lds_bytes = static_cast<size_t>(NBUF) * (BM / 32 + BN / 32) * KT * 64;
+  static_assert(lds_bytes <= 160 * 1024, "LDS");
+  auto kfn = gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true, KT, NBUF>;
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true, KT, NBUF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr;
   const long grid = 2L * (N1 / BM) * (N2 / BN) * n_split;
-  hipLaunchKernelGGL((gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true>), dim3(static_cast<unsigned>(grid)), dim3(64 * WI * WJ), lds_bytes, s,
+  hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(grid)), dim3(64 * WI * WJ), lds_bytes, s,
                      A0, static_cast<long>(N1), B0, ldb0, ws, M, N1, N2, rows_per_split, n_split, 0, A1, B1, ldb1);
   int rc = launch_status();
   if (rc) return rc;
@@ -738,6 +789,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 }  // namespace
+
+int tn_pair_ring_switch(int value) {
+  const int prev = g_pair_ring;
+  if (value >= 0) g_pair_ring = value > 2 ? 1 : value;
+  return prev;
+}
 
 extern "C" {
 
@@ -901,9 +958,13 @@ int cnx_gemm_tn_pair(const void* A0, const void* B0, int64_t ldb0, const void* A
   const auto* a1 = static_cast<const uint16_t*>(A1);
   const auto* b1 = static_cast<const uint16_t*>(B1);
   const int m = static_cast<int>(M);
-#define TN_PAIR(FF, II, JJ) \
-  if (code == FF * 100 + II * 10 + JJ) return launch_gemm_tn_pair<FF, II, JJ>(a0, b0, ldb0, a1, b1, ldb1, D0, colsum_a0, D1, colsum_b1, ws, m, N1, N2, rows, ns, s);
-  TN_PAIR(3, 4, 2) TN_PAIR(2, 4, 2) TN_PAIR(3, 4, 1) TN_PAIR(2, 4, 1)
+  // (stage rows, stages in LDS) of the ring per tile: 36 / 24 / 30 / 20 KiB per 32-row stage -> 144 / 144 / 150 / 120 KiB
+#define TN_PAIR(FF, II, JJ, NB)                                                                                                       \
+  if (code == FF * 100 + II * 10 + JJ) {                                                                                              \
+    if (g_pair_ring == 2 || (g_pair_ring == 1 && N2 <= 128)) return launch_gemm_tn_pair<FF, II, JJ, 32, NB>(a0, b0, ldb0, a1, b1, ldb1, D0, colsum_a0, D1, colsum_b1, ws, m, N1, N2, rows, ns, s); \
+    return launch_gemm_tn_pair<FF, II, JJ, 64, 2>(a0, b0, ldb0, a1, b1, ldb1, D0, colsum_a0, D1, colsum_b1, ws, m, N1, N2, rows, ns, s);     \
+  }
+  TN_PAIR(3, 4, 2, 4) TN_PAIR(2, 4, 2, 6) TN_PAIR(3, 4, 1, 5) TN_PAIR(2, 4, 1, 6)
 #undef TN_PAIR
   return APGD_ERR_ARG;
 }

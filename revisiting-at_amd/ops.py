@@ -1919,7 +1919,8 @@ KERNEL_SETS = {
     # the tree as shipped
     "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
                     blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2, gemm_auto_max=0,
-                    tn_pair=True, share_derived=True, gemm_nt_tile=0),
+                    tn_pair=True, share_derived=True, gemm_nt_tile=0,
+                    tn_ring=1),
     # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_STEM_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
     # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
     # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
@@ -1935,6 +1936,8 @@ KERNEL_SETS = {
     "nt128": dict(gemm_nt_tile=1), "nt256x192": dict(gemm_nt_tile=2), "nt256": dict(gemm_nt_tile=3),
     # one launch per weight gradient (two cnx_gemm_tn_ex calls per block) instead of the paired launch
     "tn2": dict(tn_pair=False),
+    # the paired launch on the two-buffer loop of the single contractions instead of the ring of 32-row stages
+    "tn2buf": dict(tn_ring=0), "tnring": dict(tn_ring=2),
     # single-switch experiments of round 6 (profiles/r06_ab.md)
     "stemln": dict(stem_ln_fused=True), "streams3": dict(attack_streams=3), "streams1": dict(attack_streams=1),
     # the C = 768 blocks of the TRAINING pass on cnx_gemm_nt with its fused epilogues instead of library GEMMs + one-pass tails
@@ -1965,9 +1968,12 @@ def kernel_set(name_or_dict):
                 blk2=int(lib.cnx_runtime_switch(0, -1)), pool_rows=_POOL_ROWS, dw_shared_halo=int(lib.cnx_runtime_switch(1, -1)),
                 fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))), blk2b=int(lib.cnx_runtime_switch(3, -1)),
                 stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS, gemm_auto_max=_GEMM_AUTO_MAX, tn_pair=_TN_PAIR,
-                share_derived=SHARE_DERIVED, gemm_nt_tile=int(lib.cnx_runtime_switch(4, -1)))
+                share_derived=SHARE_DERIVED, gemm_nt_tile=int(lib.cnx_runtime_switch(4, -1)),
+                tn_ring=int(lib.cnx_runtime_switch(5, -1)))
     if "gemm_nt_tile" in new:
         lib.cnx_runtime_switch(4, int(new["gemm_nt_tile"]) & 3)
+    if "tn_ring" in new:
+        lib.cnx_runtime_switch(5, int(new["tn_ring"]) % 3)
     if "share_derived" in new:
         SHARE_DERIVED = bool(new["share_derived"])
     if "tn_pair" in new:

@@ -239,6 +239,14 @@ def test_gemm_tn_pair_vs_fp32_reference_and_the_two_single_launches(M, C):
                                     db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M, N1, N2, S) == 0
         return dw1, db1, dw2, db2
     dw1, db1, dw2, db2 = run()
+    # the same contraction on the other stage loop (ring of 32-row stages / two 64-row buffers): the same MFMA sequence per
+    # accumulator - bit for bit
+    was = lib.cnx_runtime_switch(5, 0 if N2 <= 128 else 2)
+    try:
+        for x, y in zip(run(), (dw1, db1, dw2, db2)):
+            assert torch.equal(x, y)
+    finally:
+        lib.cnx_runtime_switch(5, was)
     rel = lambda t, r: float((t - r).norm() / r.norm())
     assert rel(dw1, dhp.float().t() @ a.float()) < 2e-6 and rel(dw2, do.float().t() @ h.float()) < 2e-6
     assert rel(db1, dhp.float().sum(0)) < 2e-6 and rel(db2, do.float().sum(0)) < 2e-6
