@@ -48,9 +48,9 @@ int cnx_dwconv7x7_win_policy(int policy);
  *                              (APGD_BLK2B)
  *   CNX_SWITCH_GEMM_NT_TILE    workgroup tile of cnx_gemm_nt: 0 = by the grid-size rule (default); 1 / 2 / 3 force 128 x 192 / 256 x 192 / 256 x 256
  *                              (256 x 192 where N is no multiple of 256) - measurement runs
- *   CNX_SWITCH_TN_PAIR_RING    cnx_gemm_tn_pair on a ring of four or more 32-row stages (three or more in flight) instead of the two 64-row
- *                              buffers of the single contractions: 1 = where it measured faster (N2 <= 128: the HBM-bound shapes; default),
- *                              0 = never, 2 = always
+ *   CNX_SWITCH_TN_PAIR_RING    stage loop of cnx_gemm_tn_pair (bit-identical results): 1 = two 64-row buffers with the stage hand-over one k-step
+ *                              early (the next stage's first fragments are read under the last MFMAs; default), 0 = hand-over at the stage
+ *                              boundary (the loop of the single contractions), 2 = a ring of four or more 32-row stages (three or more in flight)
  *   CNX_SWITCH_FWD_WAVES8      widths whose single-wavefront-per-tile forward runs eight wavefronts (256 rows) per workgroup on one weight
  *                              stream instead of four: bit 0 = C 128, bit 1 = C 192 (APGD_FWD_W8).  A measured negative of round 6
  *                              (profiles/r06_fused_mlp.md): only in libraries built with -DBLK_FWD_W8_BUILD=1, otherwise -1 */

@@ -405,7 +405,10 @@ __device__ __forceinline__ void wait_stages_ahead(int ahead) {        // until a
   }
 }
 
-template <int F, int WI, int WJ, int LA, int LB, bool CS, bool PAIR = false, int KT = 64, int NBUF = 2>
+// PIPE (two buffers): the stage hand-over sits in front of the LAST k-step of a stage instead of behind it - the first fragments of
+// stage t + 1 are read while the last MFMAs of stage t run.  Behind a barrier at the stage boundary all eight wavefronts read their
+// first fragments at once (96 transpose reads = 48 KiB through the LDS pipe) with nothing on the matrix pipe: ~0.25 us per stage.
+template <int F, int WI, int WJ, int LA, int LB, bool CS, bool PAIR = false, int KT = 64, int NBUF = 2, bool PIPE = false>
 __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_kernel(
     const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, float* __restrict__ ws, int M, int N1, int N2,
     int rows_per_split, int n_split, int dbg, const uint16_t* __restrict__ A2, const uint16_t* __restrict__ B2, long ldb2) {
@@ -536,7 +539,59 @@ __global__ __launch_bounds__(64 * WI * WJ, WI * WJ == 8 ? 2 : 1) void gemm_tn_ke
       }
     }
   };
-  if constexpr (NBUF == 2) {
+  if constexpr (NBUF == 2 && PIPE) {
+    static_assert(KS % 2 == 0, "fragment register sets alternate across the stage boundary");
+    bf16x8 af[2][F], bfr[2][F];
+    auto read_frags = [&](int set, int buf, int ks) {
+      const uint32_t ab = a_lane + static_cast<uint32_t>(buf) * STAGE + static_cast<uint32_t>(ks * 1024);
+      const uint32_t bb = b_lane + static_cast<uint32_t>(buf) * STAGE + static_cast<uint32_t>(ks * 1024);
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        af[set][f] = tr_fragment(ab + static_cast<uint32_t>(f) * SUB, 64u);
+        bfr[set][f] = tr_fragment(bb + static_cast<uint32_t>(f) * SUB, 64u);
+      }
+    };
+    if (n_stage > 0) dma_stage(0, 0, -1);
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (n_stage > 1) dma_stage(1, 1, 0);
+    if (n_stage > 0) read_frags(0, 0, 0);
+    for (int t = 0; t < n_stage; ++t) {
+      const int buf = t & 1;
+      const bool more = t + 1 < n_stage;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+          if (more) dma_stage(t + 1, buf ^ 1, ks + 1);
+          read_frags((ks + 1) & 1, buf, ks + 1);
+        } else if (more) {
+          // stage t + 1 has landed (its last share was issued a k-step ago); this wavefront's reads of stage t are complete, so behind
+          // the barrier its buffer is free for stage t + 2
+          wait_vmcnt<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (t + 2 < n_stage) dma_stage(t + 2, buf, 0);
+          read_frags(0, buf ^ 1, 0);
+        }
+#pragma unroll
+        for (int fi = 0; fi < F; ++fi)
+#pragma unroll
+          for (int fj = 0; fj < F; ++fj)
+            acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][fi], bfr[ks & 1][fj], acc[fi][fj], 0, 0, 0);
+        if constexpr (CS) {
+          if (cs_wave) {
+            if (PAIR && prob) {
+#pragma unroll
+              for (int fj = 0; fj < F; ++fj) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones[fj], bfr[ks & 1][fj], accs, 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int fi = 0; fi < F; ++fi) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][fi], ones[fi], accs, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  } else if constexpr (NBUF == 2) {
     if (n_stage > 0) dma_stage(0, 0, -1);
     wait_vmcnt<0>();
     __syncthreads();
@@ -706,20 +761,24 @@ int launch_gemm_tn(const uint16_t* A, long lda, const uint16_t* B, long ldb, flo
   return launch_status();
 }
 
-// cnx_runtime_switch(CNX_SWITCH_TN_PAIR_RING): 1 = the ring where it measured faster - the HBM-bound shapes, N2 = C <= 128 (C = 96:
-// 295 -> 278 us, C = 128: 109 -> 105 us; at C = 256 / 384, where half the staged bytes are L2 hits, the ring's barrier per 32 rows costs
-// more than its third stage in flight returns: 87 -> 96 us, 150 -> 175 us; C = 192: equal); 0 = never; 2 = always
+// cnx_runtime_switch(CNX_SWITCH_TN_PAIR_RING) - the stage loop of the pair (all bit-identical; tools/gemm_tn_bench.py, us per block at batch 256):
+//   0 = two 64-row buffers, hand-over at the stage boundary      C = 96: 283   128: 106   192: 175   256: 88   384: 148
+//   2 = ring of 32-row stages, three or more in flight                   275        103        179        96        173
+//   1, 3 = two buffers, hand-over one k-step early (default)             269        105        173        83        148
+// Deeper prefetch and the hidden first-fragment reads return 5 % on the HBM-bound shapes and nothing at C = 384: there the kernel sits
+// at what a CU ingests (28.9 GB/s per CU = 7.4 TB/s over the chip, 52 % of it L2 hits), as every GEMM-shaped kernel of this library and
+// hipBLASLt's own (MT256x256x64: 990 TFLOP/s at 128 FLOP per staged byte = 7.7 TB/s) - FLOP per staged byte is the only lever left.
 int g_pair_ring = 1;
 
-template <int F, int WI, int WJ, int KT, int NBUF>
+template <int F, int WI, int WJ, int KT, int NBUF, bool PIPE = false>
 int launch_gemm_tn_pair(const uint16_t* A0, const uint16_t* B0, long ldb0, const uint16_t* A1, const uint16_t* B1, long ldb1, float* D0,
                         float* cs0, float* D1, float* cs1, float* ws, int M, int N1, int N2, int rows_per_split, int n_split, hipStream_t s) {
   constexpr int BM = 32 * F * WI, BN = 32 * F * WJ;
   constexpr size_t lds_bytes = static_cast<size_t>(NBUF) * (BM / 32 + BN / 32) * KT * 64;
   static_assert(lds_bytes <= 160 * 1024, "LDS");
-  auto kfn = gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true, KT, NBUF>;
+  auto kfn = gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true, KT, NBUF, PIPE>;
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true, KT, NBUF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<F, WI, WJ, kAcc, kRows, true, true, KT, NBUF, PIPE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
@@ -792,7 +851,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 int tn_pair_ring_switch(int value) {
   const int prev = g_pair_ring;
-  if (value >= 0) g_pair_ring = value > 2 ? 1 : value;
+  if (value >= 0) g_pair_ring = value > 3 ? 1 : value;
   return prev;
 }
 
@@ -961,7 +1020,8 @@ int cnx_gemm_tn_pair(const void* A0, const void* B0, int64_t ldb0, const void* A
   // (stage rows, stages in LDS) of the ring per tile: 36 / 24 / 30 / 20 KiB per 32-row stage -> 144 / 144 / 150 / 120 KiB
 #define TN_PAIR(FF, II, JJ, NB)                                                                                                       \
   if (code == FF * 100 + II * 10 + JJ) {                                                                                              \
-    if (g_pair_ring == 2 || (g_pair_ring == 1 && N2 <= 128)) return launch_gemm_tn_pair<FF, II, JJ, 32, NB>(a0, b0, ldb0, a1, b1, ldb1, D0, colsum_a0, D1, colsum_b1, ws, m, N1, N2, rows, ns, s); \
+    if (g_pair_ring == 2) return launch_gemm_tn_pair<FF, II, JJ, 32, NB>(a0, b0, ldb0, a1, b1, ldb1, D0, colsum_a0, D1, colsum_b1, ws, m, N1, N2, rows, ns, s); \
+    if (g_pair_ring & 1) return launch_gemm_tn_pair<FF, II, JJ, 64, 2, true>(a0, b0, ldb0, a1, b1, ldb1, D0, colsum_a0, D1, colsum_b1, ws, m, N1, N2, rows, ns, s); \
     return launch_gemm_tn_pair<FF, II, JJ, 64, 2>(a0, b0, ldb0, a1, b1, ldb1, D0, colsum_a0, D1, colsum_b1, ws, m, N1, N2, rows, ns, s);     \
   }
   TN_PAIR(3, 4, 2, 4) TN_PAIR(2, 4, 2, 6) TN_PAIR(3, 4, 1, 5) TN_PAIR(2, 4, 1, 6)

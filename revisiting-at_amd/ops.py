@@ -14,6 +14,7 @@ The residual stream stays fp32 exactly as in the reference's autocast run (``gam
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import weakref
@@ -171,7 +172,51 @@ def _stem_dgrad(lib, x, gr, wq, N, H, W, P):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _SIDE.handle if _SIDE is not None else torch.cuda.current_stream().cuda_stream
+
+
+# The weight-gradient work of a block's backward - the paired contraction, its fixed-order sum, the per-channel identities: matrix-pipe /
+# ingest bound, nothing downstream waits for it - runs on a SIDE stream under the depthwise stencil's input- and filter-gradient kernels
+# of the same backward call (HBM / VALU bound), joined before the call returns (round 6).  Every tensor stays a tensor of the CURRENT
+# stream for the allocator: only the launches of our own entry points move (``_stream()``), no torch kernel may run inside the context,
+# and temporaries made inside are kept alive until the join (``_keep``) - freed earlier, the current stream could be handed their memory
+# while the side stream still uses it.
+_SIDE = None
+_WGRAD_SIDE = os.environ.get("APGD_WGRAD_SIDE", "1") != "0"
+_side_streams = {}
+
+
+class _SideLaunch:
+    def __init__(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = _side_streams.get(idx)
+        if st is None:
+            st = _side_streams[idx] = torch.cuda.Stream(device=idx)
+        self.stream, self.handle, self.kept = st, st.cuda_stream, []
+
+    def __enter__(self):
+        global _SIDE
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        _SIDE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _SIDE
+        _SIDE = None
+        return False
+
+    def join(self):
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        torch.cuda.current_stream().wait_event(ev)
+        self.kept.clear()
+
+
+def _keep(*tensors):
+    if _SIDE is not None:
+        _SIDE.kept.extend(t for t in tensors if t is not None)
 
 
 def _act_dtype(x):
@@ -1166,6 +1211,7 @@ def _block_dln(lib, w1, dw1, db1, lw, lb, da, dhp_tiles, u, mean, rstd, M, C):
     dlb = torch.empty(C, device=u.device, dtype=torch.float32)
     # (workspace of the direct sums that ill-conditioned channels - |ln_b| > 4 |ln_w| - take instead of the identity)
     ws = torch.empty(lib.cnx_block_dln_ws_floats(C), device=u.device, dtype=torch.float32)
+    _keep(ws)
     _lib.check(lib.cnx_block_dln(w1.data_ptr(), dw1.data_ptr(), db1.data_ptr(), lw.data_ptr(), lb.data_ptr(), _lib.ptr(da),
                                  dhp_tiles.data_ptr() if da is None else None, u.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                  dlw.data_ptr(), dlb.data_ptr(), ws.data_ptr(), M, C, 4 * C, _stream()), "cnx_block_dln")
@@ -1193,6 +1239,7 @@ def _block_dgamma(lib, g2, y2, h_tiles, gf, w2, b2f, dw2, db2, M, C):
         raise _lib.ApgdHipError("d(gamma) by the one-pass sums needs the forward's pre-gamma output")
     db2_ = torch.empty(C, device=g2.device, dtype=torch.float32)
     ws = torch.empty(lib.cnx_colsum_ws_floats(C), device=g2.device, dtype=torch.float32)
+    _keep(ws, db2_)
     _lib.check(lib.cnx_scale_residual_bwd(g2.data_ptr(), _code(g2), y2.reshape(M, C).data_ptr(), gf.data_ptr(), None,
                                           dgamma.data_ptr(), db2_.data_ptr(), ws.data_ptr(), M, C, _stream()), "cnx_scale_residual_bwd")
     return dgamma
@@ -1205,6 +1252,7 @@ def _wgrad_acc(a_t, a_acc, b_t, b_acc, M, N1, N2):
     d = torch.empty(N1, N2, device=a_t.device, dtype=torch.float32)
     cs = torch.empty(N1, device=a_t.device, dtype=torch.float32)
     ws = torch.empty(lib.cnx_gemm_tn_ws_floats(M, N1, N2), device=a_t.device, dtype=torch.float32)
+    _keep(ws)
     _lib.check(lib.cnx_gemm_tn_ex(a_t.data_ptr(), N1, 1 if a_acc else 0, b_t.data_ptr(), N2, 1 if b_acc else 0, d.data_ptr(),
                                   cs.data_ptr(), ws.data_ptr(), M, N1, N2, _stream()), "cnx_gemm_tn_ex")
     return d, cs
@@ -1224,6 +1272,7 @@ def _wgrad_block(dhp, a_rows, h, dos, M, C):
         dw2 = torch.empty(C, 4 * C, device=dev, dtype=torch.float32)
         db = torch.empty(5 * C, device=dev, dtype=torch.float32)
         ws = torch.empty(lib.cnx_gemm_tn_pair_ws_floats(M, 4 * C, C), device=dev, dtype=torch.float32)
+        _keep(ws)
         _lib.check(lib.cnx_gemm_tn_pair(dhp.data_ptr(), a_rows.data_ptr(), C, h.data_ptr(), dos.data_ptr(), C, dw1.data_ptr(), db.data_ptr(),
                                         dw2.data_ptr(), db[4 * C:].data_ptr(), ws.data_ptr(), M, 4 * C, C, _stream()), "cnx_gemm_tn_pair")
         return dw1, db[:4 * C], dw2, db[4 * C:]
@@ -1605,6 +1654,7 @@ class _BlockFused(torch.autograd.Function):
         g = g.contiguous()
         g2 = g.reshape(M, C)
         dw1 = db1 = dw2 = db2 = dgamma = None
+        side = None                                                              # _SideLaunch of the weight-gradient work, joined at the end
         dln_id = False                                                           # d(ln_w), d(ln_b) from dW1 / d(b1) (cnx_block_dln)
         dlw_id = dlb_id = None                                                   # ... already computed (LayerNorm backward inside the block kernel)
         da = torch.empty(M, C, device=x.device, dtype=torch.bfloat16)            # gradient w.r.t. LN(u)
@@ -1641,12 +1691,18 @@ class _BlockFused(torch.autograd.Function):
                                                             da.data_ptr(), dos.data_ptr(), dhp.data_ptr(), M, C, _stream()),
                            "cnx_block_mlp_bwd_train_hpre")
             if want_p:
-                dw1, db1, dw2, db2 = _wgrad_block(dhp, a_s, h, dos, M, C)
-                dln_id = _DLN_FROM_DW1
-                if ln_in:
-                    dlw_id, dlb_id = _block_dln(lib, w1p, dw1, db1, lw, lb, None, dhp, u, mean, rstd, M, C)
-                if gf is not None:
-                    dgamma = _block_dgamma(lib, g2, y2, h, gf, ctx.w2, b2f, dw2, db2, M, C)
+                # (with the LayerNorm backward in the kernel above nothing below needs these results: they run on the side stream,
+                #  under the depthwise gradients, and are joined in front of the return)
+                side = _SideLaunch(x.device) if (_WGRAD_SIDE and ln_in) else None
+                with side if side is not None else contextlib.nullcontext():
+                    dw1, db1, dw2, db2 = _wgrad_block(dhp, a_s, h, dos, M, C)
+                    dln_id = _DLN_FROM_DW1
+                    if ln_in:
+                        dlw_id, dlb_id = _block_dln(lib, w1p, dw1, db1, lw, lb, None, dhp, u, mean, rstd, M, C)
+                    if gf is not None:
+                        dgamma = _block_dgamma(lib, g2, y2, h, gf, ctx.w2, b2f, dw2, db2, M, C)
+                if side is not None:
+                    side.kept.extend((dos, dhp))
             del dos, dhp
         elif ctx.fused and not want_p:
             # ---- attack backward: ONE kernel down to the depthwise-conv output (LayerNorm backward in its epilogue)
@@ -1679,12 +1735,16 @@ class _BlockFused(torch.autograd.Function):
                               g2.data_ptr(), _code(g2), _lib.ptr(gf), w1b.data_ptr(), b1f.data_ptr(),
                               da.data_ptr(), a.data_ptr(), dos.data_ptr(), ht.data_ptr(), dhpt.data_ptr(),
                               M, C, _stream()), "cnx_block_mlp_bwd_acc_ln" if ln_in else "cnx_block_mlp_bwd_acc")
-                dw1, db1, dw2, db2 = _wgrad_block(dhpt, a, ht, dos, M, C)
-                dln_id = _DLN_FROM_DW1
-                if ln_in:
-                    dlw_id, dlb_id = _block_dln(lib, w1p, dw1, db1, lw, lb, None, dhpt, u, mean, rstd, M, C)
-                if gf is not None:
-                    dgamma = _block_dgamma(lib, g2, y2, ht, gf, ctx.w2, b2f, dw2, db2, M, C)
+                side = _SideLaunch(x.device) if (_WGRAD_SIDE and ln_in) else None
+                with side if side is not None else contextlib.nullcontext():
+                    dw1, db1, dw2, db2 = _wgrad_block(dhpt, a, ht, dos, M, C)
+                    dln_id = _DLN_FROM_DW1
+                    if ln_in:
+                        dlw_id, dlb_id = _block_dln(lib, w1p, dw1, db1, lw, lb, None, dhpt, u, mean, rstd, M, C)
+                    if gf is not None:
+                        dgamma = _block_dgamma(lib, g2, y2, ht, gf, ctx.w2, b2f, dw2, db2, M, C)
+                if side is not None:
+                    side.kept.extend((a, dos, ht, dhpt))
                 del a, dos, ht, dhpt
                 want_emit = False
             else:
@@ -1781,6 +1841,8 @@ class _BlockFused(torch.autograd.Function):
             dww = g49.t().reshape(C, 1, 7, 7)
             if not ctx.has_dw_bias:
                 dwb = None
+        if side is not None:
+            side.join()
         return dx, dww, dwb, dlw, dlb, None, dw1, db1, dw2, db2, dgamma, None
 
 
@@ -1920,23 +1982,25 @@ KERNEL_SETS = {
     "default": dict(wgrad="hip", stem_wgrad=True, train_hpre={128, 192, 256, 384}, dgamma=True, dln="dw1", fused_tracking=True,
                     blk2=3, pool_rows=True, dw_shared_halo=1, fwd_w8=0, blk2b=3, stem_ln_fused=False, attack_streams=2, gemm_auto_max=0,
                     tn_pair=True, share_derived=True, gemm_nt_tile=0,
-                    tn_ring=1),
+                    tn_ring=1, wgrad_side=True),
     # the kernel set of the END OF ROUND 4 inside today's library (= APGD_WGRAD=lib APGD_STEM_WGRAD=lib APGD_TRAIN_HPRE="" APGD_DGAMMA=pass
     # APGD_DLN=pass APGD_FUSED_TRACKING=0 APGD_BLK2="" APGD_POOL_ROWS=0 APGD_DW_SH=0): library weight gradients, recomputing training
     # backward, the per-channel gradient passes, separate tracking pass, single-wavefront forward, round-4 depthwise strips
     # (library convolutions are never asked for a bias gradient any more - ops.conv_bias_grad: under hipGraph replay MIOpen's came back
     #  non-finite, which is how this set's first run found the hazard, gpurun_out/r6b - so the set runs the library stem gradients again)
     "round4": dict(wgrad="lib", stem_wgrad=False, train_hpre=set(), dgamma=False, dln="pass", fused_tracking=False, blk2=0,
-                   pool_rows=False, dw_shared_halo=0, blk2b=0, tn_pair=False, share_derived=False),
+                   pool_rows=False, dw_shared_halo=0, blk2b=0, tn_pair=False, share_derived=False, wgrad_side=False),
     # the end-of-round-5 selection: today's tree without round 6's wavefront-pair Hpre backward and paired weight-gradient launch
-    "round5": dict(blk2b=0, tn_pair=False, share_derived=False),
+    "round5": dict(blk2b=0, tn_pair=False, share_derived=False, wgrad_side=False),
+    # the weight-gradient work of a block's backward on the stream of the backward chain instead of a side stream
+    "wgrad_main": dict(wgrad_side=False),
     # every graph rebuilds its own derived weight copies (packed / bf16 weights twice per step)
     "own_copies": dict(share_derived=False),
     # cnx_gemm_nt workgroup tile forced (0 = by the grid-size rule)
     "nt128": dict(gemm_nt_tile=1), "nt256x192": dict(gemm_nt_tile=2), "nt256": dict(gemm_nt_tile=3),
     # one launch per weight gradient (two cnx_gemm_tn_ex calls per block) instead of the paired launch
     "tn2": dict(tn_pair=False),
-    # the paired launch on the two-buffer loop of the single contractions instead of the ring of 32-row stages
+    # the paired launch on the stage loop of the single contractions / on a ring of 32-row stages instead of the early hand-over
     "tn2buf": dict(tn_ring=0), "tnring": dict(tn_ring=2),
     # single-switch experiments of round 6 (profiles/r06_ab.md)
     "stemln": dict(stem_ln_fused=True), "streams3": dict(attack_streams=3), "streams1": dict(attack_streams=1),
@@ -1955,7 +2019,7 @@ def kernel_set(name_or_dict):
     drops what was captured or cached under the old set (``graphed.reset()``, a fresh ``ATTrainStep``); results stay inside the parity
     bars either way - the sets differ in kernels and summation order, not in arithmetic."""
     global _WGRAD_MODE, STEM_WGRAD_HIP, _TRAIN_HPRE_WIDTHS, _DGAMMA_FROM_DW2, _DLN_FROM_DW1, _LN_IN_TRAIN_BWD, _POOL_ROWS, _STEM_LN_FUSED, _GEMM_AUTO_MAX
-    global _TN_PAIR, SHARE_DERIVED
+    global _TN_PAIR, SHARE_DERIVED, _WGRAD_SIDE
     from . import apgd as _apgd
     from . import graphed as _graphed
     new = KERNEL_SETS[name_or_dict] if isinstance(name_or_dict, str) else dict(name_or_dict)
@@ -1969,11 +2033,13 @@ def kernel_set(name_or_dict):
                 fwd_w8=max(0, int(lib.cnx_runtime_switch(2, -1))), blk2b=int(lib.cnx_runtime_switch(3, -1)),
                 stem_ln_fused=_STEM_LN_FUSED, attack_streams=_graphed.STREAMS, gemm_auto_max=_GEMM_AUTO_MAX, tn_pair=_TN_PAIR,
                 share_derived=SHARE_DERIVED, gemm_nt_tile=int(lib.cnx_runtime_switch(4, -1)),
-                tn_ring=int(lib.cnx_runtime_switch(5, -1)))
+                tn_ring=int(lib.cnx_runtime_switch(5, -1)), wgrad_side=_WGRAD_SIDE)
+    if "wgrad_side" in new:
+        _WGRAD_SIDE = bool(new["wgrad_side"])
     if "gemm_nt_tile" in new:
         lib.cnx_runtime_switch(4, int(new["gemm_nt_tile"]) & 3)
     if "tn_ring" in new:
-        lib.cnx_runtime_switch(5, int(new["tn_ring"]) % 3)
+        lib.cnx_runtime_switch(5, int(new["tn_ring"]) & 3)
     if "share_derived" in new:
         SHARE_DERIVED = bool(new["share_derived"])
     if "tn_pair" in new:

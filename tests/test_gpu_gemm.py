@@ -241,10 +241,12 @@ def test_gemm_tn_pair_vs_fp32_reference_and_the_two_single_launches(M, C):
     dw1, db1, dw2, db2 = run()
     # the same contraction on the other stage loop (ring of 32-row stages / two 64-row buffers): the same MFMA sequence per
     # accumulator - bit for bit
-    was = lib.cnx_runtime_switch(5, 0 if N2 <= 128 else 2)
+    was = lib.cnx_runtime_switch(5, -1)
     try:
-        for x, y in zip(run(), (dw1, db1, dw2, db2)):
-            assert torch.equal(x, y)
+        for mode in (0, 2, 3):
+            lib.cnx_runtime_switch(5, mode)
+            for x, y in zip(run(), (dw1, db1, dw2, db2)):
+                assert torch.equal(x, y), mode
     finally:
         lib.cnx_runtime_switch(5, was)
     rel = lambda t, r: float((t - r).norm() / r.norm())

@@ -90,12 +90,14 @@ for M, C in ((802816, 96), (200704, 192), (50176, 384), (200704, 128), (50176, 2
     err = max(float((dw1 - r[0]).norm() / r[0].norm()), float((dw2 - r[1]).norm() / r[1].norm()))
     res = []
     for _ in range(3):
-        lib.cnx_runtime_switch(5, 0)
-        t_2buf = med(pair)
-        lib.cnx_runtime_switch(5, 2)
-        res.append((med(two), t_2buf, med(pair)))
-    t2, tb, tp = (sorted(v[i] for v in res)[1] for i in range(3))
-    gf = 4.0 * M * N1 * N2 / 1e9
+        row = [med(two)]
+        for mode in (0, 2, 3):
+            lib.cnx_runtime_switch(5, mode)
+            row.append(med(pair))
+        res.append(row)
     lib.cnx_runtime_switch(5, 1)
-    print(f"M={M:7d} C={C:4d}: two launches {t2:7.1f} us ({gf / t2 * 1e3:5.0f} TF/s; partials {ws1.numel() * 4 / 1e6 * 2:6.1f} MB) | pair, two buffers {tb:7.1f} us | "
-          f"pair, ring {tp:7.1f} us ({gf / tp * 1e3:5.0f} TF/s; partials {wsp.numel() * 4 / 1e6:6.1f} MB) | {t2 / tp:5.3f} x | rel diff {err:.1e}", flush=True)
+    t2, tb, tr_, tpp = (sorted(v[i] for v in res)[1] for i in range(4))
+    gf = 4.0 * M * N1 * N2 / 1e9
+    print(f"M={M:7d} C={C:4d}: two launches {t2:7.1f} us ({gf / t2 * 1e3:5.0f} TF/s; partials {ws1.numel() * 4 / 1e6 * 2:6.1f} MB) | pair: two buffers {tb:7.1f} us "
+          f"({gf / tb * 1e3:5.0f} TF/s) | ring {tr_:7.1f} us | two buffers, hand-over one k-step early {tpp:7.1f} us ({gf / tpp * 1e3:5.0f} TF/s) | "
+          f"partials {wsp.numel() * 4 / 1e6:6.1f} MB | rel diff {err:.1e}", flush=True)
