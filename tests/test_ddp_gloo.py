@@ -363,3 +363,72 @@ def test_eval_counts_are_summed_over_ranks():
     for r in range(2):
         ca, ra = res[r]
         assert abs(ca - 17 / 21) < 1e-12 and abs(ra - 8 / 21) < 1e-12
+
+
+def test_training_graph_is_keyed_on_the_attack_program_whose_weight_copies_it_reads():
+    """Round 6: a training-pass graph that reads the derived weight copies of attack program P may only replay behind a replay of P.
+    ATTrainStep._graph_step on CPU with stand-ins for the attack (which "replays" a chosen program or runs "eagerly") and for the
+    graph class: the first program a batch shape is captured behind is the one it shares with; behind another program or an eager
+    attack a second, self-contained graph runs (attack_prog=None); with ops.SHARE_DERIVED off nothing is ever shared."""
+    from revisiting_at_amd import graphed, ops
+
+    class Prog:                                             # stands for graphed._Program
+        def __init__(self):
+            self.derived = {}
+
+    made = []
+
+    class Pass(_RecordedPass):
+        def __init__(self, step, x, target, x_is_static=False, attack_prog=None):
+            super().__init__(step, x, target, x_is_static)
+            self.attack_prog, self.x_is_static = attack_prog, x_is_static
+            made.append(self)
+
+    state = {"prog": None}
+
+    def attack(model, x, y):                                # what graphed.run does around a replay / an eager call
+        out = _sign_attack(model, x, y)
+        if state["prog"] is not None:
+            graphed.STATS["replays"] += 1
+            graphed.LAST = state["prog"]
+        return out
+
+    def trainer():
+        tr = R.ATTrainStep(_model("seq"), "toy", R.AdvConfig(), "cpu", lr=1e-2, channels_last=False, amp_dtype=None, ema=False, perturb=attack)
+        tr._graph_cls, tr.graph_train = Pass, True
+        return tr
+    x, y = _data(8)
+    _RecordedPass.fail = False
+    P, Q = Prog(), Prog()
+    tr = trainer()
+    for _ in range(R.train_step.TRAIN_GRAPH_WARMUP):         # eager warm-up steps: nothing captured
+        tr.step(x, y)
+    assert not made
+    seq = [P, P, None, Q, P, None, Q]
+    for prog in seq:
+        state["prog"] = prog
+        tr.step(x, y)
+    # one graph shared with P (captured behind its first replay, static input), one self-contained graph for everything else
+    assert [(m.attack_prog is P, m.x_is_static) for m in made] == [(True, True), (False, False)], [(m.attack_prog, m.x_is_static) for m in made]
+    assert made[1].attack_prog is None
+    assert (made[0].replays, made[1].replays) == (3, 4)
+    # captured behind an EAGER attack first: the self-contained graph; the first program that replays later gets the shared one
+    made.clear()
+    tr = trainer()
+    for prog in [None] * R.train_step.TRAIN_GRAPH_WARMUP + [None, Q, Q, P]:
+        state["prog"] = prog
+        tr.step(x, y)
+    assert [m.attack_prog for m in made] == [None, Q] and (made[0].replays, made[1].replays) == (2, 2)
+    # switched off: one self-contained graph whatever attack ran
+    made.clear()
+    prev = ops.SHARE_DERIVED
+    ops.SHARE_DERIVED = False
+    try:
+        tr = trainer()
+        for prog in [None] * R.train_step.TRAIN_GRAPH_WARMUP + [P, Q, None]:
+            state["prog"] = prog
+            tr.step(x, y)
+    finally:
+        ops.SHARE_DERIVED = prev
+    assert [m.attack_prog for m in made] == [None] and made[0].replays == 3
+    graphed.LAST = None
