@@ -18,6 +18,11 @@
 //                               iterate): D[(ci,kh,kw) | 1][p] = sum_pos patch[pos][.] dy[pos][p]; the patch values are gathered
 //                               straight from the image (rounded to bf16 as the autocast convolution does), dy rows through LDS
 //   wgrad_reduce_kernel         fixed-order sum of the workgroups' partial results (deterministic)
+//   conv2_wgrad_kernel<CI,CO>   filter / bias gradient of the second ConvStem convolution (3x3, stride 2) as an implicit GEMM over the positions
+//   gemm_tn_kernel<...>         cnx_gemm_tn / _ex: D = A^T B over the rows of two row-major (or accumulator-order tile) operands - every
+//                               pointwise weight gradient; PAIR: both weight gradients of one block in one launch (cnx_gemm_tn_pair, round 6);
+//                               stage loops: two 64-row buffers (hand-over at the stage boundary or one k-step early), ring of 32-row stages
+//   gemm_tn_reduce_kernel, gemm_tn_pair_reduce_kernel   fixed-order sums of the split partials (the pair's also transposes dW2 back)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
